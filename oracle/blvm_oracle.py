@@ -1,0 +1,331 @@
+"""CPU oracle for the blvm hot path — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A plain-PyTorch (CPU, fp32 with fp64 where the reference is fp64) restatement of the arithmetic on the
+hot path of JakobHavtorn/benchmarking-lvms (`blvm`).  Only `tests/`, `__graft_entry__.smoke()` and the
+`cpu_baseline` leg of `bench.py` may import this module; the product (`benchmarking-lvms_amd/`) never does.
+
+Parity status: PINNED.  Every function here is checked in `tests/test_oracle_golden.py` against golden
+vectors in `tests/golden/` that were produced by importing the unmodified reference in the build container
+(`oracle/gen_golden.py`).  The reference's own tests pin only `reverse_sequences` and `CausalConv1d`
+(SURVEY.md §4); those known-answer vectors are restated in the tests as well.
+
+All citations are `path:line` relative to the reference checkout.  Everything is functional: models take a
+`state_dict` with the reference's key names and explicit noise `eps` instead of drawing from
+the global RNG (the reference draws `randn_like` once per step, `blvm/utils/variational.py:141-152`).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+LN2 = math.log(2.0)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# data synthesis (blvm/data/transforms.py:192-201 MuLawEncode; SURVEY.md §8d synthetic inputs)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def mu_law_encode(u: torch.Tensor, bits: int = 16) -> torch.Tensor:
+    """sign(u) * log(1 + mu |u|) / log(mu + 1), mu = 2^bits - 1  (transforms.py:192-201)."""
+    mu = 2**bits - 1
+    return u.sign() * torch.log(1 + mu * u.abs()) / math.log(mu + 1)
+
+
+def synth_batch(B: int, T: int, seed: int = 0, ragged: bool = False, bits: int = 16):
+    """Synthetic µ-law waveform batch x [B,T] float32 in (-1,1) and lengths x_sl [B] int64."""
+    g = torch.Generator().manual_seed(seed)
+    u = (torch.rand(B, T, generator=g) * 2 - 1) * 0.5
+    x = mu_law_encode(u, bits).to(torch.float32)
+    if ragged:
+        x_sl = torch.tensor([T - k * (T // (2 * B)) for k in range(B)], dtype=torch.int64)
+    else:
+        x_sl = torch.full((B,), T, dtype=torch.int64)
+    # zero the right padding like the batcher does (batchers.py:120-143 pads with zeros)
+    mask = torch.arange(T).unsqueeze(0) < x_sl.unsqueeze(1)
+    return x * mask, x_sl
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# shape helpers (blvm/utils/operations.py)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def stack_tensor(x: torch.Tensor, stack_size: int):
+    """[B,T] -> ([B,ceil(T/s),s], padding): right zero-pad T to a multiple of s (operations.py:14-32, dim=1)."""
+    T = x.size(1)
+    pad = (-T) % stack_size
+    if pad:
+        x = F.pad(x, (0, pad))
+    return x.reshape(x.size(0), (T + pad) // stack_size, stack_size), pad
+
+
+def sequence_mask(x_sl: torch.Tensor, max_len: int = None, dtype=torch.bool):
+    """arange(T) < x_sl[:,None]  (operations.py:90-119, stride=1)."""
+    T = int(max_len) if max_len is not None else int(x_sl.max())
+    return (torch.arange(T).unsqueeze(0) < x_sl.unsqueeze(1)).to(dtype)
+
+
+def reverse_sequences(x: torch.Tensor, x_sl: torch.Tensor):
+    """Time-major [T,B,*] per-row reversal that leaves right padding in place (operations.py:56-87)."""
+    T = int(x_sl.max())
+    out = x.clone()
+    for b in range(x.size(1)):
+        n = int(x_sl[b])
+        out[:n, b] = x[:n, b].flip(0)
+    return out[:T] if out.size(0) == T else out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# likelihoods (blvm/utils/log_likelihoods.py)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def gaussian_ll(y, mu, sd, epsilon: float = 1e-6):
+    """Element-wise Gaussian log density (log_likelihoods.py:17-39).
+
+    With epsilon != 0 the reference clamps sd under `torch.no_grad()`, which also DETACHES it: no gradient reaches
+    sd on that branch.  The latent heads call with epsilon=0 (distributions.py:140-141)."""
+    if epsilon:
+        sd = sd.clamp(min=epsilon).detach()
+    return -((y - mu) ** 2) / (2 * sd**2) - sd.log() - 0.5 * math.log(2 * math.pi)
+
+
+def gaussian_mixture_ll(y, logits, mu, sd, epsilon: float = 1e-6):
+    """y [*,D], logits [*,K], mu/sd [*,D,K] -> [*,D]; D must be 1 on this path (log_likelihoods.py:42-60)."""
+    lp = gaussian_ll(y.unsqueeze(-1), mu, sd, epsilon)  # [*,D,K]
+    lp = lp.squeeze(-2) if lp.size(-2) == 1 else lp.sum(-2)  # reduce(D) per component (`reduce`, :10-14)
+    return torch.logsumexp(lp + logits.log_softmax(-1), dim=-1)
+
+
+def dmol_ll(y, logits, locs, log_scales, num_bins: int = 256):
+    """Discretized mixture-of-logistics log-likelihood (log_likelihoods.py:170-231).
+
+    y [*,1] in [-1,1]; logits [*,K]; locs, log_scales [*,1,K]  ->  [*].
+    Half-bin width 1/(bins-1), edge thresholds 2/bins, fallback offset log(bins/2).
+    """
+    K = logits.size(-1)
+    yk = y.unsqueeze(-1).expand(*y.shape, K)
+    c = yk - locs
+    inv = torch.exp(-log_scales)
+    half = 1.0 / (num_bins - 1)
+    plus = inv * (c + half)
+    minus = inv * (c - half)
+    delta = torch.sigmoid(plus) - torch.sigmoid(minus)
+    low = plus - F.softplus(plus)
+    high = -F.softplus(minus)
+    mid = inv * c
+    log_pdf_mid = mid - log_scales - 2.0 * F.softplus(mid)
+    inner = torch.where(delta > 1e-5, torch.log(torch.clamp(delta, min=1e-10)), log_pdf_mid - math.log(num_bins / 2))
+    lp = torch.where(yk < 2 / num_bins - 1, low, inner)
+    lp = torch.where(yk > 1 - 2 / num_bins, high, lp)
+    lp = lp.squeeze(-2) if lp.size(-2) == 1 else lp.sum(-2)
+    return torch.logsumexp(lp + torch.log_softmax(logits, dim=-1), dim=-1)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# variational helpers (blvm/utils/variational.py)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def kl_gaussian(mu_q, sd_q, mu_p, sd_p):
+    """log sd_p - log sd_q + (sd_q^2 + (mu_q-mu_p)^2) / (2 sd_p^2) - 1/2  (variational.py:67-70)."""
+    return sd_p.log() - sd_q.log() + (sd_q.pow(2) + (mu_q - mu_p).pow(2)) / (2 * sd_p.pow(2)) - 0.5
+
+
+def discount_free_nats(kld, free_nats, shared_last: bool = True):
+    """max(kld, free_nats / size(-1)); identity for free_nats in {None, 0}  (variational.py:86-122)."""
+    if free_nats is None or free_nats == 0:
+        return kld
+    floor = free_nats / kld.shape[-1] if shared_last else free_nats
+    return torch.maximum(kld, torch.tensor(floor, dtype=kld.dtype))
+
+
+def precision_weighted_gaussian(mu_1, sd_1, mu_2, sd_2):
+    """Product of two Gaussians (variational.py:125-138)."""
+    pr_1, pr_2 = sd_1.pow(-2), sd_2.pow(-2)
+    var = (pr_1 + pr_2).pow(-1)
+    return var * (mu_1 * pr_1 + mu_2 * pr_2), var.sqrt()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# heads (blvm/modules/distributions.py)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def gaussian_head(x, weight, bias, initial_sd: float = 1.0, epsilon: float = 1e-6):
+    """DiagonalGaussianDense.forward: Linear -> chunk -> softplus_beta(s) + eps  (distributions.py:105-150)."""
+    p = F.linear(x, weight, bias)
+    mu, s = p.chunk(2, dim=-1)
+    beta = LN2 / (initial_sd - epsilon)
+    sd = F.softplus(s, beta=beta)
+    if epsilon > 0:
+        sd = sd + epsilon
+    return mu, sd
+
+
+def dmol_head(x, weight, bias, num_mix: int = 10, log_epsilon: float = -7.0):
+    """DiscretizedLogisticMixtureDense.forward for y_dim=1 (distributions.py:381-387)."""
+    p = F.linear(x, weight, bias)
+    logits = p[..., :num_mix]
+    rest = p[..., num_mix:].reshape(*p.shape[:-1], 1, 2 * num_mix)
+    locs, log_scales = rest.chunk(2, dim=-1)
+    return logits, locs, log_scales.clamp(min=log_epsilon)
+
+
+def dmol_mode(logits, locs):
+    """loc of the arg-max-logit component (distributions.py:359-368)."""
+    idx = logits.argmax(-1, keepdim=True).unsqueeze(-2)
+    return torch.gather(locs, -1, idx).squeeze(-1)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# recurrent cells (torch.nn.GRUCell / LSTM semantics, as used at vrnn.py:94,136, srnn.py:113-116, lstm.py:46-55)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def gru_cell(x, h, w_ih, w_hh, b_ih, b_hh):
+    """r=s(Wir x+bir+Whr h+bhr), z=s(..), n=tanh(Win x+bin+r*(Whn h+bhn)), h'=(1-z)n+z h; rows [r|z|n]."""
+    gi = F.linear(x, w_ih, b_ih)
+    gh = F.linear(h, w_hh, b_hh)
+    i_r, i_z, i_n = gi.chunk(3, -1)
+    h_r, h_z, h_n = gh.chunk(3, -1)
+    r = torch.sigmoid(i_r + h_r)
+    z = torch.sigmoid(i_z + h_z)
+    n = torch.tanh(i_n + r * h_n)
+    return (1 - z) * n + z * h
+
+
+def lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh):
+    """rows [i|f|g|o]; c' = f c + i g; h' = o tanh(c')."""
+    g = F.linear(x, w_ih, b_ih) + F.linear(h, w_hh, b_hh)
+    i, f, gg, o = g.chunk(4, -1)
+    c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+    return torch.sigmoid(o) * torch.tanh(c2), c2
+
+
+def _mlp(x, sd, prefix, idxs, act):
+    for i in idxs:
+        x = act(F.linear(x, sd[f"{prefix}.{i}.weight"], sd[f"{prefix}.{i}.bias"]))
+    return x
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# VRNN (blvm/models/vrnn.py)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def vrnn_cell_step(sd, x_t, h, eps_t, residual_posterior: bool = True, prefix: str = "vrnn.vrnn_cell"):
+    """One VRNNCell.forward (vrnn.py:109-141) with explicit noise."""
+    p = _mlp(h, sd, f"{prefix}.prior", (0, 2, 4), F.relu)
+    mu_p, sd_p = gaussian_head(p, sd[f"{prefix}.prior.6.params.weight"], sd[f"{prefix}.prior.6.params.bias"])
+    q = _mlp(torch.cat([h, x_t], -1), sd, f"{prefix}.posterior", (0, 2, 4), F.relu)
+    mu_q, sd_q = gaussian_head(q, sd[f"{prefix}.posterior.6.params.weight"], sd[f"{prefix}.posterior.6.params.bias"])
+    if residual_posterior:
+        mu_q = mu_q + mu_p
+    z = eps_t * sd_q + mu_q
+    phi = _mlp(z, sd, f"{prefix}.phi_z", (0, 2, 4, 6), F.relu)
+    h_new = gru_cell(
+        torch.cat([x_t, phi], -1),
+        h,
+        sd[f"{prefix}.gru_cell.weight_ih"],
+        sd[f"{prefix}.gru_cell.weight_hh"],
+        sd[f"{prefix}.gru_cell.bias_ih"],
+        sd[f"{prefix}.gru_cell.bias_hh"],
+    )
+    return h_new, dict(z=z, mu_q=mu_q, sd_q=sd_q, mu_p=mu_p, sd_p=sd_p, phi=phi)
+
+
+def elbo_terms(ll_twise, kld_twise, x_sl, stride, beta, free_nats, mask_dtype=torch.float64):
+    """VRNN.compute_elbo (vrnn.py:255-279): fp64 masks, loss = -sum(log_prob - beta*kld_fn)/sum(x_sl).
+
+    Returns loss, elbo, log_prob, kld (raw), kld_fn (free-nats clamped).
+    """
+    T = ll_twise.size(1)
+    mask = sequence_mask(x_sl, max_len=T, dtype=mask_dtype)
+    log_prob = (ll_twise * mask).flatten(1).sum(1)
+    mask_kl = mask[:, ::stride].unsqueeze(-1)
+    kld = (kld_twise * mask_kl).sum((1, 2))
+    elbo = log_prob - kld
+    kld_fn = (discount_free_nats(kld_twise, free_nats) * mask_kl).sum((1, 2))
+    loss = -(log_prob - beta * kld_fn).sum() / x_sl.sum()
+    return loss, elbo, log_prob, kld, kld_fn
+
+
+def vrnn_audio_forward(sd, x, x_sl, eps, beta=1.0, free_nats=0.0, h0=None, stack=64, residual_posterior=True, num_bins=2**16):
+    """VRNNAudio(likelihood="DMoL").forward (vrnn.py:281-369, 487-527).  eps: [T',B,z].
+
+    Returns dict(loss, elbo, log_prob, kl, kl_raw, z, h_n, parameters, bpd, metrics...).  `kl` is the
+    free-nats-clamped KL, as the reference returns it; `elbo` uses the raw KL.
+    """
+    B, T = x.shape
+    y = x.unsqueeze(-1)
+    xs, _ = stack_tensor(x, stack)  # [B,T',s]
+    enc = _mlp(xs, sd, "vrnn.encoder", (2, 4, 6), F.leaky_relu)  # [B,T',h]
+    Tp = enc.size(1)
+    stride = math.ceil(T / Tp)
+    r_dim = sd["vrnn.vrnn_cell.gru_cell.weight_hh"].size(1)
+    h = torch.zeros(B, r_dim, dtype=x.dtype) if h0 is None else h0
+    hs, outs = [h], []
+    for t in range(Tp):
+        h, o = vrnn_cell_step(sd, enc[:, t], h, eps[t], residual_posterior)
+        hs.append(h)
+        outs.append(o)
+    hs.pop()  # initial state included, last state dropped (vrnn.py:310-311)
+    st = lambda k: torch.stack([o[k] for o in outs], 1)  # noqa: E731
+    phi, hprev = st("phi"), torch.stack(hs, 1)
+    dec = _mlp(torch.cat([phi, hprev], -1), sd, "vrnn.decoder", (0, 2, 4), F.leaky_relu)  # [B,T',s*30]
+    dec = dec.reshape(B, Tp * stack, -1)[:, : int(x_sl.max())]
+    logits, locs, log_scales = dmol_head(dec, sd["vrnn.likelihood.params.weight"], sd["vrnn.likelihood.params.bias"])
+    ll = dmol_ll(y[:, : dec.size(1)], logits, locs, log_scales, num_bins)  # [B,T]
+    kld_twise = kl_gaussian(st("mu_q"), st("sd_q"), st("mu_p"), st("sd_p"))  # [B,T',z]
+    loss, elbo, log_prob, kld, kld_fn = elbo_terms(ll, kld_twise, x_sl, stride, beta, free_nats)
+    return dict(
+        loss=loss,
+        elbo=elbo,
+        log_prob=log_prob,
+        kl=kld_fn,
+        kl_raw=kld,
+        z=st("z"),
+        h_n=hs[-1],
+        enc=enc,
+        ll_twise=ll,
+        kld_twise=kld_twise,
+        parameters=(logits, locs, log_scales),
+        bpd=float((-elbo.detach() / LN2).sum() / x_sl.sum()),
+    )
+
+
+def vrnn_metrics(out, x_sl, beta, free_nats):
+    """Metric values as built at vrnn.py:346-355 + metrics.py:209-264 (RunningMeanMetric value = sum/reduce_by)."""
+    B = out["elbo"].numel()
+    n = float(x_sl.sum())
+    return {
+        "loss": float(out["loss"]),
+        "elbo": float(out["elbo"].sum()) / B,
+        "rec": float(out["log_prob"].sum()) / B,
+        "kl": float(out["kl"].sum()) / B,
+        "kl (bpt)": float((out["kl"] / LN2).sum()) / n,
+        "bpd": float((-out["elbo"] / LN2).sum()) / n,
+        "beta": float(beta),
+        "free_nats": float(free_nats),
+    }
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# annealer (blvm/training/annealers.py:21-72)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def cosine_anneal_trace(n_calls, anneal_steps, constant_steps=0, start_value=0.0, end_value=1.0):
+    """Values returned by successive CosineAnnealer.step() calls (annealers.py:52-63)."""
+    vals = []
+    for s in range(1, n_calls + 1):
+        if s >= anneal_steps + constant_steps:
+            v = end_value
+        elif s <= constant_steps:
+            v = start_value
+        else:
+            v = end_value + 0.5 * (start_value - end_value) * (1 + math.cos((s - constant_steps - 1) / anneal_steps * math.pi))
+        vals.append(v)
+    return vals

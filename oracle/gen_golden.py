@@ -1,0 +1,186 @@
+"""Generate golden vectors by importing the UNMODIFIED reference (build container only).
+
+    BLVM_DATA_ROOT_DIRECTORY=/tmp/blvm_data PYTHONDONTWRITEBYTECODE=1 \
+    PYTHONPATH=oracle/refshim:/root/reference python oracle/gen_golden.py
+
+Writes small `.npz` fixtures (inputs + expected outputs only — no reference source) into `tests/golden/`.
+The reference never travels to the GPU box; the fixtures do.  `oracle/refshim/` holds annotation/logging
+no-op modules for third-party packages the reference imports but that are off the arithmetic path.
+
+TEST INFRASTRUCTURE: not imported by the product.
+"""
+import math
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+warnings.filterwarnings("ignore")
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "..", "tests", "golden")
+sys.path.insert(0, HERE)
+
+import blvm  # noqa: E402  (the reference, from /root/reference via PYTHONPATH)
+import blvm.models as RM  # noqa: E402
+from blvm.data.transforms import MuLawEncode  # noqa: E402
+from blvm.modules.distributions import DiagonalGaussianDense, DiscretizedLogisticMixtureDense  # noqa: E402
+from blvm.training.annealers import CosineAnnealer  # noqa: E402
+from blvm.utils import log_likelihoods as RLL  # noqa: E402
+from blvm.utils import operations as ROP  # noqa: E402
+from blvm.utils import variational as RV  # noqa: E402
+
+import blvm_oracle as O  # noqa: E402  (only for the input synthesiser, so inputs are defined in ONE place)
+
+assert "/root/reference" in blvm.__file__, blvm.__file__
+
+
+def npy(t):
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **{k: npy(v) for k, v in arrays.items()})
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def gen_functions():
+    g = torch.Generator().manual_seed(7)
+    R = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    out = {}
+
+    # DMoL log-likelihood incl. edge cases (y = +-1, near edges, tiny scales -> delta fallback, clamp at -7)
+    N, K = 64, 10
+    y = torch.rand(N, 1, generator=g) * 1.9 - 0.95
+    y[0], y[1], y[2], y[3] = 1.0, -1.0, 1 - 1.0 / 65536, -1 + 1.0 / 65536
+    logits, locs, ls = R(N, K), R(N, 1, K) * 0.5, R(N, 1, K) * 2 - 4
+    ls[4:8] = -7.0  # clamp floor: sharp components -> delta < 1e-5 fallback when far from loc
+    ls[8:10] = 3.0
+    out.update(dmol_y=y, dmol_logits=logits, dmol_locs=locs, dmol_ls=ls)
+    out["dmol_ll_65536"] = RLL.discretized_logistic_mixture_ll(y, logits, locs, ls, num_bins=2**16)
+    out["dmol_ll_256"] = RLL.discretized_logistic_mixture_ll(y, logits, locs, ls, num_bins=256)
+
+    # DMoL head (Linear 30->30, split, clamp)
+    torch.manual_seed(3)
+    head = DiscretizedLogisticMixtureDense(x_dim=30, y_dim=1, num_mix=10, num_bins=2**16)
+    xh = R(5, 7, 30) * 3
+    lg, lc, lsc = head(xh)
+    out.update(dmolhead_w=head.params.weight, dmolhead_b=head.params.bias, dmolhead_x=xh, dmolhead_logits=lg, dmolhead_locs=lc, dmolhead_ls=lsc)
+    out["dmolhead_mode"] = head.mode((lg, lc, lsc))
+
+    # Gaussian head (softplus beta) incl. values beyond the softplus threshold
+    torch.manual_seed(4)
+    gh = DiagonalGaussianDense(12, 6)
+    xg = R(9, 12) * 30
+    mu, sd = gh(xg)
+    out.update(ghead_w=gh.params.weight, ghead_b=gh.params.bias, ghead_x=xg, ghead_mu=mu, ghead_sd=sd)
+
+    # Gaussian / GMM ll
+    yg, mug, sdg = R(6, 5), R(6, 5), R(6, 5).abs() + 1e-3
+    out.update(gll_y=yg, gll_mu=mug, gll_sd=sdg, gll_eps0=RLL.gaussian_ll(yg, mug, sdg, epsilon=0, reduce_dim=None))
+    ym, lgm, mum, sdm = R(6, 1), R(6, 4), R(6, 1, 4), R(6, 1, 4).abs() + 1e-3
+    out.update(gmm_y=ym, gmm_logits=lgm, gmm_mu=mum, gmm_sd=sdm, gmm_ll=RLL.gaussian_mixture_ll(ym, lgm, mum, sdm, epsilon=1e-4))
+
+    # KL, free nats, precision weighting
+    mq, sq, mp, sp = R(4, 6, 8), R(4, 6, 8).abs() + 0.05, R(4, 6, 8), R(4, 6, 8).abs() + 0.05
+    kl = RV.kl_divergence_gaussian(mq, sq, mp, sp)
+    out.update(kl_mq=mq, kl_sq=sq, kl_mp=mp, kl_sp=sp, kl_out=kl)
+    out["kl_fn2"] = RV.discount_free_nats(kl, 2.0, shared_dims=-1)
+    out["kl_fn0"] = RV.discount_free_nats(kl, 0, shared_dims=-1)
+    pm, ps = RV.precision_weighted_gaussian(mq, sq, mp, sp)
+    out.update(pw_mu=pm, pw_sd=ps)
+
+    # stack / mask / reverse
+    xs = R(3, 21)
+    st, pad = ROP.stack_tensor(xs, 8, dim=1)
+    out.update(stack_x=xs, stack_out=st, stack_pad=np.int64(pad))
+    sl = torch.tensor([10, 7, 5, 2])
+    out.update(mask_sl=sl, mask_bool=ROP.sequence_mask(sl), mask_f64=ROP.sequence_mask(sl, dtype=float))
+    xr = R(10, 4, 3)
+    out.update(rev_x=xr, rev_out=ROP.reverse_sequences(xr, sl))
+
+    # mu-law
+    u = torch.linspace(-1, 1, 41)
+    out.update(mulaw_u=u, mulaw_16=MuLawEncode(16)(u), mulaw_8=MuLawEncode(8)(u))
+
+    # annealer traces (beta: 0->1 over 10; free nats: constant 5 then cosine over 7 to 0)
+    a = CosineAnnealer(anneal_steps=10, constant_steps=0, start_value=0, end_value=1)
+    b = CosineAnnealer(anneal_steps=7, constant_steps=5, start_value=2.0, end_value=0.0)
+    out["anneal_beta"] = np.array([a.step() for _ in range(15)])
+    out["anneal_fn"] = np.array([b.step() for _ in range(15)])
+    save("functions.npz", **out)
+
+
+def replay_eps(seed, Tp, B, z):
+    """The scripted cell draws randn_like(mu) once per step (variational.py:141-152): replay that order."""
+    torch.manual_seed(seed)
+    return torch.stack([torch.randn(B, z) for _ in range(Tp)], 0)
+
+
+def run_vrnn(model, x, x_sl, seed, beta, free_nats, stack, z):
+    model.zero_grad()
+    Tp = math.ceil(x.size(1) / stack)
+    eps = replay_eps(seed, Tp, x.size(0), z)
+    torch.manual_seed(seed)
+    loss, metrics, o = model(x, x_sl, beta=beta, free_nats=free_nats)
+    loss.backward()
+    # the replayed noise must reproduce the sampled latents exactly, or the fixture is useless
+    z_replay = o.z.detach()
+    return loss, metrics, o, eps, z_replay
+
+
+def gen_vrnn_small():
+    torch.manual_seed(11)
+    m = RM.VRNNAudio(likelihood="DMoL", input_size=8, hidden_size=32, latent_size=16, residual_posterior=True, num_mix=10, num_bins=2**16)
+    x, x_sl = O.synth_batch(3, 76, seed=5, ragged=True)  # T=76 -> T'=10 with 4 frames of stack padding
+    x_sl = torch.tensor([76, 61, 40])
+    x = x * (torch.arange(76).unsqueeze(0) < x_sl.unsqueeze(1))
+    arrays = {}
+    for tag, (beta, fn) in {"a": (1.0, 2.0), "b": (0.3, 0.0)}.items():
+        loss, metrics, o, eps, _ = run_vrnn(m, x, x_sl, 123, beta, fn, 8, 16)
+        arrays.update({f"{tag}_loss": loss, f"{tag}_elbo": o.elbo, f"{tag}_log_prob": o.log_prob, f"{tag}_kl": o.kl, f"{tag}_z": o.z, f"{tag}_h_n": o.h_n})
+        arrays[f"{tag}_eps"] = eps
+        arrays[f"{tag}_metric_names"] = np.array([mm.name for mm in metrics])
+        arrays[f"{tag}_metric_values"] = np.array([mm.value for mm in metrics], dtype=np.float64)
+        for k, p in m.named_parameters():
+            arrays[f"{tag}_grad.{k}"] = p.grad
+    arrays.update(x=x, x_sl=x_sl)
+    for k, v in m.state_dict().items():
+        arrays[f"sd.{k}"] = v
+    save("vrnn_small.npz", **arrays)
+
+
+def gen_vrnn_full():
+    """Full C2 dimensions (h=256, z=256, s=64) on a short batch; weights are NOT stored — they are reproduced from
+    `torch.manual_seed(0)` + identical construction order, pinned by per-tensor checksums."""
+    torch.manual_seed(0)
+    m = RM.VRNNAudio(likelihood="DMoL", input_size=64, hidden_size=256, latent_size=256, residual_posterior=True, num_mix=10, num_bins=2**16)
+    arrays = {}
+    names = []
+    for k, v in m.state_dict().items():
+        names.append(k)
+        arrays[f"cks.{k}"] = np.array([v.double().sum().item(), v.double().abs().sum().item(), *v.shape], dtype=np.float64)
+    arrays["param_names"] = np.array(names)
+    B, T = 4, 1280
+    x, x_sl = O.synth_batch(B, T, seed=0, ragged=True)
+    loss, metrics, o, eps, _ = run_vrnn(m, x, x_sl, 123, 1.0, 2.0, 64, 256)
+    arrays.update(x_sl=x_sl, x_cks=np.array([x.double().sum().item(), x.double().abs().sum().item()]))
+    arrays.update(eps_cks=np.array([eps.double().sum().item(), eps.double().abs().sum().item()]))
+    arrays.update(loss=loss, elbo=o.elbo, log_prob=o.log_prob, kl=o.kl, h_n_cks=np.array([o.h_n.double().sum().item(), o.h_n.double().abs().sum().item()]))
+    arrays["metric_names"] = np.array([mm.name for mm in metrics])
+    arrays["metric_values"] = np.array([mm.value for mm in metrics], dtype=np.float64)
+    arrays["grad_norms"] = np.array([p.grad.double().norm().item() for _, p in m.named_parameters()])
+    arrays["grad_names"] = np.array([k for k, _ in m.named_parameters()])
+    # a few full gradient tensors (small ones) for element-wise checks
+    for k in ["vrnn.likelihood.params.weight", "vrnn.likelihood.params.bias", "vrnn.vrnn_cell.gru_cell.bias_hh", "vrnn.encoder.2.bias"]:
+        arrays[f"grad.{k}"] = dict(m.named_parameters())[k].grad
+    save("vrnn_full.npz", **arrays)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full"]
+    for w in which:
+        globals()[f"gen_{w}"]()

@@ -1,0 +1,114 @@
+"""CPU: the oracle (oracle/blvm_oracle.py) against golden vectors produced by the imported reference
+(oracle/gen_golden.py) and against the reference's own known-answer tests."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import blvm_oracle as O
+
+from conftest import GOLDEN
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def fn():
+    return np.load(os.path.join(GOLDEN, "functions.npz"))
+
+
+def close(a, b, rtol=1e-6, atol=1e-6):
+    torch.testing.assert_close(a, T(b) if not isinstance(b, torch.Tensor) else b, rtol=rtol, atol=atol)
+
+
+def test_dmol_ll(fn):
+    y, lg, lc, ls = T(fn["dmol_y"]), T(fn["dmol_logits"]), T(fn["dmol_locs"]), T(fn["dmol_ls"])
+    close(O.dmol_ll(y, lg, lc, ls, 2**16), fn["dmol_ll_65536"], 1e-6, 1e-6)
+    close(O.dmol_ll(y, lg, lc, ls, 256), fn["dmol_ll_256"], 1e-6, 1e-6)
+
+
+def test_dmol_head(fn):
+    lg, lc, ls = O.dmol_head(T(fn["dmolhead_x"]), T(fn["dmolhead_w"]), T(fn["dmolhead_b"]))
+    close(lg, fn["dmolhead_logits"])
+    close(lc, fn["dmolhead_locs"])
+    close(ls, fn["dmolhead_ls"])
+    assert float(ls.min()) >= -7.0
+    close(O.dmol_mode(lg, lc), fn["dmolhead_mode"])
+
+
+def test_gaussian_head(fn):
+    mu, sd = O.gaussian_head(T(fn["ghead_x"]), T(fn["ghead_w"]), T(fn["ghead_b"]))
+    close(mu, fn["ghead_mu"])
+    close(sd, fn["ghead_sd"])
+
+
+def test_gaussian_lls(fn):
+    close(O.gaussian_ll(T(fn["gll_y"]), T(fn["gll_mu"]), T(fn["gll_sd"]), epsilon=0), fn["gll_eps0"])
+    close(O.gaussian_mixture_ll(T(fn["gmm_y"]), T(fn["gmm_logits"]), T(fn["gmm_mu"]), T(fn["gmm_sd"]), 1e-4), fn["gmm_ll"], 1e-5, 1e-5)
+
+
+def test_kl_freenats_precision(fn):
+    mq, sq, mp, sp = (T(fn[k]) for k in ("kl_mq", "kl_sq", "kl_mp", "kl_sp"))
+    kl = O.kl_gaussian(mq, sq, mp, sp)
+    close(kl, fn["kl_out"], 1e-6, 1e-5)
+    close(O.discount_free_nats(T(fn["kl_out"]), 2.0), fn["kl_fn2"])
+    close(O.discount_free_nats(T(fn["kl_out"]), 0), fn["kl_fn0"])
+    mu, sd = O.precision_weighted_gaussian(mq, sq, mp, sp)
+    close(mu, fn["pw_mu"], 1e-6, 1e-6)
+    close(sd, fn["pw_sd"], 1e-6, 1e-6)
+
+
+def test_stack_mask_reverse(fn):
+    st, pad = O.stack_tensor(T(fn["stack_x"]), 8)
+    close(st, fn["stack_out"], 0, 0)
+    assert pad == int(fn["stack_pad"])
+    sl = T(fn["mask_sl"])
+    assert torch.equal(O.sequence_mask(sl), T(fn["mask_bool"]))
+    assert torch.equal(O.sequence_mask(sl, dtype=torch.float64), T(fn["mask_f64"]))
+    close(O.reverse_sequences(T(fn["rev_x"]), sl), fn["rev_out"], 0, 0)
+
+
+def test_reverse_sequences_reference_known_answer():
+    """Known-answer vectors of the reference's tests/utils/test_operations.py:7-48 (lengths 10,7,5,2)."""
+    x_sl = torch.tensor([10, 7, 5, 2])
+    x = torch.zeros(10, 4)
+    for b, n in enumerate(x_sl.tolist()):
+        x[:n, b] = torch.arange(1, n + 1, dtype=torch.float32)
+    out = O.reverse_sequences(x, x_sl)
+    for b, n in enumerate(x_sl.tolist()):
+        assert out[:n, b].tolist() == list(range(n, 0, -1))
+        assert out[n:, b].abs().sum() == 0
+
+
+def test_mulaw_and_annealer(fn):
+    u = T(fn["mulaw_u"])
+    close(O.mu_law_encode(u, 16), fn["mulaw_16"])
+    close(O.mu_law_encode(u, 8), fn["mulaw_8"])
+    np.testing.assert_allclose(O.cosine_anneal_trace(15, 10, 0, 0.0, 1.0), fn["anneal_beta"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(O.cosine_anneal_trace(15, 7, 5, 2.0, 0.0), fn["anneal_fn"], rtol=0, atol=1e-15)
+
+
+@pytest.mark.parametrize("tag,beta,fn_", [("a", 1.0, 2.0), ("b", 0.3, 0.0)])
+def test_vrnn_small_forward_backward(tag, beta, fn_):
+    g = np.load(os.path.join(GOLDEN, "vrnn_small.npz"))
+    sd = {k[3:]: T(g[k]).clone().requires_grad_(True) for k in g.files if k.startswith("sd.")}
+    x, x_sl, eps = T(g["x"]), T(g["x_sl"]), T(g[f"{tag}_eps"])
+    out = O.vrnn_audio_forward(sd, x, x_sl, eps, beta=beta, free_nats=fn_, stack=8)
+    assert out["loss"].dtype == torch.float64
+    close(out["z"], g[f"{tag}_z"], 1e-5, 1e-6)
+    close(out["loss"], g[f"{tag}_loss"], 1e-7, 0)
+    close(out["elbo"], g[f"{tag}_elbo"], 1e-7, 0)
+    close(out["log_prob"], g[f"{tag}_log_prob"], 1e-7, 0)
+    close(out["kl"], g[f"{tag}_kl"], 1e-6, 1e-6)
+    close(out["h_n"], g[f"{tag}_h_n"], 1e-5, 1e-6)
+    m = O.vrnn_metrics(out, x_sl, beta, fn_)
+    for name, val in zip(g[f"{tag}_metric_names"].tolist(), g[f"{tag}_metric_values"].tolist()):
+        assert m[name] == pytest.approx(val, rel=1e-6, abs=1e-9), name
+    out["loss"].backward()
+    for k, p in sd.items():
+        ref = T(g[f"{tag}_grad.{k}"])
+        err = (p.grad - ref).norm() / (ref.norm() + 1e-12)
+        assert err < 2e-5, (k, float(err))
