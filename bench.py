@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""bench.py — training throughput of the VRNN hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run, one rank/GPU)
+
+A "step" is one full optimisation step of VRNNAudio(DMoL, s=64, h=256, z=256) on a synthetic 16 kHz µ-law batch
+[B,16000] per GPU that is resident in HBM: forward (encoder MLP, recurrent cell over T'=250 steps, decoder MLP, DMoL
+head, KL) + backward (BPTT) + gradient all-reduce (N > 1) + clip-by-value + clip-by-norm + Adam — the loop body of
+the reference's experiments/experiment_vrnn_audio.py:213-232 in fp32.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "benchmarking-lvms_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak (= fp32 vector peak)
+
+
+def cell_macs(X, H, Z, R):
+    prior = R * H + 2 * H * H + 2 * Z * H
+    post = (R + X) * H + 2 * H * H + 2 * Z * H
+    phi = Z * H + 3 * H * H
+    gru = 3 * R * (X + H) + 3 * R * R
+    return prior + post + phi + gru  # 2,686,976 at X=H=Z=256, R=512
+
+
+def cpu_baseline(B, T, steps, threads):
+    """The CPU oracle (a restatement of the reference's PyTorch path, pinned to it by golden vectors) timed on the
+    host cores: forward + backward + Adam on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import blvm_oracle as O
+    from blvm.models import VRNNAudio
+
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    m = VRNNAudio(likelihood="DMoL", input_size=64, hidden_size=256, latent_size=256, residual_posterior=True)
+    sd = {k: v.clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    opt = torch.optim.Adam(list(sd.values()), lr=3e-4)
+    x, x_sl = O.synth_batch(B, T, seed=0)
+    Tp = math.ceil(T / 64)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        eps = torch.randn(Tp, B, 256)
+        opt.zero_grad()
+        out = O.vrnn_audio_forward(sd, x, x_sl, eps, beta=1.0, free_nats=2.0, stack=64)
+        out["loss"].backward()
+        torch.nn.utils.clip_grad_value_(list(sd.values()), 1000.0)
+        torch.nn.utils.clip_grad_norm_(list(sd.values()), 3000.0)
+        opt.step()
+        if i > 0:  # first step is warm-up
+            times.append(time.perf_counter() - t0)
+    dt = sorted(times)[len(times) // 2]
+    return dict(value=B * T / dt, unit="frames/s", cores=threads, kind="port",
+                sample=f"oracle VRNN train step (fwd+bwd+clip+Adam, fp32) on [{B},{T}], median of {steps} steps after 1 warm-up",
+                ms_per_step=dt * 1e3, bits_per_dim=out["bpd"])  # fmt: skip
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU (reference benchmark: --batch_len 64 s of audio)")
+    ap.add_argument("--length", type=int, default=16000, help="samples per utterance (1 s at 16 kHz)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from blvm import _hip, ops
+    from blvm.models import VRNNAudio
+    from blvm.training.ddp import FlatGradAllReduce
+
+    assert _hip.load().blvm_device_ok() == 1, "libblvm_hip: no gfx950 device"
+    B, T, S, H, Z = args.batch, args.length, 64, 256, 256
+    Tp = math.ceil(T / S)
+    torch.manual_seed(0)  # identical weights on every rank
+    model = VRNNAudio(likelihood="DMoL", input_size=S, hidden_size=H, latent_size=Z, residual_posterior=True).to(dev)
+    params = list(model.parameters())
+    opt = torch.optim.Adam(params, lr=3e-4)
+    reducer = FlatGradAllReduce(params) if world > 1 else None
+
+    # synthetic µ-law batch, resident in HBM before the timed region (rank-offset seed: different utterances per GPU)
+    g = torch.Generator().manual_seed(1000 + rank)
+    u = (torch.rand(B, T, generator=g) * 2 - 1) * 0.5
+    x = (u.sign() * torch.log1p(65535 * u.abs()) / math.log(65536)).to(dev)
+    x_sl = torch.full((B,), T, dtype=torch.int64)
+    torch.manual_seed(123 + rank)  # eps stream differs per rank
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    # time the recurrent-cell calls (the dominant kernels) with HIP events on the launching stream
+    cur = {"i": -1}
+    slot = {"fwd_begin": 0, "fwd_end": 1, "bwd_begin": 2, "bwd_end": 3}
+
+    def hook(tag):
+        if cur["i"] >= 0:
+            ev[cur["i"]][slot[tag]].record()
+
+    ops.seq_timer_hook = hook
+
+    last = {}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss, metrics, out = model(x, x_sl, beta=1.0, free_nats=2.0)
+        loss.backward()
+        if reducer is not None:
+            reducer(float(B * T))
+        torch.nn.utils.clip_grad_value_(params, 1000.0)  # experiment_vrnn_audio.py:41-42 defaults
+        torch.nn.utils.clip_grad_norm_(params, 3000.0)
+        opt.step()
+        last["metrics"] = metrics
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        cur["i"] = i
+        step()
+    cur["i"] = -1
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+
+    ms_step = dt / args.steps * 1e3
+    frames = world * B * T * args.steps
+    cell_ms = [(e[0].elapsed_time(e[1]), e[2].elapsed_time(e[3])) for e in ev]
+    fwd_ms = sum(c[0] for c in cell_ms) / len(cell_ms)
+    bwd_ms = sum(c[1] for c in cell_ms) / len(cell_ms)
+    macs = cell_macs(H, H, Z, 2 * H) * B * Tp
+    flops_fb = 3 * 2 * macs  # forward + dgrad + wgrad
+    achieved = flops_fb / ((fwd_ms + bwd_ms) * 1e-3) / 1e12
+    bpd = {m.name: m.value for m in last["metrics"]}["bpd"]
+
+    if rank == 0:
+        res = {
+            "metric": "audio frames/sec training (VRNN, 16 kHz mu-law)",
+            "value": frames / dt,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "bits_per_dim": bpd,
+            "config": {
+                "workload": f"experiment_vrnn_audio.py: VRNNAudio DMoL s=64 h=256 z=256, synthetic mu-law [{B},1,{T}] per GPU "
+                            f"(T'={Tp} recurrent steps), full train step fwd+bwd+clip+Adam, random init",
+                "batch_per_gpu": B, "global_batch": world * B, "samples_per_utterance": T, "parallelism": f"dp{world}",
+            },
+            "roofline": {
+                "kernel": "VRNN recurrent cell, forward+BPTT (blvm_vrnn_seq_fwd + blvm_vrnn_seq_bwd: stage-kernel chain + hoisted MFMA GEMMs)",
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                "traffic": None,
+                "flops_per_call": flops_fb,
+                "fwd_ms": fwd_ms,
+                "bwd_ms": bwd_ms,
+            },
+        }  # fmt: skip
+        if world == 1 and not args.no_cpu_baseline:
+            threads = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0))))
+            res["cpu_baseline"] = cpu_baseline(args.cpu_batch, T, args.cpu_steps, threads)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,105 @@
+"""ctypes binding of libblvm_hip.so (the C ABI declared in include/blvm_hip.h).
+
+No torch types cross this boundary: tensors are passed as raw device pointers (`tensor.data_ptr()`), sizes as ints,
+the stream as the current torch HIP stream handle.  There is NO CPU fallback: every wrapper raises if the library
+is missing or if it is handed a tensor that does not live on a HIP device.
+"""
+import ctypes
+import os
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libblvm_hip.so")
+_lib = None
+
+c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+
+class BlvmHipError(RuntimeError):
+    pass
+
+
+class VrnnWeights(ctypes.Structure):
+    """struct BlvmVrnnWeights / BlvmVrnnGrads (identical field order)."""
+
+    _fields_ = [
+        ("prior_w", c_void_p * 3), ("prior_b", c_void_p * 3), ("prior_hw", c_void_p), ("prior_hb", c_void_p),
+        ("post_w", c_void_p * 3), ("post_b", c_void_p * 3), ("post_hw", c_void_p), ("post_hb", c_void_p),
+        ("phi_w", c_void_p * 4), ("phi_b", c_void_p * 4),
+        ("gru_wih", c_void_p), ("gru_whh", c_void_p), ("gru_bih", c_void_p), ("gru_bhh", c_void_p),
+    ]  # fmt: skip
+
+
+_SIGNATURES = {
+    "blvm_version": (c_int, []),
+    "blvm_last_error": (ctypes.c_char_p, []),
+    "blvm_device_ok": (c_int, []),
+    "blvm_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                              c_void_p, c_int, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "blvm_act_bwd_f32": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
+    "blvm_colsum_f32": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "blvm_dmol_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                              c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "blvm_dmol_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                              c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "blvm_kl_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                            c_float, c_void_p, c_void_p, c_void_p]),
+    "blvm_kl_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                            c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "blvm_vrnn_reserve_floats": (c_size_t, [c_int] * 6),
+    "blvm_vrnn_bwd_workspace_floats": (c_size_t, [c_int] * 6),
+    "blvm_vrnn_seq_fwd": (c_int, [ctypes.POINTER(VrnnWeights), c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                  c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p]),
+    "blvm_vrnn_seq_bwd": (c_int, [ctypes.POINTER(VrnnWeights), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p,
+                                  c_void_p, ctypes.POINTER(VrnnWeights), c_void_p, c_void_p]),
+}  # fmt: skip
+
+EXPORTS = tuple(_SIGNATURES)
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load libblvm_hip.so (once) and attach argument/return types.  Raises BlvmHipError if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise BlvmHipError(
+                f"libblvm_hip.so not found at {_LIB_PATH}: build it with benchmarking-lvms_amd/csrc/build.sh "
+                "(or __graft_entry__.build()).  There is no CPU/PyTorch fallback for the blvm hot path."
+            )
+        lib = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().blvm_last_error().decode(errors="replace")
+        raise BlvmHipError(f"{what} failed (code {rc}): {msg}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses anything that is not a contiguous HIP tensor."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise BlvmHipError(
+            "blvm HIP kernels were handed a CPU tensor: this build runs the hot path on gfx950 only "
+            "(no CPU fallback); move the model and inputs to a HIP device."
+        )
+    if not t.is_contiguous():
+        raise BlvmHipError("blvm HIP kernels need contiguous tensors")
+    return t.data_ptr()

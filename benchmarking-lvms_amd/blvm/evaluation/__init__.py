@@ -1,0 +1,11 @@
+from .metrics import (  # noqa: F401
+    BitsPerDimMetric,
+    DeferredScalars,
+    KLMetric,
+    LatestMeanMetric,
+    LLMetric,
+    LossMetric,
+    Metric,
+    RunningMeanMetric,
+)
+from .tracker import Tracker  # noqa: F401

@@ -1,0 +1,2 @@
+from blvm.models.base_model import BaseModel, load_model  # noqa: F401
+from blvm.models.vrnn import VRNN, VRNNAudio, VRNNCell  # noqa: F401

@@ -1,0 +1,276 @@
+"""VRNN [Chung et al. 2015] with the reference's construction API and state_dict layout, computed by HIP kernels.
+
+Reference: blvm/models/vrnn.py — `VRNNCell` :36-164, `VRNN` :167-434 (`compute_elbo` :255-279, `forward` :281-369),
+`VRNNAudio` :437-545.  The modules below own the parameters in the same registration order (so seeded
+initialisation and checkpoints are interchangeable with the reference) while `forward` hands whole sequences to
+`libblvm_hip.so`: encoder/decoder MLPs (K6), the recurrent cell over all steps incl. BPTT (K1), the Gaussian KL with
+free nats (K8, its backward fused into K1) and the DMoL head (K7).
+"""
+import math
+from types import SimpleNamespace
+from typing import Optional, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.init as init
+
+from blvm import ops
+from blvm.data.transforms import StackTensor
+from blvm.evaluation import BitsPerDimMetric, DeferredScalars, KLMetric, LatestMeanMetric, LLMetric, LossMetric
+from blvm.models.base_model import BaseModel
+from blvm.modules.convenience import View
+from blvm.modules.distributions import DiagonalGaussianDense, DiscretizedLogisticMixtureDense
+
+
+class LazyNamespace(SimpleNamespace):
+    """SimpleNamespace whose expensive fields are computed on first access (the reference computes samples / modes /
+    masks on every forward although the loss never uses them, vrnn.py:332-333)."""
+
+    def __init__(self, _lazy=None, **kwargs):
+        super().__init__(**kwargs)
+        object.__setattr__(self, "_lazy", dict(_lazy or {}))
+
+    def __getattr__(self, name):
+        lazy = object.__getattribute__(self, "_lazy")
+        if name in lazy:
+            value = lazy.pop(name)()
+            setattr(self, name, value)
+            return value
+        raise AttributeError(name)
+
+
+class VRNNCell(nn.Module):
+    def __init__(self, x_dim: int, h_dim: int, z_dim: int, r_dim: Optional[int] = None, condition_h_on_x: bool = True,
+                 residual_posterior: bool = False):  # fmt: skip
+        super().__init__()
+        r_dim = r_dim if r_dim else 2 * h_dim
+        self.x_dim, self.h_dim, self.z_dim, self.r_dim = x_dim, h_dim, z_dim, r_dim
+        self.condition_h_on_x = condition_h_on_x
+        self.residual_posterior = residual_posterior
+
+        def mlp(i, n):
+            layers = []
+            for k in range(n):
+                layers += [nn.Linear(i if k == 0 else h_dim, h_dim), nn.ReLU()]
+            return layers
+
+        # registration (and therefore RNG) order as in the reference: phi_z, prior, posterior, gru_cell (vrnn.py:63-94)
+        self.phi_z = nn.Sequential(*mlp(z_dim, 4))
+        self.prior = nn.Sequential(*mlp(r_dim, 3), DiagonalGaussianDense(h_dim, z_dim))
+        self.posterior = nn.Sequential(*mlp(x_dim + r_dim, 3), DiagonalGaussianDense(h_dim, z_dim))
+        self.gru_cell = nn.GRUCell(x_dim + h_dim if condition_h_on_x else h_dim, r_dim)
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        init.orthogonal_(self.gru_cell.weight_hh)
+
+    def get_initial_state(self, batch_size: int, device=None):
+        device = device if device is not None else self.prior[0].weight.device
+        return torch.zeros(batch_size, self.r_dim, device=device)
+
+    def kernel_params(self):
+        """Parameters in the order of `ops._VRNN_PARAM_ORDER` / struct BlvmVrnnWeights."""
+        p, q, f, g = self.prior, self.posterior, self.phi_z, self.gru_cell
+        out = []
+        for seq in (p, q):
+            for i in (0, 2, 4):
+                out += [seq[i].weight, seq[i].bias]
+            out += [seq[6].params.weight, seq[6].params.bias]
+        for i in (0, 2, 4, 6):
+            out += [f[i].weight, f[i].bias]
+        out += [g.weight_ih, g.weight_hh, g.bias_ih, g.bias_hh]
+        return out
+
+    def sequence(self, enc, h0, eps, x_sl_dev, stride: int, free_nats: float = 0.0):
+        if not self.condition_h_on_x:
+            raise NotImplementedError("libblvm_hip: VRNN cell kernels implement condition_h_on_x=True (the VRNNAudio form)")
+        head = self.prior[6]
+        if head.initial_sd != 1 or self.posterior[6].epsilon != head.epsilon:
+            raise NotImplementedError("libblvm_hip: Gaussian heads with initial_sd != 1 are not supported")
+        return ops.vrnn_sequence(enc, h0, eps, x_sl_dev, self.kernel_params(), self.x_dim, self.h_dim, self.z_dim,
+                                 self.r_dim, self.residual_posterior, stride, free_nats, head.epsilon)  # fmt: skip
+
+    def forward(self, x: torch.Tensor, h: torch.Tensor, eps: Optional[torch.Tensor] = None):
+        """Single step (vrnn.py:109-141): a length-1 sequence through the same kernels."""
+        B = x.size(0)
+        eps = torch.randn(1, B, self.z_dim, device=x.device) if eps is None else eps.view(1, B, self.z_dim)
+        x_sl = torch.ones(B, dtype=torch.int32, device=x.device)
+        decin, _, _, mu_q, sd_q, mu_p, sd_p, z = self.sequence(x.unsqueeze(0).contiguous(), h, eps, x_sl, 1, 0.0)
+        h_new = decin[1, :, self.h_dim :]
+        out = SimpleNamespace(h=h_new, z=z[0], enc_mu=mu_q[0], enc_sd=sd_q[0], prior_mu=mu_p[0], prior_sd=sd_p[0],
+                              phi_z=decin[0, :, : self.h_dim])  # fmt: skip
+        return h_new, out
+
+
+def _linears(seq: nn.Sequential):
+    return [m for m in seq if isinstance(m, nn.Linear)]
+
+
+class VRNN(nn.Module):
+    def __init__(self, encoder: nn.Module, likelihood: nn.Module, x_dim: int, h_dim: int, z_dim: int,
+                 r_dim: Optional[int] = None, decoder: nn.Module = None, residual_posterior: bool = False,
+                 condition_h_on_x: bool = True, condition_x_on_h: bool = True, dropout: float = 0):  # fmt: skip
+        super().__init__()
+        r_dim = r_dim if r_dim else 2 * h_dim
+        self.x_dim, self.h_dim, self.z_dim, self.r_dim = x_dim, h_dim, z_dim, r_dim
+        self.residual_posterior = residual_posterior
+        self.condition_h_on_x = condition_h_on_x
+        self.condition_x_on_h = condition_x_on_h
+        if dropout:
+            raise NotImplementedError("libblvm_hip: dropout is not on the benchmark path (all runs use dropout 0)")
+
+        self.encoder = encoder
+        self.likelihood = likelihood
+        if decoder is None:
+            d_in = h_dim + r_dim if condition_x_on_h else h_dim
+            self.decoder = nn.Sequential(nn.Linear(d_in, h_dim), nn.ReLU(), nn.Linear(h_dim, h_dim), nn.ReLU(),
+                                         nn.Linear(h_dim, h_dim), nn.ReLU())  # fmt: skip
+        else:
+            self.decoder = decoder
+        self.vrnn_cell = VRNNCell(x_dim=x_dim, h_dim=h_dim, z_dim=z_dim, condition_h_on_x=condition_h_on_x,
+                                  residual_posterior=residual_posterior)  # fmt: skip
+        self.dropout = None
+
+    # ---- structure recognised by the fused path --------------------------------------------------------------------
+    def _plan(self):
+        enc, dec, lik = self.encoder, self.decoder, self.likelihood
+        stack = next((m for m in enc if isinstance(m, StackTensor)), None) if isinstance(enc, nn.Sequential) else None
+        ok = (
+            stack is not None
+            and isinstance(dec, nn.Sequential)
+            and isinstance(lik, DiscretizedLogisticMixtureDense)
+            and self.condition_h_on_x
+            and self.condition_x_on_h
+            and all(isinstance(m, (nn.Linear, nn.LeakyReLU, View, StackTensor)) for m in list(enc) + list(dec))
+            and isinstance(dec[-2], nn.LeakyReLU)
+        )
+        if not ok:
+            raise NotImplementedError(
+                "libblvm_hip accelerates the VRNNAudio(likelihood='DMoL') structure (stacked-frame MLP encoder, MLP "
+                "decoder, DMoL head, condition_h_on_x = condition_x_on_h = True); other compositions are not built yet"
+            )
+        return stack.n_frames, _linears(enc), _linears(dec), lik
+
+    def forward(self, x: torch.Tensor, x_sl: torch.Tensor, beta: float = 1, free_nats: float = 0,
+                h0: Optional[torch.Tensor] = None, eps: Optional[torch.Tensor] = None):  # fmt: skip
+        """x [B,T] or [B,T,1] in [-1,1]; x_sl [B] lengths (host int tensor, as the reference's loaders give it).
+        `eps` [T',B,z] optionally supplies the reparameterisation noise (otherwise drawn on the device)."""
+        S, enc_lin, dec_lin, lik = self._plan()
+        if x.ndim == 3:
+            x = x.squeeze(-1)
+        dev = x.device
+        B, T = x.shape
+        x_sl_host = x_sl.detach().cpu().to(torch.int64)
+        x_sl_dev = x_sl_host.to(device=dev, dtype=torch.int32)
+        y = x.detach().to(torch.float32).contiguous()
+        Tp = (T + S - 1) // S
+        stride = math.ceil(T / Tp)
+        H, Z, R = self.h_dim, self.z_dim, self.r_dim
+
+        # frames stacked time-major: [T', B, S]   (StackTensor, operations.py:14-32: right zero-pad)
+        xs = torch.nn.functional.pad(y, (0, Tp * S - T)) if Tp * S != T else y
+        xs = xs.view(B, Tp, S).transpose(0, 1).contiguous().view(Tp * B, S)
+        enc = ops.mlp(xs, enc_lin, ops.ACT_LEAKY, ops.LEAKY_SLOPE).view(Tp, B, -1)
+
+        if eps is None:
+            eps = torch.randn(Tp, B, Z, device=dev, dtype=torch.float32)
+        decin, kld, kld_fn, mu_q, sd_q, mu_p, sd_p, z = self.vrnn_cell.sequence(enc, h0, eps, x_sl_dev, stride, free_nats)
+
+        dec = ops.mlp(decin[:Tp].view(Tp * B, H + R), dec_lin, ops.ACT_LEAKY, ops.LEAKY_SLOPE)  # [T'*B, S*F]
+        log_prob = ops.dmol_log_prob(dec, lik.params.weight, lik.params.bias, y, x_sl_dev, ops.LAYOUT_TIME_MAJOR, B, T, Tp,
+                                     S, lik.num_mix, lik.num_bins, lik.log_epsilon)  # fmt: skip
+
+        # ELBO assembly in float64 as the reference does (mask dtype `float`, vrnn.py:266-279)
+        n_frames = float(x_sl_host.sum())
+        elbo = log_prob - kld
+        loss = -(log_prob - beta * kld_fn).sum() / n_frames
+        kl = kld_fn  # the reference returns the free-nats-clamped KL as `kl` (vrnn.py:275-279); == kld when free_nats is 0
+
+        sums = DeferredScalars(torch.stack([loss.detach(), elbo.detach().sum(), log_prob.detach().sum(), kl.detach().sum()]))
+        ln2 = math.log(2)
+        metrics = [
+            LossMetric(sums[0], weight_by=B),
+            LLMetric(sums[1], name="elbo", reduce_by=B),
+            LLMetric(sums[2], name="rec", reduce_by=B),
+            KLMetric(sums[3], reduce_by=B),
+            KLMetric(sums[3] / ln2, name="kl (bpt)", reduce_by=n_frames),
+            BitsPerDimMetric(sums[1], reduce_by=n_frames),
+            LatestMeanMetric(beta, name="beta"),
+            LatestMeanMetric(free_nats, name="free_nats"),
+        ]
+
+        max_len = int(x_sl_host.max())
+        F = lik.out_features
+
+        def parameters():
+            d = dec.detach().view(Tp, B, S, F).permute(1, 0, 2, 3).reshape(B, Tp * S, F)[:, :max_len]
+            return lik(d.contiguous())
+
+        lazy = dict(
+            reconstructions_parameters=parameters,
+            reconstructions=lambda: lik.sample(outputs.reconstructions_parameters),
+            reconstructions_mode=lambda: lik.mode(outputs.reconstructions_parameters),
+            seq_mask=lambda: (torch.arange(max_len, device=dev).unsqueeze(0) < x_sl_dev.unsqueeze(1)).to(torch.float64),
+        )
+        outputs = LazyNamespace(
+            lazy,
+            elbo=elbo,
+            log_prob=log_prob,
+            kl=kl,
+            y=y.unsqueeze(-1),
+            z=z.transpose(0, 1),
+            z_sl=(x_sl_host / stride).ceil().int(),
+            h_n=decin[Tp - 1, :, H:],  # all_h[-1] after the pop at vrnn.py:310-311: the state ENTERING the last step
+        )
+        return loss, metrics, outputs
+
+
+class VRNNAudio(BaseModel):
+    def __init__(self, likelihood: Union[str, nn.Module], input_size: int = 200, hidden_size: int = 256,
+                 latent_size: int = 64, residual_posterior: bool = False, condition_h_on_x: bool = True,
+                 condition_x_on_h: bool = True, num_mix: int = 10, num_bins: int = 256):  # fmt: skip
+        super().__init__()
+        self.likelihood = likelihood
+        self.input_size = input_size
+        self.hidden_size = hidden_size
+        self.latent_size = latent_size
+        self.residual_posterior = residual_posterior
+        self.condition_h_on_x = condition_h_on_x
+        self.condition_x_on_h = condition_x_on_h
+        self.num_mix = num_mix
+        self.num_bins = num_bins
+
+        if likelihood == "DMoL":
+            # the reference hard-codes num_mix=10, num_bins=2**16 on this branch whatever the ctor args say
+            # (vrnn.py:464-469); x_dim still follows num_mix.
+            likelihood_module = DiscretizedLogisticMixtureDense(x_dim=2 * num_mix + num_mix, y_dim=1, num_mix=10, num_bins=2**16)
+        elif likelihood in ("GMM", "Gaussian"):
+            raise NotImplementedError(f"libblvm_hip: likelihood '{likelihood}' is not built yet (DMoL is the benchmark head)")
+        else:
+            raise ValueError(f"Unknown likelihood type {likelihood}")
+
+        encoder = nn.Sequential(
+            View(-1),
+            StackTensor(input_size, dim=1),
+            nn.Linear(input_size, hidden_size),
+            nn.LeakyReLU(),
+            nn.Linear(hidden_size, hidden_size),
+            nn.LeakyReLU(),
+            nn.Linear(hidden_size, hidden_size),
+            nn.LeakyReLU(),
+        )
+        decoder = nn.Sequential(
+            nn.Linear(3 * hidden_size, hidden_size),
+            nn.LeakyReLU(),
+            nn.Linear(hidden_size, hidden_size),
+            nn.LeakyReLU(),
+            nn.Linear(hidden_size, input_size * likelihood_module.out_features),
+            nn.LeakyReLU(),
+            View(-1, likelihood_module.out_features),
+        )
+        self.vrnn = VRNN(encoder=encoder, decoder=decoder, likelihood=likelihood_module, x_dim=hidden_size, h_dim=hidden_size,
+                         z_dim=latent_size, residual_posterior=residual_posterior, condition_h_on_x=condition_h_on_x,
+                         condition_x_on_h=condition_x_on_h)  # fmt: skip
+
+    def forward(self, x, x_sl, beta: float = 1, free_nats: float = 0, h0=None, eps=None):
+        return self.vrnn(x, x_sl, beta, free_nats, h0, eps)

@@ -1,0 +1,80 @@
+"""Distribution heads with the reference's constructor signatures and parameter names
+(blvm/modules/distributions.py:105-150 DiagonalGaussianDense, :310-387 DiscretizedLogisticMixtureDense).
+
+The modules own the parameters (`params` = nn.Linear, so state_dict keys and initialisation order match the
+reference); the arithmetic runs in HIP kernels.  Inside the recurrent models the heads are consumed by the fused
+sequence kernels directly and these `forward`s are not on the hot path.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .convenience import AddConstant
+
+
+class ConditionalDistribution(nn.Module):
+    def reset_parameters(self):
+        pass
+
+
+class DiagonalGaussianDense(ConditionalDistribution):
+    def __init__(self, x_dim, y_dim, initial_sd: float = 1, epsilon: float = 1e-6):
+        super().__init__()
+        self.x_dim, self.y_dim, self.initial_sd, self.epsilon = x_dim, y_dim, initial_sd, epsilon
+        self.out_features = 2 * y_dim
+        self.params = nn.Linear(x_dim, 2 * y_dim)
+        # kept for repr/state parity with the reference; the softplus itself is fused into the HIP epilogues
+        beta = math.log(2) / (initial_sd - epsilon)
+        self.sd_activation = nn.Sequential(nn.Softplus(beta=beta), AddConstant(epsilon)) if epsilon > 0 else nn.Softplus(beta=beta)
+        self.reset_parameters()
+
+    @property
+    def softplus_beta(self) -> float:
+        return math.log(2) / (self.initial_sd - self.epsilon)
+
+    def mode(self, params):
+        return params[0].contiguous()
+
+    def forward(self, x: torch.Tensor):
+        lead = x.shape[:-1]
+        p = ops.mlp(x.reshape(-1, x.shape[-1]), [self.params], act=ops.ACT_NONE)
+        mu, raw = p.view(*lead, -1).chunk(2, dim=-1)
+        # softplus on a small [*, y_dim] tensor: torch element-wise (not on the fused hot path)
+        return mu, self.sd_activation(raw)
+
+
+class DiscretizedLogisticMixtureDense(ConditionalDistribution):
+    def __init__(self, x_dim: int, y_dim: int, num_mix: int = 10, num_bins: int = 256, log_epsilon: float = -7.0):
+        super().__init__()
+        self.x_dim, self.y_dim, self.num_mix, self.num_bins, self.log_epsilon = x_dim, y_dim, num_mix, num_bins, log_epsilon
+        self.out_features = num_mix * (2 * y_dim + 1)
+        self.params = nn.Linear(x_dim, self.out_features)
+        self.reset_parameters()
+
+    def forward(self, x):
+        """(logits [*,K], locs [*,1,K], log_scales [*,1,K]) as the reference returns them (distributions.py:381-387)."""
+        if self.y_dim != 1:
+            raise NotImplementedError("DMoL head: y_dim must be 1 on the audio path")
+        lead = x.shape[:-1]
+        p = ops.mlp(x.reshape(-1, x.shape[-1]), [self.params], act=ops.ACT_NONE).view(*lead, -1)
+        logits = p[..., : self.num_mix]
+        locs, log_scales = p[..., self.num_mix :].reshape(*lead, 1, 2 * self.num_mix).chunk(2, dim=-1)
+        return logits, locs, log_scales.clamp(min=self.log_epsilon)
+
+    def mode(self, params):
+        idx = params[0].argmax(-1, keepdim=True).unsqueeze(-2)
+        return torch.gather(params[1], index=idx, dim=-1).squeeze(-1).contiguous()
+
+    @torch.no_grad()
+    def sample(self, params, eps: float = 1e-5):
+        """Gumbel-max component pick + logistic sample clamped to [-1,1] (blvm/utils/variational.py:309-349)."""
+        logits, locs, log_scales = params
+        u = torch.empty_like(logits).uniform_(eps, 1.0 - eps)
+        idx = (logits - torch.log(-torch.log(u))).argmax(-1, keepdim=True).unsqueeze(-2)
+        loc = torch.gather(locs, -1, idx.expand(*locs.shape[:-1], 1)).squeeze(-1)
+        ls = torch.gather(log_scales, -1, idx.expand(*log_scales.shape[:-1], 1)).squeeze(-1)
+        u2 = torch.empty_like(loc).uniform_(1e-8, 1.0 - 1e-8)  # rsample_logistic default bounds (variational.py:281)
+        x = loc + torch.exp(ls) * (torch.log(u2) - torch.log(1.0 - u2))
+        return x.clamp(-1.0, 1.0)

@@ -1,0 +1,328 @@
+"""autograd glue over the C ABI: each Function enqueues hand-written gfx950 kernels (csrc/*.hip) on the current
+torch HIP stream.  PyTorch is used for device memory, streams and autograd bookkeeping only — no ATen math on the
+hot path, and no CPU fallback (``_hip.ptr`` refuses CPU tensors).
+
+Layout convention: sequence tensors are time-major ``[T', B, F]``.
+"""
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _hip
+from ._hip import VrnnWeights, check, load, ptr, stream_ptr
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+LEAKY_SLOPE = 0.01  # nn.LeakyReLU default (blvm/models/vrnn.py:491)
+
+LAYOUT_BATCH_MAJOR, LAYOUT_TIME_MAJOR = 0, 1
+
+# optional profiling hook: called with "fwd_begin"/"fwd_end"/"bwd_begin"/"bwd_end" around the recurrent-cell calls so
+# a caller (bench.py) can record HIP events on the launching stream.  None = disabled.
+seq_timer_hook = None
+
+
+def _tick(tag):
+    if seq_timer_hook is not None:
+        seq_timer_hook(tag)
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise _hip.BlvmHipError(f"blvm HIP kernels compute in fp32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# raw launch helpers (no autograd)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def gemm(op_a, op_b, M, N, K, A, lda, B, ldb, C, ldc, bias=None, act=ACT_NONE, slope=0.0, gate=None, ldg=0,
+         accumulate=False, split_k=1):  # fmt: skip
+    check(
+        load().blvm_gemm_f32(op_a, op_b, M, N, K, ptr(A), lda, ptr(B), ldb, ptr(C), ldc, ptr(bias), act, slope,
+                             ptr(gate), ldg, int(accumulate), split_k, stream_ptr()),
+        "blvm_gemm_f32",
+    )  # fmt: skip
+
+
+def colsum(X2d: torch.Tensor, out: torch.Tensor, accumulate=False):
+    M, N = X2d.shape
+    check(load().blvm_colsum_f32(M, N, ptr(X2d), X2d.stride(0), ptr(out), int(accumulate), stream_ptr()), "blvm_colsum_f32")
+
+
+def _pick_split(M, N, K):
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    s = (768 + tiles - 1) // tiles
+    return max(1, min(s, (K + 255) // 256))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# K6: MLP = chain of Linear + (Leaky)ReLU, one autograd node for the whole chain
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+class _MLPFunction(torch.autograd.Function):
+    """y = act(...act(x W1^T + b1)... Wn^T + bn) for a 2-D x; activation after EVERY layer (the reference's
+    encoders/decoders end in an activation)."""
+
+    @staticmethod
+    def forward(ctx, x, act, slope, *params):
+        x = _f32c(x)
+        n_layers = len(params) // 2
+        acts = [x]
+        for l in range(n_layers):
+            W, b = params[2 * l], params[2 * l + 1]
+            inp = acts[-1]
+            M, K = inp.shape
+            N = W.shape[0]
+            out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+            gemm(0, 0, M, N, K, inp, inp.stride(0), _f32c(W), K, out, N, bias=_f32c(b), act=act, slope=slope)
+            acts.append(out)
+        ctx.act, ctx.slope, ctx.n_layers = act, slope, n_layers
+        ctx.save_for_backward(*acts, *params)
+        return acts[-1]
+
+    @staticmethod
+    def backward(ctx, dy):
+        n = ctx.n_layers
+        saved = ctx.saved_tensors
+        acts, params = saved[: n + 1], saved[n + 1 :]
+        slope = ctx.slope if ctx.act == ACT_LEAKY else 0.0
+        dy = _f32c(dy)
+        # derivative of the last activation (no producing GEMM to fuse it into)
+        if ctx.act != ACT_NONE:
+            dz = torch.empty_like(dy)
+            check(load().blvm_act_bwd_f32(ptr(dy), ptr(acts[n]), slope, ptr(dz), dz.numel(), stream_ptr()), "blvm_act_bwd_f32")
+        else:
+            dz = dy
+        grads: List[Optional[torch.Tensor]] = [None] * (2 * n)
+        for l in range(n - 1, -1, -1):
+            W, b = params[2 * l], params[2 * l + 1]
+            inp = acts[l]
+            M, K = inp.shape
+            N = W.shape[0]
+            if ctx.needs_input_grad[3 + 2 * l]:
+                dW = torch.zeros_like(W, dtype=torch.float32)
+                gemm(1, 1, N, K, M, dz, N, inp, inp.stride(0), dW, K, accumulate=True, split_k=_pick_split(N, K, M))
+                grads[2 * l] = dW
+            if ctx.needs_input_grad[4 + 2 * l]:
+                db = torch.empty(N, device=dz.device, dtype=torch.float32)
+                colsum(dz, db)
+                grads[2 * l + 1] = db
+            if l > 0 or ctx.needs_input_grad[0]:
+                dx = torch.empty(M, K, device=dz.device, dtype=torch.float32)
+                # dgrad with the derivative of the PREVIOUS layer's activation fused into the epilogue
+                gate = acts[l] if (l > 0 and ctx.act != ACT_NONE) else None
+                gemm(0, 1, M, K, N, dz, N, _f32c(W), K, dx, K, slope=slope, gate=gate, ldg=K)
+                dz = dx
+        return (dz if ctx.needs_input_grad[0] else None, None, None, *grads)
+
+
+def mlp(x2d: torch.Tensor, layers: Sequence[torch.nn.Linear], act: int = ACT_LEAKY, slope: float = LEAKY_SLOPE):
+    params = []
+    for lin in layers:
+        params += [lin.weight, lin.bias]
+    return _MLPFunction.apply(x2d, act, slope, *params)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# K7: DMoL head (Linear + log-likelihood + masked per-utterance sums)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+class _DMoLFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dec, W, b, y, x_sl_dev, layout, B, T, Tp, S, num_mix, num_bins, log_eps):
+        dec, W, b, y = _f32c(dec), _f32c(W), _f32c(b), _f32c(y)
+        log_prob = torch.zeros(B, device=dec.device, dtype=torch.float64)
+        check(
+            load().blvm_dmol_fwd(ptr(dec), layout, ptr(W), ptr(b), ptr(y), ptr(x_sl_dev), B, T, Tp, S, num_mix, num_bins,
+                                 log_eps, ptr(log_prob), None, stream_ptr()),
+            "blvm_dmol_fwd",
+        )  # fmt: skip
+        ctx.save_for_backward(dec, W, b, y, x_sl_dev)
+        ctx.cfg = (layout, B, T, Tp, S, num_mix, num_bins, log_eps)
+        return log_prob
+
+    @staticmethod
+    def backward(ctx, g):
+        dec, W, b, y, x_sl_dev = ctx.saved_tensors
+        layout, B, T, Tp, S, num_mix, num_bins, log_eps = ctx.cfg
+        g32 = g.to(torch.float32).contiguous()
+        F = 3 * num_mix
+        d_dec = torch.empty_like(dec)
+        d_par = torch.empty_like(dec)
+        check(
+            load().blvm_dmol_bwd(ptr(dec), layout, ptr(W), ptr(b), ptr(y), ptr(x_sl_dev), ptr(g32), B, T, Tp, S, num_mix,
+                                 num_bins, log_eps, ptr(d_dec), ptr(d_par), stream_ptr()),
+            "blvm_dmol_bwd",
+        )  # fmt: skip
+        n_frames = dec.numel() // F
+        dW = db = None
+        if ctx.needs_input_grad[1]:
+            dW = torch.zeros_like(W)
+            gemm(1, 1, F, F, n_frames, d_par, F, dec, F, dW, F, accumulate=True, split_k=256)
+        if ctx.needs_input_grad[2]:
+            db = torch.empty_like(b)
+            colsum(d_par.view(n_frames, F), db)
+        return (d_dec if ctx.needs_input_grad[0] else None, dW, db) + (None,) * 10
+
+
+def dmol_log_prob(dec, W, b, y, x_sl_dev, layout, B, T, Tp, S, num_mix=10, num_bins=256, log_eps=-7.0):
+    """Per-utterance masked DMoL log-likelihood sums [B] (float64) of targets y [B,T] given decoder activations
+    `dec` ([rows, S*3*num_mix], rows ordered by `layout`)."""
+    return _DMoLFunction.apply(dec, W, b, y, x_sl_dev, layout, B, T, Tp, S, num_mix, num_bins, log_eps)
+
+
+def dmol_ll_twise(dec, W, b, y, x_sl_dev, layout, B, T, Tp, S, num_mix=10, num_bins=256, log_eps=-7.0):
+    """Masked frame-wise log-likelihood [B,T] (no autograd)."""
+    dec, W, b, y = _f32c(dec), _f32c(W), _f32c(b), _f32c(y)
+    lp = torch.zeros(B, device=dec.device, dtype=torch.float64)
+    ll = torch.zeros(B, T, device=dec.device, dtype=torch.float32)
+    check(
+        load().blvm_dmol_fwd(ptr(dec), layout, ptr(W), ptr(b), ptr(y), ptr(x_sl_dev), B, T, Tp, S, num_mix, num_bins,
+                             log_eps, ptr(lp), ptr(ll), stream_ptr()),
+        "blvm_dmol_fwd",
+    )  # fmt: skip
+    return ll, lp
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# K8: Gaussian KL + free nats + masked sums (stand-alone form; the VRNN path fuses the backward into K1)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+class _KLFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu_q, sd_q, mu_p, sd_p, x_sl_dev, layout, B, Tp, Z, stride, fn_floor):
+        mu_q, sd_q, mu_p, sd_p = (_f32c(t) for t in (mu_q, sd_q, mu_p, sd_p))
+        kld = torch.zeros(B, device=mu_q.device, dtype=torch.float64)
+        kld_fn = torch.zeros(B, device=mu_q.device, dtype=torch.float64)
+        check(
+            load().blvm_kl_fwd(ptr(mu_q), ptr(sd_q), ptr(mu_p), ptr(sd_p), layout, ptr(x_sl_dev), B, Tp, Z, stride,
+                               fn_floor, ptr(kld), ptr(kld_fn), stream_ptr()),
+            "blvm_kl_fwd",
+        )  # fmt: skip
+        ctx.save_for_backward(mu_q, sd_q, mu_p, sd_p, x_sl_dev)
+        ctx.cfg = (layout, B, Tp, Z, stride, fn_floor)
+        return kld, kld_fn
+
+    @staticmethod
+    def backward(ctx, g_raw, g_fn):
+        mu_q, sd_q, mu_p, sd_p, x_sl_dev = ctx.saved_tensors
+        layout, B, Tp, Z, stride, fn_floor = ctx.cfg
+        c_raw = g_raw.to(torch.float32).contiguous()
+        c_fn = g_fn.to(torch.float32).contiguous()
+        outs = [torch.empty_like(mu_q) for _ in range(4)]
+        check(
+            load().blvm_kl_bwd(ptr(mu_q), ptr(sd_q), ptr(mu_p), ptr(sd_p), layout, ptr(x_sl_dev), ptr(c_raw), ptr(c_fn),
+                               B, Tp, Z, stride, fn_floor, *(ptr(o) for o in outs), stream_ptr()),
+            "blvm_kl_bwd",
+        )  # fmt: skip
+        return (*outs, None, None, None, None, None, None, None)
+
+
+def gaussian_kl_sums(mu_q, sd_q, mu_p, sd_p, x_sl_dev, layout, B, Tp, Z, stride, free_nats=0.0):
+    """(kld[B], kld_fn[B]) in float64: masked sums of the analytic KL and of max(KL, free_nats/Z)."""
+    fn_floor = float(free_nats) / Z if free_nats else 0.0
+    return _KLFunction.apply(mu_q, sd_q, mu_p, sd_p, x_sl_dev, layout, B, Tp, Z, stride, fn_floor)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# K1: VRNN cell over a sequence
+# ----------------------------------------------------------------------------------------------------------------------
+
+_VRNN_PARAM_ORDER = (
+    ["prior_w0", "prior_b0", "prior_w1", "prior_b1", "prior_w2", "prior_b2", "prior_hw", "prior_hb"]
+    + ["post_w0", "post_b0", "post_w1", "post_b1", "post_w2", "post_b2", "post_hw", "post_hb"]
+    + ["phi_w0", "phi_b0", "phi_w1", "phi_b1", "phi_w2", "phi_b2", "phi_w3", "phi_b3"]
+    + ["gru_wih", "gru_whh", "gru_bih", "gru_bhh"]
+)
+
+
+def _pack_weights(ts: Sequence[Optional[torch.Tensor]]) -> VrnnWeights:
+    d = dict(zip(_VRNN_PARAM_ORDER, ts))
+    p = lambda k: ptr(d[k]) if d[k] is not None else None  # noqa: E731
+    w = VrnnWeights()
+    for i in range(3):
+        w.prior_w[i], w.prior_b[i] = p(f"prior_w{i}"), p(f"prior_b{i}")
+        w.post_w[i], w.post_b[i] = p(f"post_w{i}"), p(f"post_b{i}")
+    for i in range(4):
+        w.phi_w[i], w.phi_b[i] = p(f"phi_w{i}"), p(f"phi_b{i}")
+    w.prior_hw, w.prior_hb, w.post_hw, w.post_hb = p("prior_hw"), p("prior_hb"), p("post_hw"), p("post_hb")
+    w.gru_wih, w.gru_whh, w.gru_bih, w.gru_bhh = p("gru_wih"), p("gru_whh"), p("gru_bih"), p("gru_bhh")
+    return w
+
+
+class _VRNNSeqFunction(torch.autograd.Function):
+    """(enc, h0, eps, 28 params) -> decin [T'+1,B,H+R], kld [B], kld_fn [B]  (+ non-differentiable mu/sd/z)."""
+
+    @staticmethod
+    def forward(ctx, enc, h0, eps, x_sl_dev, cfg, *params):
+        Tp, B, X, H, Z, R, residual, sd_eps, stride, fn_floor = cfg
+        enc, eps = _f32c(enc), _f32c(eps)
+        params = tuple(_f32c(p) for p in params)
+        dev = enc.device
+        lib = load()
+        f32 = dict(device=dev, dtype=torch.float32)
+        decin = torch.empty(Tp + 1, B, H + R, **f32)
+        decin[Tp, :, :H].zero_()  # the phi-part of the extra row is never written by the kernels
+        mu_q, sd_q, mu_p, sd_p, z = (torch.empty(Tp, B, Z, **f32) for _ in range(5))
+        reserve = torch.empty(lib.blvm_vrnn_reserve_floats(Tp, B, X, H, Z, R), **f32)
+        w = _pack_weights(params)
+        _tick("fwd_begin")
+        check(
+            lib.blvm_vrnn_seq_fwd(w, ptr(enc), ptr(_f32c(h0)) if h0 is not None else None, ptr(eps), Tp, B, X, H, Z, R,
+                                  int(residual), sd_eps, ptr(decin), ptr(mu_q), ptr(sd_q), ptr(mu_p), ptr(sd_p), ptr(z),
+                                  ptr(reserve), stream_ptr()),
+            "blvm_vrnn_seq_fwd",
+        )  # fmt: skip
+        _tick("fwd_end")
+        kld = torch.zeros(B, device=dev, dtype=torch.float64)
+        kld_fn = torch.zeros(B, device=dev, dtype=torch.float64)
+        check(
+            lib.blvm_kl_fwd(ptr(mu_q), ptr(sd_q), ptr(mu_p), ptr(sd_p), LAYOUT_TIME_MAJOR, ptr(x_sl_dev), B, Tp, Z, stride,
+                            fn_floor, ptr(kld), ptr(kld_fn), stream_ptr()),
+            "blvm_kl_fwd",
+        )  # fmt: skip
+        ctx.cfg = cfg
+        ctx.has_h0 = h0 is not None
+        ctx.save_for_backward(enc, eps, x_sl_dev, decin, mu_q, sd_q, mu_p, sd_p, z, reserve, *params)
+        ctx.mark_non_differentiable(mu_q, sd_q, mu_p, sd_p, z)
+        return decin, kld, kld_fn, mu_q, sd_q, mu_p, sd_p, z
+
+    @staticmethod
+    def backward(ctx, d_decin, g_kld, g_kld_fn, *_unused):
+        Tp, B, X, H, Z, R, residual, sd_eps, stride, fn_floor = ctx.cfg
+        enc, eps, x_sl_dev, decin, mu_q, sd_q, mu_p, sd_p, z, reserve, *params = ctx.saved_tensors
+        dev = enc.device
+        lib = load()
+        f32 = dict(device=dev, dtype=torch.float32)
+        d_decin = _f32c(d_decin) if d_decin is not None else torch.zeros_like(decin)
+        c_raw = g_kld.to(torch.float32).contiguous() if g_kld is not None else None
+        c_fn = g_kld_fn.to(torch.float32).contiguous() if g_kld_fn is not None else None
+        grads = [torch.zeros_like(p) for p in params]
+        d_enc = torch.empty_like(enc)
+        d_h0 = torch.empty(B, R, **f32) if ctx.has_h0 else None
+        ws = torch.empty(lib.blvm_vrnn_bwd_workspace_floats(Tp, B, X, H, Z, R), **f32)
+        w, g = _pack_weights(params), _pack_weights(grads)
+        _tick("bwd_begin")
+        check(
+            lib.blvm_vrnn_seq_bwd(w, ptr(enc), ptr(eps), ptr(decin), ptr(mu_q), ptr(sd_q), ptr(mu_p), ptr(sd_p), ptr(z),
+                                  ptr(reserve), ptr(d_decin), ptr(x_sl_dev), ptr(c_raw), ptr(c_fn), stride, fn_floor, Tp, B,
+                                  X, H, Z, R, int(residual), sd_eps, ptr(d_enc), ptr(d_h0), g, ptr(ws), stream_ptr()),
+            "blvm_vrnn_seq_bwd",
+        )  # fmt: skip
+        _tick("bwd_end")
+        return (d_enc, d_h0, None, None, None, *grads)
+
+
+def vrnn_sequence(enc, h0, eps, x_sl_dev, params: Sequence[torch.Tensor], X, H, Z, R, residual_posterior, stride,
+                  free_nats=0.0, sd_eps=1e-6):  # fmt: skip
+    """Run the VRNN cell over enc [T',B,X].  `params` in `_VRNN_PARAM_ORDER`.  Returns
+    (decin [T'+1,B,H+R], kld [B] f64, kld_fn [B] f64, mu_q, sd_q, mu_p, sd_p, z)."""
+    Tp, B, _ = enc.shape
+    fn_floor = float(free_nats) / Z if free_nats else 0.0
+    cfg = (Tp, B, X, H, Z, R, bool(residual_posterior), float(sd_eps), int(stride), fn_floor)
+    return _VRNNSeqFunction.apply(enc, h0, eps, x_sl_dev, cfg, *params)

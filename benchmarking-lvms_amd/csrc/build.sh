@@ -1,0 +1,10 @@
+#!/bin/bash
+# Build libblvm_hip.so for gfx950 in-tree (the .so travels to the GPU box with the repo snapshot).
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="$HERE/../blvm/lib"
+mkdir -p "$OUT"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I"$HERE/../../include" \
+  -o "$OUT/libblvm_hip.so" "$HERE"/core.hip "$HERE"/gemm.hip "$HERE"/dmol.hip "$HERE"/kl.hip "$HERE"/vrnn.hip
+echo "built $OUT/libblvm_hip.so"

@@ -1,0 +1,138 @@
+// common.h — shared host/device helpers for libblvm_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "blvm_hip.h"
+
+namespace blvm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+void set_error(const char* fmt, ...);
+
+#define BLVM_REQUIRE(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      blvm::set_error(__VA_ARGS__);        \
+      return BLVM_EINVAL;                  \
+    }                                      \
+  } while (0)
+
+#define BLVM_CHECK_LAUNCH(what)                                                     \
+  do {                                                                              \
+    hipError_t e__ = hipGetLastError();                                             \
+    if (e__ != hipSuccess) {                                                        \
+      blvm::set_error("%s: launch failed: %s", what, hipGetErrorString(e__));       \
+      return BLVM_ELAUNCH;                                                          \
+    }                                                                               \
+  } while (0)
+
+#define BLVM_HIP(call)                                                              \
+  do {                                                                              \
+    hipError_t e__ = (call);                                                        \
+    if (e__ != hipSuccess) {                                                        \
+      blvm::set_error("%s failed: %s", #call, hipGetErrorString(e__));              \
+      return BLVM_ELAUNCH;                                                          \
+    }                                                                               \
+  } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- device math -----------------------------------------------------------------------------------------------
+// Accurate libm forms (parity first: ELBO must match the fp32 CPU path to 1e-4 relative over ~1e6 frames).
+__device__ __forceinline__ float exp_(float x) { return expf(x); }
+__device__ __forceinline__ float log_(float x) { return logf(x); }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// torch.nn.functional.softplus(x) (beta=1, threshold=20): x > 20 ? x : log1p(exp(x))
+__device__ __forceinline__ float softplusf_(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+// softplus with beta (threshold on beta*x, as torch does)
+__device__ __forceinline__ float softplus_beta(float x, float beta, float inv_beta) {
+  float bx = beta * x;
+  return bx > 20.0f ? x : inv_beta * log1pf(expf(bx));
+}
+
+// ---- 16x16 output tile, K split over the 4 waves of a 256-thread workgroup --------------------------------------
+// acc += A[r0+i][k] * W[c0+j][k] for the k-chunks owned by `wave` (chunk = 16 k, waves interleave chunks).
+// A rows >= nrows read as zero.  A, W must be 16-byte aligned with lda, ldw multiples of 4 and K a multiple of 16.
+// v_mfma_f32_16x16x4_f32: lane l supplies A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D: col=l&15, row=(l>>4)*4+reg.
+__device__ __forceinline__ f32x4 wave_gemm16(const float* __restrict__ A, int lda, int r0, int nrows,
+                                              const float* __restrict__ W, int ldw, int c0, int K, int wave,
+                                              f32x4 acc) {
+  const int lane = threadIdx.x & 63;
+  const int rr = lane & 15, q = lane >> 4;
+  const bool aok = (r0 + rr) < nrows;
+  const float* ap = A + (size_t)(aok ? r0 + rr : 0) * lda + 4 * q;
+  const float* wp = W + (size_t)(c0 + rr) * ldw + 4 * q;
+  int kc = wave * 16;
+  // 4 chunks (64 k per wave) per trip keeps 8 x 16-byte loads in flight
+  for (; kc + 192 < K; kc += 256) {
+    float4 a0 = *reinterpret_cast<const float4*>(ap + kc);
+    float4 a1 = *reinterpret_cast<const float4*>(ap + kc + 64);
+    float4 a2 = *reinterpret_cast<const float4*>(ap + kc + 128);
+    float4 a3 = *reinterpret_cast<const float4*>(ap + kc + 192);
+    float4 w0 = *reinterpret_cast<const float4*>(wp + kc);
+    float4 w1 = *reinterpret_cast<const float4*>(wp + kc + 64);
+    float4 w2 = *reinterpret_cast<const float4*>(wp + kc + 128);
+    float4 w3 = *reinterpret_cast<const float4*>(wp + kc + 192);
+    if (!aok) { a0 = a1 = a2 = a3 = make_float4(0.f, 0.f, 0.f, 0.f); }
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, w0.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, w0.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, w0.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, w0.w, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, w1.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, w1.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, w1.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, w1.w, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, w2.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, w2.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.z, w2.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.w, w2.w, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.x, w3.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.y, w3.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.z, w3.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.w, w3.w, acc, 0, 0, 0);
+  }
+  for (; kc < K; kc += 64) {
+    float4 a0 = *reinterpret_cast<const float4*>(ap + kc);
+    float4 w0 = *reinterpret_cast<const float4*>(wp + kc);
+    if (!aok) a0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, w0.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, w0.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, w0.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, w0.w, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// Combine the 4 waves' partial 16x16 tiles of G groups through LDS.  `red` must hold G*4*256 floats.
+// After the call thread tid owns element (i = tid>>4, j = tid&15) of every group: out[g].
+template <int G>
+__device__ __forceinline__ void reduce_tiles(const f32x4 (&acc)[G], float* __restrict__ red, float (&out)[G]) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    // element (row=(lane>>4)*4+reg, col=lane&15) stored at [g][wave][row*16+col]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(g * 4 + wave) * 256 + ((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc[g][r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    out[g] = red[(g * 4 + 0) * 256 + tid] + red[(g * 4 + 1) * 256 + tid] + red[(g * 4 + 2) * 256 + tid] +
+             red[(g * 4 + 3) * 256 + tid];
+  }
+}
+
+// internal launchers shared between translation units (defined in gemm.hip)
+int gemm_f32(int op_a, int op_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+             int ldc, const float* bias, int act, float slope, const float* gate, int ldg, int accumulate,
+             int split_k, hipStream_t stream);
+int colsum_f32(int M, int N, const float* X, int ldx, float* out, int accumulate, hipStream_t stream);
+int transpose_f32(int M, int N, const float* X, int ldx, float* out, int ldo, hipStream_t stream);
+
+}  // namespace blvm

@@ -1,0 +1,321 @@
+// gemm.hip — K6: fp32 GEMM on v_mfma_f32_32x32x2_f32 with fused bias / activation / activation-derivative epilogue.
+//
+// Replaces the nn.Linear(+LeakyReLU/ReLU) chains of the reference's encoder/decoder MLPs
+// (blvm/models/vrnn.py:487-505, srnn.py:456-474, lstm.py:38-64) and their autograd backward (dgrad / wgrad).
+//
+// Design (gfx950): 256-thread workgroups = 4 waves in a 2x2 arrangement, block tile BMxBN (128x128 or 64x64),
+// BK = 16.  Both operands are staged k-major in LDS (As[k][m], Bs[k][n], row pad 4 floats) so that every MFMA
+// operand fetch is a conflict-free ds_read_b32 whatever the global layout (op_a/op_b) was; the transposition is
+// done by the global->LDS stage.  Next tile is prefetched into registers while the current one is multiplied.
+// f32-in MFMA is an exact fp32 fma chain (guide §3 'FP32-input MFMA'), so results are bit-reproducible except
+// for split-K (atomic) accumulation order.
+#include "common.h"
+
+namespace blvm {
+
+namespace {
+
+constexpr int BK = 16;
+constexpr int PAD = 4;
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  const float* gate;
+  int M, N, K, lda, ldb, ldc, ldg;
+  int act;
+  float slope;
+  int accumulate;
+  int k_per_split;  // multiple of BK
+  int a_vec, b_vec;  // 16-byte vector loads allowed for A / B
+};
+
+// Load 4 consecutive elements p[0..3] with element-wise validity n_valid (0..4).
+__device__ __forceinline__ float4 ld4(const float* p, int n_valid, bool vec) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (n_valid >= 4 && vec) {
+    v = *reinterpret_cast<const float4*>(p);
+  } else {
+    if (n_valid > 0) v.x = p[0];
+    if (n_valid > 1) v.y = p[1];
+    if (n_valid > 2) v.z = p[2];
+    if (n_valid > 3) v.w = p[3];
+  }
+  return v;
+}
+
+template <int BM, int BN, int OPA, int OPB>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD;
+  constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave in m / n
+  constexpr int A_V = BM * BK / 4 / 256;     // float4 per thread per stage
+  constexpr int B_V = BN * BK / 4 / 256;
+  __shared__ __attribute__((aligned(16))) float As[BK * LDA_S];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB_S];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * g.k_per_split;
+  const int kend = min(g.K, kbeg + g.k_per_split);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[A_V], rb[B_V];
+
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int v = 0; v < A_V; ++v) {
+      const int id = tid + v * 256;
+      if (OPA == 0) {  // A[m][k], k contiguous: 4 float4 per row of the tile
+        const int m = id >> 2, k4 = (id & 3) * 4;
+        const int gm = m0 + m, gk = k0 + k4;
+        const int nv = (gm < g.M) ? max(0, min(4, kend - gk)) : 0;
+        ra[v] = ld4(g.A + (size_t)(gm < g.M ? gm : 0) * g.lda + gk, nv, g.a_vec);
+      } else {  // A[k][m], m contiguous
+        const int k = id / (BM / 4), m4 = (id % (BM / 4)) * 4;
+        const int gm = m0 + m4, gk = k0 + k;
+        const int nv = (gk < kend) ? max(0, min(4, g.M - gm)) : 0;
+        ra[v] = ld4(g.A + (size_t)(gk < kend ? gk : 0) * g.lda + gm, nv, g.a_vec);
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < B_V; ++v) {
+      const int id = tid + v * 256;
+      if (OPB == 0) {  // B[n][k], k contiguous
+        const int n = id >> 2, k4 = (id & 3) * 4;
+        const int gn = n0 + n, gk = k0 + k4;
+        const int nv = (gn < g.N) ? max(0, min(4, kend - gk)) : 0;
+        rb[v] = ld4(g.B + (size_t)(gn < g.N ? gn : 0) * g.ldb + gk, nv, g.b_vec);
+      } else {  // B[k][n], n contiguous
+        const int k = id / (BN / 4), n4 = (id % (BN / 4)) * 4;
+        const int gn = n0 + n4, gk = k0 + k;
+        const int nv = (gk < kend) ? max(0, min(4, g.N - gn)) : 0;
+        rb[v] = ld4(g.B + (size_t)(gk < kend ? gk : 0) * g.ldb + gn, nv, g.b_vec);
+      }
+    }
+  };
+
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int v = 0; v < A_V; ++v) {
+      const int id = tid + v * 256;
+      if (OPA == 0) {
+        const int m = id >> 2, k4 = (id & 3) * 4;
+        As[(k4 + 0) * LDA_S + m] = ra[v].x;
+        As[(k4 + 1) * LDA_S + m] = ra[v].y;
+        As[(k4 + 2) * LDA_S + m] = ra[v].z;
+        As[(k4 + 3) * LDA_S + m] = ra[v].w;
+      } else {
+        const int k = id / (BM / 4), m4 = (id % (BM / 4)) * 4;
+        *reinterpret_cast<float4*>(&As[k * LDA_S + m4]) = ra[v];
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < B_V; ++v) {
+      const int id = tid + v * 256;
+      if (OPB == 0) {
+        const int n = id >> 2, k4 = (id & 3) * 4;
+        Bs[(k4 + 0) * LDB_S + n] = rb[v].x;
+        Bs[(k4 + 1) * LDB_S + n] = rb[v].y;
+        Bs[(k4 + 2) * LDB_S + n] = rb[v].z;
+        Bs[(k4 + 3) * LDB_S + n] = rb[v].w;
+      } else {
+        const int k = id / (BN / 4), n4 = (id % (BN / 4)) * 4;
+        *reinterpret_cast<float4*>(&Bs[k * LDB_S + n4]) = rb[v];
+      }
+    }
+  };
+
+  if (kbeg < kend) load_tiles(kbeg);
+  const int li = lane & 31, lh = lane >> 5;
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    __syncthreads();  // previous tile fully consumed
+    store_tiles();
+    __syncthreads();
+    if (k0 + BK < kend) load_tiles(k0 + BK);  // prefetch next tile into registers
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[(kk + lh) * LDA_S + wm * (BM / 2) + i * 32 + li];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[(kk + lh) * LDB_S + wn * (BN / 2) + j * 32 + li];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const bool atomic = gridDim.z > 1;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (BN / 2) + j * 32 + li;
+      if (n >= g.N) continue;
+      const float bv = (g.bias != nullptr && blockIdx.z == 0) ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= g.M) continue;
+        float v = acc[i][j][r] + bv;
+        if (g.act == 1) v = v > 0.f ? v : 0.f;
+        else if (g.act == 2) v = v > 0.f ? v : v * g.slope;
+        if (g.gate != nullptr) v *= (g.gate[(size_t)m * g.ldg + n] > 0.f) ? 1.f : g.slope;
+        float* cp = g.C + (size_t)m * g.ldc + n;
+        if (atomic) atomicAdd(cp, v);
+        else if (g.accumulate) *cp += v;
+        else *cp = v;
+      }
+    }
+}
+
+template <int BM, int BN>
+void launch_gemm(const GemmArgs& g, int op_a, int op_b, dim3 grid, hipStream_t s) {
+  if (op_a == 0 && op_b == 0) hipLaunchKernelGGL((gemm_kernel<BM, BN, 0, 0>), grid, dim3(256), 0, s, g);
+  else if (op_a == 0 && op_b == 1) hipLaunchKernelGGL((gemm_kernel<BM, BN, 0, 1>), grid, dim3(256), 0, s, g);
+  else if (op_a == 1 && op_b == 0) hipLaunchKernelGGL((gemm_kernel<BM, BN, 1, 0>), grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL((gemm_kernel<BM, BN, 1, 1>), grid, dim3(256), 0, s, g);
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const float* __restrict__ X, int ldx,
+                                                     float* __restrict__ out, int rows_per_block) {
+  // block (bx, by): columns bx*64.., rows by*rows_per_block..; 4 row-lanes x 64 columns
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float s = 0.f;
+  if (c < N)
+    for (int r = r0 + rl; r < r1; r += 4) s += X[(size_t)r * ldx + c];
+  part[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < N) atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* dy, const float* y, float slope, float* dz, size_t n4,
+                                                      size_t n) {
+  // 16 bytes per lane, grid-stride
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 g = reinterpret_cast<const float4*>(dy)[i];
+    const float4 v = reinterpret_cast<const float4*>(y)[i];
+    float4 o;
+    o.x = v.x > 0.f ? g.x : g.x * slope;
+    o.y = v.y > 0.f ? g.y : g.y * slope;
+    o.z = v.z > 0.f ? g.z : g.z * slope;
+    o.w = v.w > 0.f ? g.w : g.w * slope;
+    reinterpret_cast<float4*>(dz)[i] = o;
+  }
+  if (blockIdx.x == 0) {
+    const size_t i = n4 * 4 + threadIdx.x;
+    if (i < n) dz[i] = y[i] > 0.f ? dy[i] : dy[i] * slope;
+  }
+}
+
+__global__ __launch_bounds__(256) void transpose_kernel(int M, int N, const float* __restrict__ X, int ldx,
+                                                        float* __restrict__ out, int ldo) {
+  __shared__ float t[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  for (int i = ty; i < 32; i += 8)
+    if (m0 + i < M && n0 + tx < N) t[i][tx] = X[(size_t)(m0 + i) * ldx + n0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (n0 + i < N && m0 + tx < M) out[(size_t)(n0 + i) * ldo + m0 + tx] = t[tx][i];
+}
+
+}  // namespace
+
+int gemm_f32(int op_a, int op_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+             int ldc, const float* bias, int act, float slope, const float* gate, int ldg, int accumulate,
+             int split_k, hipStream_t stream) {
+  BLVM_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm: negative dimension");
+  if (M == 0 || N == 0) return BLVM_OK;
+  BLVM_REQUIRE(A && B && C, "gemm: null operand");
+  BLVM_REQUIRE(act >= 0 && act <= 2, "gemm: unknown activation %d", act);
+  BLVM_REQUIRE(lda >= (op_a ? M : K) && ldb >= (op_b ? N : K) && ldc >= N, "gemm: leading dimension too small");
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C; g.bias = bias; g.gate = gate;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldg = ldg;
+  g.act = act; g.slope = slope; g.accumulate = accumulate;
+  g.a_vec = aligned16(A) && (lda % 4 == 0);
+  g.b_vec = aligned16(B) && (ldb % 4 == 0);
+  if (split_k < 1) split_k = 1;
+  const bool big = (M >= 128 && N >= 128 && (size_t)((M + 127) / 128) * ((N + 127) / 128) * split_k >= 192);
+  const int bm = big ? 128 : 64;
+  int ksteps = (K + BK - 1) / BK;
+  if (split_k > ksteps) split_k = ksteps > 0 ? ksteps : 1;
+  g.k_per_split = ((ksteps + split_k - 1) / split_k) * BK;
+  if (g.k_per_split == 0) g.k_per_split = BK;
+  split_k = (K + g.k_per_split - 1) / g.k_per_split;
+  if (split_k < 1) split_k = 1;
+  BLVM_REQUIRE(split_k == 1 || (act == 0 && gate == nullptr), "gemm: split-K needs a linear epilogue");
+  dim3 grid((N + bm - 1) / bm, (M + bm - 1) / bm, split_k);
+  BLVM_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
+  if (split_k > 1 && !accumulate)  // atomic accumulation needs a zeroed destination
+    BLVM_HIP(hipMemset2DAsync(C, sizeof(float) * (size_t)ldc, 0, sizeof(float) * (size_t)N, (size_t)M, stream));
+  if (big) launch_gemm<128, 128>(g, op_a, op_b, grid, stream);
+  else launch_gemm<64, 64>(g, op_a, op_b, grid, stream);
+  BLVM_CHECK_LAUNCH("gemm_f32");
+  return BLVM_OK;
+}
+
+int colsum_f32(int M, int N, const float* X, int ldx, float* out, int accumulate, hipStream_t stream) {
+  if (N == 0) return BLVM_OK;
+  BLVM_REQUIRE(X && out, "colsum: null operand");
+  if (!accumulate) BLVM_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, stream));
+  if (M == 0) return BLVM_OK;
+  const int rows_per_block = 512;
+  dim3 grid((N + 63) / 64, (M + rows_per_block - 1) / rows_per_block);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, M, N, X, ldx, out, rows_per_block);
+  BLVM_CHECK_LAUNCH("colsum_f32");
+  return BLVM_OK;
+}
+
+int transpose_f32(int M, int N, const float* X, int ldx, float* out, int ldo, hipStream_t stream) {
+  if (M == 0 || N == 0) return BLVM_OK;
+  dim3 grid((N + 31) / 32, (M + 31) / 32);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, M, N, X, ldx, out, ldo);
+  BLVM_CHECK_LAUNCH("transpose_f32");
+  return BLVM_OK;
+}
+
+}  // namespace blvm
+
+extern "C" int blvm_gemm_f32(int op_a, int op_b, int M, int N, int K, const float* A, int lda, const float* B,
+                             int ldb, float* C, int ldc, const float* bias, int act, float slope,
+                             const float* gate, int ldg, int accumulate, int split_k, void* stream) {
+  return blvm::gemm_f32(op_a, op_b, M, N, K, A, lda, B, ldb, C, ldc, bias, act, slope, gate, ldg, accumulate,
+                        split_k, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int blvm_act_bwd_f32(const float* dy, const float* y, float slope, float* dz, size_t n, void* stream) {
+  using namespace blvm;
+  if (n == 0) return BLVM_OK;
+  BLVM_REQUIRE(dy && y && dz, "act_bwd: null pointer");
+  BLVM_REQUIRE(aligned16(dy) && aligned16(y) && aligned16(dz), "act_bwd: buffers must be 16-byte aligned");
+  const size_t n4 = n / 4;
+  size_t blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dy, y,
+                     slope, dz, n4, n);
+  BLVM_CHECK_LAUNCH("act_bwd_f32");
+  return BLVM_OK;
+}
+
+extern "C" int blvm_colsum_f32(int M, int N, const float* X, int ldx, float* out, int accumulate, void* stream) {
+  return blvm::colsum_f32(M, N, X, ldx, out, accumulate, static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,131 @@
+// kl.hip — K8: fused analytic Gaussian KL + free-nats floor + stride mask + per-utterance fp64 sums.
+//
+// Replaces kl_divergence_gaussian (blvm/utils/variational.py:67-70), discount_free_nats (:86-122, shared over the
+// last dim) and the masked sums of VRNN/SRNN.compute_elbo (blvm/models/vrnn.py:271-276, srnn.py:150-156).
+// HBM-bound: 4 x 4 B read per latent element forward (64 B per audio frame at z=256, s=64 — SURVEY.md §8d).
+//
+// Mapping: one wave per latent row (t, b): 16-byte loads along Z, in-register KL, wave reduction in fp64, one
+// atomic per (row, output).  Rows are independent, so the grid is (rows / 4) workgroups of 4 waves.
+#include "common.h"
+
+namespace blvm {
+namespace {
+
+struct KlArgs {
+  const float *mu_q, *sd_q, *mu_p, *sd_p;
+  const int32_t* x_sl;
+  const float *c_raw, *c_fn;
+  double *kld, *kld_fn;
+  float *d_mu_q, *d_sd_q, *d_mu_p, *d_sd_p;
+  int layout, B, Tp, Z, stride;
+  float fn_floor;
+};
+
+__device__ __forceinline__ void row_coord(const KlArgs& a, int row, int& b, int& t) {
+  if (a.layout == 0) { b = row / a.Tp; t = row - b * a.Tp; }
+  else { t = row / a.B; b = row - t * a.B; }
+}
+
+__device__ __forceinline__ float kl_elem(float mq, float sq, float mp, float sp) {
+  const float d = mq - mp;
+  return log_(sp) - log_(sq) + (sq * sq + d * d) / (2.f * sp * sp) - 0.5f;
+}
+
+__global__ __launch_bounds__(256) void kl_fwd_kernel(KlArgs a) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= a.B * a.Tp) return;
+  int b, t;
+  row_coord(a, row, b, t);
+  if ((long long)t * a.stride >= a.x_sl[b]) return;  // masked step: contributes nothing
+  const size_t base = (size_t)row * a.Z;
+  double s_raw = 0.0, s_fn = 0.0;
+  const bool use_fn = a.fn_floor > 0.f;
+  for (int c = lane; c < a.Z; c += 64) {
+    const float k = kl_elem(a.mu_q[base + c], a.sd_q[base + c], a.mu_p[base + c], a.sd_p[base + c]);
+    s_raw += (double)k;
+    s_fn += (double)(use_fn ? fmaxf(k, a.fn_floor) : k);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s_raw += __shfl_down(s_raw, off, 64);
+    s_fn += __shfl_down(s_fn, off, 64);
+  }
+  if (lane == 0) {
+    atomicAdd(a.kld + b, s_raw);
+    atomicAdd(a.kld_fn + b, s_fn);
+  }
+}
+
+__global__ __launch_bounds__(256) void kl_bwd_kernel(KlArgs a) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= a.B * a.Tp) return;
+  int b, t;
+  row_coord(a, row, b, t);
+  const bool live = (long long)t * a.stride < a.x_sl[b];
+  const float cr = (live && a.c_raw) ? a.c_raw[b] : 0.f;
+  const float cf = (live && a.c_fn) ? a.c_fn[b] : 0.f;
+  const size_t base = (size_t)row * a.Z;
+  const bool use_fn = a.fn_floor > 0.f;
+  for (int c = lane; c < a.Z; c += 64) {
+    const float mq = a.mu_q[base + c], sq = a.sd_q[base + c], mp = a.mu_p[base + c], sp = a.sd_p[base + c];
+    float coef = cr;
+    if (cf != 0.f) {
+      // d max(kl, floor)/d kl: 1 above the floor, 0 below (ties have measure zero)
+      const float k = kl_elem(mq, sq, mp, sp);
+      coef += (!use_fn || k > a.fn_floor) ? cf : 0.f;
+    }
+    const float d = mq - mp, ip2 = 1.f / (sp * sp);
+    a.d_mu_q[base + c] = coef * d * ip2;
+    a.d_mu_p[base + c] = -coef * d * ip2;
+    a.d_sd_q[base + c] = coef * (sq * ip2 - 1.f / sq);
+    a.d_sd_p[base + c] = coef * (1.f / sp - (sq * sq + d * d) * ip2 / sp);
+  }
+}
+
+int check(const float* mu_q, const float* sd_q, const float* mu_p, const float* sd_p, int layout,
+          const int32_t* x_sl, int B, int Tp, int Z, int stride) {
+  BLVM_REQUIRE(mu_q && sd_q && mu_p && sd_p && x_sl, "kl: null pointer");
+  BLVM_REQUIRE(B > 0 && Tp > 0 && Z > 0 && stride > 0, "kl: bad shape B=%d Tp=%d Z=%d stride=%d", B, Tp, Z, stride);
+  BLVM_REQUIRE(layout == 0 || layout == 1, "kl: layout must be 0 or 1");
+  BLVM_REQUIRE((long long)B * Tp < (1ll << 31), "kl: too many rows");
+  return BLVM_OK;
+}
+
+}  // namespace
+}  // namespace blvm
+
+extern "C" int blvm_kl_fwd(const float* mu_q, const float* sd_q, const float* mu_p, const float* sd_p, int layout,
+                           const int32_t* x_sl, int B, int Tp, int Z, int stride, float fn_floor, double* kld,
+                           double* kld_fn, void* stream) {
+  using namespace blvm;
+  int rc = check(mu_q, sd_q, mu_p, sd_p, layout, x_sl, B, Tp, Z, stride);
+  if (rc) return rc;
+  BLVM_REQUIRE(kld && kld_fn, "kl_fwd: null output");
+  KlArgs a{};
+  a.mu_q = mu_q; a.sd_q = sd_q; a.mu_p = mu_p; a.sd_p = sd_p; a.x_sl = x_sl;
+  a.kld = kld; a.kld_fn = kld_fn;
+  a.layout = layout; a.B = B; a.Tp = Tp; a.Z = Z; a.stride = stride; a.fn_floor = fn_floor;
+  hipLaunchKernelGGL(kl_fwd_kernel, dim3((B * Tp + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  BLVM_CHECK_LAUNCH("kl_fwd");
+  return BLVM_OK;
+}
+
+extern "C" int blvm_kl_bwd(const float* mu_q, const float* sd_q, const float* mu_p, const float* sd_p, int layout,
+                           const int32_t* x_sl, const float* c_raw, const float* c_fn, int B, int Tp, int Z,
+                           int stride, float fn_floor, float* d_mu_q, float* d_sd_q, float* d_mu_p, float* d_sd_p,
+                           void* stream) {
+  using namespace blvm;
+  int rc = check(mu_q, sd_q, mu_p, sd_p, layout, x_sl, B, Tp, Z, stride);
+  if (rc) return rc;
+  BLVM_REQUIRE(d_mu_q && d_sd_q && d_mu_p && d_sd_p, "kl_bwd: null output");
+  KlArgs a{};
+  a.mu_q = mu_q; a.sd_q = sd_q; a.mu_p = mu_p; a.sd_p = sd_p; a.x_sl = x_sl;
+  a.c_raw = c_raw; a.c_fn = c_fn;
+  a.d_mu_q = d_mu_q; a.d_sd_q = d_sd_q; a.d_mu_p = d_mu_p; a.d_sd_p = d_sd_p;
+  a.layout = layout; a.B = B; a.Tp = Tp; a.Z = Z; a.stride = stride; a.fn_floor = fn_floor;
+  hipLaunchKernelGGL(kl_bwd_kernel, dim3((B * Tp + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  BLVM_CHECK_LAUNCH("kl_bwd");
+  return BLVM_OK;
+}

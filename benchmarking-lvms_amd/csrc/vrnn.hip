@@ -1,0 +1,556 @@
+// vrnn.hip — K1: the VRNN recurrent cell over a whole sequence, forward and BPTT, as hand-written gfx950 kernels.
+//
+// Replaces the scripted per-step loop of the reference (blvm/models/vrnn.py:305-308 calling VRNNCell.forward,
+// vrnn.py:109-141: prior MLP + DiagonalGaussianDense, posterior MLP + DiagonalGaussianDense on cat[h,x], residual
+// posterior, rsample, phi_z MLP, nn.GRUCell on cat[x,phi_z]) and the autograd backward of that loop.
+//
+// Structure (v1, "stage kernels"): every recurrent step is a chain of nine dependent small GEMMs with M = batch.
+// Each link is ONE launch whose workgroups own a 16(batch) x 16(feature) output tile; the four waves of a
+// workgroup split K and combine through LDS, so one launch spreads over (B/16) x (N/16) workgroups and a wave
+// issues only K/64 v_mfma_f32_16x16x4_f32.  All element-wise work (bias, ReLU, softplus head, residual mean,
+// reparameterisation, GRU gates, and in the backward pass the KL/free-nats gradient, activation derivatives and the
+// GRU gate derivatives) is fused into the epilogue of the producing GEMM.  Everything that does not depend on the
+// recurrent state is hoisted out of the loop into large MFMA GEMMs (gemm.hip): the x-halves of the posterior's
+// first layer and of the GRU input projection before the loop; all weight gradients and d(enc) after it.
+//
+// Numerics: fp32 operands, fp32 MFMA accumulation (an exact fma chain), so a sequence is reproducible run-to-run.
+#include "common.h"
+
+namespace blvm {
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// generic multi-segment linear stage:  out = gate( act( A W^T + bias + add ) )
+// ---------------------------------------------------------------------------------------------------------------
+struct LinSeg {
+  const float* A;     int lda;     // [B,K]
+  const float* W;     int ldw;     // [ncols,K], k contiguous
+  const float* bias;               // [ncols] or null
+  const float* add;   int ldadd;   // [B,ncols] or null (may alias out)
+  const float* gate;  int ldgate;  // [B,ncols] or null: result *= (gate > 0)
+  float* out;         int ldo;     // [B,ncols]
+  int ncols, K, relu;
+};
+
+struct LinArgs {
+  LinSeg seg[3];
+  int nseg, B;
+};
+
+__global__ __launch_bounds__(256) void lin_stage_kernel(LinArgs a) {
+  __shared__ float red[4 * 256];
+  int ct = blockIdx.x, s = 0;
+  while (s + 1 < a.nseg && ct >= a.seg[s].ncols / 16) { ct -= a.seg[s].ncols / 16; ++s; }
+  const LinSeg& g = a.seg[s];
+  const int r0 = blockIdx.y * 16, c0 = ct * 16;
+  f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+  acc[0] = wave_gemm16(g.A, g.lda, r0, a.B, g.W, g.ldw, c0, g.K, threadIdx.x >> 6, acc[0]);
+  float v[1];
+  reduce_tiles<1>(acc, red, v);
+  const int row = r0 + (threadIdx.x >> 4), col = c0 + (threadIdx.x & 15);
+  if (row >= a.B) return;
+  float x = v[0];
+  if (g.bias) x += g.bias[col];
+  if (g.add) x += g.add[(size_t)row * g.ldadd + col];
+  if (g.relu) x = x > 0.f ? x : 0.f;
+  if (g.gate) x = g.gate[(size_t)row * g.ldgate + col] > 0.f ? x : 0.f;
+  g.out[(size_t)row * g.ldo + col] = x;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// F4: both Gaussian heads + residual mean + reparameterised sample
+// ---------------------------------------------------------------------------------------------------------------
+struct HeadArgs {
+  const float *P, *Q;                 // [B,H] last hidden of prior / posterior MLP
+  const float *Wp, *bp, *Wq, *bq;     // [2Z,H], [2Z]
+  const float* eps;                   // [B,Z]
+  float *mu_p, *sd_p, *mu_q, *sd_q, *z, *raw_p, *raw_q;  // [B,Z]
+  int B, H, Z, residual;
+  float beta, inv_beta, sd_eps;
+};
+
+__global__ __launch_bounds__(256) void head_stage_kernel(HeadArgs a) {
+  __shared__ float red[4 * 4 * 256];
+  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, wave = threadIdx.x >> 6;
+  f32x4 acc[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  acc[0] = wave_gemm16(a.P, a.H, r0, a.B, a.Wp, a.H, c0, a.H, wave, acc[0]);
+  acc[1] = wave_gemm16(a.P, a.H, r0, a.B, a.Wp, a.H, a.Z + c0, a.H, wave, acc[1]);
+  acc[2] = wave_gemm16(a.Q, a.H, r0, a.B, a.Wq, a.H, c0, a.H, wave, acc[2]);
+  acc[3] = wave_gemm16(a.Q, a.H, r0, a.B, a.Wq, a.H, a.Z + c0, a.H, wave, acc[3]);
+  float v[4];
+  reduce_tiles<4>(acc, red, v);
+  const int row = r0 + (threadIdx.x >> 4), col = c0 + (threadIdx.x & 15);
+  if (row >= a.B) return;
+  const size_t o = (size_t)row * a.Z + col;
+  const float mp = v[0] + a.bp[col];
+  const float rp = v[1] + a.bp[a.Z + col];
+  float mq = v[2] + a.bq[col];
+  const float rq = v[3] + a.bq[a.Z + col];
+  const float sp = softplus_beta(rp, a.beta, a.inv_beta) + a.sd_eps;
+  const float sq = softplus_beta(rq, a.beta, a.inv_beta) + a.sd_eps;
+  if (a.residual) mq += mp;
+  a.mu_p[o] = mp; a.sd_p[o] = sp; a.mu_q[o] = mq; a.sd_q[o] = sq;
+  a.raw_p[o] = rp; a.raw_q[o] = rq;
+  a.z[o] = a.eps[o] * sq + mq;  // randn_like(mu).mul(sd).add(mu)
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// F9: GRU input projection of phi + gates + state update
+// ---------------------------------------------------------------------------------------------------------------
+struct GruArgs {
+  const float* decin_t;   // row block t of decin: [B, H+R] = [phi | h_prev]
+  float* decin_next;      // row block t+1 (h-part written)
+  const float* Wih;       // [3R, X+H]
+  const float* xg;        // [B,3R] x-part of the input projection incl. b_ih
+  const float* gh;        // [B,3R] hidden projection incl. b_hh
+  float *rg, *ug, *ng;    // [B,R] saved gates
+  int B, X, H, R;
+};
+
+__global__ __launch_bounds__(256) void gru_stage_kernel(GruArgs a) {
+  __shared__ float red[3 * 4 * 256];
+  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, wave = threadIdx.x >> 6;
+  const int ldd = a.H + a.R, ldw = a.X + a.H;
+  f32x4 acc[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[g] = wave_gemm16(a.decin_t, ldd, r0, a.B, a.Wih + a.X, ldw, g * a.R + c0, a.H, wave, acc[g]);
+  }
+  float v[3];
+  reduce_tiles<3>(acc, red, v);
+  const int row = r0 + (threadIdx.x >> 4), col = c0 + (threadIdx.x & 15);
+  if (row >= a.B) return;
+  const size_t o3 = (size_t)row * 3 * a.R + col;
+  const float ir = v[0] + a.xg[o3], iz = v[1] + a.xg[o3 + a.R], in_ = v[2] + a.xg[o3 + 2 * a.R];
+  const float hr = a.gh[o3], hz = a.gh[o3 + a.R], hn = a.gh[o3 + 2 * a.R];
+  const float r = sigmoidf_(ir + hr);
+  const float u = sigmoidf_(iz + hz);
+  const float n = tanhf(in_ + r * hn);
+  const float hp = a.decin_t[(size_t)row * ldd + a.H + col];
+  a.decin_next[(size_t)row * ldd + a.H + col] = (1.f - u) * n + u * hp;
+  const size_t o = (size_t)row * a.R + col;
+  a.rg[o] = r; a.ug[o] = u; a.ng[o] = n;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// B6: dz = dphi0 W_phi0, then through rsample / residual / KL(+free nats) / softplus heads
+// ---------------------------------------------------------------------------------------------------------------
+struct DzArgs {
+  const float* D;    // [B,H] grad wrt pre-activation of phi layer 0
+  const float* WT;   // [Z,H] = phi_w[0]^T
+  const float *mu_q, *sd_q, *mu_p, *sd_p, *eps, *raw_q, *raw_p;  // [B,Z] (step t)
+  const int32_t* x_sl;
+  const float *c_raw, *c_fn;  // [B] or null
+  float *dqh, *dph;   // [B,2Z] grads wrt the heads' Linear outputs
+  int B, H, Z, residual, t, stride;
+  float fn_floor, beta;
+};
+
+__global__ __launch_bounds__(256) void dz_stage_kernel(DzArgs a) {
+  __shared__ float red[4 * 256];
+  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16;
+  f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+  acc[0] = wave_gemm16(a.D, a.H, r0, a.B, a.WT, a.H, c0, a.H, threadIdx.x >> 6, acc[0]);
+  float v[1];
+  reduce_tiles<1>(acc, red, v);
+  const int row = r0 + (threadIdx.x >> 4), col = c0 + (threadIdx.x & 15);
+  if (row >= a.B) return;
+  const size_t o = (size_t)row * a.Z + col;
+  const float dz = v[0];
+  const float mq = a.mu_q[o], sq = a.sd_q[o], mp = a.mu_p[o], sp = a.sd_p[o];
+  float coef = 0.f;
+  if ((a.c_fn != nullptr || a.c_raw != nullptr) && (long long)a.t * a.stride < a.x_sl[row]) {
+    if (a.c_raw != nullptr) coef = a.c_raw[row];
+    if (a.c_fn != nullptr) {
+      const float d0 = mq - mp;
+      const float k = logf(sp) - logf(sq) + (sq * sq + d0 * d0) / (2.f * sp * sp) - 0.5f;
+      if (!(a.fn_floor > 0.f) || k > a.fn_floor) coef += a.c_fn[row];
+    }
+  }
+  const float d = mq - mp, ip2 = 1.f / (sp * sp);
+  const float g_muq = dz + coef * d * ip2;
+  const float g_sdq = dz * a.eps[o] + coef * (sq * ip2 - 1.f / sq);
+  const float g_mup = -coef * d * ip2 + (a.residual ? g_muq : 0.f);
+  const float g_sdp = coef * (1.f / sp - (sq * sq + d * d) * ip2 / sp);
+  const size_t o2 = (size_t)row * 2 * a.Z + col;
+  a.dqh[o2] = g_muq;
+  a.dqh[o2 + a.Z] = g_sdq * sigmoidf_(a.beta * a.raw_q[o]);
+  a.dph[o2] = g_mup;
+  a.dph[o2 + a.Z] = g_sdp * sigmoidf_(a.beta * a.raw_p[o]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// B10 (+ gate derivatives of the PREVIOUS step): G <- G + DP0 W_p0 + DQ0 W_q0h, then GRU backward of step s = t-1
+// ---------------------------------------------------------------------------------------------------------------
+struct DhArgs {
+  const float *DP0, *DQ0;   // [B,H]   (null when has_gemm == 0)
+  const float *WpT, *WqT;   // [R,H]
+  float* G;                 // [B,R] running gradient wrt the recurrent state (in/out)
+  // step s (the step whose OUTPUT state G refers to); has_gates == 0 for the very first state
+  const float *rg, *ug, *ng, *gh;   // [B,R] x3, [B,3R]
+  const float* decin_s;             // [B,H+R] (h-part = state entering step s)
+  const float* ddecin_s;            // [B,H+R] decoder gradient wrt decin row s
+  float *dgi, *dgh;                 // [B,3R]
+  int B, H, R, has_gemm, has_gates;
+};
+
+__global__ __launch_bounds__(256) void dh_stage_kernel(DhArgs a) {
+  __shared__ float red[2 * 4 * 256];
+  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, wave = threadIdx.x >> 6;
+  float v[2] = {0.f, 0.f};
+  if (a.has_gemm) {
+    f32x4 acc[2];
+    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[0] = wave_gemm16(a.DP0, a.H, r0, a.B, a.WpT, a.H, c0, a.H, wave, acc[0]);
+    acc[1] = wave_gemm16(a.DQ0, a.H, r0, a.B, a.WqT, a.H, c0, a.H, wave, acc[1]);
+    reduce_tiles<2>(acc, red, v);
+  }
+  const int row = r0 + (threadIdx.x >> 4), col = c0 + (threadIdx.x & 15);
+  if (row >= a.B) return;
+  const size_t o = (size_t)row * a.R + col;
+  const float g = a.G[o] + v[0] + v[1];
+  if (!a.has_gates) { a.G[o] = g; return; }
+  const int ldd = a.H + a.R;
+  const float r = a.rg[o], u = a.ug[o], n = a.ng[o];
+  const size_t o3 = (size_t)row * 3 * a.R + col;
+  const float hn = a.gh[o3 + 2 * a.R];
+  const float hp = a.decin_s[(size_t)row * ldd + a.H + col];
+  const float dn_pre = g * (1.f - u) * (1.f - n * n);
+  const float du_pre = g * (hp - n) * u * (1.f - u);
+  const float dr_pre = dn_pre * hn * r * (1.f - r);
+  a.dgi[o3] = dr_pre; a.dgi[o3 + a.R] = du_pre; a.dgi[o3 + 2 * a.R] = dn_pre;
+  a.dgh[o3] = dr_pre; a.dgh[o3 + a.R] = du_pre; a.dgh[o3 + 2 * a.R] = dn_pre * r;
+  a.G[o] = g * u + a.ddecin_s[(size_t)row * ldd + a.H + col];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// reserve / workspace carving
+// ---------------------------------------------------------------------------------------------------------------
+struct Reserve {
+  float *P[3], *Q[3], *FZ[3], *GHb, *RG, *UG, *NG, *XQ, *XG, *RAWQ, *RAWP;
+};
+
+size_t carve_reserve(float* base, int Tp, int B, int H, int Z, int R, Reserve* r) {
+  const size_t n = (size_t)Tp * B;
+  size_t off = 0;
+  auto take = [&](size_t cnt) { float* p = base ? base + off : nullptr; off += (cnt + 3) & ~(size_t)3; return p; };
+  Reserve tmp;
+  for (int i = 0; i < 3; ++i) tmp.P[i] = take(n * H);
+  for (int i = 0; i < 3; ++i) tmp.Q[i] = take(n * H);
+  for (int i = 0; i < 3; ++i) tmp.FZ[i] = take(n * H);
+  tmp.GHb = take(n * 3 * R);
+  tmp.RG = take(n * R); tmp.UG = take(n * R); tmp.NG = take(n * R);
+  tmp.XQ = take(n * H);
+  tmp.XG = take(n * 3 * R);
+  tmp.RAWQ = take(n * Z); tmp.RAWP = take(n * Z);
+  if (r) *r = tmp;
+  return off;
+}
+
+struct BwdWs {
+  float *pT[3], *phT, *qT[3], *qhT, *fT[4], *wihT, *whhT;   // transposed weights
+  float *DGI, *DGH, *DPHI[4], *DQH, *DPH, *DP[3], *DQ[3], *G;
+};
+
+size_t carve_ws(float* base, int Tp, int B, int X, int H, int Z, int R, BwdWs* w) {
+  (void)X;
+  const size_t n = (size_t)Tp * B;
+  size_t off = 0;
+  auto take = [&](size_t cnt) { float* p = base ? base + off : nullptr; off += (cnt + 3) & ~(size_t)3; return p; };
+  BwdWs t;
+  t.pT[0] = take((size_t)R * H); t.pT[1] = take((size_t)H * H); t.pT[2] = take((size_t)H * H);
+  t.phT = take((size_t)H * 2 * Z);
+  t.qT[0] = take((size_t)R * H); t.qT[1] = take((size_t)H * H); t.qT[2] = take((size_t)H * H);
+  t.qhT = take((size_t)H * 2 * Z);
+  t.fT[0] = take((size_t)Z * H);
+  for (int i = 1; i < 4; ++i) t.fT[i] = take((size_t)H * H);
+  t.wihT = take((size_t)H * 3 * R);
+  t.whhT = take((size_t)R * 3 * R);
+  t.DGI = take(n * 3 * R); t.DGH = take(n * 3 * R);
+  for (int i = 0; i < 4; ++i) t.DPHI[i] = take(n * H);
+  t.DQH = take(n * 2 * Z); t.DPH = take(n * 2 * Z);
+  for (int i = 0; i < 3; ++i) t.DP[i] = take(n * H);
+  for (int i = 0; i < 3; ++i) t.DQ[i] = take(n * H);
+  t.G = take((size_t)B * R);
+  if (w) *w = t;
+  return off;
+}
+
+int check_dims(int Tp, int B, int X, int H, int Z, int R) {
+  BLVM_REQUIRE(Tp > 0 && B > 0, "vrnn: bad Tp=%d B=%d", Tp, B);
+  BLVM_REQUIRE(X > 0 && H > 0 && Z > 0 && R > 0 && X % 16 == 0 && H % 16 == 0 && Z % 16 == 0 && R % 16 == 0,
+               "vrnn: X,H,Z,R must be positive multiples of 16 (got %d,%d,%d,%d)", X, H, Z, R);
+  BLVM_REQUIRE((B + 15) / 16 <= 65535, "vrnn: batch too large");
+  return BLVM_OK;
+}
+
+inline LinSeg seg(const float* A, int lda, const float* W, int ldw, const float* bias, const float* add, int ldadd,
+                  const float* gate, int ldgate, float* out, int ldo, int ncols, int K, int relu) {
+  LinSeg s;
+  s.A = A; s.lda = lda; s.W = W; s.ldw = ldw; s.bias = bias; s.add = add; s.ldadd = ldadd;
+  s.gate = gate; s.ldgate = ldgate; s.out = out; s.ldo = ldo; s.ncols = ncols; s.K = K; s.relu = relu;
+  return s;
+}
+
+inline void launch_lin(const LinArgs& a, hipStream_t s) {
+  int tiles = 0;
+  for (int i = 0; i < a.nseg; ++i) tiles += a.seg[i].ncols / 16;
+  hipLaunchKernelGGL(lin_stage_kernel, dim3(tiles, (a.B + 15) / 16), dim3(256), 0, s, a);
+}
+
+int pick_split(int M, int N, int K) {
+  const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+  int s = (int)((768 + tiles - 1) / tiles);
+  const int kmax = (K + 255) / 256;  // at least 256 k per slice
+  if (s > kmax) s = kmax;
+  return s < 1 ? 1 : s;
+}
+
+// dW (+)= D^T Act over all rows
+int wgrad(const float* D, int ldd, int n_out, const float* Act, int lda, int k_in, float* dW, int ldw, size_t rows,
+          hipStream_t s) {
+  if (!dW) return BLVM_OK;
+  return gemm_f32(1, 1, n_out, k_in, (int)rows, D, ldd, Act, lda, dW, ldw, nullptr, 0, 0.f, nullptr, 0, 1,
+                  pick_split(n_out, k_in, (int)rows), s);
+}
+
+int bgrad(const float* D, int ldd, int n_out, float* db, size_t rows, hipStream_t s) {
+  if (!db) return BLVM_OK;
+  return colsum_f32((int)rows, n_out, D, ldd, db, 1, s);
+}
+
+}  // namespace
+}  // namespace blvm
+
+using namespace blvm;
+
+extern "C" size_t blvm_vrnn_reserve_floats(int Tp, int B, int X, int H, int Z, int R) {
+  (void)X;
+  return carve_reserve(nullptr, Tp, B, H, Z, R, nullptr);
+}
+
+extern "C" size_t blvm_vrnn_bwd_workspace_floats(int Tp, int B, int X, int H, int Z, int R) {
+  return carve_ws(nullptr, Tp, B, X, H, Z, R, nullptr);
+}
+
+extern "C" int blvm_vrnn_seq_fwd(const BlvmVrnnWeights* w, const float* enc, const float* h0, const float* eps,
+                                 int Tp, int B, int X, int H, int Z, int R, int residual_posterior, float sd_eps,
+                                 float* decin, float* mu_q, float* sd_q, float* mu_p, float* sd_p, float* z,
+                                 float* reserve, void* stream_) {
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  int rc = check_dims(Tp, B, X, H, Z, R);
+  if (rc) return rc;
+  BLVM_REQUIRE(w && enc && eps && decin && mu_q && sd_q && mu_p && sd_p && z && reserve, "vrnn_fwd: null pointer");
+  BLVM_REQUIRE(aligned16(enc) && aligned16(decin) && aligned16(reserve) && aligned16(z),
+               "vrnn_fwd: buffers must be 16-byte aligned");
+  Reserve rs;
+  carve_reserve(reserve, Tp, B, H, Z, R, &rs);
+  const size_t n = (size_t)Tp * B;
+  const int ldd = H + R;
+  const float beta = (float)(0.6931471805599453 / (1.0 - (double)sd_eps));  // ln2 / (initial_sd - eps), initial_sd = 1
+
+  // hoisted, state-independent halves of the two concatenated-input layers
+  rc = gemm_f32(0, 0, (int)n, H, X, enc, X, w->post_w[0] + R, R + X, rs.XQ, H, w->post_b[0], 0, 0.f, nullptr, 0, 0, 1, s);
+  if (rc) return rc;
+  rc = gemm_f32(0, 0, (int)n, 3 * R, X, enc, X, w->gru_wih, X + H, rs.XG, 3 * R, w->gru_bih, 0, 0.f, nullptr, 0, 0, 1, s);
+  if (rc) return rc;
+
+  // initial state -> h-part of decin row 0
+  if (h0) BLVM_HIP(hipMemcpy2DAsync(decin + H, sizeof(float) * ldd, h0, sizeof(float) * R, sizeof(float) * R, B, hipMemcpyDeviceToDevice, s));
+  else BLVM_HIP(hipMemset2DAsync(decin + H, sizeof(float) * ldd, 0, sizeof(float) * R, B, s));
+
+  const dim3 blk(256);
+  const int rt = (B + 15) / 16;
+  for (int t = 0; t < Tp; ++t) {
+    const size_t oH = (size_t)t * B * H, oZ = (size_t)t * B * Z, oR = (size_t)t * B * R, o3R = (size_t)t * B * 3 * R;
+    const float* dec_t = decin + (size_t)t * B * ldd;
+    float* dec_n = decin + (size_t)(t + 1) * B * ldd;
+    const float* hprev = dec_t + H;
+    LinArgs a;
+    a.B = B;
+    // F1: first prior layer | h-half of first posterior layer | GRU hidden projection
+    a.nseg = 3;
+    a.seg[0] = seg(hprev, ldd, w->prior_w[0], R, w->prior_b[0], nullptr, 0, nullptr, 0, rs.P[0] + oH, H, H, R, 1);
+    a.seg[1] = seg(hprev, ldd, w->post_w[0], R + X, nullptr, rs.XQ + oH, H, nullptr, 0, rs.Q[0] + oH, H, H, R, 1);
+    a.seg[2] = seg(hprev, ldd, w->gru_whh, R, w->gru_bhh, nullptr, 0, nullptr, 0, rs.GHb + o3R, 3 * R, 3 * R, R, 0);
+    launch_lin(a, s);
+    // F2, F3
+    a.nseg = 2;
+    for (int l = 1; l < 3; ++l) {
+      a.seg[0] = seg(rs.P[l - 1] + oH, H, w->prior_w[l], H, w->prior_b[l], nullptr, 0, nullptr, 0, rs.P[l] + oH, H, H, H, 1);
+      a.seg[1] = seg(rs.Q[l - 1] + oH, H, w->post_w[l], H, w->post_b[l], nullptr, 0, nullptr, 0, rs.Q[l] + oH, H, H, H, 1);
+      launch_lin(a, s);
+    }
+    // F4: heads + sample
+    HeadArgs h;
+    h.P = rs.P[2] + oH; h.Q = rs.Q[2] + oH;
+    h.Wp = w->prior_hw; h.bp = w->prior_hb; h.Wq = w->post_hw; h.bq = w->post_hb;
+    h.eps = eps + oZ;
+    h.mu_p = mu_p + oZ; h.sd_p = sd_p + oZ; h.mu_q = mu_q + oZ; h.sd_q = sd_q + oZ; h.z = z + oZ;
+    h.raw_p = rs.RAWP + oZ; h.raw_q = rs.RAWQ + oZ;
+    h.B = B; h.H = H; h.Z = Z; h.residual = residual_posterior;
+    h.beta = beta; h.inv_beta = 1.f / beta; h.sd_eps = sd_eps;
+    hipLaunchKernelGGL(head_stage_kernel, dim3(Z / 16, rt), blk, 0, s, h);
+    // F5..F8: phi_z MLP (last layer writes phi into decin row t)
+    a.nseg = 1;
+    a.seg[0] = seg(z + oZ, Z, w->phi_w[0], Z, w->phi_b[0], nullptr, 0, nullptr, 0, rs.FZ[0] + oH, H, H, Z, 1);
+    launch_lin(a, s);
+    a.seg[0] = seg(rs.FZ[0] + oH, H, w->phi_w[1], H, w->phi_b[1], nullptr, 0, nullptr, 0, rs.FZ[1] + oH, H, H, H, 1);
+    launch_lin(a, s);
+    a.seg[0] = seg(rs.FZ[1] + oH, H, w->phi_w[2], H, w->phi_b[2], nullptr, 0, nullptr, 0, rs.FZ[2] + oH, H, H, H, 1);
+    launch_lin(a, s);
+    a.seg[0] = seg(rs.FZ[2] + oH, H, w->phi_w[3], H, w->phi_b[3], nullptr, 0, nullptr, 0, decin + (size_t)t * B * ldd, ldd, H, H, 1);
+    launch_lin(a, s);
+    // F9: GRU
+    GruArgs g;
+    g.decin_t = dec_t; g.decin_next = dec_n; g.Wih = w->gru_wih;
+    g.xg = rs.XG + o3R; g.gh = rs.GHb + o3R;
+    g.rg = rs.RG + oR; g.ug = rs.UG + oR; g.ng = rs.NG + oR;
+    g.B = B; g.X = X; g.H = H; g.R = R;
+    hipLaunchKernelGGL(gru_stage_kernel, dim3(R / 16, rt), blk, 0, s, g);
+  }
+  BLVM_CHECK_LAUNCH("vrnn_seq_fwd");
+  return BLVM_OK;
+}
+
+extern "C" int blvm_vrnn_seq_bwd(const BlvmVrnnWeights* w, const float* enc, const float* eps, const float* decin,
+                                 const float* mu_q, const float* sd_q, const float* mu_p, const float* sd_p,
+                                 const float* z, const float* reserve, const float* d_decin, const int32_t* x_sl,
+                                 const float* c_raw, const float* c_fn, int stride, float fn_floor, int Tp, int B, int X, int H, int Z,
+                                 int R, int residual_posterior, float sd_eps, float* d_enc, float* d_h0,
+                                 const BlvmVrnnGrads* gr, float* workspace, void* stream_) {
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  int rc = check_dims(Tp, B, X, H, Z, R);
+  if (rc) return rc;
+  BLVM_REQUIRE(w && enc && eps && decin && mu_q && sd_q && mu_p && sd_p && z && reserve && d_decin && workspace && gr,
+               "vrnn_bwd: null pointer");
+  BLVM_REQUIRE((c_fn == nullptr && c_raw == nullptr) || x_sl != nullptr, "vrnn_bwd: KL coefficients need x_sl");
+  BLVM_REQUIRE(aligned16(workspace) && aligned16(reserve) && aligned16(d_decin), "vrnn_bwd: buffers must be 16-byte aligned");
+  Reserve rs;
+  carve_reserve(const_cast<float*>(reserve), Tp, B, H, Z, R, &rs);
+  BwdWs ws;
+  carve_ws(workspace, Tp, B, X, H, Z, R, &ws);
+  const size_t n = (size_t)Tp * B;
+  const int ldd = H + R;
+  const float beta = (float)(0.6931471805599453 / (1.0 - (double)sd_eps));
+
+  // k-contiguous (transposed) copies of every weight the chain multiplies from the right
+  rc = transpose_f32(H, R, w->prior_w[0], R, ws.pT[0], H, s); if (rc) return rc;
+  rc = transpose_f32(H, H, w->prior_w[1], H, ws.pT[1], H, s); if (rc) return rc;
+  rc = transpose_f32(H, H, w->prior_w[2], H, ws.pT[2], H, s); if (rc) return rc;
+  rc = transpose_f32(2 * Z, H, w->prior_hw, H, ws.phT, 2 * Z, s); if (rc) return rc;
+  rc = transpose_f32(H, R, w->post_w[0], R + X, ws.qT[0], H, s); if (rc) return rc;
+  rc = transpose_f32(H, H, w->post_w[1], H, ws.qT[1], H, s); if (rc) return rc;
+  rc = transpose_f32(H, H, w->post_w[2], H, ws.qT[2], H, s); if (rc) return rc;
+  rc = transpose_f32(2 * Z, H, w->post_hw, H, ws.qhT, 2 * Z, s); if (rc) return rc;
+  rc = transpose_f32(H, Z, w->phi_w[0], Z, ws.fT[0], H, s); if (rc) return rc;
+  for (int i = 1; i < 4; ++i) { rc = transpose_f32(H, H, w->phi_w[i], H, ws.fT[i], H, s); if (rc) return rc; }
+  rc = transpose_f32(3 * R, H, w->gru_wih + X, X + H, ws.wihT, 3 * R, s); if (rc) return rc;
+  rc = transpose_f32(3 * R, R, w->gru_whh, R, ws.whhT, 3 * R, s); if (rc) return rc;
+
+  BLVM_HIP(hipMemsetAsync(ws.G, 0, sizeof(float) * (size_t)B * R, s));
+  const dim3 blk(256);
+  const int rt = (B + 15) / 16;
+
+  auto launch_dh = [&](int t_gemm, int s_gates) {
+    DhArgs d;
+    d.has_gemm = t_gemm >= 0; d.has_gates = s_gates >= 0;
+    d.DP0 = d.has_gemm ? ws.DP[0] + (size_t)t_gemm * B * H : nullptr;
+    d.DQ0 = d.has_gemm ? ws.DQ[0] + (size_t)t_gemm * B * H : nullptr;
+    d.WpT = ws.pT[0]; d.WqT = ws.qT[0]; d.G = ws.G;
+    const size_t sg = d.has_gates ? (size_t)s_gates : 0;
+    d.rg = rs.RG + sg * B * R; d.ug = rs.UG + sg * B * R; d.ng = rs.NG + sg * B * R;
+    d.gh = rs.GHb + sg * B * 3 * R;
+    d.decin_s = decin + sg * B * ldd; d.ddecin_s = d_decin + sg * B * ldd;
+    d.dgi = ws.DGI + sg * B * 3 * R; d.dgh = ws.DGH + sg * B * 3 * R;
+    d.B = B; d.H = H; d.R = R;
+    hipLaunchKernelGGL(dh_stage_kernel, dim3(R / 16, rt), blk, 0, s, d);
+  };
+
+  launch_dh(-1, Tp - 1);  // G(T') = 0: gate derivatives of the last step, G <- d_decin h-part of row T'-1
+  for (int t = Tp - 1; t >= 0; --t) {
+    const size_t oH = (size_t)t * B * H, oZ = (size_t)t * B * Z, o3R = (size_t)t * B * 3 * R, o2Z = (size_t)t * B * 2 * Z;
+    const float* dec_t = decin + (size_t)t * B * ldd;
+    const float* ddec_t = d_decin + (size_t)t * B * ldd;
+    LinArgs a;
+    a.B = B;
+    // B2: dphi (through ReLU of phi, plus the decoder's gradient) | G += DGH Whh
+    a.nseg = 2;
+    a.seg[0] = seg(ws.DGI + o3R, 3 * R, ws.wihT, 3 * R, nullptr, ddec_t, ldd, dec_t, ldd, ws.DPHI[3] + oH, H, H, 3 * R, 0);
+    a.seg[1] = seg(ws.DGH + o3R, 3 * R, ws.whhT, 3 * R, nullptr, ws.G, R, nullptr, 0, ws.G, R, R, 3 * R, 0);
+    launch_lin(a, s);
+    // B3..B5: back through phi_z layers 3,2,1
+    a.nseg = 1;
+    for (int l = 3; l >= 1; --l) {
+      a.seg[0] = seg(ws.DPHI[l] + oH, H, ws.fT[l], H, nullptr, nullptr, 0, rs.FZ[l - 1] + oH, H, ws.DPHI[l - 1] + oH, H, H, H, 0);
+      launch_lin(a, s);
+    }
+    // B6: dz and the heads
+    DzArgs d;
+    d.D = ws.DPHI[0] + oH; d.WT = ws.fT[0];
+    d.mu_q = mu_q + oZ; d.sd_q = sd_q + oZ; d.mu_p = mu_p + oZ; d.sd_p = sd_p + oZ; d.eps = eps + oZ;
+    d.raw_q = rs.RAWQ + oZ; d.raw_p = rs.RAWP + oZ;
+    d.x_sl = x_sl; d.c_raw = c_raw; d.c_fn = c_fn;
+    d.dqh = ws.DQH + o2Z; d.dph = ws.DPH + o2Z;
+    d.B = B; d.H = H; d.Z = Z; d.residual = residual_posterior; d.t = t; d.stride = stride;
+    d.fn_floor = fn_floor; d.beta = beta;
+    hipLaunchKernelGGL(dz_stage_kernel, dim3(Z / 16, rt), blk, 0, s, d);
+    // B7: heads -> last hidden layers
+    a.nseg = 2;
+    a.seg[0] = seg(ws.DPH + o2Z, 2 * Z, ws.phT, 2 * Z, nullptr, nullptr, 0, rs.P[2] + oH, H, ws.DP[2] + oH, H, H, 2 * Z, 0);
+    a.seg[1] = seg(ws.DQH + o2Z, 2 * Z, ws.qhT, 2 * Z, nullptr, nullptr, 0, rs.Q[2] + oH, H, ws.DQ[2] + oH, H, H, 2 * Z, 0);
+    launch_lin(a, s);
+    // B8, B9
+    for (int l = 2; l >= 1; --l) {
+      a.seg[0] = seg(ws.DP[l] + oH, H, ws.pT[l], H, nullptr, nullptr, 0, rs.P[l - 1] + oH, H, ws.DP[l - 1] + oH, H, H, H, 0);
+      a.seg[1] = seg(ws.DQ[l] + oH, H, ws.qT[l], H, nullptr, nullptr, 0, rs.Q[l - 1] + oH, H, ws.DQ[l - 1] + oH, H, H, H, 0);
+      launch_lin(a, s);
+    }
+    // B10 (+ gate derivatives of step t-1)
+    launch_dh(t, t - 1);
+  }
+  BLVM_CHECK_LAUNCH("vrnn_seq_bwd");
+  if (d_h0) BLVM_HIP(hipMemcpyAsync(d_h0, ws.G, sizeof(float) * (size_t)B * R, hipMemcpyDeviceToDevice, s));
+
+  // ---- batched, state-independent part: d(enc) and every weight gradient as large MFMA GEMMs -------------------
+  if (d_enc) {
+    rc = gemm_f32(0, 1, (int)n, X, H, ws.DQ[0], H, w->post_w[0] + R, R + X, d_enc, X, nullptr, 0, 0.f, nullptr, 0, 0, 1, s);
+    if (rc) return rc;
+    rc = gemm_f32(0, 1, (int)n, X, 3 * R, ws.DGI, 3 * R, w->gru_wih, X + H, d_enc, X, nullptr, 0, 0.f, nullptr, 0, 1, 1, s);
+    if (rc) return rc;
+  }
+  const float* hprev_all = decin + H;  // [n rows, ld = H+R]
+#define TRY(x) do { rc = (x); if (rc) return rc; } while (0)
+  TRY(wgrad(ws.DGI, 3 * R, 3 * R, enc, X, X, gr->gru_wih, X + H, n, s));
+  TRY(wgrad(ws.DGI, 3 * R, 3 * R, decin, ldd, H, gr->gru_wih ? gr->gru_wih + X : nullptr, X + H, n, s));
+  TRY(wgrad(ws.DGH, 3 * R, 3 * R, hprev_all, ldd, R, gr->gru_whh, R, n, s));
+  TRY(bgrad(ws.DGI, 3 * R, 3 * R, gr->gru_bih, n, s));
+  TRY(bgrad(ws.DGH, 3 * R, 3 * R, gr->gru_bhh, n, s));
+  TRY(wgrad(ws.DPHI[0], H, H, z, Z, Z, gr->phi_w[0], Z, n, s));
+  TRY(bgrad(ws.DPHI[0], H, H, gr->phi_b[0], n, s));
+  for (int l = 1; l < 4; ++l) {
+    TRY(wgrad(ws.DPHI[l], H, H, rs.FZ[l - 1], H, H, gr->phi_w[l], H, n, s));
+    TRY(bgrad(ws.DPHI[l], H, H, gr->phi_b[l], n, s));
+  }
+  TRY(wgrad(ws.DPH, 2 * Z, 2 * Z, rs.P[2], H, H, gr->prior_hw, H, n, s));
+  TRY(bgrad(ws.DPH, 2 * Z, 2 * Z, gr->prior_hb, n, s));
+  TRY(wgrad(ws.DQH, 2 * Z, 2 * Z, rs.Q[2], H, H, gr->post_hw, H, n, s));
+  TRY(bgrad(ws.DQH, 2 * Z, 2 * Z, gr->post_hb, n, s));
+  for (int l = 2; l >= 1; --l) {
+    TRY(wgrad(ws.DP[l], H, H, rs.P[l - 1], H, H, gr->prior_w[l], H, n, s));
+    TRY(bgrad(ws.DP[l], H, H, gr->prior_b[l], n, s));
+    TRY(wgrad(ws.DQ[l], H, H, rs.Q[l - 1], H, H, gr->post_w[l], H, n, s));
+    TRY(bgrad(ws.DQ[l], H, H, gr->post_b[l], n, s));
+  }
+  TRY(wgrad(ws.DP[0], H, H, hprev_all, ldd, R, gr->prior_w[0], R, n, s));
+  TRY(bgrad(ws.DP[0], H, H, gr->prior_b[0], n, s));
+  TRY(wgrad(ws.DQ[0], H, H, hprev_all, ldd, R, gr->post_w[0], R + X, n, s));
+  TRY(wgrad(ws.DQ[0], H, H, enc, X, X, gr->post_w[0] ? gr->post_w[0] + R : nullptr, R + X, n, s));
+  TRY(bgrad(ws.DQ[0], H, H, gr->post_b[0], n, s));
+#undef TRY
+  return BLVM_OK;
+}

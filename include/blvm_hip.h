@@ -1,0 +1,147 @@
+/* blvm_hip.h — C ABI of libblvm_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the blvm hot path.
+ *
+ * The reference (JakobHavtorn/benchmarking-lvms, package `blvm`) is pure Python on PyTorch and has NO FFI of its
+ * own (`setup.py:57` ext_modules=[]); every entry point below replaces a chain of ATen ops at the cited reference
+ * lines (paths relative to the reference checkout).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - All tensors are device pointers to row-major fp32 unless stated; reductions that the reference carries in
+ *     float64 (`blvm/models/vrnn.py:266`) are double.
+ *   - The caller owns every buffer (inputs, outputs, workspace/reserve); the library never allocates, frees or
+ *     retains a pointer past the call.
+ *   - All work is enqueued on the caller's `stream` (a hipStream_t passed as void*); no implicit device sync.
+ *   - Return value: 0 on success, a negative BLVM_E* code otherwise; text via blvm_last_error() (thread-local).
+ *   - Sequence tensors are TIME-MAJOR [T', B, F] (one contiguous slab per recurrent step).
+ */
+#ifndef BLVM_HIP_H
+#define BLVM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLVM_OK 0
+#define BLVM_EINVAL (-1)  /* bad shape / alignment / null pointer */
+#define BLVM_ELAUNCH (-2) /* HIP launch or runtime error */
+#define BLVM_ENOSUP (-3)  /* configuration not supported by this build */
+
+int blvm_version(void);
+const char* blvm_last_error(void);
+/* 1 if a gfx950 device is visible to the HIP runtime, else 0 (never throws). */
+int blvm_device_ok(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * K6  fp32 MFMA GEMM with fused epilogue — replaces nn.Linear(+LeakyReLU/ReLU) chains
+ *     (`blvm/models/vrnn.py:487-505` encoder/decoder MLPs; autograd of the same for the backward forms).
+ *
+ *   C[M,N] (=|+=) epi( sum_k A'(m,k) * B'(k,n) )
+ *     op_a = 0: A'(m,k) = A[m*lda + k]      op_a = 1: A'(m,k) = A[k*lda + m]
+ *     op_b = 0: B'(k,n) = B[n*ldb + k]      op_b = 1: B'(k,n) = B[k*ldb + n]
+ *   epilogue (in this order): + bias[n] (if bias) ; activation act (0 none, 1 ReLU, 2 LeakyReLU(slope)) ;
+ *     * dact(gate[m*ldg+n]) (if gate: 1 where gate>0 else slope — derivative of the activation whose OUTPUT is gate)
+ *   accumulate != 0: C += result (split_k > 1 forces atomic accumulation; caller zeroes C unless accumulating).
+ * ------------------------------------------------------------------------------------------------------------- */
+int blvm_gemm_f32(int op_a, int op_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                  float* C, int ldc, const float* bias, int act, float slope, const float* gate, int ldg,
+                  int accumulate, int split_k, void* stream);
+
+/* dz[i] = dy[i] * (y[i] > 0 ? 1 : slope) over n contiguous floats: derivative of ReLU / LeakyReLU from its OUTPUT y
+ * (used where no producing GEMM exists to fuse it into, e.g. behind the DMoL head).  dz may alias dy. */
+int blvm_act_bwd_f32(const float* dy, const float* y, float slope, float* dz, size_t n, void* stream);
+
+/* out[n] (=|+=) sum_m X[m*ldx + n]   (bias gradients). */
+int blvm_colsum_f32(int M, int N, const float* X, int ldx, float* out, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * K7  fused DMoL head: Linear(30->30) + split/clamp + discretized-logistic-mixture log-likelihood + mask + per-
+ *     utterance sum.  Replaces `blvm/modules/distributions.py:381-387` + `blvm/utils/log_likelihoods.py:170-231`
+ *     + the masked sum at `blvm/models/vrnn.py:266-269`.
+ *
+ *   dec      [rows, S*F] contiguous, F = 3*num_mix features per audio frame (frame f = row*S + j at dec + f*F)
+ *   layout   0: rows are batch-major (row = b*Tp + t)   1: rows are time-major (row = t*B + b)
+ *   y        [B, T] targets in [-1,1];  x_sl [B] int32 on device;  frame (b, tau=t*S+j) counts iff tau < x_sl[b]
+ *   W [F,F], bias [F]: the likelihood's Linear;  log_eps: clamp floor of the log-scales (-7)
+ *   log_prob [B] double, ACCUMULATED (caller zeroes);  ll_twise optional [B,T] fp32 (masked ll, may be NULL)
+ * ------------------------------------------------------------------------------------------------------------- */
+int blvm_dmol_fwd(const float* dec, int layout, const float* W, const float* bias, const float* y,
+                  const int32_t* x_sl, int B, int T, int Tp, int S, int num_mix, int num_bins, float log_eps,
+                  double* log_prob, float* ll_twise, void* stream);
+
+/*   g_b [B] fp32 = dLoss/dlog_prob[b].  Writes d_dec (same shape as dec; zero on masked frames) and d_par
+ *   [rows*S, F] = gradient wrt the Linear's OUTPUT (for dW = d_par^T dec, db = colsum(d_par)). */
+int blvm_dmol_bwd(const float* dec, int layout, const float* W, const float* bias, const float* y,
+                  const int32_t* x_sl, const float* g_b, int B, int T, int Tp, int S, int num_mix, int num_bins,
+                  float log_eps, float* d_dec, float* d_par, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * K8  fused analytic Gaussian KL + free-nats + mask + per-utterance sums.  Replaces
+ *     `blvm/utils/variational.py:67-70,86-122` + `blvm/models/vrnn.py:271-276`.
+ *   mu_q, sd_q, mu_p, sd_p [rows=Tp*B, Z] (layout as above); step t of row b counts iff t*stride < x_sl[b]
+ *   fn_floor = free_nats / Z (<= 0 disables);  kld, kld_fn [B] double, ACCUMULATED (caller zeroes)
+ * ------------------------------------------------------------------------------------------------------------- */
+int blvm_kl_fwd(const float* mu_q, const float* sd_q, const float* mu_p, const float* sd_p, int layout,
+                const int32_t* x_sl, int B, int Tp, int Z, int stride, float fn_floor, double* kld,
+                double* kld_fn, void* stream);
+
+/*   c_raw[b] = dLoss/dkld[b], c_fn[b] = dLoss/dkld_fn[b] (fp32, either may be NULL = 0). */
+int blvm_kl_bwd(const float* mu_q, const float* sd_q, const float* mu_p, const float* sd_p, int layout,
+                const int32_t* x_sl, const float* c_raw, const float* c_fn, int B, int Tp, int Z, int stride,
+                float fn_floor, float* d_mu_q, float* d_sd_q, float* d_mu_p, float* d_sd_p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * K1  VRNN recurrent cell over a whole sequence (forward and BPTT).  Replaces the scripted per-step loop
+ *     `blvm/models/vrnn.py:305-308` over `VRNNCell.forward` (`vrnn.py:109-141`) and its autograd backward.
+ *     condition_h_on_x = True (the only form VRNNAudio builds, `vrnn.py:506-516`).
+ *
+ *   weights: reference layout, Linear [out,in], GRU rows [r|z|n] (`SURVEY.md` §8b).
+ *   X = x_dim (encoder feature size), H = h_dim (MLP width), Z = z_dim, R = r_dim (GRU state).
+ *   All of X, H, Z, R must be multiples of 16; B is arbitrary (row-guarded tiles).
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct BlvmVrnnWeights {
+  const float *prior_w[3], *prior_b[3]; /* [H,R], [H,H], [H,H] */
+  const float *prior_hw, *prior_hb;     /* [2Z,H] */
+  const float *post_w[3], *post_b[3];   /* [H,R+X] (input order cat[h,x]), [H,H], [H,H] */
+  const float *post_hw, *post_hb;       /* [2Z,H] */
+  const float *phi_w[4], *phi_b[4];     /* [H,Z], [H,H] x3 */
+  const float *gru_wih, *gru_whh;       /* [3R, X+H] (input order cat[x,phi]), [3R,R] */
+  const float *gru_bih, *gru_bhh;       /* [3R] */
+} BlvmVrnnWeights;
+
+typedef struct BlvmVrnnGrads { /* same shapes as the weights; ACCUMULATED into (caller zeroes) */
+  float *prior_w[3], *prior_b[3], *prior_hw, *prior_hb;
+  float *post_w[3], *post_b[3], *post_hw, *post_hb;
+  float *phi_w[4], *phi_b[4];
+  float *gru_wih, *gru_whh, *gru_bih, *gru_bhh;
+} BlvmVrnnGrads;
+
+/* number of floats of `reserve` (activations kept for BPTT) / `workspace` (backward scratch). */
+size_t blvm_vrnn_reserve_floats(int Tp, int B, int X, int H, int Z, int R);
+size_t blvm_vrnn_bwd_workspace_floats(int Tp, int B, int X, int H, int Z, int R);
+
+/*   enc [Tp,B,X]; h0 [B,R] (NULL = zeros); eps [Tp,B,Z] standard-normal noise (reference draws it per step,
+ *   `blvm/utils/variational.py:141-152`); sd_eps = epsilon of the Gaussian heads (1e-6), initial_sd = 1.
+ *   decin [Tp+1,B,H+R]: row t = [phi_t | h_{t-1}] — the decoder input `cat([phi_z, h])` of `vrnn.py:321-324`;
+ *     row Tp carries the final state in its h-part.
+ *   mu_q (residual already added), sd_q, mu_p, sd_p, z: [Tp,B,Z]. */
+int blvm_vrnn_seq_fwd(const BlvmVrnnWeights* w, const float* enc, const float* h0, const float* eps, int Tp, int B,
+                      int X, int H, int Z, int R, int residual_posterior, float sd_eps, float* decin,
+                      float* mu_q, float* sd_q, float* mu_p, float* sd_p, float* z, float* reserve, void* stream);
+
+/*   d_decin [Tp+1,B,H+R]: gradient wrt decin (row Tp ignored).  KL term folded in: loss += sum_b (c_raw[b] *
+ *   kld[b] + c_fn[b] * kld_fn[b]) with the mask t*stride < x_sl[b] and floor fn_floor (see blvm_kl_fwd);
+ *   c_raw / c_fn may be NULL (= 0).
+ *   Outputs: d_enc [Tp,B,X], d_h0 [B,R] (may be NULL), grads (accumulated). */
+int blvm_vrnn_seq_bwd(const BlvmVrnnWeights* w, const float* enc, const float* eps, const float* decin,
+                      const float* mu_q, const float* sd_q, const float* mu_p, const float* sd_p, const float* z,
+                      const float* reserve, const float* d_decin, const int32_t* x_sl, const float* c_raw,
+                      const float* c_fn, int stride, float fn_floor, int Tp, int B, int X, int H, int Z, int R,
+                      int residual_posterior, float sd_eps, float* d_enc, float* d_h0, const BlvmVrnnGrads* grads,
+                      float* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLVM_HIP_H */

@@ -1,0 +1,283 @@
+"""GPU (MI355X): parity of the HIP path, called through the C ABI (ctypes), against
+  (1) golden vectors produced by the imported reference (tests/golden/*.npz), and
+  (2) the CPU oracle (oracle/blvm_oracle.py) on the same seeded inputs,
+plus size-independent properties at BASELINE's full sizes.
+
+Tolerances (fp32 kernels vs fp32/fp64 CPU): ELBO / log-likelihood / loss 1e-4 relative (north_star), usually far
+tighter; gradients: relative L2 per tensor <= 1e-3 (SURVEY §8d parity bar).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import blvm_oracle as O
+from blvm import _hip, ops
+from blvm.models import VRNNAudio
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_hip():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    assert _hip.load().blvm_device_ok() == 1, "libblvm_hip: no gfx950 device visible"
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# K6 GEMM
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("op_a,op_b", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (130, 70, 50), (256, 1920, 768), (1000, 30, 30), (16, 256, 1003)])
+def test_gemm_layouts_and_edges(op_a, op_b, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + op_a * 2 + op_b)
+    A = torch.randn(*((K, M) if op_a else (M, K)), generator=g)
+    Bm = torch.randn(*((K, N) if op_b else (N, K)), generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = (A.t() if op_a else A).double() @ (Bm if op_b else Bm.t()).double() + bias.double()
+    ref = torch.where(ref > 0, ref, 0.01 * ref)
+    C = torch.empty(M, N, device=DEV)
+    ops.gemm(op_a, op_b, M, N, K, A.to(DEV), A.shape[1], Bm.to(DEV), Bm.shape[1], C, N, bias=bias.to(DEV), act=ops.ACT_LEAKY, slope=0.01)
+    assert rel_l2(C, ref) < 2e-6
+
+
+def test_gemm_split_k_gate_accumulate_and_strides():
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 96, 80, 4096
+    A, Bm = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+    ref = A.t().double() @ Bm.double()
+    C = torch.ones(M, N + 8, device=DEV)  # ldc > N, accumulate onto ones
+    ops.gemm(1, 1, M, N, K, A.to(DEV), M, Bm.to(DEV), N, C, N + 8, accumulate=True, split_k=16)
+    assert rel_l2(C[:, :N], ref + 1) < 2e-6
+    assert torch.all(C[:, N:] == 1)
+    # activation-derivative gate in the epilogue (dgrad form)
+    gate = torch.randn(M, N, generator=g)
+    C2 = torch.empty(M, N, device=DEV)
+    ops.gemm(1, 1, M, N, K, A.to(DEV), M, Bm.to(DEV), N, C2, N, slope=0.01, gate=gate.to(DEV), ldg=N)
+    assert rel_l2(C2, ref * torch.where(gate > 0, 1.0, 0.01)) < 2e-6
+
+
+def test_mlp_function_forward_backward_vs_torch():
+    torch.manual_seed(3)
+    lins = [torch.nn.Linear(24, 64), torch.nn.Linear(64, 64), torch.nn.Linear(64, 48)]
+    x = torch.randn(300, 24)
+    xr = x.clone().requires_grad_(True)
+    y = xr
+    for l in lins:
+        y = torch.nn.functional.leaky_relu(l(y))
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    ref = [p.grad.clone() for l in lins for p in (l.weight, l.bias)] + [xr.grad.clone()]
+    for l in lins:
+        l.zero_grad()
+        l.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    yd = ops.mlp(xd, lins)
+    assert rel_l2(yd, y) < 2e-6
+    (yd * w.to(DEV)).sum().backward()
+    got = [p.grad for l in lins for p in (l.weight, l.bias)] + [xd.grad]
+    for a, b in zip(got, ref):
+        assert rel_l2(a, b) < 5e-6
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# K7 DMoL head
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def test_dmol_golden_edge_cases_identity_linear():
+    """Reference's own outputs incl. y=+-1, near-edge values, delta<1e-5 fallback and the -7 clamp."""
+    fn = np.load(os.path.join(GOLDEN, "functions.npz"))
+    y, lg, lc, ls = T(fn["dmol_y"]), T(fn["dmol_logits"]), T(fn["dmol_locs"]), T(fn["dmol_ls"])
+    N = y.shape[0]
+    dec = torch.cat([lg, lc.squeeze(-2), ls.squeeze(-2)], -1).contiguous()  # [N,30], head = identity
+    W, b = torch.eye(30), torch.zeros(30)
+    x_sl = torch.tensor([N], dtype=torch.int32)
+    for bins, key in ((2**16, "dmol_ll_65536"), (256, "dmol_ll_256")):
+        ll, lp = ops.dmol_ll_twise(dec.to(DEV), W.to(DEV), b.to(DEV), y.view(1, N).to(DEV), x_sl.to(DEV), 0, 1, N, N, 1, 10, bins, -7.0)
+        torch.testing.assert_close(ll.cpu().view(-1), T(fn[key]), rtol=2e-5, atol=2e-5)
+        assert float(lp.cpu()) == pytest.approx(float(T(fn[key]).double().sum()), rel=1e-6)
+
+
+@pytest.mark.parametrize("layout,S", [(0, 1), (1, 8), (1, 64), (0, 5)])
+def test_dmol_forward_backward_vs_oracle(layout, S):
+    g = torch.Generator().manual_seed(11 + S)
+    B, Tp = 3, 7
+    T_ = Tp * S - (S // 2)
+    x, x_sl = O.synth_batch(B, T_, seed=S, ragged=True)
+    x[0, 0], x[1, 1] = 1.0, -1.0
+    dec_bm = torch.randn(B, Tp * S, 30, generator=g) * 1.5  # batch-major frames
+    W, b = torch.randn(30, 30, generator=g) * 0.3, torch.randn(30, generator=g) * 0.1
+    coef = torch.randn(B, generator=g).double()
+    # oracle
+    d0, W0, b0 = dec_bm.clone().requires_grad_(True), W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    lgt, lc, ls = O.dmol_head(d0[:, :T_], W0, b0)
+    ll = O.dmol_ll(x.unsqueeze(-1), lgt, lc, ls, 2**16)
+    lp_ref = (ll * O.sequence_mask(x_sl, T_, torch.float64)).sum(1)
+    (lp_ref * coef).sum().backward()
+    # device
+    if layout == 0:
+        dec = dec_bm.view(B * Tp, S * 30)
+    else:
+        dec = dec_bm.view(B, Tp, S * 30).transpose(0, 1).contiguous().view(Tp * B, S * 30)
+    dd = dec.to(DEV).requires_grad_(True)
+    Wd, bd = W.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    lp = ops.dmol_log_prob(dd, Wd, bd, x.to(DEV), x_sl.to(DEV, torch.int32), layout, B, T_, Tp, S, 10, 2**16, -7.0)
+    assert lp.dtype == torch.float64
+    torch.testing.assert_close(lp.cpu(), lp_ref.detach(), rtol=1e-5, atol=1e-4)
+    (lp * coef.to(DEV)).sum().backward()
+    gd = dd.grad.cpu()
+    gd = gd.view(B, Tp * S, 30) if layout == 0 else gd.view(Tp, B, S * 30).transpose(0, 1).reshape(B, Tp * S, 30)
+    assert rel_l2(gd, d0.grad) < 1e-4
+    assert rel_l2(Wd.grad, W0.grad) < 1e-4
+    assert rel_l2(bd.grad, b0.grad) < 1e-4
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# K8 KL
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("free_nats", [0.0, 2.0])
+def test_kl_forward_backward_vs_oracle(free_nats):
+    g = torch.Generator().manual_seed(2)
+    B, Tp, Z, stride = 5, 9, 48, 8
+    x_sl = torch.tensor([72, 65, 40, 9, 1])
+    mq, mp = torch.randn(Tp, B, Z, generator=g), torch.randn(Tp, B, Z, generator=g)
+    sq, sp = torch.rand(Tp, B, Z, generator=g) + 0.05, torch.rand(Tp, B, Z, generator=g) + 0.05
+    c = torch.randn(2, B, generator=g).double()
+    ins = [t.clone().requires_grad_(True) for t in (mq, sq, mp, sp)]
+    kl = O.kl_gaussian(*[t.transpose(0, 1) for t in ins])  # [B,Tp,Z]
+    mask = (torch.arange(Tp).unsqueeze(0) * stride < x_sl.unsqueeze(1)).double().unsqueeze(-1)
+    k_raw = (kl * mask).sum((1, 2))
+    k_fn = (O.discount_free_nats(kl, free_nats) * mask).sum((1, 2))
+    (k_raw * c[0] + k_fn * c[1]).sum().backward()
+    dins = [t.to(DEV).requires_grad_(True) for t in (mq, sq, mp, sp)]
+    kd, kfd = ops.gaussian_kl_sums(*dins, x_sl.to(DEV, torch.int32), 1, B, Tp, Z, stride, free_nats)
+    torch.testing.assert_close(kd.cpu(), k_raw.detach(), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(kfd.cpu(), k_fn.detach(), rtol=1e-6, atol=1e-6)
+    (kd * c[0].to(DEV) + kfd * c[1].to(DEV)).sum().backward()
+    for a, b in zip(dins, ins):
+        assert rel_l2(a.grad, b.grad) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# K1 + whole VRNNAudio step against the REFERENCE's own outputs
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def _run(model, x, x_sl, eps, beta, fn, h0=None):
+    model.zero_grad()
+    loss, metrics, out = model(x.to(DEV), x_sl, beta=beta, free_nats=fn, eps=eps.to(DEV), h0=h0)
+    loss.backward()
+    return loss, metrics, out
+
+
+@pytest.mark.parametrize("tag,beta,fn_", [("a", 1.0, 2.0), ("b", 0.3, 0.0)])
+def test_vrnn_small_vs_reference_golden(tag, beta, fn_):
+    g = np.load(os.path.join(GOLDEN, "vrnn_small.npz"))
+    m = VRNNAudio(likelihood="DMoL", input_size=8, hidden_size=32, latent_size=16, residual_posterior=True, num_mix=10, num_bins=2**16)
+    m.load_state_dict({k[3:]: T(g[k]) for k in g.files if k.startswith("sd.")})
+    m.to(DEV)
+    x, x_sl, eps = T(g["x"]), T(g["x_sl"]), T(g[f"{tag}_eps"])
+    loss, metrics, out = _run(m, x, x_sl, eps, beta, fn_)
+    assert loss.dtype == torch.float64
+    assert float(loss) == pytest.approx(float(g[f"{tag}_loss"]), rel=1e-5)
+    torch.testing.assert_close(out.elbo.cpu(), T(g[f"{tag}_elbo"]), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(out.log_prob.cpu(), T(g[f"{tag}_log_prob"]), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(out.kl.cpu(), T(g[f"{tag}_kl"]), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(out.z.cpu(), T(g[f"{tag}_z"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(out.h_n.cpu(), T(g[f"{tag}_h_n"]), rtol=1e-4, atol=1e-5)
+    vals = {mm.name: mm.value for mm in metrics}
+    for name, val in zip(g[f"{tag}_metric_names"].tolist(), g[f"{tag}_metric_values"].tolist()):
+        assert vals[name] == pytest.approx(val, rel=1e-5, abs=1e-7), name
+    for k, p in m.named_parameters():
+        assert rel_l2(p.grad, T(g[f"{tag}_grad.{k}"])) < 1e-3, k
+    # lazily computed outputs exist and have the reference's shapes
+    assert out.reconstructions_mode.shape == (3, 76, 1) and out.reconstructions.shape == (3, 76, 1)
+    assert out.seq_mask.shape == (3, 76)
+
+
+def test_vrnn_full_dims_vs_reference_golden():
+    g = np.load(os.path.join(GOLDEN, "vrnn_full.npz"))
+    torch.manual_seed(0)
+    m = VRNNAudio(likelihood="DMoL", input_size=64, hidden_size=256, latent_size=256, residual_posterior=True).to(DEV)
+    x, x_sl = O.synth_batch(4, 1280, seed=0, ragged=True)
+    torch.manual_seed(123)
+    eps = torch.stack([torch.randn(4, 256) for _ in range(20)], 0)
+    loss, metrics, out = _run(m, x, x_sl, eps, 1.0, 2.0)
+    assert float(loss) == pytest.approx(float(g["loss"]), rel=1e-5)
+    torch.testing.assert_close(out.elbo.cpu(), T(g["elbo"]), rtol=1e-5, atol=0)
+    torch.testing.assert_close(out.kl.cpu(), T(g["kl"]), rtol=1e-5, atol=0)
+    vals = {mm.name: mm.value for mm in metrics}
+    for name, val in zip(g["metric_names"].tolist(), g["metric_values"].tolist()):
+        assert vals[name] == pytest.approx(val, rel=1e-5), name
+    grads = dict(m.named_parameters())
+    for name, ref in zip(g["grad_names"].tolist(), g["grad_norms"].tolist()):
+        assert grads[name].grad.double().norm().item() == pytest.approx(ref, rel=1e-3), name
+    for k in [f[5:] for f in g.files if f.startswith("grad.")]:
+        assert rel_l2(grads[k].grad, T(g[f"grad.{k}"])) < 1e-3, k
+
+
+def test_vrnn_vs_oracle_ragged_with_initial_state():
+    """Ragged batch, non-zero h0, batch not a multiple of 16, T not a multiple of the stack: oracle on the CPU."""
+    torch.manual_seed(4)
+    m = VRNNAudio(likelihood="DMoL", input_size=16, hidden_size=48, latent_size=32, residual_posterior=True)
+    sd = {k: v.clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    B, T_ = 19, 16 * 12 - 5
+    x, x_sl = O.synth_batch(B, T_, seed=9, ragged=True)
+    g = torch.Generator().manual_seed(8)
+    eps = torch.randn(12, B, 32, generator=g)
+    h0 = torch.randn(B, 96, generator=g) * 0.3
+    ref = O.vrnn_audio_forward(sd, x, x_sl, eps, beta=0.7, free_nats=1.5, h0=h0, stack=16)
+    ref["loss"].backward()
+    m.to(DEV)
+    loss, _, out = _run(m, x, x_sl, eps, 0.7, 1.5, h0=h0.to(DEV))
+    assert float(loss) == pytest.approx(float(ref["loss"]), rel=1e-5)
+    torch.testing.assert_close(out.elbo.cpu(), ref["elbo"].detach(), rtol=1e-5, atol=1e-3)
+    for k, p in m.named_parameters():
+        assert rel_l2(p.grad, sd[k].grad) < 1e-3, k
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# full BASELINE size: properties that need no oracle run
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def test_full_size_properties():
+    """C2 workload [64,16000]: (i) per-utterance terms do not depend on the other rows of the batch, (ii) samples
+    beyond x_sl do not influence anything, (iii) bits/dim at random init sits at ~log2(65536)+1."""
+    torch.manual_seed(0)
+    m = VRNNAudio(likelihood="DMoL", input_size=64, hidden_size=256, latent_size=256, residual_posterior=True).to(DEV)
+    B, T_ = 64, 16000
+    x, x_sl = O.synth_batch(B, T_, seed=0, ragged=True)
+    eps = torch.randn(250, B, 256, generator=torch.Generator().manual_seed(1))
+    sub = slice(16, 48)
+    Ts = int(x_sl[sub].max())
+    Tps = (Ts + 63) // 64
+    xs = x[sub, :Ts].clone()
+    for i, n in enumerate(x_sl[sub].tolist()):
+        xs[i, ((n + 63) // 64) * 64 :] = 0.77  # garbage behind the last (partially) valid stack of each row
+    with torch.no_grad():
+        _, metrics, full = m(x.to(DEV), x_sl, beta=1.0, free_nats=2.0, eps=eps.to(DEV))
+        _, _, part = m(xs.to(DEV), x_sl[sub], beta=1.0, free_nats=2.0, eps=eps[:Tps, sub].contiguous().to(DEV))
+    torch.testing.assert_close(part.elbo, full.elbo[sub], rtol=1e-6, atol=0)
+    torch.testing.assert_close(part.kl, full.kl[sub], rtol=1e-6, atol=0)
+    bpd = {mm.name: mm.value for mm in metrics}["bpd"]
+    assert 16.5 < bpd < 18.0

@@ -1,0 +1,121 @@
+"""CPU: host-side logic of the product (no GPU compute): library exports, construction/initialisation parity with
+the reference, state_dict layout, shape helpers, metrics, annealer, and the loud failure on CPU tensors."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import blvm_oracle as O
+from blvm import _hip
+from blvm.evaluation import BitsPerDimMetric, DeferredScalars, KLMetric, LLMetric, LossMetric, Tracker
+from blvm.models import VRNNAudio
+from blvm.training.annealers import CosineAnnealer
+from blvm.utils import operations as OP
+
+from conftest import GOLDEN, ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "blvm_hip.h")).read()
+    declared = set(re.findall(r"\b(blvm_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_hip.EXPORTS)
+    lib = ctypes.CDLL(_hip.lib_path())  # loads without a GPU
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _hip.load().blvm_version() >= 100
+
+
+def test_cpu_tensor_is_refused_loudly():
+    m = VRNNAudio(likelihood="DMoL", input_size=8, hidden_size=32, latent_size=16)
+    x, x_sl = O.synth_batch(2, 32, seed=1)
+    with pytest.raises(_hip.BlvmHipError, match="no CPU fallback"):
+        m(x, x_sl)
+
+
+def test_vrnn_audio_init_and_state_dict_match_reference():
+    """Same seed + same construction order => identical parameters as the reference (pinned by checksums)."""
+    g = np.load(os.path.join(GOLDEN, "vrnn_full.npz"))
+    torch.manual_seed(0)
+    m = VRNNAudio(likelihood="DMoL", input_size=64, hidden_size=256, latent_size=256, residual_posterior=True, num_mix=10, num_bins=2**16)
+    sd = m.state_dict()
+    assert list(sd.keys()) == g["param_names"].tolist()
+    for k, v in sd.items():
+        cks = g[f"cks.{k}"]
+        assert list(v.shape) == [int(s) for s in cks[2:]], k
+        assert v.double().sum().item() == pytest.approx(cks[0], rel=1e-12, abs=1e-9), k
+        assert v.double().abs().sum().item() == pytest.approx(cks[1], rel=1e-12), k
+
+
+def test_oracle_full_size_against_reference_outputs():
+    """Full C2 dimensions: oracle (fed with the product's seeded parameters) reproduces the reference's outputs."""
+    g = np.load(os.path.join(GOLDEN, "vrnn_full.npz"))
+    torch.manual_seed(0)
+    m = VRNNAudio(likelihood="DMoL", input_size=64, hidden_size=256, latent_size=256, residual_posterior=True)
+    sd = {k: v.clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    x, x_sl = O.synth_batch(4, 1280, seed=0, ragged=True)
+    assert x_sl.tolist() == g["x_sl"].tolist()
+    assert x.double().sum().item() == pytest.approx(g["x_cks"][0], rel=1e-12)
+    torch.manual_seed(123)
+    eps = torch.stack([torch.randn(4, 256) for _ in range(20)], 0)
+    assert eps.double().abs().sum().item() == pytest.approx(g["eps_cks"][1], rel=1e-12)
+    out = O.vrnn_audio_forward(sd, x, x_sl, eps, beta=1.0, free_nats=2.0, stack=64)
+    np.testing.assert_allclose(out["loss"].item(), g["loss"], rtol=1e-7)
+    np.testing.assert_allclose(out["elbo"].detach().numpy(), g["elbo"], rtol=1e-7)
+    np.testing.assert_allclose(out["kl"].detach().numpy(), g["kl"], rtol=1e-6)
+    out["loss"].backward()
+    for name, ref in zip(g["grad_names"].tolist(), g["grad_norms"].tolist()):
+        assert sd[name].grad.double().norm().item() == pytest.approx(ref, rel=2e-4), name
+
+
+def test_operations_match_oracle_and_reference_vectors():
+    fn = np.load(os.path.join(GOLDEN, "functions.npz"))
+    st, pad = OP.stack_tensor(torch.from_numpy(fn["stack_x"]), 8, dim=1)
+    assert pad == int(fn["stack_pad"]) and torch.equal(st, torch.from_numpy(fn["stack_out"]))
+    # like the reference, unstacking [B,T',S] keeps a trailing singleton dim: [B,T,1] (operations.py:44-47)
+    assert torch.equal(OP.unstack_tensor(st, 8, pad, dim=-1).squeeze(-1), torch.from_numpy(fn["stack_x"]))
+    sl = torch.from_numpy(fn["mask_sl"])
+    assert torch.equal(OP.sequence_mask(sl), torch.from_numpy(fn["mask_bool"]))
+    assert torch.equal(OP.reverse_sequences(torch.from_numpy(fn["rev_x"]), sl), torch.from_numpy(fn["rev_out"]))
+    # split_sequence: consume / extend bookkeeping
+    x = torch.arange(2 * 10).view(2, 10).float()
+    xs, sls = OP.split_sequence(x, torch.tensor([10, 6]), length=4, overlap=0)
+    assert [tuple(t.shape) for t in xs] == [(2, 4), (2, 4), (1, 2)] and [s.tolist() for s in sls] == [[4, 4], [4, 2], [2]]
+    with pytest.raises(ValueError):
+        OP.split_sequence(x, torch.tensor([10, 6]), length=4, overlap=4)
+
+
+def test_annealer_matches_reference_trace_and_contract():
+    fn = np.load(os.path.join(GOLDEN, "functions.npz"))
+    a = CosineAnnealer(anneal_steps=10, constant_steps=0, start_value=0, end_value=1)
+    assert a.value is None  # None before the first step (reference test_annealers.py)
+    np.testing.assert_allclose([a.step() for _ in range(15)], fn["anneal_beta"], atol=1e-15)
+    b = CosineAnnealer(anneal_steps=7, constant_steps=5, start_value=2.0, end_value=0.0)
+    tr = [b.step() for _ in range(15)]
+    np.testing.assert_allclose(tr, fn["anneal_fn"], atol=1e-15)
+    assert all(x > y for x, y in zip(tr[5:11], tr[6:12]))  # strictly monotone while annealing
+    assert tr[-1] == 0.0
+    for bad in [dict(anneal_steps=-1), dict(anneal_steps=1, constant_steps=-2), dict(anneal_steps=1, start_value=float("inf"))]:
+        with pytest.raises(ValueError):
+            CosineAnnealer(**bad)
+
+
+def test_metrics_merge_like_reference():
+    elbo1, sl1 = torch.tensor([-100.0, -50.0]), torch.tensor([10, 5])
+    elbo2, sl2 = torch.tensor([-30.0]), torch.tensor([3])
+    m1, m2 = BitsPerDimMetric(elbo1, reduce_by=sl1), BitsPerDimMetric(elbo2, reduce_by=sl2)
+    assert m1.value == pytest.approx(150 / np.log(2) / 15)
+    m1.update(m2)
+    assert m1.value == pytest.approx(180 / np.log(2) / 18) and m1.weight_by == 18
+    # deferred device scalars behave like the tensors they summarise
+    d = DeferredScalars(torch.tensor([1.5, -150.0]))
+    assert LossMetric(d[0], weight_by=2).value == 1.5
+    assert LLMetric(d[1], name="elbo", reduce_by=2).value == -75.0
+    assert KLMetric(d[1] / np.log(2), name="kl (bpt)", reduce_by=15).value == pytest.approx(-150 / np.log(2) / 15)
+    t = Tracker()
+    t.update([LLMetric(elbo1, name="elbo")], source="train")
+    t.update([LLMetric(elbo2, name="elbo")], source="train")
+    assert t.values("train")["elbo"] == pytest.approx(-60.0)
