@@ -22,6 +22,12 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak (= fp32 vector peak)
+_T0 = time.time()
+
+
+def log(msg):
+    """Progress on stderr (stdout carries exactly one JSON line)."""
+    print(f"[bench {time.time() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def cell_macs(X, H, Z, R):
@@ -56,6 +62,7 @@ def cpu_baseline(B, T, steps, threads):
         torch.nn.utils.clip_grad_value_(list(sd.values()), 1000.0)
         torch.nn.utils.clip_grad_norm_(list(sd.values()), 3000.0)
         opt.step()
+        log(f"cpu_baseline step {i}: {time.perf_counter() - t0:.2f} s")
         if i > 0:  # first step is warm-up
             times.append(time.perf_counter() - t0)
     dt = sorted(times)[len(times) // 2]
@@ -131,9 +138,14 @@ def main():
         opt.step()
         last["metrics"] = metrics
 
-    for _ in range(args.warmup):
+    log(f"rank {rank}/{world}: model + data resident, starting {args.warmup} warm-up steps")
+    for i in range(args.warmup):
         step()
+        if i == 0:
+            torch.cuda.synchronize()
+            log("first step done")
     torch.cuda.synchronize()
+    log("warm-up done, timing")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -153,6 +165,7 @@ def main():
         dt = float(t)
 
     ms_step = dt / args.steps * 1e3
+    log(f"timed {args.steps} steps: {ms_step:.2f} ms/step")
     frames = world * B * T * args.steps
     cell_ms = [(e[0].elapsed_time(e[1]), e[2].elapsed_time(e[3])) for e in ev]
     fwd_ms = sum(c[0] for c in cell_ms) / len(cell_ms)
@@ -196,7 +209,8 @@ def main():
             },
         }  # fmt: skip
         if world == 1 and not args.no_cpu_baseline:
-            threads = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0))))
+            # the box's CPU share for one GPU is 16 cores (more threads than that only thrash the cgroup quota)
+            threads = max(1, min(16, os.cpu_count() or 1, len(os.sched_getaffinity(0))))
             res["cpu_baseline"] = cpu_baseline(args.cpu_batch, T, args.cpu_steps, threads)
         print(json.dumps(res), flush=True)
     if world > 1:
