@@ -79,8 +79,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU (reference benchmark: --batch_len 64 s of audio)")
     ap.add_argument("--length", type=int, default=16000, help="samples per utterance (1 s at 16 kHz)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=8)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-steps", type=int, default=10)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -119,9 +119,16 @@ def main():
     cur = {"i": -1}
     slot = {"fwd_begin": 0, "fwd_end": 1, "bwd_begin": 2, "bwd_end": 3}
 
+    host = {"fwd": 0.0, "bwd": 0.0, "t": 0.0}
+
     def hook(tag):
         if cur["i"] >= 0:
             ev[cur["i"]][slot[tag]].record()
+            # host-side enqueue time of the call (is the chain launch-bound on the CPU?)
+            if tag.endswith("begin"):
+                host["t"] = time.perf_counter()
+            else:
+                host[tag[:3]] += time.perf_counter() - host["t"]
 
     ops.seq_timer_hook = hook
 
@@ -165,7 +172,8 @@ def main():
         dt = float(t)
 
     ms_step = dt / args.steps * 1e3
-    log(f"timed {args.steps} steps: {ms_step:.2f} ms/step")
+    log(f"timed {args.steps} steps: {ms_step:.2f} ms/step; host enqueue per step: seq_fwd {host['fwd'] / args.steps * 1e3:.2f} ms, "
+        f"seq_bwd {host['bwd'] / args.steps * 1e3:.2f} ms")
     frames = world * B * T * args.steps
     cell_ms = [(e[0].elapsed_time(e[1]), e[2].elapsed_time(e[3])) for e in ev]
     fwd_ms = sum(c[0] for c in cell_ms) / len(cell_ms)
