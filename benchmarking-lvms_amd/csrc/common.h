@@ -56,30 +56,35 @@ __device__ __forceinline__ float softplus_beta(float x, float beta, float inv_be
   return bx > 20.0f ? x : inv_beta * log1pf(expf(bx));
 }
 
-// ---- 16x16 output tile, K split over the 4 waves of a 256-thread workgroup --------------------------------------
+// ---- 16x16 output tile, K split over the NW waves of a workgroup ------------------------------------------------
 // acc += A[r0+i][k] * W[c0+j][k] for the k-chunks owned by `wave` (chunk = 16 k, waves interleave chunks).
 // A rows >= nrows read as zero.  A, W must be 16-byte aligned with lda, ldw multiples of 4 and K a multiple of 16.
 // v_mfma_f32_16x16x4_f32: lane l supplies A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D: col=l&15, row=(l>>4)*4+reg.
+// Each lane fetches 4 consecutive k as one 16-byte load and feeds them to 4 MFMAs; A and B use the same
+// k-permutation, so the sum over k is complete.
+template <int NW>
 __device__ __forceinline__ f32x4 wave_gemm16(const float* __restrict__ A, int lda, int r0, int nrows,
                                               const float* __restrict__ W, int ldw, int c0, int K, int wave,
                                               f32x4 acc) {
+  constexpr int STEP = NW * 16;
   const int lane = threadIdx.x & 63;
   const int rr = lane & 15, q = lane >> 4;
   const bool aok = (r0 + rr) < nrows;
   const float* ap = A + (size_t)(aok ? r0 + rr : 0) * lda + 4 * q;
   const float* wp = W + (size_t)(c0 + rr) * ldw + 4 * q;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   int kc = wave * 16;
-  // 4 chunks (64 k per wave) per trip keeps 8 x 16-byte loads in flight
-  for (; kc + 192 < K; kc += 256) {
+  // 4 chunks per trip keeps 8 x 16-byte loads in flight
+  for (; kc + 3 * STEP < K; kc += 4 * STEP) {
     float4 a0 = *reinterpret_cast<const float4*>(ap + kc);
-    float4 a1 = *reinterpret_cast<const float4*>(ap + kc + 64);
-    float4 a2 = *reinterpret_cast<const float4*>(ap + kc + 128);
-    float4 a3 = *reinterpret_cast<const float4*>(ap + kc + 192);
-    float4 w0 = *reinterpret_cast<const float4*>(wp + kc);
-    float4 w1 = *reinterpret_cast<const float4*>(wp + kc + 64);
-    float4 w2 = *reinterpret_cast<const float4*>(wp + kc + 128);
-    float4 w3 = *reinterpret_cast<const float4*>(wp + kc + 192);
-    if (!aok) { a0 = a1 = a2 = a3 = make_float4(0.f, 0.f, 0.f, 0.f); }
+    float4 a1 = *reinterpret_cast<const float4*>(ap + kc + STEP);
+    float4 a2 = *reinterpret_cast<const float4*>(ap + kc + 2 * STEP);
+    float4 a3 = *reinterpret_cast<const float4*>(ap + kc + 3 * STEP);
+    const float4 w0 = *reinterpret_cast<const float4*>(wp + kc);
+    const float4 w1 = *reinterpret_cast<const float4*>(wp + kc + STEP);
+    const float4 w2 = *reinterpret_cast<const float4*>(wp + kc + 2 * STEP);
+    const float4 w3 = *reinterpret_cast<const float4*>(wp + kc + 3 * STEP);
+    if (!aok) { a0 = a1 = a2 = a3 = zero; }
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, w0.x, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, w0.y, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, w0.z, acc, 0, 0, 0);
@@ -97,10 +102,10 @@ __device__ __forceinline__ f32x4 wave_gemm16(const float* __restrict__ A, int ld
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.z, w3.z, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.w, w3.w, acc, 0, 0, 0);
   }
-  for (; kc < K; kc += 64) {
+  for (; kc < K; kc += STEP) {
     float4 a0 = *reinterpret_cast<const float4*>(ap + kc);
-    float4 w0 = *reinterpret_cast<const float4*>(wp + kc);
-    if (!aok) a0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 w0 = *reinterpret_cast<const float4*>(wp + kc);
+    if (!aok) a0 = zero;
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, w0.x, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, w0.y, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, w0.z, acc, 0, 0, 0);
@@ -109,22 +114,26 @@ __device__ __forceinline__ f32x4 wave_gemm16(const float* __restrict__ A, int ld
   return acc;
 }
 
-// Combine the 4 waves' partial 16x16 tiles of G groups through LDS.  `red` must hold G*4*256 floats.
-// After the call thread tid owns element (i = tid>>4, j = tid&15) of every group: out[g].
-template <int G>
+// Combine the NW waves' partial 16x16 tiles of G groups through LDS.  `red` must hold G*NW*256 floats.
+// After the call threads 0..255 own element (i = tid>>4, j = tid&15) of every group: out[g]; other threads get 0.
+template <int G, int NW>
 __device__ __forceinline__ void reduce_tiles(const f32x4 (&acc)[G], float* __restrict__ red, float (&out)[G]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     // element (row=(lane>>4)*4+reg, col=lane&15) stored at [g][wave][row*16+col]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[(g * 4 + wave) * 256 + ((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc[g][r];
+    for (int r = 0; r < 4; ++r) red[(g * NW + wave) * 256 + ((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc[g][r];
   }
   __syncthreads();
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    out[g] = red[(g * 4 + 0) * 256 + tid] + red[(g * 4 + 1) * 256 + tid] + red[(g * 4 + 2) * 256 + tid] +
-             red[(g * 4 + 3) * 256 + tid];
+    float s = 0.f;
+    if (tid < 256) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += red[(g * NW + w) * 256 + tid];
+    }
+    out[g] = s;
   }
 }
 

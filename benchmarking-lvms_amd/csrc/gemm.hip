@@ -277,7 +277,8 @@ int colsum_f32(int M, int N, const float* X, int ldx, float* out, int accumulate
   BLVM_REQUIRE(X && out, "colsum: null operand");
   if (!accumulate) BLVM_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, stream));
   if (M == 0) return BLVM_OK;
-  const int rows_per_block = 512;
+  int rows_per_block = 64;
+  while ((M + rows_per_block - 1) / rows_per_block > 32768) rows_per_block *= 2;
   dim3 grid((N + 63) / 64, (M + rows_per_block - 1) / rows_per_block);
   hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, M, N, X, ldx, out, rows_per_block);
   BLVM_CHECK_LAUNCH("colsum_f32");

@@ -20,41 +20,61 @@ namespace blvm {
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------------
-// generic multi-segment linear stage:  out = gate( act( A W^T + bias + add ) )
+// Launch-latency notes (measured, profiles/r01_*): a link of the chain costs the kernel boundary (~1.5 us) plus every
+// DEPENDENT memory round trip inside the kernel.  So: (1) no dynamically indexed kernel arguments (each would be a
+// dependent scalar load) — segments are selected with scalar selects on values that arrive with the first kernarg
+// fetch; (2) every epilogue operand (bias, addend, gate, saved activations) is loaded BEFORE the K loop so it
+// travels with the operand loads; (3) the K split is as wide as the reduction allows (NW = 4/8/16 waves) so a
+// wave's dependent MFMA chain is <= 24 instructions.
 // ---------------------------------------------------------------------------------------------------------------
-struct LinSeg {
-  const float* A;     int lda;     // [B,K]
-  const float* W;     int ldw;     // [ncols,K], k contiguous
-  const float* bias;               // [ncols] or null
-  const float* add;   int ldadd;   // [B,ncols] or null (may alias out)
-  const float* gate;  int ldgate;  // [B,ncols] or null: result *= (gate > 0)
-  float* out;         int ldo;     // [B,ncols]
-  int ncols, K, relu;
-};
 
+// generic multi-segment linear stage:  out = gate( act( A W^T + bias + add ) )
 struct LinArgs {
-  LinSeg seg[3];
-  int nseg, B;
+  const float* A[3];     int lda[3];     // [B,K]
+  const float* W[3];     int ldw[3];     // [ncols,K], k contiguous
+  const float* bias[3];                  // [ncols] or null
+  const float* add[3];   int ldadd[3];   // [B,ncols] or null (may alias out)
+  const float* gate[3];  int ldgate[3];  // [B,ncols] or null: result *= (gate > 0)
+  float* out[3];         int ldo[3];     // [B,ncols]
+  int tiles[3];                          // ncols / 16 per segment
+  int relu[3];
+  int nseg, B, K;
 };
 
-__global__ __launch_bounds__(256) void lin_stage_kernel(LinArgs a) {
-  __shared__ float red[4 * 256];
+#define SEL3(f, s) ((s) == 0 ? (f)[0] : ((s) == 1 ? (f)[1] : (f)[2]))
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void lin_stage_kernel(LinArgs a) {
+  __shared__ float red[NW * 256];
   int ct = blockIdx.x, s = 0;
-  while (s + 1 < a.nseg && ct >= a.seg[s].ncols / 16) { ct -= a.seg[s].ncols / 16; ++s; }
-  const LinSeg& g = a.seg[s];
+  if (a.nseg > 1 && ct >= a.tiles[0]) { ct -= a.tiles[0]; s = 1; }
+  if (a.nseg > 2 && s == 1 && ct >= a.tiles[1]) { ct -= a.tiles[1]; s = 2; }
+  const float* A = SEL3(a.A, s);       const int lda = SEL3(a.lda, s);
+  const float* W = SEL3(a.W, s);       const int ldw = SEL3(a.ldw, s);
+  const float* bias = SEL3(a.bias, s);
+  const float* add = SEL3(a.add, s);   const int ldadd = SEL3(a.ldadd, s);
+  const float* gate = SEL3(a.gate, s); const int ldgate = SEL3(a.ldgate, s);
+  float* out = SEL3(a.out, s);         const int ldo = SEL3(a.ldo, s);
+  const int relu = SEL3(a.relu, s);
   const int r0 = blockIdx.y * 16, c0 = ct * 16;
-  f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-  acc[0] = wave_gemm16(g.A, g.lda, r0, a.B, g.W, g.ldw, c0, g.K, threadIdx.x >> 6, acc[0]);
-  float v[1];
-  reduce_tiles<1>(acc, red, v);
   const int row = r0 + (threadIdx.x >> 4), col = c0 + (threadIdx.x & 15);
-  if (row >= a.B) return;
-  float x = v[0];
-  if (g.bias) x += g.bias[col];
-  if (g.add) x += g.add[(size_t)row * g.ldadd + col];
-  if (g.relu) x = x > 0.f ? x : 0.f;
-  if (g.gate) x = g.gate[(size_t)row * g.ldgate + col] > 0.f ? x : 0.f;
-  g.out[(size_t)row * g.ldo + col] = x;
+  const bool own = threadIdx.x < 256 && row < a.B;
+  // epilogue operands first: they travel with the operand loads instead of after the reduction
+  float e_bias = 0.f, e_add = 0.f, e_gate = 1.f;
+  if (own) {
+    if (bias) e_bias = bias[col];
+    if (add) e_add = add[(size_t)row * ldadd + col];
+    if (gate) e_gate = gate[(size_t)row * ldgate + col];
+  }
+  f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+  acc[0] = wave_gemm16<NW>(A, lda, r0, a.B, W, ldw, c0, a.K, threadIdx.x >> 6, acc[0]);
+  float v[1];
+  reduce_tiles<1, NW>(acc, red, v);
+  if (!own) return;
+  float x = v[0] + e_bias + e_add;
+  if (relu) x = x > 0.f ? x : 0.f;
+  x = e_gate > 0.f ? x : 0.f;
+  out[(size_t)row * ldo + col] = x;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -69,31 +89,35 @@ struct HeadArgs {
   float beta, inv_beta, sd_eps;
 };
 
-__global__ __launch_bounds__(256) void head_stage_kernel(HeadArgs a) {
-  __shared__ float red[4 * 4 * 256];
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void head_stage_kernel(HeadArgs a) {
+  __shared__ float red[4 * NW * 256];
   const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, wave = threadIdx.x >> 6;
+  const int row = r0 + (threadIdx.x >> 4), col = c0 + (threadIdx.x & 15);
+  const bool own = threadIdx.x < 256 && row < a.B;
+  const size_t o = (size_t)row * a.Z + col;
+  float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f, e = 0.f;
+  if (own) { b0 = a.bp[col]; b1 = a.bp[a.Z + col]; b2 = a.bq[col]; b3 = a.bq[a.Z + col]; e = a.eps[o]; }
   f32x4 acc[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  acc[0] = wave_gemm16(a.P, a.H, r0, a.B, a.Wp, a.H, c0, a.H, wave, acc[0]);
-  acc[1] = wave_gemm16(a.P, a.H, r0, a.B, a.Wp, a.H, a.Z + c0, a.H, wave, acc[1]);
-  acc[2] = wave_gemm16(a.Q, a.H, r0, a.B, a.Wq, a.H, c0, a.H, wave, acc[2]);
-  acc[3] = wave_gemm16(a.Q, a.H, r0, a.B, a.Wq, a.H, a.Z + c0, a.H, wave, acc[3]);
+  acc[0] = wave_gemm16<NW>(a.P, a.H, r0, a.B, a.Wp, a.H, c0, a.H, wave, acc[0]);
+  acc[1] = wave_gemm16<NW>(a.P, a.H, r0, a.B, a.Wp, a.H, a.Z + c0, a.H, wave, acc[1]);
+  acc[2] = wave_gemm16<NW>(a.Q, a.H, r0, a.B, a.Wq, a.H, c0, a.H, wave, acc[2]);
+  acc[3] = wave_gemm16<NW>(a.Q, a.H, r0, a.B, a.Wq, a.H, a.Z + c0, a.H, wave, acc[3]);
   float v[4];
-  reduce_tiles<4>(acc, red, v);
-  const int row = r0 + (threadIdx.x >> 4), col = c0 + (threadIdx.x & 15);
-  if (row >= a.B) return;
-  const size_t o = (size_t)row * a.Z + col;
-  const float mp = v[0] + a.bp[col];
-  const float rp = v[1] + a.bp[a.Z + col];
-  float mq = v[2] + a.bq[col];
-  const float rq = v[3] + a.bq[a.Z + col];
+  reduce_tiles<4, NW>(acc, red, v);
+  if (!own) return;
+  const float mp = v[0] + b0;
+  const float rp = v[1] + b1;
+  float mq = v[2] + b2;
+  const float rq = v[3] + b3;
   const float sp = softplus_beta(rp, a.beta, a.inv_beta) + a.sd_eps;
   const float sq = softplus_beta(rq, a.beta, a.inv_beta) + a.sd_eps;
   if (a.residual) mq += mp;
   a.mu_p[o] = mp; a.sd_p[o] = sp; a.mu_q[o] = mq; a.sd_q[o] = sq;
   a.raw_p[o] = rp; a.raw_q[o] = rq;
-  a.z[o] = a.eps[o] * sq + mq;  // randn_like(mu).mul(sd).add(mu)
+  a.z[o] = e * sq + mq;  // randn_like(mu).mul(sd).add(mu)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -109,27 +133,32 @@ struct GruArgs {
   int B, X, H, R;
 };
 
-__global__ __launch_bounds__(256) void gru_stage_kernel(GruArgs a) {
-  __shared__ float red[3 * 4 * 256];
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void gru_stage_kernel(GruArgs a) {
+  __shared__ float red[3 * NW * 256];
   const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, wave = threadIdx.x >> 6;
   const int ldd = a.H + a.R, ldw = a.X + a.H;
+  const int row = r0 + (threadIdx.x >> 4), col = c0 + (threadIdx.x & 15);
+  const bool own = threadIdx.x < 256 && row < a.B;
+  const size_t o3 = (size_t)row * 3 * a.R + col;
+  float x0 = 0.f, x1 = 0.f, x2 = 0.f, hr = 0.f, hz = 0.f, hn = 0.f, hp = 0.f;
+  if (own) {
+    x0 = a.xg[o3]; x1 = a.xg[o3 + a.R]; x2 = a.xg[o3 + 2 * a.R];
+    hr = a.gh[o3]; hz = a.gh[o3 + a.R]; hn = a.gh[o3 + 2 * a.R];
+    hp = a.decin_t[(size_t)row * ldd + a.H + col];
+  }
   f32x4 acc[3];
 #pragma unroll
   for (int g = 0; g < 3; ++g) {
     acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[g] = wave_gemm16(a.decin_t, ldd, r0, a.B, a.Wih + a.X, ldw, g * a.R + c0, a.H, wave, acc[g]);
+    acc[g] = wave_gemm16<NW>(a.decin_t, ldd, r0, a.B, a.Wih + a.X, ldw, g * a.R + c0, a.H, wave, acc[g]);
   }
   float v[3];
-  reduce_tiles<3>(acc, red, v);
-  const int row = r0 + (threadIdx.x >> 4), col = c0 + (threadIdx.x & 15);
-  if (row >= a.B) return;
-  const size_t o3 = (size_t)row * 3 * a.R + col;
-  const float ir = v[0] + a.xg[o3], iz = v[1] + a.xg[o3 + a.R], in_ = v[2] + a.xg[o3 + 2 * a.R];
-  const float hr = a.gh[o3], hz = a.gh[o3 + a.R], hn = a.gh[o3 + 2 * a.R];
-  const float r = sigmoidf_(ir + hr);
-  const float u = sigmoidf_(iz + hz);
-  const float n = tanhf(in_ + r * hn);
-  const float hp = a.decin_t[(size_t)row * ldd + a.H + col];
+  reduce_tiles<3, NW>(acc, red, v);
+  if (!own) return;
+  const float r = sigmoidf_(v[0] + x0 + hr);
+  const float u = sigmoidf_(v[1] + x1 + hz);
+  const float n = tanhf(v[2] + x2 + r * hn);
   a.decin_next[(size_t)row * ldd + a.H + col] = (1.f - u) * n + u * hp;
   const size_t o = (size_t)row * a.R + col;
   a.rg[o] = r; a.ug[o] = u; a.ng[o] = n;
@@ -149,37 +178,42 @@ struct DzArgs {
   float fn_floor, beta;
 };
 
-__global__ __launch_bounds__(256) void dz_stage_kernel(DzArgs a) {
-  __shared__ float red[4 * 256];
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void dz_stage_kernel(DzArgs a) {
+  __shared__ float red[NW * 256];
   const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16;
-  f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-  acc[0] = wave_gemm16(a.D, a.H, r0, a.B, a.WT, a.H, c0, a.H, threadIdx.x >> 6, acc[0]);
-  float v[1];
-  reduce_tiles<1>(acc, red, v);
   const int row = r0 + (threadIdx.x >> 4), col = c0 + (threadIdx.x & 15);
-  if (row >= a.B) return;
+  const bool own = threadIdx.x < 256 && row < a.B;
   const size_t o = (size_t)row * a.Z + col;
-  const float dz = v[0];
-  const float mq = a.mu_q[o], sq = a.sd_q[o], mp = a.mu_p[o], sp = a.sd_p[o];
-  float coef = 0.f;
-  if ((a.c_fn != nullptr || a.c_raw != nullptr) && (long long)a.t * a.stride < a.x_sl[row]) {
-    if (a.c_raw != nullptr) coef = a.c_raw[row];
-    if (a.c_fn != nullptr) {
-      const float d0 = mq - mp;
-      const float k = logf(sp) - logf(sq) + (sq * sq + d0 * d0) / (2.f * sp * sp) - 0.5f;
-      if (!(a.fn_floor > 0.f) || k > a.fn_floor) coef += a.c_fn[row];
+  float mq = 0.f, sq = 1.f, mp = 0.f, sp = 1.f, e = 0.f, rq = 0.f, rp = 0.f, c_raw = 0.f, c_fn = 0.f;
+  if (own) {
+    mq = a.mu_q[o]; sq = a.sd_q[o]; mp = a.mu_p[o]; sp = a.sd_p[o]; e = a.eps[o]; rq = a.raw_q[o]; rp = a.raw_p[o];
+    if ((a.c_fn != nullptr || a.c_raw != nullptr) && (long long)a.t * a.stride < a.x_sl[row]) {
+      if (a.c_raw != nullptr) c_raw = a.c_raw[row];
+      if (a.c_fn != nullptr) c_fn = a.c_fn[row];
     }
   }
+  f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+  acc[0] = wave_gemm16<NW>(a.D, a.H, r0, a.B, a.WT, a.H, c0, a.H, threadIdx.x >> 6, acc[0]);
+  float v[1];
+  reduce_tiles<1, NW>(acc, red, v);
+  if (!own) return;
+  const float dz = v[0];
   const float d = mq - mp, ip2 = 1.f / (sp * sp);
+  float coef = c_raw;
+  if (c_fn != 0.f) {
+    const float k = logf(sp) - logf(sq) + (sq * sq + d * d) * 0.5f * ip2 - 0.5f;
+    if (!(a.fn_floor > 0.f) || k > a.fn_floor) coef += c_fn;
+  }
   const float g_muq = dz + coef * d * ip2;
-  const float g_sdq = dz * a.eps[o] + coef * (sq * ip2 - 1.f / sq);
+  const float g_sdq = dz * e + coef * (sq * ip2 - 1.f / sq);
   const float g_mup = -coef * d * ip2 + (a.residual ? g_muq : 0.f);
   const float g_sdp = coef * (1.f / sp - (sq * sq + d * d) * ip2 / sp);
   const size_t o2 = (size_t)row * 2 * a.Z + col;
   a.dqh[o2] = g_muq;
-  a.dqh[o2 + a.Z] = g_sdq * sigmoidf_(a.beta * a.raw_q[o]);
+  a.dqh[o2 + a.Z] = g_sdq * sigmoidf_(a.beta * rq);
   a.dph[o2] = g_mup;
-  a.dph[o2 + a.Z] = g_sdp * sigmoidf_(a.beta * a.raw_p[o]);
+  a.dph[o2 + a.Z] = g_sdp * sigmoidf_(a.beta * rp);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -197,35 +231,57 @@ struct DhArgs {
   int B, H, R, has_gemm, has_gates;
 };
 
-__global__ __launch_bounds__(256) void dh_stage_kernel(DhArgs a) {
-  __shared__ float red[2 * 4 * 256];
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void dh_stage_kernel(DhArgs a) {
+  __shared__ float red[2 * NW * 256];
   const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, wave = threadIdx.x >> 6;
+  const int ldd = a.H + a.R;
+  const int row = r0 + (threadIdx.x >> 4), col = c0 + (threadIdx.x & 15);
+  const bool own = threadIdx.x < 256 && row < a.B;
+  const size_t o = (size_t)row * a.R + col, o3 = (size_t)row * 3 * a.R + col;
+  float g0 = 0.f, r = 0.f, u = 0.f, n = 0.f, hn = 0.f, hp = 0.f, dd = 0.f;
+  if (own) {
+    g0 = a.G[o];
+    if (a.has_gates) {
+      r = a.rg[o]; u = a.ug[o]; n = a.ng[o]; hn = a.gh[o3 + 2 * a.R];
+      hp = a.decin_s[(size_t)row * ldd + a.H + col];
+      dd = a.ddecin_s[(size_t)row * ldd + a.H + col];
+    }
+  }
   float v[2] = {0.f, 0.f};
   if (a.has_gemm) {
     f32x4 acc[2];
     acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[0] = wave_gemm16(a.DP0, a.H, r0, a.B, a.WpT, a.H, c0, a.H, wave, acc[0]);
-    acc[1] = wave_gemm16(a.DQ0, a.H, r0, a.B, a.WqT, a.H, c0, a.H, wave, acc[1]);
-    reduce_tiles<2>(acc, red, v);
+    acc[0] = wave_gemm16<NW>(a.DP0, a.H, r0, a.B, a.WpT, a.H, c0, a.H, wave, acc[0]);
+    acc[1] = wave_gemm16<NW>(a.DQ0, a.H, r0, a.B, a.WqT, a.H, c0, a.H, wave, acc[1]);
+    reduce_tiles<2, NW>(acc, red, v);
   }
-  const int row = r0 + (threadIdx.x >> 4), col = c0 + (threadIdx.x & 15);
-  if (row >= a.B) return;
-  const size_t o = (size_t)row * a.R + col;
-  const float g = a.G[o] + v[0] + v[1];
+  if (!own) return;
+  const float g = g0 + v[0] + v[1];
   if (!a.has_gates) { a.G[o] = g; return; }
-  const int ldd = a.H + a.R;
-  const float r = a.rg[o], u = a.ug[o], n = a.ng[o];
-  const size_t o3 = (size_t)row * 3 * a.R + col;
-  const float hn = a.gh[o3 + 2 * a.R];
-  const float hp = a.decin_s[(size_t)row * ldd + a.H + col];
   const float dn_pre = g * (1.f - u) * (1.f - n * n);
   const float du_pre = g * (hp - n) * u * (1.f - u);
   const float dr_pre = dn_pre * hn * r * (1.f - r);
   a.dgi[o3] = dr_pre; a.dgi[o3 + a.R] = du_pre; a.dgi[o3 + 2 * a.R] = dn_pre;
   a.dgh[o3] = dr_pre; a.dgh[o3 + a.R] = du_pre; a.dgh[o3 + 2 * a.R] = dn_pre * r;
-  a.G[o] = g * u + a.ddecin_s[(size_t)row * ldd + a.H + col];
+  a.G[o] = g * u + dd;
 }
+
+// number of waves for a K-deep reduction: <= 4 chunks of 16 per wave where possible
+inline int pick_nw(int K, int groups) {
+  const int chunks = (K / 16) * groups;
+  if (chunks > 32) return 16;
+  if (chunks > 16) return 8;
+  return 4;
+}
+
+#define LAUNCH_NW(kernel, nw, grid, stream, args)                                          \
+  do {                                                                                     \
+    if ((nw) == 16) hipLaunchKernelGGL((kernel<16>), grid, dim3(1024), 0, stream, args);   \
+    else if ((nw) == 8) hipLaunchKernelGGL((kernel<8>), grid, dim3(512), 0, stream, args); \
+    else hipLaunchKernelGGL((kernel<4>), grid, dim3(256), 0, stream, args);                \
+  } while (0)
 
 // ---------------------------------------------------------------------------------------------------------------
 // reserve / workspace carving
@@ -288,18 +344,35 @@ int check_dims(int Tp, int B, int X, int H, int Z, int R) {
   return BLVM_OK;
 }
 
-inline LinSeg seg(const float* A, int lda, const float* W, int ldw, const float* bias, const float* add, int ldadd,
-                  const float* gate, int ldgate, float* out, int ldo, int ncols, int K, int relu) {
-  LinSeg s;
-  s.A = A; s.lda = lda; s.W = W; s.ldw = ldw; s.bias = bias; s.add = add; s.ldadd = ldadd;
-  s.gate = gate; s.ldgate = ldgate; s.out = out; s.ldo = ldo; s.ncols = ncols; s.K = K; s.relu = relu;
-  return s;
+struct LinSegH {  // host-side description of one segment
+  const float* A; int lda; const float* W; int ldw; const float* bias; const float* add; int ldadd;
+  const float* gate; int ldgate; float* out; int ldo; int ncols, K, relu;
+};
+
+inline LinSegH seg(const float* A, int lda, const float* W, int ldw, const float* bias, const float* add, int ldadd,
+                   const float* gate, int ldgate, float* out, int ldo, int ncols, int K, int relu) {
+  return LinSegH{A, lda, W, ldw, bias, add, ldadd, gate, ldgate, out, ldo, ncols, K, relu};
 }
 
-inline void launch_lin(const LinArgs& a, hipStream_t s) {
+struct LinLaunch {
+  LinSegH seg[3];
+  int nseg, B;
+};
+
+inline void launch_lin(const LinLaunch& l, hipStream_t s) {
+  LinArgs a{};
   int tiles = 0;
-  for (int i = 0; i < a.nseg; ++i) tiles += a.seg[i].ncols / 16;
-  hipLaunchKernelGGL(lin_stage_kernel, dim3(tiles, (a.B + 15) / 16), dim3(256), 0, s, a);
+  for (int i = 0; i < 3; ++i) {
+    const LinSegH& g = l.seg[i < l.nseg ? i : 0];
+    a.A[i] = g.A; a.lda[i] = g.lda; a.W[i] = g.W; a.ldw[i] = g.ldw; a.bias[i] = g.bias;
+    a.add[i] = g.add; a.ldadd[i] = g.ldadd; a.gate[i] = g.gate; a.ldgate[i] = g.ldgate;
+    a.out[i] = g.out; a.ldo[i] = g.ldo; a.tiles[i] = g.ncols / 16; a.relu[i] = g.relu;
+    if (i < l.nseg) tiles += g.ncols / 16;
+  }
+  a.nseg = l.nseg; a.B = l.B; a.K = l.seg[0].K;  // all segments of one launch share K
+  const int nw = pick_nw(a.K, 1);
+  const dim3 grid(tiles, (l.B + 15) / 16);
+  LAUNCH_NW(lin_stage_kernel, nw, grid, s, a);
 }
 
 int pick_split(int M, int N, int K) {
@@ -363,14 +436,13 @@ extern "C" int blvm_vrnn_seq_fwd(const BlvmVrnnWeights* w, const float* enc, con
   if (h0) BLVM_HIP(hipMemcpy2DAsync(decin + H, sizeof(float) * ldd, h0, sizeof(float) * R, sizeof(float) * R, B, hipMemcpyDeviceToDevice, s));
   else BLVM_HIP(hipMemset2DAsync(decin + H, sizeof(float) * ldd, 0, sizeof(float) * R, B, s));
 
-  const dim3 blk(256);
   const int rt = (B + 15) / 16;
   for (int t = 0; t < Tp; ++t) {
     const size_t oH = (size_t)t * B * H, oZ = (size_t)t * B * Z, oR = (size_t)t * B * R, o3R = (size_t)t * B * 3 * R;
     const float* dec_t = decin + (size_t)t * B * ldd;
     float* dec_n = decin + (size_t)(t + 1) * B * ldd;
     const float* hprev = dec_t + H;
-    LinArgs a;
+    LinLaunch a;
     a.B = B;
     // F1: first prior layer | h-half of first posterior layer | GRU hidden projection
     a.nseg = 3;
@@ -394,7 +466,7 @@ extern "C" int blvm_vrnn_seq_fwd(const BlvmVrnnWeights* w, const float* enc, con
     h.raw_p = rs.RAWP + oZ; h.raw_q = rs.RAWQ + oZ;
     h.B = B; h.H = H; h.Z = Z; h.residual = residual_posterior;
     h.beta = beta; h.inv_beta = 1.f / beta; h.sd_eps = sd_eps;
-    hipLaunchKernelGGL(head_stage_kernel, dim3(Z / 16, rt), blk, 0, s, h);
+    LAUNCH_NW(head_stage_kernel, pick_nw(H, 4), dim3(Z / 16, rt), s, h);
     // F5..F8: phi_z MLP (last layer writes phi into decin row t)
     a.nseg = 1;
     a.seg[0] = seg(z + oZ, Z, w->phi_w[0], Z, w->phi_b[0], nullptr, 0, nullptr, 0, rs.FZ[0] + oH, H, H, Z, 1);
@@ -411,7 +483,7 @@ extern "C" int blvm_vrnn_seq_fwd(const BlvmVrnnWeights* w, const float* enc, con
     g.xg = rs.XG + o3R; g.gh = rs.GHb + o3R;
     g.rg = rs.RG + oR; g.ug = rs.UG + oR; g.ng = rs.NG + oR;
     g.B = B; g.X = X; g.H = H; g.R = R;
-    hipLaunchKernelGGL(gru_stage_kernel, dim3(R / 16, rt), blk, 0, s, g);
+    LAUNCH_NW(gru_stage_kernel, pick_nw(H, 3), dim3(R / 16, rt), s, g);
   }
   BLVM_CHECK_LAUNCH("vrnn_seq_fwd");
   return BLVM_OK;
@@ -453,7 +525,6 @@ extern "C" int blvm_vrnn_seq_bwd(const BlvmVrnnWeights* w, const float* enc, con
   rc = transpose_f32(3 * R, R, w->gru_whh, R, ws.whhT, 3 * R, s); if (rc) return rc;
 
   BLVM_HIP(hipMemsetAsync(ws.G, 0, sizeof(float) * (size_t)B * R, s));
-  const dim3 blk(256);
   const int rt = (B + 15) / 16;
 
   auto launch_dh = [&](int t_gemm, int s_gates) {
@@ -468,7 +539,7 @@ extern "C" int blvm_vrnn_seq_bwd(const BlvmVrnnWeights* w, const float* enc, con
     d.decin_s = decin + sg * B * ldd; d.ddecin_s = d_decin + sg * B * ldd;
     d.dgi = ws.DGI + sg * B * 3 * R; d.dgh = ws.DGH + sg * B * 3 * R;
     d.B = B; d.H = H; d.R = R;
-    hipLaunchKernelGGL(dh_stage_kernel, dim3(R / 16, rt), blk, 0, s, d);
+    LAUNCH_NW(dh_stage_kernel, pick_nw(H, 2), dim3(R / 16, rt), s, d);
   };
 
   launch_dh(-1, Tp - 1);  // G(T') = 0: gate derivatives of the last step, G <- d_decin h-part of row T'-1
@@ -476,7 +547,7 @@ extern "C" int blvm_vrnn_seq_bwd(const BlvmVrnnWeights* w, const float* enc, con
     const size_t oH = (size_t)t * B * H, oZ = (size_t)t * B * Z, o3R = (size_t)t * B * 3 * R, o2Z = (size_t)t * B * 2 * Z;
     const float* dec_t = decin + (size_t)t * B * ldd;
     const float* ddec_t = d_decin + (size_t)t * B * ldd;
-    LinArgs a;
+    LinLaunch a;
     a.B = B;
     // B2: dphi (through ReLU of phi, plus the decoder's gradient) | G += DGH Whh
     a.nseg = 2;
@@ -498,7 +569,7 @@ extern "C" int blvm_vrnn_seq_bwd(const BlvmVrnnWeights* w, const float* enc, con
     d.dqh = ws.DQH + o2Z; d.dph = ws.DPH + o2Z;
     d.B = B; d.H = H; d.Z = Z; d.residual = residual_posterior; d.t = t; d.stride = stride;
     d.fn_floor = fn_floor; d.beta = beta;
-    hipLaunchKernelGGL(dz_stage_kernel, dim3(Z / 16, rt), blk, 0, s, d);
+    LAUNCH_NW(dz_stage_kernel, pick_nw(H, 1), dim3(Z / 16, rt), s, d);
     // B7: heads -> last hidden layers
     a.nseg = 2;
     a.seg[0] = seg(ws.DPH + o2Z, 2 * Z, ws.phT, 2 * Z, nullptr, nullptr, 0, rs.P[2] + oH, H, ws.DP[2] + oH, H, H, 2 * Z, 0);
