@@ -29,51 +29,58 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------
 
 // generic multi-segment linear stage:  out = gate( act( A W^T + bias + add ) )
+// Struct-of-arrays + scalar selects: every field is a plain kernarg scalar (s_load -> SGPR -> s_cselect); absent
+// operands are replaced on the host by a valid dummy pointer (W) plus a flag bit, so all prefetches are unconditional.
+enum { LF_BIAS = 1, LF_ADD = 2, LF_GATE = 4, LF_RELU = 8 };
+
+template <int NSEG>
 struct LinArgs {
-  const float* A[3];     int lda[3];     // [B,K]
-  const float* W[3];     int ldw[3];     // [ncols,K], k contiguous
-  const float* bias[3];                  // [ncols] or null
-  const float* add[3];   int ldadd[3];   // [B,ncols] or null (may alias out)
-  const float* gate[3];  int ldgate[3];  // [B,ncols] or null: result *= (gate > 0)
-  float* out[3];         int ldo[3];     // [B,ncols]
-  int tiles[3];                          // ncols / 16 per segment
-  int relu[3];
-  int nseg, B, K;
+  const float* A[NSEG];     // [B,K]
+  const float* W[NSEG];     // [ncols,K], k contiguous
+  const float* bias[NSEG];  // [ncols]
+  const float* add[NSEG];   // [B,ncols] (may alias out)
+  const float* gate[NSEG];  // [B,ncols]: result *= (gate > 0)
+  float* out[NSEG];         // [B,ncols]
+  int lda[NSEG], ldw[NSEG], ldadd[NSEG], ldgate[NSEG], ldo[NSEG], tiles[NSEG], flags[NSEG];
+  int B, K;
 };
 
-#define SEL3(f, s) ((s) == 0 ? (f)[0] : ((s) == 1 ? (f)[1] : (f)[2]))
+#define PICK(f) (NSEG == 1 ? a.f[0] : (s == 0 ? a.f[0] : (NSEG == 2 || s == 1 ? a.f[NSEG > 1 ? 1 : 0] : a.f[NSEG > 2 ? 2 : 0])))
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void lin_stage_kernel(LinArgs a) {
+template <int NW, int NSEG>
+__global__ __launch_bounds__(NW * 64) void lin_stage_kernel(LinArgs<NSEG> a) {
   __shared__ float red[NW * 256];
   int ct = blockIdx.x, s = 0;
-  if (a.nseg > 1 && ct >= a.tiles[0]) { ct -= a.tiles[0]; s = 1; }
-  if (a.nseg > 2 && s == 1 && ct >= a.tiles[1]) { ct -= a.tiles[1]; s = 2; }
-  const float* A = SEL3(a.A, s);       const int lda = SEL3(a.lda, s);
-  const float* W = SEL3(a.W, s);       const int ldw = SEL3(a.ldw, s);
-  const float* bias = SEL3(a.bias, s);
-  const float* add = SEL3(a.add, s);   const int ldadd = SEL3(a.ldadd, s);
-  const float* gate = SEL3(a.gate, s); const int ldgate = SEL3(a.ldgate, s);
-  float* out = SEL3(a.out, s);         const int ldo = SEL3(a.ldo, s);
-  const int relu = SEL3(a.relu, s);
-  const int r0 = blockIdx.y * 16, c0 = ct * 16;
-  const int row = r0 + (threadIdx.x >> 4), col = c0 + (threadIdx.x & 15);
-  const bool own = threadIdx.x < 256 && row < a.B;
-  // epilogue operands first: they travel with the operand loads instead of after the reduction
-  float e_bias = 0.f, e_add = 0.f, e_gate = 1.f;
-  if (own) {
-    if (bias) e_bias = bias[col];
-    if (add) e_add = add[(size_t)row * ldadd + col];
-    if (gate) e_gate = gate[(size_t)row * ldgate + col];
+  if (NSEG > 1) {
+    const int t0 = a.tiles[0], t1 = a.tiles[NSEG > 1 ? 1 : 0];
+    s = (ct >= t0 ? 1 : 0) + ((NSEG > 2 && ct >= t0 + t1) ? 1 : 0);
+    ct -= (s >= 1 ? t0 : 0) + (s >= 2 ? t1 : 0);
   }
+  const float* A = PICK(A);
+  const float* W = PICK(W);
+  const float* bias = PICK(bias);
+  const float* add = PICK(add);
+  const float* gate = PICK(gate);
+  float* out = PICK(out);
+  const int lda = PICK(lda), ldw = PICK(ldw), ldadd = PICK(ldadd), ldgate = PICK(ldgate), ldo = PICK(ldo);
+  const int flags = PICK(flags);
+  const int r0 = blockIdx.y * 16, c0 = ct * 16;
+  const int t = threadIdx.x & 255;
+  const int row = r0 + (t >> 4), col = c0 + (t & 15);
+  const bool own = threadIdx.x < 256 && row < a.B;
+  const int rowc = row < a.B ? row : r0;  // clamped row: the prefetches below are unconditional
+  // epilogue operands first: they travel with the operand loads instead of after the reduction
+  const float e_bias = bias[(flags & LF_BIAS) ? col : 0];
+  const float e_add = add[(flags & LF_ADD) ? (size_t)rowc * ldadd + col : 0];
+  const float e_gate = gate[(flags & LF_GATE) ? (size_t)rowc * ldgate + col : 0];
   f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
   acc[0] = wave_gemm16<NW>(A, lda, r0, a.B, W, ldw, c0, a.K, threadIdx.x >> 6, acc[0]);
   float v[1];
   reduce_tiles<1, NW>(acc, red, v);
   if (!own) return;
-  float x = v[0] + e_bias + e_add;
-  if (relu) x = x > 0.f ? x : 0.f;
-  x = e_gate > 0.f ? x : 0.f;
+  float x = v[0] + ((flags & LF_BIAS) ? e_bias : 0.f) + ((flags & LF_ADD) ? e_add : 0.f);
+  if (flags & LF_RELU) x = x > 0.f ? x : 0.f;
+  if (flags & LF_GATE) x = e_gate > 0.f ? x : 0.f;
   out[(size_t)row * ldo + col] = x;
 }
 
@@ -359,20 +366,33 @@ struct LinLaunch {
   int nseg, B;
 };
 
-inline void launch_lin(const LinLaunch& l, hipStream_t s) {
-  LinArgs a{};
+template <int NSEG>
+inline void launch_lin_n(const LinLaunch& l, hipStream_t s) {
+  LinArgs<NSEG> a{};
   int tiles = 0;
-  for (int i = 0; i < 3; ++i) {
-    const LinSegH& g = l.seg[i < l.nseg ? i : 0];
-    a.A[i] = g.A; a.lda[i] = g.lda; a.W[i] = g.W; a.ldw[i] = g.ldw; a.bias[i] = g.bias;
-    a.add[i] = g.add; a.ldadd[i] = g.ldadd; a.gate[i] = g.gate; a.ldgate[i] = g.ldgate;
-    a.out[i] = g.out; a.ldo[i] = g.ldo; a.tiles[i] = g.ncols / 16; a.relu[i] = g.relu;
-    if (i < l.nseg) tiles += g.ncols / 16;
+  for (int i = 0; i < NSEG; ++i) {
+    const LinSegH& g = l.seg[i];
+    a.A[i] = g.A; a.W[i] = g.W; a.out[i] = g.out;
+    a.bias[i] = g.bias ? g.bias : g.W;   // valid dummy for absent operands
+    a.add[i] = g.add ? g.add : g.W;
+    a.gate[i] = g.gate ? g.gate : g.W;
+    a.lda[i] = g.lda; a.ldw[i] = g.ldw; a.ldadd[i] = g.ldadd; a.ldgate[i] = g.ldgate; a.ldo[i] = g.ldo;
+    a.tiles[i] = g.ncols / 16;
+    a.flags[i] = (g.bias ? LF_BIAS : 0) | (g.add ? LF_ADD : 0) | (g.gate ? LF_GATE : 0) | (g.relu ? LF_RELU : 0);
+    tiles += g.ncols / 16;
   }
-  a.nseg = l.nseg; a.B = l.B; a.K = l.seg[0].K;  // all segments of one launch share K
+  a.B = l.B; a.K = l.seg[0].K;  // all segments of one launch share K
   const int nw = pick_nw(a.K, 1);
   const dim3 grid(tiles, (l.B + 15) / 16);
-  LAUNCH_NW(lin_stage_kernel, nw, grid, s, a);
+  if (nw == 16) hipLaunchKernelGGL((lin_stage_kernel<16, NSEG>), grid, dim3(1024), 0, s, a);
+  else if (nw == 8) hipLaunchKernelGGL((lin_stage_kernel<8, NSEG>), grid, dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((lin_stage_kernel<4, NSEG>), grid, dim3(256), 0, s, a);
+}
+
+inline void launch_lin(const LinLaunch& l, hipStream_t s) {
+  if (l.nseg == 1) launch_lin_n<1>(l, s);
+  else if (l.nseg == 2) launch_lin_n<2>(l, s);
+  else launch_lin_n<3>(l, s);
 }
 
 int pick_split(int M, int N, int K) {
