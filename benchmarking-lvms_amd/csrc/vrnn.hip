@@ -100,11 +100,12 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64) void head_stage_kernel(HeadArgs a) {
   __shared__ float red[4 * NW * 256];
   const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, wave = threadIdx.x >> 6;
-  const int row = r0 + (threadIdx.x >> 4), col = c0 + (threadIdx.x & 15);
+  const int t = threadIdx.x & 255;
+  const int row = r0 + (t >> 4), col = c0 + (t & 15);
   const bool own = threadIdx.x < 256 && row < a.B;
   const size_t o = (size_t)row * a.Z + col;
-  float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f, e = 0.f;
-  if (own) { b0 = a.bp[col]; b1 = a.bp[a.Z + col]; b2 = a.bq[col]; b3 = a.bq[a.Z + col]; e = a.eps[o]; }
+  const size_t oc = (size_t)(row < a.B ? row : r0) * a.Z + col;  // clamped: unconditional prefetch
+  const float b0 = a.bp[col], b1 = a.bp[a.Z + col], b2 = a.bq[col], b3 = a.bq[a.Z + col], e = a.eps[oc];
   f32x4 acc[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -145,15 +146,14 @@ __global__ __launch_bounds__(NW * 64) void gru_stage_kernel(GruArgs a) {
   __shared__ float red[3 * NW * 256];
   const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, wave = threadIdx.x >> 6;
   const int ldd = a.H + a.R, ldw = a.X + a.H;
-  const int row = r0 + (threadIdx.x >> 4), col = c0 + (threadIdx.x & 15);
+  const int t = threadIdx.x & 255;
+  const int row = r0 + (t >> 4), col = c0 + (t & 15);
   const bool own = threadIdx.x < 256 && row < a.B;
-  const size_t o3 = (size_t)row * 3 * a.R + col;
-  float x0 = 0.f, x1 = 0.f, x2 = 0.f, hr = 0.f, hz = 0.f, hn = 0.f, hp = 0.f;
-  if (own) {
-    x0 = a.xg[o3]; x1 = a.xg[o3 + a.R]; x2 = a.xg[o3 + 2 * a.R];
-    hr = a.gh[o3]; hz = a.gh[o3 + a.R]; hn = a.gh[o3 + 2 * a.R];
-    hp = a.decin_t[(size_t)row * ldd + a.H + col];
-  }
+  const int rowc = row < a.B ? row : r0;  // clamped: unconditional prefetch
+  const size_t o3 = (size_t)rowc * 3 * a.R + col;
+  const float x0 = a.xg[o3], x1 = a.xg[o3 + a.R], x2 = a.xg[o3 + 2 * a.R];
+  const float hr = a.gh[o3], hz = a.gh[o3 + a.R], hn = a.gh[o3 + 2 * a.R];
+  const float hp = a.decin_t[(size_t)rowc * ldd + a.H + col];
   f32x4 acc[3];
 #pragma unroll
   for (int g = 0; g < 3; ++g) {
@@ -189,16 +189,19 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64) void dz_stage_kernel(DzArgs a) {
   __shared__ float red[NW * 256];
   const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16;
-  const int row = r0 + (threadIdx.x >> 4), col = c0 + (threadIdx.x & 15);
+  const int t = threadIdx.x & 255;
+  const int row = r0 + (t >> 4), col = c0 + (t & 15);
   const bool own = threadIdx.x < 256 && row < a.B;
-  const size_t o = (size_t)row * a.Z + col;
-  float mq = 0.f, sq = 1.f, mp = 0.f, sp = 1.f, e = 0.f, rq = 0.f, rp = 0.f, c_raw = 0.f, c_fn = 0.f;
-  if (own) {
-    mq = a.mu_q[o]; sq = a.sd_q[o]; mp = a.mu_p[o]; sp = a.sd_p[o]; e = a.eps[o]; rq = a.raw_q[o]; rp = a.raw_p[o];
-    if ((a.c_fn != nullptr || a.c_raw != nullptr) && (long long)a.t * a.stride < a.x_sl[row]) {
-      if (a.c_raw != nullptr) c_raw = a.c_raw[row];
-      if (a.c_fn != nullptr) c_fn = a.c_fn[row];
-    }
+  const int rowc = row < a.B ? row : r0;  // clamped: unconditional prefetch
+  const size_t o = (size_t)rowc * a.Z + col;
+  const float mq = a.mu_q[o], sq = a.sd_q[o], mp = a.mu_p[o], sp = a.sd_p[o], e = a.eps[o], rq = a.raw_q[o], rp = a.raw_p[o];
+  float c_raw = 0.f, c_fn = 0.f;
+  if (a.c_fn != nullptr || a.c_raw != nullptr) {  // wave-uniform
+    const bool live = (long long)a.t * a.stride < a.x_sl[rowc];
+    const float cr = a.c_raw != nullptr ? a.c_raw[rowc] : 0.f;
+    const float cf = a.c_fn != nullptr ? a.c_fn[rowc] : 0.f;
+    c_raw = live ? cr : 0.f;
+    c_fn = live ? cf : 0.f;
   }
   f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
   acc[0] = wave_gemm16<NW>(a.D, a.H, r0, a.B, a.WT, a.H, c0, a.H, threadIdx.x >> 6, acc[0]);
@@ -243,17 +246,17 @@ __global__ __launch_bounds__(NW * 64) void dh_stage_kernel(DhArgs a) {
   __shared__ float red[2 * NW * 256];
   const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, wave = threadIdx.x >> 6;
   const int ldd = a.H + a.R;
-  const int row = r0 + (threadIdx.x >> 4), col = c0 + (threadIdx.x & 15);
+  const int t = threadIdx.x & 255;
+  const int row = r0 + (t >> 4), col = c0 + (t & 15);
   const bool own = threadIdx.x < 256 && row < a.B;
-  const size_t o = (size_t)row * a.R + col, o3 = (size_t)row * 3 * a.R + col;
-  float g0 = 0.f, r = 0.f, u = 0.f, n = 0.f, hn = 0.f, hp = 0.f, dd = 0.f;
-  if (own) {
-    g0 = a.G[o];
-    if (a.has_gates) {
-      r = a.rg[o]; u = a.ug[o]; n = a.ng[o]; hn = a.gh[o3 + 2 * a.R];
-      hp = a.decin_s[(size_t)row * ldd + a.H + col];
-      dd = a.ddecin_s[(size_t)row * ldd + a.H + col];
-    }
+  const int rowc = row < a.B ? row : r0;  // clamped: unconditional prefetch
+  const size_t o = (size_t)rowc * a.R + col, o3 = (size_t)rowc * 3 * a.R + col;
+  const float g0 = a.G[o];
+  float r = 0.f, u = 0.f, n = 0.f, hn = 0.f, hp = 0.f, dd = 0.f;
+  if (a.has_gates) {  // wave-uniform
+    r = a.rg[o]; u = a.ug[o]; n = a.ng[o]; hn = a.gh[o3 + 2 * a.R];
+    hp = a.decin_s[(size_t)rowc * ldd + a.H + col];
+    dd = a.ddecin_s[(size_t)rowc * ldd + a.H + col];
   }
   float v[2] = {0.f, 0.f};
   if (a.has_gemm) {
