@@ -55,6 +55,16 @@ _SIGNATURES = {
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p,
                                   c_void_p, ctypes.POINTER(VrnnWeights), c_void_p, c_void_p]),
+    "blvm_lstm_reserve_floats": (c_size_t, [c_int] * 3),
+    "blvm_lstm_bwd_workspace_floats": (c_size_t, [c_int] * 3),
+    "blvm_lstm_seq_fwd": (c_int, [c_void_p] * 8 + [c_int] * 4 + [c_void_p] * 5),
+    "blvm_lstm_seq_bwd": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 9),
+    "blvm_gru_reserve_floats": (c_size_t, [c_int] * 3),
+    "blvm_gru_bwd_workspace_floats": (c_size_t, [c_int] * 3),
+    "blvm_gru_seq_fwd": (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p, ctypes.c_longlong, c_int]
+                         + [c_void_p] * 3),
+    "blvm_gru_seq_bwd": (c_int, [c_void_p] * 3 + [c_int, c_void_p, c_int, c_void_p, c_void_p, ctypes.c_longlong, c_int]
+                         + [c_int] * 4 + [c_void_p, c_int, c_int] + [c_void_p] * 7),
 }  # fmt: skip
 
 EXPORTS = tuple(_SIGNATURES)

@@ -1,2 +1,3 @@
 from blvm.models.base_model import BaseModel, load_model  # noqa: F401
+from blvm.models.lstm import LSTMAudio  # noqa: F401
 from blvm.models.vrnn import VRNN, VRNNAudio, VRNNCell  # noqa: F401

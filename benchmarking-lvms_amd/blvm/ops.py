@@ -326,3 +326,111 @@ def vrnn_sequence(enc, h0, eps, x_sl_dev, params: Sequence[torch.Tensor], X, H, 
     fn_floor = float(free_nats) / Z if free_nats else 0.0
     cfg = (Tp, B, X, H, Z, R, bool(residual_posterior), float(sd_eps), int(stride), fn_floor)
     return _VRNNSeqFunction.apply(enc, h0, eps, x_sl_dev, cfg, *params)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# K4: LSTM over a sequence (packed-sequence semantics through `lens`)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+class _LSTMSeqFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inp, h0, c0, lens_dev, Wih, Whh, bih, bhh):
+        inp, Wih, Whh, bih, bhh = (_f32c(t) for t in (inp, Wih, Whh, bih, bhh))
+        T, B, I = inp.shape
+        H = Whh.shape[1]
+        lib = load()
+        f32 = dict(device=inp.device, dtype=torch.float32)
+        out = torch.empty(T, B, H, **f32)
+        hn, cn = torch.empty(B, H, **f32), torch.empty(B, H, **f32)
+        reserve = torch.empty(lib.blvm_lstm_reserve_floats(T, B, H), **f32)
+        check(
+            lib.blvm_lstm_seq_fwd(ptr(Wih), ptr(Whh), ptr(bih), ptr(bhh), ptr(inp), ptr(_f32c(h0)) if h0 is not None else None,
+                                  ptr(_f32c(c0)) if c0 is not None else None, ptr(lens_dev), T, B, I, H, ptr(out), ptr(hn), ptr(cn),
+                                  ptr(reserve), stream_ptr()),
+            "blvm_lstm_seq_fwd",
+        )  # fmt: skip
+        ctx.dims = (T, B, I, H)
+        ctx.has_state = (h0 is not None, c0 is not None)
+        ctx.save_for_backward(inp, Wih, Whh, reserve)
+        ctx.mark_non_differentiable(hn, cn)
+        return out, hn, cn
+
+    @staticmethod
+    def backward(ctx, d_out, _dhn, _dcn):
+        T, B, I, H = ctx.dims
+        inp, Wih, Whh, reserve = ctx.saved_tensors
+        lib = load()
+        f32 = dict(device=inp.device, dtype=torch.float32)
+        d_out = _f32c(d_out)
+        d_in = torch.empty_like(inp) if ctx.needs_input_grad[0] else None
+        d_h0 = torch.empty(B, H, **f32) if ctx.has_state[0] and ctx.needs_input_grad[1] else None
+        d_c0 = torch.empty(B, H, **f32) if ctx.has_state[1] and ctx.needs_input_grad[2] else None
+        dWih, dWhh = torch.zeros_like(Wih), torch.zeros_like(Whh)
+        dbih, dbhh = torch.zeros(4 * H, **f32), torch.zeros(4 * H, **f32)
+        ws = torch.empty(lib.blvm_lstm_bwd_workspace_floats(T, B, H), **f32)
+        check(
+            lib.blvm_lstm_seq_bwd(ptr(Wih), ptr(Whh), ptr(inp), ptr(reserve), ptr(d_out), T, B, I, H, ptr(d_in), ptr(d_h0),
+                                  ptr(d_c0), ptr(dWih), ptr(dWhh), ptr(dbih), ptr(dbhh), ptr(ws), stream_ptr()),
+            "blvm_lstm_seq_bwd",
+        )  # fmt: skip
+        return d_in, d_h0, d_c0, None, dWih, dWhh, dbih, dbhh
+
+
+def lstm_sequence(inp, h0, c0, lens_dev, Wih, Whh, bih, bhh):
+    """inp [T,B,I] -> (out [T,B,H] zero past each row's length, h_n, c_n [B,H])."""
+    return _LSTMSeqFunction.apply(inp, h0, c0, lens_dev, Wih, Whh, bih, bhh)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# K2: GRU over a sequence, optionally reversed per row (reverse_sequences folded into the kernel's index map)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+class _GRUSeqFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inp, h0, lens_dev, reverse, Wih, Whh, bih, bhh):
+        inp, Wih, Whh, bih, bhh = (_f32c(t) for t in (inp, Wih, Whh, bih, bhh))
+        T, B, I = inp.shape
+        R = Whh.shape[1]
+        lib = load()
+        f32 = dict(device=inp.device, dtype=torch.float32)
+        out = torch.empty(T, B, R, **f32)
+        hn = torch.empty(B, R, **f32)
+        reserve = torch.empty(lib.blvm_gru_reserve_floats(T, B, R), **f32)
+        check(
+            lib.blvm_gru_seq_fwd(ptr(Wih), ptr(Whh), ptr(bih), ptr(bhh), ptr(inp), I, ptr(_f32c(h0)) if h0 is not None else None,
+                                 ptr(lens_dev), int(reverse), T, B, I, R, ptr(out), B * R, R, ptr(hn), ptr(reserve), stream_ptr()),
+            "blvm_gru_seq_fwd",
+        )  # fmt: skip
+        ctx.dims = (T, B, I, R, int(reverse))
+        ctx.has_h0 = h0 is not None
+        ctx.save_for_backward(inp, Wih, Whh, reserve, lens_dev)
+        ctx.mark_non_differentiable(hn)
+        return out, hn
+
+    @staticmethod
+    def backward(ctx, d_out, _dhn):
+        T, B, I, R, reverse = ctx.dims
+        inp, Wih, Whh, reserve, lens_dev = ctx.saved_tensors
+        lib = load()
+        f32 = dict(device=inp.device, dtype=torch.float32)
+        d_out = _f32c(d_out)
+        d_in = torch.empty_like(inp) if ctx.needs_input_grad[0] else None
+        d_h0 = torch.empty(B, R, **f32) if ctx.has_h0 and ctx.needs_input_grad[1] else None
+        dWih, dWhh = torch.zeros_like(Wih), torch.zeros_like(Whh)
+        dbih, dbhh = torch.zeros(3 * R, **f32), torch.zeros(3 * R, **f32)
+        ws = torch.empty(lib.blvm_gru_bwd_workspace_floats(T, B, R), **f32)
+        check(
+            lib.blvm_gru_seq_bwd(ptr(Wih), ptr(Whh), ptr(inp), I, ptr(lens_dev), reverse, ptr(reserve), ptr(d_out), B * R, R, T, B,
+                                 I, R, ptr(d_in), I, 0, ptr(d_h0), ptr(dWih), ptr(dWhh), ptr(dbih), ptr(dbhh), ptr(ws),
+                                 stream_ptr()),
+            "blvm_gru_seq_bwd",
+        )  # fmt: skip
+        return d_in, d_h0, None, None, dWih, dWhh, dbih, dbhh
+
+
+def gru_sequence(inp, h0, Wih, Whh, bih, bhh, lens_dev=None, reverse=False):
+    """inp [T,B,I] -> (out [T,B,R], h_n [B,R]).  reverse=True: per-row time reversal that leaves right padding in
+    place (needs lens_dev [B] int32) — equivalent to reverse_sequences -> GRU -> reverse_sequences."""
+    return _GRUSeqFunction.apply(inp, h0, lens_dev, reverse, Wih, Whh, bih, bhh)

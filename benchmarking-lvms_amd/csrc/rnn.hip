@@ -1,0 +1,463 @@
+// rnn.hip — K4 / K2: single-layer LSTM and GRU over a whole sequence (forward + BPTT) as stage-kernel chains.
+//
+// Replaces the vendor RNN calls of the reference:
+//   nn.LSTM on a packed sequence        blvm/models/lstm.py:46-55,96-98   (pack_padded_sequence semantics via `lens`)
+//   nn.GRU forward / time-reversed      blvm/models/srnn.py:113-116,196,200-206 (reverse_sequences folded into an
+//                                        index map: operations.py:56-87 — per-row reversal, right padding in place)
+// One launch per recurrent step in each direction: the hidden projection (M = batch, K = hidden) runs on
+// v_mfma_f32_16x16x4_f32 with the K split over the waves of a workgroup, and ALL gate math (forward) / gate
+// derivatives (backward, fused into the dgrad that completes dL/dh of the step) lives in the epilogue.  The input
+// projection and every weight gradient are hoisted out of the loop into the big MFMA GEMM (gemm.hip).
+#include "common.h"
+
+namespace blvm {
+namespace {
+
+#define LAUNCH_NW(kernel, nw, grid, stream, args)                                          \
+  do {                                                                                     \
+    if ((nw) == 16) hipLaunchKernelGGL((kernel<16>), grid, dim3(1024), 0, stream, args);   \
+    else if ((nw) == 8) hipLaunchKernelGGL((kernel<8>), grid, dim3(512), 0, stream, args); \
+    else hipLaunchKernelGGL((kernel<4>), grid, dim3(256), 0, stream, args);                \
+  } while (0)
+
+inline int pick_nw(int K, int groups) {
+  const int chunks = (K / 16) * groups;
+  if (chunks > 32) return 16;
+  if (chunks > 16) return 8;
+  return 4;
+}
+
+inline int pick_split(int M, int N, int K) {
+  const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+  int s = (int)((768 + tiles - 1) / tiles);
+  const int kmax = (K + 255) / 256;
+  if (s > kmax) s = kmax;
+  return s < 1 ? 1 : s;
+}
+
+// time index processed by row `b` at recurrence step j: forward j; reversed: len-1-j inside the row's length, j in
+// the right padding (reverse_sequences leaves padding where it is).
+__device__ __forceinline__ int time_index(int j, int reverse, const int32_t* lens, int row) {
+  if (!reverse) return j;
+  const int n = lens[row];
+  return j < n ? n - 1 - j : j;
+}
+
+// ===================================================================================================================
+// LSTM
+// ===================================================================================================================
+struct LstmFwdArgs {
+  const float *hprev, *cprev;   // [B,H]
+  const float* Whh;             // [4H,H] rows [i|f|g|o]
+  const float* bhh;             // [4H]
+  const float* xg;              // [B,4H] input projection incl. b_ih
+  const int32_t* lens;          // [B] valid steps per row (packed-sequence semantics) or null
+  float *hnext, *cnext;         // [B,H]
+  float* out;                   // [B,H]   zero where the row is past its length (pad_packed_sequence)
+  float* gates;                 // [B,4H]  saved i,f,g,o (zero where masked)
+  int B, H, t;
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void lstm_fwd_kernel(LstmFwdArgs a) {
+  __shared__ float red[4 * NW * 256];
+  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, wave = threadIdx.x >> 6, H = a.H;
+  const int t = threadIdx.x & 255;
+  const int row = r0 + (t >> 4), col = c0 + (t & 15);
+  const bool own = threadIdx.x < 256 && row < a.B;
+  const int rowc = row < a.B ? row : r0;
+  const size_t o = (size_t)rowc * H + col, o4 = (size_t)rowc * 4 * H + col;
+  const float x0 = a.xg[o4] + a.bhh[col], x1 = a.xg[o4 + H] + a.bhh[H + col];
+  const float x2 = a.xg[o4 + 2 * H] + a.bhh[2 * H + col], x3 = a.xg[o4 + 3 * H] + a.bhh[3 * H + col];
+  const float hp = a.hprev[o], cp = a.cprev[o];
+  const bool live = a.lens == nullptr || a.t < a.lens[rowc];
+  f32x4 acc[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[g] = wave_gemm16<NW>(a.hprev, H, r0, a.B, a.Whh, H, g * H + c0, H, wave, acc[g]);
+  }
+  float v[4];
+  reduce_tiles<4, NW>(acc, red, v);
+  if (!own) return;
+  const float i = sigmoidf_(v[0] + x0), f = sigmoidf_(v[1] + x1), g = tanhf(v[2] + x2), og = sigmoidf_(v[3] + x3);
+  const float c2 = f * cp + i * g;
+  const float h2 = og * tanhf(c2);
+  a.cnext[o] = live ? c2 : cp;
+  a.hnext[o] = live ? h2 : hp;
+  a.out[o] = live ? h2 : 0.f;
+  a.gates[o4] = live ? i : 0.f;
+  a.gates[o4 + H] = live ? f : 0.f;
+  a.gates[o4 + 2 * H] = live ? g : 0.f;
+  a.gates[o4 + 3 * H] = live ? og : 0.f;
+}
+
+struct LstmBwdArgs {
+  const float* DGn;     // [B,4H] gate pre-activation grads of step s+1 (unused when has_gemm == 0)
+  const float* WhhT;    // [H,4H]
+  const float* dout;    // [B,H] grad wrt out_s
+  const float* gates;   // [B,4H] step s
+  const float *c_s, *c_s1;  // cell state entering / leaving step s
+  float* DC;            // [B,H] running grad wrt the cell state (in/out)
+  float* DG;            // [B,4H] out: gate pre-activation grads of step s
+  float* dh0;           // [B,H] out when has_gates == 0
+  int B, H, has_gemm, has_gates;
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
+  __shared__ float red[NW * 256];
+  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, H = a.H;
+  const int t = threadIdx.x & 255;
+  const int row = r0 + (t >> 4), col = c0 + (t & 15);
+  const bool own = threadIdx.x < 256 && row < a.B;
+  const int rowc = row < a.B ? row : r0;
+  const size_t o = (size_t)rowc * H + col, o4 = (size_t)rowc * 4 * H + col;
+  float dh = 0.f, ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cs = 0.f, cs1 = 0.f, dc = 0.f;
+  if (a.has_gates) {  // wave-uniform
+    dh = a.dout[o];
+    ig = a.gates[o4]; fg = a.gates[o4 + H]; gg = a.gates[o4 + 2 * H]; og = a.gates[o4 + 3 * H];
+    cs = a.c_s[o]; cs1 = a.c_s1[o]; dc = a.DC[o];
+  }
+  float v[1] = {0.f};
+  if (a.has_gemm) {
+    f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+    acc[0] = wave_gemm16<NW>(a.DGn, 4 * H, r0, a.B, a.WhhT, 4 * H, c0, 4 * H, threadIdx.x >> 6, acc[0]);
+    reduce_tiles<1, NW>(acc, red, v);
+  }
+  if (!own) return;
+  dh += v[0];
+  if (!a.has_gates) { a.dh0[o] = dh; return; }
+  const float tc = tanhf(cs1);
+  const float d_o = dh * tc;
+  const float dct = dc + dh * og * (1.f - tc * tc);
+  a.DG[o4] = dct * gg * ig * (1.f - ig);
+  a.DG[o4 + H] = dct * cs * fg * (1.f - fg);
+  a.DG[o4 + 2 * H] = dct * ig * (1.f - gg * gg);
+  a.DG[o4 + 3 * H] = d_o * og * (1.f - og);
+  a.DC[o] = dct * fg;
+}
+
+struct LstmReserve { float *XG, *Hs, *Cs, *GATES; };
+size_t carve_lstm(float* base, int T, int B, int H, LstmReserve* r) {
+  size_t off = 0;
+  auto take = [&](size_t cnt) { float* p = base ? base + off : nullptr; off += (cnt + 3) & ~(size_t)3; return p; };
+  LstmReserve t;
+  t.XG = take((size_t)T * B * 4 * H);
+  t.Hs = take((size_t)(T + 1) * B * H);
+  t.Cs = take((size_t)(T + 1) * B * H);
+  t.GATES = take((size_t)T * B * 4 * H);
+  if (r) *r = t;
+  return off;
+}
+struct LstmWs { float *WhhT, *DG, *DC; };
+size_t carve_lstm_ws(float* base, int T, int B, int H, LstmWs* w) {
+  size_t off = 0;
+  auto take = [&](size_t cnt) { float* p = base ? base + off : nullptr; off += (cnt + 3) & ~(size_t)3; return p; };
+  LstmWs t;
+  t.WhhT = take((size_t)H * 4 * H);
+  t.DG = take((size_t)T * B * 4 * H);
+  t.DC = take((size_t)B * H);
+  if (w) *w = t;
+  return off;
+}
+
+// ===================================================================================================================
+// GRU
+// ===================================================================================================================
+struct GruFwdArgs {
+  const float* hprev;    // [B,R] state entering recurrence step j
+  const float* Whh;      // [3R,R] rows [r|z|n]
+  const float* bhh;      // [3R]
+  const float* xg;       // [T,B,3R] input projection incl. b_ih, TIME indexed
+  const int32_t* lens;   // [B] (reverse map) or null
+  float* hnext;          // [B,R]
+  float* out;            // time-indexed output base: element (idx,row,col) at out + idx*out_ts + row*out_ld + col
+  float *rg, *ug, *ng, *ghn;  // [B,R] saves of recurrence step j
+  long long out_ts;
+  int out_ld, B, R, j, reverse;
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void gru_fwd_kernel(GruFwdArgs a) {
+  __shared__ float red[3 * NW * 256];
+  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, wave = threadIdx.x >> 6, R = a.R;
+  const int t = threadIdx.x & 255;
+  const int row = r0 + (t >> 4), col = c0 + (t & 15);
+  const bool own = threadIdx.x < 256 && row < a.B;
+  const int rowc = row < a.B ? row : r0;
+  const int idx = time_index(a.j, a.reverse, a.lens, rowc);
+  const size_t o = (size_t)rowc * R + col;
+  const size_t ox = ((size_t)idx * a.B + rowc) * 3 * R + col;
+  const float x0 = a.xg[ox], x1 = a.xg[ox + R], x2 = a.xg[ox + 2 * R];
+  const float b0 = a.bhh[col], b1 = a.bhh[R + col], b2 = a.bhh[2 * R + col];
+  const float hp = a.hprev[o];
+  f32x4 acc[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[g] = wave_gemm16<NW>(a.hprev, R, r0, a.B, a.Whh, R, g * R + c0, R, wave, acc[g]);
+  }
+  float v[3];
+  reduce_tiles<3, NW>(acc, red, v);
+  if (!own) return;
+  const float hn = v[2] + b2;
+  const float r = sigmoidf_(x0 + v[0] + b0);
+  const float u = sigmoidf_(x1 + v[1] + b1);
+  const float n = tanhf(x2 + r * hn);
+  const float h2 = (1.f - u) * n + u * hp;
+  a.hnext[o] = h2;
+  a.out[(size_t)idx * a.out_ts + (size_t)row * a.out_ld + col] = h2;
+  a.rg[o] = r; a.ug[o] = u; a.ng[o] = n; a.ghn[o] = hn;
+}
+
+struct GruBwdArgs {
+  const float* DGHn;    // [B,3R] hidden-projection grads of recurrence step j+1 (unused when has_gemm == 0)
+  const float* WhhT;    // [R,3R]
+  const float* dout;    // time-indexed grad wrt the outputs (same addressing as GruFwdArgs::out)
+  const float *rg, *ug, *ng, *ghn, *hprev;  // saves of step j; hprev = state entering step j
+  const int32_t* lens;
+  float* G;             // [B,R] running grad through the u-gate path (in/out)
+  float* DGI;           // [T,B,3R] TIME indexed: grads wrt the input projection
+  float* DGH;           // [B,3R] step j: grads wrt the hidden projection
+  float* dh0;           // [B,R] out when has_gates == 0
+  long long out_ts;
+  int out_ld, B, R, j, reverse, has_gemm, has_gates;
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void gru_bwd_kernel(GruBwdArgs a) {
+  __shared__ float red[NW * 256];
+  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, R = a.R;
+  const int t = threadIdx.x & 255;
+  const int row = r0 + (t >> 4), col = c0 + (t & 15);
+  const bool own = threadIdx.x < 256 && row < a.B;
+  const int rowc = row < a.B ? row : r0;
+  const size_t o = (size_t)rowc * R + col;
+  float g = a.G[o];
+  float r = 0.f, u = 0.f, n = 0.f, hn = 0.f, hp = 0.f;
+  int idx = 0;
+  if (a.has_gates) {  // wave-uniform
+    idx = time_index(a.j, a.reverse, a.lens, rowc);
+    g += a.dout[(size_t)idx * a.out_ts + (size_t)rowc * a.out_ld + col];
+    r = a.rg[o]; u = a.ug[o]; n = a.ng[o]; hn = a.ghn[o]; hp = a.hprev[o];
+  }
+  float v[1] = {0.f};
+  if (a.has_gemm) {
+    f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+    acc[0] = wave_gemm16<NW>(a.DGHn, 3 * R, r0, a.B, a.WhhT, 3 * R, c0, 3 * R, threadIdx.x >> 6, acc[0]);
+    reduce_tiles<1, NW>(acc, red, v);
+  }
+  if (!own) return;
+  g += v[0];
+  if (!a.has_gates) { a.dh0[o] = g; return; }
+  const float dn_pre = g * (1.f - u) * (1.f - n * n);
+  const float du_pre = g * (hp - n) * u * (1.f - u);
+  const float dr_pre = dn_pre * hn * r * (1.f - r);
+  const size_t oi = ((size_t)idx * a.B + row) * 3 * R + col, oh = (size_t)row * 3 * R + col;
+  a.DGI[oi] = dr_pre; a.DGI[oi + R] = du_pre; a.DGI[oi + 2 * R] = dn_pre;
+  a.DGH[oh] = dr_pre; a.DGH[oh + R] = du_pre; a.DGH[oh + 2 * R] = dn_pre * r;
+  a.G[o] = g * u;
+}
+
+struct GruReserve { float *XG, *Hs, *RG, *UG, *NG, *GHN; };
+size_t carve_gru(float* base, int T, int B, int R, GruReserve* r) {
+  size_t off = 0;
+  auto take = [&](size_t cnt) { float* p = base ? base + off : nullptr; off += (cnt + 3) & ~(size_t)3; return p; };
+  GruReserve t;
+  const size_t n = (size_t)T * B;
+  t.XG = take(n * 3 * R);
+  t.Hs = take((size_t)(T + 1) * B * R);
+  t.RG = take(n * R); t.UG = take(n * R); t.NG = take(n * R); t.GHN = take(n * R);
+  if (r) *r = t;
+  return off;
+}
+struct GruWs { float *WhhT, *DGI, *DGH, *G; };
+size_t carve_gru_ws(float* base, int T, int B, int R, GruWs* w) {
+  size_t off = 0;
+  auto take = [&](size_t cnt) { float* p = base ? base + off : nullptr; off += (cnt + 3) & ~(size_t)3; return p; };
+  GruWs t;
+  const size_t n = (size_t)T * B;
+  t.WhhT = take((size_t)R * 3 * R);
+  t.DGI = take(n * 3 * R);
+  t.DGH = take(n * 3 * R);
+  t.G = take((size_t)B * R);
+  if (w) *w = t;
+  return off;
+}
+
+int check_rnn(int T, int B, int I, int H) {
+  BLVM_REQUIRE(T > 0 && B > 0 && I > 0 && H > 0, "rnn: bad shape T=%d B=%d I=%d H=%d", T, B, I, H);
+  BLVM_REQUIRE(H % 16 == 0, "rnn: hidden size must be a multiple of 16 (got %d)", H);
+  BLVM_REQUIRE((B + 15) / 16 <= 65535, "rnn: batch too large");
+  return BLVM_OK;
+}
+
+}  // namespace
+}  // namespace blvm
+
+using namespace blvm;
+
+// --------------------------------------------------------------------------------------------------------------------
+extern "C" size_t blvm_lstm_reserve_floats(int T, int B, int H) { return carve_lstm(nullptr, T, B, H, nullptr); }
+extern "C" size_t blvm_lstm_bwd_workspace_floats(int T, int B, int H) { return carve_lstm_ws(nullptr, T, B, H, nullptr); }
+
+extern "C" int blvm_lstm_seq_fwd(const float* Wih, const float* Whh, const float* bih, const float* bhh, const float* in,
+                                 const float* h0, const float* c0, const int32_t* lens, int T, int B, int I, int H,
+                                 float* out, float* hn, float* cn, float* reserve, void* stream_) {
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  int rc = check_rnn(T, B, I, H);
+  if (rc) return rc;
+  BLVM_REQUIRE(Wih && Whh && bih && bhh && in && out && reserve, "lstm_fwd: null pointer");
+  BLVM_REQUIRE(aligned16(reserve) && aligned16(Whh), "lstm_fwd: buffers must be 16-byte aligned");
+  LstmReserve rs;
+  carve_lstm(reserve, T, B, H, &rs);
+  const size_t n = (size_t)T * B, bh = (size_t)B * H;
+  rc = gemm_f32(0, 0, (int)n, 4 * H, I, in, I, Wih, I, rs.XG, 4 * H, bih, 0, 0.f, nullptr, 0, 0, 1, s);
+  if (rc) return rc;
+  if (h0) BLVM_HIP(hipMemcpyAsync(rs.Hs, h0, sizeof(float) * bh, hipMemcpyDeviceToDevice, s));
+  else BLVM_HIP(hipMemsetAsync(rs.Hs, 0, sizeof(float) * bh, s));
+  if (c0) BLVM_HIP(hipMemcpyAsync(rs.Cs, c0, sizeof(float) * bh, hipMemcpyDeviceToDevice, s));
+  else BLVM_HIP(hipMemsetAsync(rs.Cs, 0, sizeof(float) * bh, s));
+  const int nw = pick_nw(H, 4);
+  const dim3 grid(H / 16, (B + 15) / 16);
+  for (int t = 0; t < T; ++t) {
+    LstmFwdArgs a;
+    a.hprev = rs.Hs + t * bh; a.cprev = rs.Cs + t * bh; a.Whh = Whh; a.bhh = bhh;
+    a.xg = rs.XG + (size_t)t * B * 4 * H; a.lens = lens;
+    a.hnext = rs.Hs + (t + 1) * bh; a.cnext = rs.Cs + (t + 1) * bh;
+    a.out = out + t * bh; a.gates = rs.GATES + (size_t)t * B * 4 * H;
+    a.B = B; a.H = H; a.t = t;
+    LAUNCH_NW(lstm_fwd_kernel, nw, grid, s, a);
+  }
+  BLVM_CHECK_LAUNCH("lstm_seq_fwd");
+  if (hn) BLVM_HIP(hipMemcpyAsync(hn, rs.Hs + T * bh, sizeof(float) * bh, hipMemcpyDeviceToDevice, s));
+  if (cn) BLVM_HIP(hipMemcpyAsync(cn, rs.Cs + T * bh, sizeof(float) * bh, hipMemcpyDeviceToDevice, s));
+  return BLVM_OK;
+}
+
+extern "C" int blvm_lstm_seq_bwd(const float* Wih, const float* Whh, const float* in, const float* reserve,
+                                 const float* d_out, int T, int B, int I, int H, float* d_in, float* d_h0, float* d_c0,
+                                 float* dWih, float* dWhh, float* dbih, float* dbhh, float* workspace, void* stream_) {
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  int rc = check_rnn(T, B, I, H);
+  if (rc) return rc;
+  BLVM_REQUIRE(Wih && Whh && in && reserve && d_out && workspace, "lstm_bwd: null pointer");
+  BLVM_REQUIRE(aligned16(reserve) && aligned16(workspace), "lstm_bwd: buffers must be 16-byte aligned");
+  LstmReserve rs;
+  carve_lstm(const_cast<float*>(reserve), T, B, H, &rs);
+  LstmWs ws;
+  carve_lstm_ws(workspace, T, B, H, &ws);
+  const size_t n = (size_t)T * B, bh = (size_t)B * H;
+  rc = transpose_f32(4 * H, H, Whh, H, ws.WhhT, 4 * H, s);
+  if (rc) return rc;
+  BLVM_HIP(hipMemsetAsync(ws.DC, 0, sizeof(float) * bh, s));
+  const int nw = pick_nw(4 * H, 1);
+  const dim3 grid(H / 16, (B + 15) / 16);
+  // scratch for dh0 when the caller does not want it
+  for (int st = T - 1; st >= -1; --st) {
+    LstmBwdArgs a;
+    a.has_gemm = st < T - 1; a.has_gates = st >= 0;
+    a.DGn = ws.DG + (size_t)(st + 1 < T ? st + 1 : 0) * B * 4 * H;
+    a.WhhT = ws.WhhT;
+    const int sg = st >= 0 ? st : 0;
+    a.dout = d_out + sg * bh; a.gates = rs.GATES + (size_t)sg * B * 4 * H;
+    a.c_s = rs.Cs + sg * bh; a.c_s1 = rs.Cs + (sg + 1) * bh;
+    a.DC = ws.DC; a.DG = ws.DG + (size_t)sg * B * 4 * H;
+    a.dh0 = d_h0;
+    a.B = B; a.H = H;
+    if (st == -1 && d_h0 == nullptr) break;
+    LAUNCH_NW(lstm_bwd_kernel, nw, grid, s, a);
+  }
+  BLVM_CHECK_LAUNCH("lstm_seq_bwd");
+  if (d_c0) BLVM_HIP(hipMemcpyAsync(d_c0, ws.DC, sizeof(float) * bh, hipMemcpyDeviceToDevice, s));
+  if (d_in) {
+    rc = gemm_f32(0, 1, (int)n, I, 4 * H, ws.DG, 4 * H, Wih, I, d_in, I, nullptr, 0, 0.f, nullptr, 0, 0, 1, s);
+    if (rc) return rc;
+  }
+  if (dWih) { rc = gemm_f32(1, 1, 4 * H, I, (int)n, ws.DG, 4 * H, in, I, dWih, I, nullptr, 0, 0.f, nullptr, 0, 1, pick_split(4 * H, I, (int)n), s); if (rc) return rc; }
+  if (dWhh) { rc = gemm_f32(1, 1, 4 * H, H, (int)n, ws.DG, 4 * H, rs.Hs, H, dWhh, H, nullptr, 0, 0.f, nullptr, 0, 1, pick_split(4 * H, H, (int)n), s); if (rc) return rc; }
+  if (dbih) { rc = colsum_f32((int)n, 4 * H, ws.DG, 4 * H, dbih, 1, s); if (rc) return rc; }
+  if (dbhh) { rc = colsum_f32((int)n, 4 * H, ws.DG, 4 * H, dbhh, 1, s); if (rc) return rc; }
+  return BLVM_OK;
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+extern "C" size_t blvm_gru_reserve_floats(int T, int B, int R) { return carve_gru(nullptr, T, B, R, nullptr); }
+extern "C" size_t blvm_gru_bwd_workspace_floats(int T, int B, int R) { return carve_gru_ws(nullptr, T, B, R, nullptr); }
+
+extern "C" int blvm_gru_seq_fwd(const float* Wih, const float* Whh, const float* bih, const float* bhh, const float* in,
+                                int ld_in, const float* h0, const int32_t* lens, int reverse, int T, int B, int I, int R,
+                                float* out, long long out_ts, int out_ld, float* hn, float* reserve, void* stream_) {
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  int rc = check_rnn(T, B, I, R);
+  if (rc) return rc;
+  BLVM_REQUIRE(Wih && Whh && bih && bhh && in && out && reserve, "gru_fwd: null pointer");
+  BLVM_REQUIRE(!reverse || lens, "gru_fwd: reverse needs lens");
+  BLVM_REQUIRE(aligned16(reserve) && aligned16(Whh), "gru_fwd: buffers must be 16-byte aligned");
+  GruReserve rs;
+  carve_gru(reserve, T, B, R, &rs);
+  const size_t n = (size_t)T * B, br = (size_t)B * R;
+  rc = gemm_f32(0, 0, (int)n, 3 * R, I, in, ld_in, Wih, I, rs.XG, 3 * R, bih, 0, 0.f, nullptr, 0, 0, 1, s);
+  if (rc) return rc;
+  if (h0) BLVM_HIP(hipMemcpyAsync(rs.Hs, h0, sizeof(float) * br, hipMemcpyDeviceToDevice, s));
+  else BLVM_HIP(hipMemsetAsync(rs.Hs, 0, sizeof(float) * br, s));
+  const int nw = pick_nw(R, 3);
+  const dim3 grid(R / 16, (B + 15) / 16);
+  for (int j = 0; j < T; ++j) {
+    GruFwdArgs a;
+    a.hprev = rs.Hs + j * br; a.Whh = Whh; a.bhh = bhh; a.xg = rs.XG; a.lens = lens;
+    a.hnext = rs.Hs + (j + 1) * br; a.out = out;
+    a.rg = rs.RG + j * br; a.ug = rs.UG + j * br; a.ng = rs.NG + j * br; a.ghn = rs.GHN + j * br;
+    a.out_ts = out_ts; a.out_ld = out_ld; a.B = B; a.R = R; a.j = j; a.reverse = reverse;
+    LAUNCH_NW(gru_fwd_kernel, nw, grid, s, a);
+  }
+  BLVM_CHECK_LAUNCH("gru_seq_fwd");
+  if (hn) BLVM_HIP(hipMemcpyAsync(hn, rs.Hs + T * br, sizeof(float) * br, hipMemcpyDeviceToDevice, s));
+  return BLVM_OK;
+}
+
+extern "C" int blvm_gru_seq_bwd(const float* Wih, const float* Whh, const float* in, int ld_in, const int32_t* lens,
+                                int reverse, const float* reserve, const float* d_out, long long out_ts, int out_ld,
+                                int T, int B, int I, int R, float* d_in, int ld_din, int accumulate_din, float* d_h0,
+                                float* dWih, float* dWhh, float* dbih, float* dbhh, float* workspace, void* stream_) {
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  int rc = check_rnn(T, B, I, R);
+  if (rc) return rc;
+  BLVM_REQUIRE(Wih && Whh && in && reserve && d_out && workspace, "gru_bwd: null pointer");
+  BLVM_REQUIRE(!reverse || lens, "gru_bwd: reverse needs lens");
+  BLVM_REQUIRE(aligned16(reserve) && aligned16(workspace), "gru_bwd: buffers must be 16-byte aligned");
+  GruReserve rs;
+  carve_gru(const_cast<float*>(reserve), T, B, R, &rs);
+  GruWs ws;
+  carve_gru_ws(workspace, T, B, R, &ws);
+  const size_t n = (size_t)T * B, br = (size_t)B * R;
+  rc = transpose_f32(3 * R, R, Whh, R, ws.WhhT, 3 * R, s);
+  if (rc) return rc;
+  BLVM_HIP(hipMemsetAsync(ws.G, 0, sizeof(float) * br, s));
+  const int nw = pick_nw(3 * R, 1);
+  const dim3 grid(R / 16, (B + 15) / 16);
+  for (int j = T - 1; j >= -1; --j) {
+    if (j == -1 && d_h0 == nullptr) break;
+    GruBwdArgs a;
+    a.has_gemm = j < T - 1; a.has_gates = j >= 0;
+    a.DGHn = ws.DGH + (size_t)(j + 1 < T ? j + 1 : 0) * B * 3 * R;
+    a.WhhT = ws.WhhT; a.dout = d_out;
+    const int jg = j >= 0 ? j : 0;
+    a.rg = rs.RG + jg * br; a.ug = rs.UG + jg * br; a.ng = rs.NG + jg * br; a.ghn = rs.GHN + jg * br;
+    a.hprev = rs.Hs + jg * br; a.lens = lens;
+    a.G = ws.G; a.DGI = ws.DGI; a.DGH = ws.DGH + (size_t)jg * B * 3 * R; a.dh0 = d_h0;
+    a.out_ts = out_ts; a.out_ld = out_ld; a.B = B; a.R = R; a.j = jg; a.reverse = reverse;
+    LAUNCH_NW(gru_bwd_kernel, nw, grid, s, a);
+  }
+  BLVM_CHECK_LAUNCH("gru_seq_bwd");
+  if (d_in) {
+    rc = gemm_f32(0, 1, (int)n, I, 3 * R, ws.DGI, 3 * R, Wih, I, d_in, ld_din, nullptr, 0, 0.f, nullptr, 0, accumulate_din, 1, s);
+    if (rc) return rc;
+  }
+  if (dWih) { rc = gemm_f32(1, 1, 3 * R, I, (int)n, ws.DGI, 3 * R, in, ld_in, dWih, I, nullptr, 0, 0.f, nullptr, 0, 1, pick_split(3 * R, I, (int)n), s); if (rc) return rc; }
+  if (dWhh) { rc = gemm_f32(1, 1, 3 * R, R, (int)n, ws.DGH, 3 * R, rs.Hs, R, dWhh, R, nullptr, 0, 0.f, nullptr, 0, 1, pick_split(3 * R, R, (int)n), s); if (rc) return rc; }
+  if (dbih) { rc = colsum_f32((int)n, 3 * R, ws.DGI, 3 * R, dbih, 1, s); if (rc) return rc; }
+  if (dbhh) { rc = colsum_f32((int)n, 3 * R, ws.DGH, 3 * R, dbhh, 1, s); if (rc) return rc; }
+  return BLVM_OK;
+}

@@ -141,6 +141,44 @@ int blvm_vrnn_seq_bwd(const BlvmVrnnWeights* w, const float* enc, const float* e
                       int residual_posterior, float sd_eps, float* d_enc, float* d_h0, const BlvmVrnnGrads* grads,
                       float* workspace, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * K4  single-layer LSTM over a sequence (forward + BPTT).  Replaces `nn.LSTM` on a packed sequence,
+ *     `blvm/models/lstm.py:46-55,96-98` (pack_padded_sequence / pad_packed_sequence semantics through `lens`:
+ *     a row past its length keeps its state and emits zeros).  Gate rows [i|f|g|o].
+ *   in [T,B,I]; h0,c0 [B,H] or NULL (zeros); lens [B] int32 valid steps per row, or NULL (all T)
+ *   out [T,B,H]; hn,cn [B,H] state after each row's last valid step (may be NULL)
+ * ------------------------------------------------------------------------------------------------------------- */
+size_t blvm_lstm_reserve_floats(int T, int B, int H);
+size_t blvm_lstm_bwd_workspace_floats(int T, int B, int H);
+int blvm_lstm_seq_fwd(const float* Wih, const float* Whh, const float* bih, const float* bhh, const float* in,
+                      const float* h0, const float* c0, const int32_t* lens, int T, int B, int I, int H, float* out,
+                      float* hn, float* cn, float* reserve, void* stream);
+/*   d_out [T,B,H]; outputs d_in [T,B,I], d_h0, d_c0 [B,H] (each may be NULL); weight grads ACCUMULATED (may be NULL). */
+int blvm_lstm_seq_bwd(const float* Wih, const float* Whh, const float* in, const float* reserve, const float* d_out,
+                      int T, int B, int I, int H, float* d_in, float* d_h0, float* d_c0, float* dWih, float* dWhh,
+                      float* dbih, float* dbhh, float* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * K2  single-layer GRU over a sequence (forward + BPTT), optionally time-reversed PER ROW.  Replaces `nn.GRU` and
+ *     the `reverse_sequences` gathers around it, `blvm/models/srnn.py:113-116,196,200-206` +
+ *     `blvm/utils/operations.py:56-87`: with reverse != 0 row b consumes time index lens[b]-1-j at recurrence step
+ *     j < lens[b] and index j in its right padding, and its outputs are written back at those time indices.
+ *     Gate rows [r|z|n] (torch.nn.GRU).
+ *   in [T,B,I] with row stride ld_in; h0 [B,R] or NULL; out element (t,b,c) at out + t*out_ts + b*out_ld + c, so the
+ *   states can be written straight into a wider time-major buffer; hn [B,R] state after the last recurrence step.
+ * ------------------------------------------------------------------------------------------------------------- */
+size_t blvm_gru_reserve_floats(int T, int B, int R);
+size_t blvm_gru_bwd_workspace_floats(int T, int B, int R);
+int blvm_gru_seq_fwd(const float* Wih, const float* Whh, const float* bih, const float* bhh, const float* in,
+                     int ld_in, const float* h0, const int32_t* lens, int reverse, int T, int B, int I, int R,
+                     float* out, long long out_ts, int out_ld, float* hn, float* reserve, void* stream);
+/*   d_out addressed like out.  d_in [T,B,I] row stride ld_din (=|+= by accumulate_din), d_h0 [B,R]; weight grads
+ *   ACCUMULATED; any output may be NULL. */
+int blvm_gru_seq_bwd(const float* Wih, const float* Whh, const float* in, int ld_in, const int32_t* lens, int reverse,
+                     const float* reserve, const float* d_out, long long out_ts, int out_ld, int T, int B, int I,
+                     int R, float* d_in, int ld_din, int accumulate_din, float* d_h0, float* dWih, float* dWhh,
+                     float* dbih, float* dbhh, float* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

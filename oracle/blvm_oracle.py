@@ -329,3 +329,45 @@ def cosine_anneal_trace(n_calls, anneal_steps, constant_steps=0, start_value=0.0
             v = end_value + 0.5 * (start_value - end_value) * (1 + math.cos((s - constant_steps - 1) / anneal_steps * math.pi))
         vals.append(v)
     return vals
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# LSTMAudio (blvm/models/lstm.py:72-131)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def lstm_packed(emb, lens, w_ih, w_hh, b_ih, b_hh, h0=None, c0=None):
+    """nn.LSTM on pack_padded_sequence(emb [B,L,H], lens) followed by pad_packed_sequence (lstm.py:96-98): a row past
+    its length keeps its state and its outputs are zero.  Returns (out [B,L,H], h_n, c_n)."""
+    B, L, _ = emb.shape
+    H = w_hh.size(1)
+    h = torch.zeros(B, H, dtype=emb.dtype) if h0 is None else h0
+    c = torch.zeros(B, H, dtype=emb.dtype) if c0 is None else c0
+    outs = []
+    for t in range(L):
+        live = (t < lens).to(emb.dtype).unsqueeze(-1)
+        h2, c2 = lstm_cell(emb[:, t], h, c, w_ih, w_hh, b_ih, b_hh)
+        h, c = live * h2 + (1 - live) * h, live * c2 + (1 - live) * c
+        outs.append(live * h2)
+    return torch.stack(outs, 1), h, c
+
+
+def lstm_audio_forward(sd, x, x_sl, stack=64, num_mix=10, num_bins=256, s_0=None):
+    """LSTMAudio.forward: predict stack t+1 from stacks <= t; loss = -sum(ll * [tau < x_sl]) / sum(x_sl) with the
+    mask on the SHIFTED target axis (lstm.py:88-115).  fp32 sums (bool mask), unlike VRNN/SRNN."""
+    B, T = x.shape
+    xs, _ = stack_tensor(x, stack)
+    inp, tgt = xs[:, :-1], xs[:, 1:].reshape(B, -1)
+    emb = _mlp(inp, sd, "embedding", (0, 2, 4), F.relu)
+    lens = (x_sl / stack).ceil().int() - 1
+    h0, c0 = (None, None) if s_0 is None else s_0
+    out, h_n, c_n = lstm_packed(emb, lens, sd["lstm.weight_ih_l0"], sd["lstm.weight_hh_l0"], sd["lstm.bias_ih_l0"],
+                                sd["lstm.bias_hh_l0"], h0, c0)
+    o = _mlp(out, sd, "decoder", (0, 2, 4), F.relu)
+    o = o.reshape(B, o.size(1) * stack, 3 * num_mix)
+    logits, locs, log_scales = dmol_head(o, sd["likelihood.params.weight"], sd["likelihood.params.bias"], num_mix)
+    mask = sequence_mask(x_sl, max_len=tgt.size(1))
+    ll = dmol_ll(tgt.unsqueeze(-1), logits, locs, log_scales, num_bins)
+    log_prob = (ll * mask).sum(1)
+    loss = -log_prob.sum() / x_sl.sum()
+    return dict(loss=loss, ll=log_prob, z=out, h_n=h_n, c_n=c_n, bpd=float((-log_prob.detach() / LN2).sum() / x_sl.sum()))

@@ -179,8 +179,50 @@ def gen_vrnn_full():
     save("vrnn_full.npz", **arrays)
 
 
+def gen_lstm():
+    """LSTMAudio: reduced size with full tensors, and BASELINE config C1 ([8,4000], h=256, s=64) pinned by checksums."""
+    arrays = {}
+    torch.manual_seed(21)
+    m = RM.LSTMAudio(stack_size=8, hidden_size=32, num_layers=1, num_mix=10, num_bins=2**16)
+    x, _ = O.synth_batch(4, 83, seed=6)
+    x_sl = torch.tensor([83, 70, 41, 17])  # descending (pack_padded_sequence enforce_sorted)
+    x = x * (torch.arange(83).unsqueeze(0) < x_sl.unsqueeze(1))
+    torch.manual_seed(5)
+    loss, metrics, o = m(x, x_sl)
+    loss.backward()
+    arrays.update(s_x=x, s_x_sl=x_sl, s_loss=loss, s_ll=o.ll, s_z=o.z, s_hn=o.s_n[0], s_cn=o.s_n[1])
+    arrays["s_metric_names"] = np.array([mm.name for mm in metrics])
+    arrays["s_metric_values"] = np.array([mm.value for mm in metrics], dtype=np.float64)
+    for k, v in m.state_dict().items():
+        arrays[f"s_sd.{k}"] = v
+    for k, p in m.named_parameters():
+        arrays[f"s_grad.{k}"] = p.grad
+
+    torch.manual_seed(0)
+    m = RM.LSTMAudio(stack_size=64, hidden_size=256, num_layers=1, num_mix=10, num_bins=2**16)
+    names = []
+    for k, v in m.state_dict().items():
+        names.append(k)
+        arrays[f"cks.{k}"] = np.array([v.double().sum().item(), v.double().abs().sum().item(), *v.shape], dtype=np.float64)
+    arrays["param_names"] = np.array(names)
+    for tag, ragged in (("full", False), ("ragged", True)):
+        m.zero_grad()
+        x, x_sl = O.synth_batch(8, 4000, seed=0, ragged=ragged)
+        torch.manual_seed(5)
+        loss, metrics, o = m(x, x_sl)
+        loss.backward()
+        arrays.update({f"{tag}_x_sl": x_sl, f"{tag}_loss": loss, f"{tag}_ll": o.ll})
+        arrays[f"{tag}_metric_names"] = np.array([mm.name for mm in metrics])
+        arrays[f"{tag}_metric_values"] = np.array([mm.value for mm in metrics], dtype=np.float64)
+        arrays[f"{tag}_grad_norms"] = np.array([p.grad.double().norm().item() for _, p in m.named_parameters()])
+        arrays[f"{tag}_grad.lstm.bias_hh_l0"] = m.lstm.bias_hh_l0.grad.clone()
+        arrays[f"{tag}_grad.likelihood.params.weight"] = m.likelihood.params.weight.grad.clone()
+    arrays["grad_names"] = np.array([k for k, _ in m.named_parameters()])
+    save("lstm.npz", **arrays)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full"]
+    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm"]
     for w in which:
         globals()[f"gen_{w}"]()

@@ -296,3 +296,109 @@ def test_full_size_properties():
     torch.testing.assert_close(part.kl, full.kl[sub], rtol=1e-6, atol=0)
     bpd = {mm.name: mm.value for mm in metrics}["bpd"]
     assert 16.5 < bpd < 18.0
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# K4 LSTM / K2 GRU sequence kernels and LSTMAudio (BASELINE config C1)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("reverse", [False, True])
+def test_gru_sequence_vs_torch(reverse):
+    """nn.GRU (and reverse_sequences -> nn.GRU -> reverse_sequences) on the CPU vs the HIP sequence kernels."""
+    torch.manual_seed(7)
+    T_, B, I, R = 11, 5, 24, 32
+    gru = torch.nn.GRU(I, R)
+    x = torch.randn(T_, B, I)
+    h0 = torch.randn(B, R) * 0.5
+    lens = torch.tensor([11, 9, 6, 2, 1])
+    w = torch.randn(T_, B, R)
+    xr = x.clone().requires_grad_(True)
+    h0r = h0.clone().requires_grad_(True)
+    if reverse:
+        out, hn = gru(O.reverse_sequences(xr, lens), h0r.unsqueeze(0))
+        out = O.reverse_sequences(out, lens)
+    else:
+        out, hn = gru(xr, h0r.unsqueeze(0))
+    (out * w).sum().backward()
+    ref = [xr.grad, h0r.grad] + [p.grad.clone() for p in gru.parameters()]
+    gru.zero_grad()
+    gru.to(DEV)
+    xd, h0d = x.to(DEV).requires_grad_(True), h0.to(DEV).requires_grad_(True)
+    od, hnd = ops.gru_sequence(xd, h0d, gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0,
+                               lens.to(DEV, torch.int32), reverse)
+    assert rel_l2(od, out) < 1e-5 and rel_l2(hnd, hn[0]) < 1e-5
+    (od * w.to(DEV)).sum().backward()
+    got = [xd.grad, h0d.grad] + [p.grad for p in gru.parameters()]
+    for a, b in zip(got, ref):
+        assert rel_l2(a, b) < 2e-5
+
+
+def test_lstm_sequence_packed_vs_torch():
+    torch.manual_seed(8)
+    T_, B, I, H = 9, 6, 16, 32
+    lstm = torch.nn.LSTM(I, H, batch_first=True)
+    x = torch.randn(B, T_, I)
+    lens = torch.tensor([9, 9, 7, 4, 2, 1])
+    w = torch.randn(B, T_, H)
+    xr = x.clone().requires_grad_(True)
+    ps = torch.nn.utils.rnn.pack_padded_sequence(xr, lens, batch_first=True)
+    out, (hn, cn) = lstm(ps)
+    out, _ = torch.nn.utils.rnn.pad_packed_sequence(out, batch_first=True)
+    (out * w).sum().backward()
+    ref = [xr.grad.clone()] + [p.grad.clone() for p in lstm.parameters()]
+    lstm.zero_grad()
+    lstm.to(DEV)
+    xd = x.transpose(0, 1).contiguous().to(DEV).requires_grad_(True)
+    od, hnd, cnd = ops.lstm_sequence(xd, None, None, lens.to(DEV, torch.int32), lstm.weight_ih_l0, lstm.weight_hh_l0,
+                                     lstm.bias_ih_l0, lstm.bias_hh_l0)
+    assert rel_l2(od.transpose(0, 1), out) < 1e-5 and rel_l2(hnd, hn[0]) < 1e-5 and rel_l2(cnd, cn[0]) < 1e-5
+    (od * w.transpose(0, 1).to(DEV)).sum().backward()
+    got = [xd.grad.transpose(0, 1)] + [p.grad for p in lstm.parameters()]
+    for a, b in zip(got, ref):
+        assert rel_l2(a, b) < 2e-5
+
+
+def test_lstm_audio_small_vs_reference_golden():
+    from blvm.models import LSTMAudio
+
+    g = np.load(os.path.join(GOLDEN, "lstm.npz"))
+    m = LSTMAudio(stack_size=8, hidden_size=32, num_layers=1, num_mix=10, num_bins=2**16)
+    m.load_state_dict({k[5:]: T(g[k]) for k in g.files if k.startswith("s_sd.")})
+    m.to(DEV)
+    loss, metrics, out = m(T(g["s_x"]).to(DEV), T(g["s_x_sl"]))
+    loss.backward()
+    assert float(loss) == pytest.approx(float(g["s_loss"]), rel=1e-5)
+    torch.testing.assert_close(out.ll.cpu(), T(g["s_ll"]), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(out.z.cpu(), T(g["s_z"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(out.s_n[0].cpu(), T(g["s_hn"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(out.s_n[1].cpu(), T(g["s_cn"]), rtol=1e-4, atol=1e-5)
+    vals = {mm.name: mm.value for mm in metrics}
+    for name, val in zip(g["s_metric_names"].tolist(), g["s_metric_values"].tolist()):
+        assert vals[name] == pytest.approx(val, rel=1e-5), name
+    for k, p in m.named_parameters():
+        assert rel_l2(p.grad, T(g[f"s_grad.{k}"])) < 1e-3, k
+    assert out.reconstruction_mode.shape == (4, 80, 1)
+
+
+@pytest.mark.parametrize("tag,ragged", [("full", False), ("ragged", True)])
+def test_lstm_audio_c1_vs_reference_golden(tag, ragged):
+    """BASELINE configs[0]: experiment_lstm_audio.py, 1-layer LSTM, synthetic mu-law [8,4000]."""
+    from blvm.models import LSTMAudio
+
+    g = np.load(os.path.join(GOLDEN, "lstm.npz"))
+    torch.manual_seed(0)
+    m = LSTMAudio(stack_size=64, hidden_size=256, num_layers=1, num_mix=10, num_bins=2**16).to(DEV)
+    x, x_sl = O.synth_batch(8, 4000, seed=0, ragged=ragged)
+    loss, metrics, out = m(x.to(DEV), x_sl)
+    loss.backward()
+    assert float(loss) == pytest.approx(float(g[f"{tag}_loss"]), rel=1e-5)
+    torch.testing.assert_close(out.ll.cpu(), T(g[f"{tag}_ll"]), rtol=1e-5, atol=0)
+    vals = {mm.name: mm.value for mm in metrics}
+    for name, val in zip(g[f"{tag}_metric_names"].tolist(), g[f"{tag}_metric_values"].tolist()):
+        assert vals[name] == pytest.approx(val, rel=1e-5), name
+    grads = dict(m.named_parameters())
+    for name, ref in zip(g["grad_names"].tolist(), g[f"{tag}_grad_norms"].tolist()):
+        assert grads[name].grad.double().norm().item() == pytest.approx(ref, rel=1e-3), name
+    for k in ("lstm.bias_hh_l0", "likelihood.params.weight"):
+        assert rel_l2(grads[k].grad, T(g[f"{tag}_grad.{k}"])) < 1e-3, k

@@ -119,3 +119,29 @@ def test_metrics_merge_like_reference():
     t.update([LLMetric(elbo1, name="elbo")], source="train")
     t.update([LLMetric(elbo2, name="elbo")], source="train")
     assert t.values("train")["elbo"] == pytest.approx(-60.0)
+
+
+def test_lstm_audio_init_matches_reference_and_oracle_c1():
+    """BASELINE config C1 (`experiment_lstm_audio.py`, [8,4000], CPU reference): seeded init identical to the
+    reference, and the oracle reproduces the reference's loss / ll / gradient norms on full and ragged batches."""
+    from blvm.models import LSTMAudio
+
+    g = np.load(os.path.join(GOLDEN, "lstm.npz"))
+    torch.manual_seed(0)
+    m = LSTMAudio(stack_size=64, hidden_size=256, num_layers=1, num_mix=10, num_bins=2**16)
+    sd0 = m.state_dict()
+    assert list(sd0.keys()) == g["param_names"].tolist()
+    for k, v in sd0.items():
+        cks = g[f"cks.{k}"]
+        assert list(v.shape) == [int(s) for s in cks[2:]], k
+        assert v.double().abs().sum().item() == pytest.approx(cks[1], rel=1e-12), k
+    for tag, ragged in (("full", False), ("ragged", True)):
+        sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+        x, x_sl = O.synth_batch(8, 4000, seed=0, ragged=ragged)
+        assert x_sl.tolist() == g[f"{tag}_x_sl"].tolist()
+        out = O.lstm_audio_forward(sd, x, x_sl, stack=64, num_bins=2**16)
+        np.testing.assert_allclose(out["loss"].item(), g[f"{tag}_loss"], rtol=1e-6)
+        np.testing.assert_allclose(out["ll"].detach().numpy(), g[f"{tag}_ll"], rtol=1e-6)
+        out["loss"].backward()
+        for name, ref in zip(g["grad_names"].tolist(), g[f"{tag}_grad_norms"].tolist()):
+            assert sd[name].grad.double().norm().item() == pytest.approx(ref, rel=2e-4), name

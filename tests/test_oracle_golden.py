@@ -112,3 +112,20 @@ def test_vrnn_small_forward_backward(tag, beta, fn_):
         ref = T(g[f"{tag}_grad.{k}"])
         err = (p.grad - ref).norm() / (ref.norm() + 1e-12)
         assert err < 2e-5, (k, float(err))
+
+
+def test_lstm_small_forward_backward():
+    g = np.load(os.path.join(GOLDEN, "lstm.npz"))
+    sd = {k[5:]: T(g[k]).clone().requires_grad_(True) for k in g.files if k.startswith("s_sd.")}
+    x, x_sl = T(g["s_x"]), T(g["s_x_sl"])
+    out = O.lstm_audio_forward(sd, x, x_sl, stack=8, num_bins=2**16)
+    assert out["loss"].dtype == torch.float32  # fp32 sums for LSTM
+    close(out["loss"], g["s_loss"], 1e-6, 0)
+    close(out["ll"], g["s_ll"], 1e-6, 1e-4)
+    close(out["z"], g["s_z"], 1e-5, 1e-6)
+    close(out["h_n"], g["s_hn"][0], 1e-5, 1e-6)
+    close(out["c_n"], g["s_cn"][0], 1e-5, 1e-6)
+    out["loss"].backward()
+    for k, p in sd.items():
+        ref = T(g[f"s_grad.{k}"])
+        assert (p.grad - ref).norm() / (ref.norm() + 1e-12) < 2e-5, k
