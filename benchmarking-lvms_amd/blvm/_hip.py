@@ -30,6 +30,15 @@ class VrnnWeights(ctypes.Structure):
     ]  # fmt: skip
 
 
+class SrnnWeights(ctypes.Structure):
+    """struct BlvmSrnnWeights / BlvmSrnnGrads."""
+
+    _fields_ = [
+        ("prior_w", c_void_p * 3), ("prior_b", c_void_p * 3), ("prior_hw", c_void_p), ("prior_hb", c_void_p),
+        ("post_w", c_void_p * 3), ("post_b", c_void_p * 3), ("post_hw", c_void_p), ("post_hb", c_void_p),
+    ]  # fmt: skip
+
+
 _SIGNATURES = {
     "blvm_version": (c_int, []),
     "blvm_last_error": (ctypes.c_char_p, []),
@@ -65,6 +74,12 @@ _SIGNATURES = {
                          + [c_void_p] * 3),
     "blvm_gru_seq_bwd": (c_int, [c_void_p] * 3 + [c_int, c_void_p, c_int, c_void_p, c_void_p, ctypes.c_longlong, c_int]
                          + [c_int] * 4 + [c_void_p, c_int, c_int] + [c_void_p] * 7),
+    "blvm_srnn_reserve_floats": (c_size_t, [c_int] * 5),
+    "blvm_srnn_bwd_workspace_floats": (c_size_t, [c_int] * 5),
+    "blvm_srnn_latent_fwd": (c_int, [ctypes.POINTER(SrnnWeights)] + [c_void_p] * 4 + [c_int] * 6 + [c_float, c_float]
+                             + [c_void_p] * 7),
+    "blvm_srnn_latent_bwd": (c_int, [ctypes.POINTER(SrnnWeights)] + [c_void_p] * 13 + [c_int, c_float] + [c_int] * 6
+                             + [c_float, c_float] + [c_void_p] * 3 + [ctypes.POINTER(SrnnWeights), c_void_p, c_void_p]),
 }  # fmt: skip
 
 EXPORTS = tuple(_SIGNATURES)

@@ -1,0 +1,224 @@
+"""SRNN [Fraccaro et al. 2016] with the reference's construction API and state_dict layout, computed by HIP kernels.
+
+Reference: blvm/models/srnn.py — `SRNN` :28-403 (`compute_elbo` :137-160, `forward` :162-302), `SRNNAudio` :406-536.
+Pipeline: encoder MLP (K6) -> forward GRU d over the shifted encoding (K2) -> time-reversed GRU a over cat[x, d] (K2,
+per-row reversal folded into the kernel) -> latent chain z_t | z_{t-1}, d_t, a_t (K3) -> decoder MLP (K6) -> DMoL (K7),
+KL + free nats (K8, backward fused into K3).  Faithful quirk: `kl` in the outputs/metrics is the RAW KL while the
+loss uses the free-nats-clamped one (srnn.py:154-160; the VRNN returns the clamped one).
+"""
+import math
+from typing import Optional, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.init as init
+
+from blvm import ops
+from blvm.data.transforms import StackTensor
+from blvm.evaluation import BitsPerDimMetric, DeferredScalars, KLMetric, LatestMeanMetric, LLMetric, LossMetric
+from blvm.models.base_model import BaseModel
+from blvm.models.vrnn import LazyNamespace, _linears
+from blvm.modules.convenience import View
+from blvm.modules.distributions import DiagonalGaussianDense, DiscretizedLogisticMixtureDense
+from blvm.utils.operations import split_sequence
+from blvm.utils.padding import get_modulo_length
+
+
+class SRNN(nn.Module):
+    def __init__(self, encoder, decoder, likelihood, x_dim, h_dim, z_dim, r_dim: Optional[int] = None,
+                 gated_stochastic_transfer: bool = False, use_phi_z: bool = False, dropout: float = 0, num_layers: int = 1,
+                 residual_posterior: bool = False, smoothing: bool = True):  # fmt: skip
+        super().__init__()
+        r_dim = 2 * h_dim if r_dim is None else r_dim
+        if gated_stochastic_transfer or use_phi_z or dropout or num_layers != 1:
+            # num_layers > 1 crashes in the reference itself (srnn.py:197); the other switches are never
+            # set by SRNNAudio (srnn.py:475-485)
+            raise NotImplementedError("libblvm_hip: SRNN is built in the form SRNNAudio constructs "
+                                      "(Elman stochastic transfer, no phi_z, no dropout, one GRU layer)")
+        self.encoder, self.decoder = encoder, decoder
+        self.x_dim, self.h_dim, self.z_dim, self.r_dim = x_dim, h_dim, z_dim, r_dim
+        self.use_phi_z, self.gated_stochastic_transfer = use_phi_z, gated_stochastic_transfer
+        self.dropout, self.num_layers = None, num_layers
+        self.residual_posterior, self.smoothing = residual_posterior, smoothing
+        self.phi_z = None
+
+        def mlp_head(i):
+            return nn.Sequential(nn.Linear(i, h_dim), nn.LeakyReLU(), nn.Linear(h_dim, h_dim), nn.LeakyReLU(),
+                                 nn.Linear(h_dim, h_dim), nn.LeakyReLU(), DiagonalGaussianDense(h_dim, z_dim))  # fmt: skip
+
+        # registration / RNG order of the reference: posterior, prior, d-GRU, a-GRU (srnn.py:92-121)
+        self.posterior = mlp_head(r_dim + z_dim)
+        self.prior = mlp_head(r_dim + z_dim)
+        self.d_forward_recurrent = nn.GRU(x_dim, r_dim, num_layers)
+        if smoothing:
+            self.a_backward_recurrent = nn.GRU(x_dim + r_dim, r_dim, num_layers)
+        else:
+            self.a_mlp = nn.Sequential(nn.Linear(x_dim + r_dim, r_dim), nn.LeakyReLU(), nn.Linear(r_dim, r_dim), nn.LeakyReLU())
+        self.likelihood = likelihood
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        init.orthogonal_(self.d_forward_recurrent.weight_hh_l0)
+        if self.smoothing:
+            init.orthogonal_(self.a_backward_recurrent.weight_hh_l0)
+
+    def _chain_params(self):
+        out = []
+        for seq in (self.prior, self.posterior):
+            for i in (0, 2, 4):
+                out += [seq[i].weight, seq[i].bias]
+            out += [seq[6].params.weight, seq[6].params.bias]
+        return out
+
+    def _plan(self):
+        enc, dec, lik = self.encoder, self.decoder, self.likelihood
+        stack = next((m for m in enc if isinstance(m, StackTensor)), None) if isinstance(enc, nn.Sequential) else None
+        ok = (
+            stack is not None
+            and isinstance(dec, nn.Sequential)
+            and isinstance(lik, DiscretizedLogisticMixtureDense)
+            and all(isinstance(m, (nn.Linear, nn.LeakyReLU, View, StackTensor)) for m in list(enc) + list(dec))
+            and isinstance(dec[-2], nn.LeakyReLU)
+        )
+        if not ok:
+            raise NotImplementedError("libblvm_hip accelerates the SRNNAudio(likelihood='DMoL') structure")
+        return stack.n_frames, _linears(enc), _linears(dec), lik
+
+    def forward(self, x, x_sl, u=None, d_0=None, a_0=None, z_0=None, h_p_0=None, h_q_0=None, beta: float = 1,
+                free_nats: float = 0, eps: Optional[torch.Tensor] = None):  # fmt: skip
+        if u is not None:
+            raise NotImplementedError("libblvm_hip: external control input u is not supported (SRNNAudio never passes it)")
+        S, enc_lin, dec_lin, lik = self._plan()
+        if x.ndim == 3:
+            x = x.squeeze(-1)
+        dev = x.device
+        B, T = x.shape
+        x_sl_host = x_sl.detach().cpu().to(torch.int64)
+        x_sl_dev = x_sl_host.to(device=dev, dtype=torch.int32)
+        y = x.detach().to(torch.float32).contiguous()
+        Tp = (T + S - 1) // S
+        stride = math.ceil(T / Tp)
+        x_sl_strided = (x_sl_host / stride).ceil().int()
+        lens_dev = x_sl_strided.to(device=dev, dtype=torch.int32)
+        H, Z, R = self.h_dim, self.z_dim, self.r_dim
+
+        xs = torch.nn.functional.pad(y, (0, Tp * S - T)) if Tp * S != T else y
+        xs = xs.view(B, Tp, S).transpose(0, 1).contiguous().view(Tp * B, S)
+        enc = ops.mlp(xs, enc_lin, ops.ACT_LEAKY, ops.LEAKY_SLOPE).view(Tp, B, -1)
+
+        # u_t = x_{t-1};  d = GRU(u);  d <- [d_0, d[:-1]]   (srnn.py:192-197)
+        u_enc = torch.cat([torch.zeros_like(enc[:1]), enc[:-1]], 0)
+        gd = self.d_forward_recurrent
+        d0 = d_0.reshape(B, R) if d_0 is not None else None
+        d_seq, d_n = ops.gru_sequence(u_enc, d0, gd.weight_ih_l0, gd.weight_hh_l0, gd.bias_ih_l0, gd.bias_hh_l0)
+        d_first = d0.unsqueeze(0) if d0 is not None else torch.zeros(1, B, R, device=dev)
+        d = torch.cat([d_first, d_seq[:-1]], 0)
+
+        cat_xd = torch.cat([enc, d], -1)
+        if self.smoothing:
+            ga = self.a_backward_recurrent
+            a0 = a_0.reshape(B, R) if a_0 is not None else None
+            a, a_n = ops.gru_sequence(cat_xd, a0, ga.weight_ih_l0, ga.weight_hh_l0, ga.bias_ih_l0, ga.bias_hh_l0, lens_dev, True)
+            a_n = a_n.unsqueeze(0)
+        else:
+            a = ops.mlp(cat_xd.view(Tp * B, -1), _linears(self.a_mlp), ops.ACT_LEAKY, ops.LEAKY_SLOPE).view(Tp, B, R)
+            a_n = None
+
+        if eps is None:
+            eps = torch.randn(Tp, B, Z, device=dev, dtype=torch.float32)
+        head = self.prior[6]
+        zs, kld, kld_fn, mu_q, sd_q, mu_p, sd_p = ops.srnn_latent_chain(
+            d, a, z_0, eps, x_sl_dev, self._chain_params(), H, Z, R, self.residual_posterior, stride, free_nats, head.epsilon
+        )
+        z = zs[1:]
+        dec = ops.mlp(torch.cat([z, d], -1).view(Tp * B, Z + R), dec_lin, ops.ACT_LEAKY, ops.LEAKY_SLOPE)
+        log_prob = ops.dmol_log_prob(dec, lik.params.weight, lik.params.bias, y, x_sl_dev, ops.LAYOUT_TIME_MAJOR, B, T, Tp, S,
+                                     lik.num_mix, lik.num_bins, lik.log_epsilon)  # fmt: skip
+
+        n_frames = float(x_sl_host.sum())
+        elbo = log_prob - kld
+        loss = -(log_prob - beta * kld_fn).sum() / n_frames
+        kl = kld  # raw KL (srnn.py:156-160)
+
+        sums = DeferredScalars(torch.stack([loss.detach(), elbo.detach().sum(), log_prob.detach().sum(), kl.detach().sum()]))
+        ln2 = math.log(2)
+        metrics = [
+            LossMetric(sums[0], weight_by=B),
+            LLMetric(sums[1], name="elbo", reduce_by=B),
+            LLMetric(sums[2], name="rec", reduce_by=B),
+            KLMetric(sums[3], reduce_by=B),
+            KLMetric(sums[3] / ln2, name="kl (bpt)", reduce_by=n_frames),
+            BitsPerDimMetric(sums[1], reduce_by=n_frames),
+            LatestMeanMetric(beta, name="beta"),
+            LatestMeanMetric(free_nats, name="free_nats"),
+        ]
+        max_len = int(x_sl_host.max())
+        F = lik.out_features
+
+        def parameters():
+            p = dec.detach().view(Tp, B, S, F).permute(1, 0, 2, 3).reshape(B, Tp * S, F)[:, :max_len]
+            return lik(p.contiguous())
+
+        lazy = dict(
+            parameters=parameters,
+            reconstructions_parameters=lambda: outputs.parameters,
+            reconstructions=lambda: lik.sample(outputs.parameters),
+            reconstructions_mode=lambda: lik.mode(outputs.parameters),
+            seq_mask=lambda: (torch.arange(max_len, device=dev).unsqueeze(0) < x_sl_dev.unsqueeze(1)).to(torch.float64),
+        )
+        outputs = LazyNamespace(
+            lazy, elbo=elbo, log_prob=log_prob, kl=kl, y=y.unsqueeze(-1), z=z.transpose(0, 1), z_sl=x_sl_strided,
+            d_n=d_n.unsqueeze(0), a_n=a_n, z_n=z[-1], h_p_n=None, h_q_n=None,
+        )  # fmt: skip
+        return loss, metrics, outputs
+
+
+class SRNNAudio(BaseModel):
+    def __init__(self, likelihood: Union[str, nn.Module], input_size: int = 200, hidden_size: int = 256, latent_size: int = 64,
+                 dropout: float = 0, residual_posterior: bool = False, smoothing: bool = True, num_mix: int = 10,
+                 num_bins: int = 256):  # fmt: skip
+        super().__init__()
+        self.likelihood = likelihood
+        self.input_size = input_size
+        self.hidden_size = hidden_size
+        self.latent_size = latent_size
+        self.dropout = dropout
+        self.residual_posterior = residual_posterior
+        self.num_mix = num_mix
+        self.num_bins = num_bins
+        self.smoothing = smoothing
+
+        if likelihood == "DMoL":
+            # hard-coded num_mix / num_bins on this branch, as in the reference (srnn.py:433-438)
+            likelihood_module = DiscretizedLogisticMixtureDense(x_dim=2 * num_mix + num_mix, y_dim=1, num_mix=10, num_bins=2**16)
+        elif likelihood in ("GMM", "Gaussian"):
+            raise NotImplementedError(f"libblvm_hip: likelihood '{likelihood}' is not built yet (DMoL is the benchmark head)")
+        else:
+            raise ValueError(f"Unknown likelihood type {likelihood}")
+
+        encoder = nn.Sequential(
+            View(-1), StackTensor(input_size, dim=1),
+            nn.Linear(input_size, hidden_size), nn.LeakyReLU(),
+            nn.Linear(hidden_size, hidden_size), nn.LeakyReLU(),
+            nn.Linear(hidden_size, hidden_size), nn.LeakyReLU(),
+        )  # fmt: skip
+        decoder = nn.Sequential(
+            nn.Linear(2 * hidden_size + latent_size, hidden_size), nn.LeakyReLU(),
+            nn.Linear(hidden_size, hidden_size), nn.LeakyReLU(),
+            nn.Linear(hidden_size, input_size * likelihood_module.out_features), nn.LeakyReLU(),
+            View(-1, likelihood_module.out_features),
+        )  # fmt: skip
+        self.srnn = SRNN(encoder=encoder, decoder=decoder, likelihood=likelihood_module, x_dim=hidden_size, h_dim=hidden_size,
+                         z_dim=latent_size, dropout=dropout, residual_posterior=residual_posterior, smoothing=smoothing)  # fmt: skip
+        self.forward_split = self.forward
+
+    def split_sequence(self, x, x_sl, length: int, drop_inactive: bool = False):
+        """Split long sequences into stack-aligned sub-sequences without overlap (srnn.py:489-499); states d_n, a_n, z_n
+        of one split are passed as d_0, a_0, z_0 of the next."""
+        length = get_modulo_length(length, self.input_size, kernel_size=self.input_size)
+        return split_sequence(x, x_sl, length=length, overlap=0, drop_inactive=drop_inactive)
+
+    def forward(self, x, x_sl, beta: float = 1, free_nats: float = 0, d_0=None, a_0=None, z_0=None, eps=None):
+        loss, metrics, outputs = self.srnn(x=x, x_sl=x_sl, d_0=d_0, a_0=a_0, z_0=z_0, beta=beta, free_nats=free_nats, eps=eps)
+        outputs._lazy["x_hat"] = lambda: self.srnn.likelihood.sample(outputs.parameters)
+        return loss, metrics, outputs

@@ -434,3 +434,94 @@ def gru_sequence(inp, h0, Wih, Whh, bih, bhh, lens_dev=None, reverse=False):
     """inp [T,B,I] -> (out [T,B,R], h_n [B,R]).  reverse=True: per-row time reversal that leaves right padding in
     place (needs lens_dev [B] int32) — equivalent to reverse_sequences -> GRU -> reverse_sequences."""
     return _GRUSeqFunction.apply(inp, h0, lens_dev, reverse, Wih, Whh, bih, bhh)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# K3: SRNN latent chain
+# ----------------------------------------------------------------------------------------------------------------------
+
+_SRNN_PARAM_ORDER = (
+    ["prior_w0", "prior_b0", "prior_w1", "prior_b1", "prior_w2", "prior_b2", "prior_hw", "prior_hb"]
+    + ["post_w0", "post_b0", "post_w1", "post_b1", "post_w2", "post_b2", "post_hw", "post_hb"]
+)
+
+
+def _pack_srnn(ts):
+    d = dict(zip(_SRNN_PARAM_ORDER, ts))
+    w = _hip.SrnnWeights()
+    for i in range(3):
+        w.prior_w[i], w.prior_b[i] = ptr(d[f"prior_w{i}"]), ptr(d[f"prior_b{i}"])
+        w.post_w[i], w.post_b[i] = ptr(d[f"post_w{i}"]), ptr(d[f"post_b{i}"])
+    w.prior_hw, w.prior_hb, w.post_hw, w.post_hb = ptr(d["prior_hw"]), ptr(d["prior_hb"]), ptr(d["post_hw"]), ptr(d["post_hb"])
+    return w
+
+
+class _SRNNLatentFunction(torch.autograd.Function):
+    """(d, a, z0, eps, 16 params) -> zs [T'+1,B,Z], kld [B], kld_fn [B]  (+ non-differentiable mu/sd)."""
+
+    @staticmethod
+    def forward(ctx, d, a, z0, eps, x_sl_dev, cfg, *params):
+        Tp, B, H, Z, R, residual, sd_eps, slope, stride, fn_floor = cfg
+        d, a, eps = _f32c(d), _f32c(a), _f32c(eps)
+        params = tuple(_f32c(p) for p in params)
+        lib = load()
+        f32 = dict(device=d.device, dtype=torch.float32)
+        zs = torch.empty(Tp + 1, B, Z, **f32)
+        mu_q, sd_q, mu_p, sd_p = (torch.empty(Tp, B, Z, **f32) for _ in range(4))
+        reserve = torch.empty(lib.blvm_srnn_reserve_floats(Tp, B, H, Z, R), **f32)
+        _tick("fwd_begin")
+        check(
+            lib.blvm_srnn_latent_fwd(_pack_srnn(params), ptr(d), ptr(a), ptr(_f32c(z0)) if z0 is not None else None, ptr(eps),
+                                     Tp, B, H, Z, R, int(residual), sd_eps, slope, ptr(zs), ptr(mu_q), ptr(sd_q), ptr(mu_p),
+                                     ptr(sd_p), ptr(reserve), stream_ptr()),
+            "blvm_srnn_latent_fwd",
+        )  # fmt: skip
+        _tick("fwd_end")
+        kld = torch.zeros(B, device=d.device, dtype=torch.float64)
+        kld_fn = torch.zeros(B, device=d.device, dtype=torch.float64)
+        check(
+            lib.blvm_kl_fwd(ptr(mu_q), ptr(sd_q), ptr(mu_p), ptr(sd_p), LAYOUT_TIME_MAJOR, ptr(x_sl_dev), B, Tp, Z, stride,
+                            fn_floor, ptr(kld), ptr(kld_fn), stream_ptr()),
+            "blvm_kl_fwd",
+        )  # fmt: skip
+        ctx.cfg = cfg
+        ctx.has_z0 = z0 is not None
+        ctx.save_for_backward(d, a, eps, x_sl_dev, zs, mu_q, sd_q, mu_p, sd_p, reserve, *params)
+        ctx.mark_non_differentiable(mu_q, sd_q, mu_p, sd_p)
+        return zs, kld, kld_fn, mu_q, sd_q, mu_p, sd_p
+
+    @staticmethod
+    def backward(ctx, d_zs, g_kld, g_kld_fn, *_unused):
+        Tp, B, H, Z, R, residual, sd_eps, slope, stride, fn_floor = ctx.cfg
+        d, a, eps, x_sl_dev, zs, mu_q, sd_q, mu_p, sd_p, reserve, *params = ctx.saved_tensors
+        lib = load()
+        f32 = dict(device=d.device, dtype=torch.float32)
+        d_zs = _f32c(d_zs) if d_zs is not None else torch.zeros_like(zs)
+        d_z = d_zs[1:]  # rows 1.. are the sampled latents; row 0 is z0 (its direct gradient is added below)
+        c_raw = g_kld.to(torch.float32).contiguous() if g_kld is not None else None
+        c_fn = g_kld_fn.to(torch.float32).contiguous() if g_kld_fn is not None else None
+        grads = [torch.zeros_like(p) for p in params]
+        d_d, d_a = torch.empty_like(d), torch.empty_like(a)
+        d_z0 = torch.empty(B, Z, **f32) if ctx.has_z0 else None
+        ws = torch.empty(lib.blvm_srnn_bwd_workspace_floats(Tp, B, H, Z, R), **f32)
+        _tick("bwd_begin")
+        check(
+            lib.blvm_srnn_latent_bwd(_pack_srnn(params), ptr(d), ptr(a), ptr(eps), ptr(zs), ptr(mu_q), ptr(sd_q), ptr(mu_p),
+                                     ptr(sd_p), ptr(reserve), ptr(d_z), ptr(x_sl_dev), ptr(c_raw), ptr(c_fn), stride, fn_floor,
+                                     Tp, B, H, Z, R, int(residual), sd_eps, slope, ptr(d_d), ptr(d_a), ptr(d_z0),
+                                     _pack_srnn(grads), ptr(ws), stream_ptr()),
+            "blvm_srnn_latent_bwd",
+        )  # fmt: skip
+        _tick("bwd_end")
+        if d_z0 is not None:
+            d_z0 = d_z0 + d_zs[0]
+        return (d_d, d_a, d_z0, None, None, None, *grads)
+
+
+def srnn_latent_chain(d, a, z0, eps, x_sl_dev, params, H, Z, R, residual_posterior, stride, free_nats=0.0, sd_eps=1e-6,
+                      slope=LEAKY_SLOPE):  # fmt: skip
+    """d, a [T',B,R] -> (zs [T'+1,B,Z] with zs[0]=z0, kld [B] f64, kld_fn [B] f64, mu_q, sd_q, mu_p, sd_p)."""
+    Tp, B, _ = d.shape
+    fn_floor = float(free_nats) / Z if free_nats else 0.0
+    cfg = (Tp, B, H, Z, R, bool(residual_posterior), float(sd_eps), float(slope), int(stride), fn_floor)
+    return _SRNNLatentFunction.apply(d, a, z0, eps, x_sl_dev, cfg, *params)

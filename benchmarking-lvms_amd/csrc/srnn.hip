@@ -1,0 +1,205 @@
+// srnn.hip — K3: the SRNN latent chain (forward + BPTT) as a stage-kernel chain.
+//
+// Replaces the Python loop over time of the reference (blvm/models/srnn.py:224-253): per step
+//   h_p = cat[d_t, z_{t-1}], h_q = cat[a_t, z_{t-1}];  prior / posterior = 3 x (Linear + LeakyReLU) + DiagonalGaussianDense
+//   (srnn.py:92-111);  enc_mu += prior_mu (residual posterior);  z_t = rsample
+// and its autograd backward.  Only the z-halves of the two first layers are recurrent: the d/a halves are hoisted
+// into one MFMA GEMM each before the loop, so a step is 4 dependent links (first layers | second | third | heads +
+// sample) forward and 4 backward, every element-wise piece fused into an epilogue (stages.h).  The KL(+free nats)
+// gradient is folded into the backward chain exactly as for the VRNN cell.
+#include "common.h"
+
+namespace blvm {
+namespace {
+
+#include "stages.h"
+
+struct SrnnReserve { float *P[3], *Q[3], *XP, *XQ, *RAWP, *RAWQ; };
+size_t carve_srnn(float* base, int Tp, int B, int H, int Z, SrnnReserve* r) {
+  const size_t n = (size_t)Tp * B;
+  size_t off = 0;
+  auto take = [&](size_t cnt) { float* p = base ? base + off : nullptr; off += (cnt + 3) & ~(size_t)3; return p; };
+  SrnnReserve t;
+  for (int i = 0; i < 3; ++i) t.P[i] = take(n * H);
+  for (int i = 0; i < 3; ++i) t.Q[i] = take(n * H);
+  t.XP = take(n * H); t.XQ = take(n * H);
+  t.RAWP = take(n * Z); t.RAWQ = take(n * Z);
+  if (r) *r = t;
+  return off;
+}
+
+struct SrnnWs { float *pzT, *qzT, *pT[3], *qT[3], *phT, *qhT, *DPH, *DQH, *DP[3], *DQ[3]; };
+size_t carve_srnn_ws(float* base, int Tp, int B, int H, int Z, SrnnWs* w) {
+  const size_t n = (size_t)Tp * B;
+  size_t off = 0;
+  auto take = [&](size_t cnt) { float* p = base ? base + off : nullptr; off += (cnt + 3) & ~(size_t)3; return p; };
+  SrnnWs t;
+  t.pzT = take((size_t)Z * H); t.qzT = take((size_t)Z * H);
+  t.pT[0] = t.qT[0] = nullptr;
+  for (int i = 1; i < 3; ++i) { t.pT[i] = take((size_t)H * H); t.qT[i] = take((size_t)H * H); }
+  t.phT = take((size_t)H * 2 * Z); t.qhT = take((size_t)H * 2 * Z);
+  t.DPH = take(n * 2 * Z); t.DQH = take(n * 2 * Z);
+  for (int i = 0; i < 3; ++i) { t.DP[i] = take(n * H); t.DQ[i] = take(n * H); }
+  if (w) *w = t;
+  return off;
+}
+
+int check_srnn(int Tp, int B, int H, int Z, int R) {
+  BLVM_REQUIRE(Tp > 0 && B > 0, "srnn: bad Tp=%d B=%d", Tp, B);
+  BLVM_REQUIRE(H > 0 && Z > 0 && R > 0 && H % 16 == 0 && Z % 16 == 0 && R % 16 == 0,
+               "srnn: H,Z,R must be positive multiples of 16 (got %d,%d,%d)", H, Z, R);
+  BLVM_REQUIRE((B + 15) / 16 <= 65535, "srnn: batch too large");
+  return BLVM_OK;
+}
+
+}  // namespace
+}  // namespace blvm
+
+using namespace blvm;
+
+extern "C" size_t blvm_srnn_reserve_floats(int Tp, int B, int H, int Z, int R) {
+  (void)R;
+  return carve_srnn(nullptr, Tp, B, H, Z, nullptr);
+}
+extern "C" size_t blvm_srnn_bwd_workspace_floats(int Tp, int B, int H, int Z, int R) {
+  (void)R;
+  return carve_srnn_ws(nullptr, Tp, B, H, Z, nullptr);
+}
+
+extern "C" int blvm_srnn_latent_fwd(const BlvmSrnnWeights* w, const float* d, const float* a, const float* z0,
+                                    const float* eps, int Tp, int B, int H, int Z, int R, int residual_posterior,
+                                    float sd_eps, float slope, float* zs, float* mu_q, float* sd_q, float* mu_p,
+                                    float* sd_p, float* reserve, void* stream_) {
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  int rc = check_srnn(Tp, B, H, Z, R);
+  if (rc) return rc;
+  BLVM_REQUIRE(w && d && a && eps && zs && mu_q && sd_q && mu_p && sd_p && reserve, "srnn_fwd: null pointer");
+  BLVM_REQUIRE(aligned16(zs) && aligned16(reserve) && aligned16(d) && aligned16(a), "srnn_fwd: buffers must be 16-byte aligned");
+  SrnnReserve rs;
+  carve_srnn(reserve, Tp, B, H, Z, &rs);
+  const size_t n = (size_t)Tp * B;
+  const int ldw0 = R + Z;
+  const float beta = (float)(0.6931471805599453 / (1.0 - (double)sd_eps));
+  // hoisted d / a halves of the two first layers (incl. bias)
+  rc = gemm_f32(0, 0, (int)n, H, R, d, R, w->prior_w[0], ldw0, rs.XP, H, w->prior_b[0], 0, 0.f, nullptr, 0, 0, 1, s);
+  if (rc) return rc;
+  rc = gemm_f32(0, 0, (int)n, H, R, a, R, w->post_w[0], ldw0, rs.XQ, H, w->post_b[0], 0, 0.f, nullptr, 0, 0, 1, s);
+  if (rc) return rc;
+  if (z0) BLVM_HIP(hipMemcpyAsync(zs, z0, sizeof(float) * (size_t)B * Z, hipMemcpyDeviceToDevice, s));
+  else BLVM_HIP(hipMemsetAsync(zs, 0, sizeof(float) * (size_t)B * Z, s));
+  const int rt = (B + 15) / 16;
+  for (int t = 0; t < Tp; ++t) {
+    const size_t oH = (size_t)t * B * H, oZ = (size_t)t * B * Z;
+    const float* zprev = zs + oZ;
+    LinLaunch l;
+    l.B = B; l.slope = slope; l.nseg = 2;
+    l.seg[0] = seg(zprev, Z, w->prior_w[0] + R, ldw0, nullptr, rs.XP + oH, H, nullptr, 0, rs.P[0] + oH, H, H, Z, 1);
+    l.seg[1] = seg(zprev, Z, w->post_w[0] + R, ldw0, nullptr, rs.XQ + oH, H, nullptr, 0, rs.Q[0] + oH, H, H, Z, 1);
+    launch_lin(l, s);
+    for (int k = 1; k < 3; ++k) {
+      l.seg[0] = seg(rs.P[k - 1] + oH, H, w->prior_w[k], H, w->prior_b[k], nullptr, 0, nullptr, 0, rs.P[k] + oH, H, H, H, 1);
+      l.seg[1] = seg(rs.Q[k - 1] + oH, H, w->post_w[k], H, w->post_b[k], nullptr, 0, nullptr, 0, rs.Q[k] + oH, H, H, H, 1);
+      launch_lin(l, s);
+    }
+    HeadArgs h;
+    h.P = rs.P[2] + oH; h.Q = rs.Q[2] + oH;
+    h.Wp = w->prior_hw; h.bp = w->prior_hb; h.Wq = w->post_hw; h.bq = w->post_hb;
+    h.eps = eps + oZ;
+    h.mu_p = mu_p + oZ; h.sd_p = sd_p + oZ; h.mu_q = mu_q + oZ; h.sd_q = sd_q + oZ;
+    h.z = zs + (size_t)(t + 1) * B * Z;
+    h.raw_p = rs.RAWP + oZ; h.raw_q = rs.RAWQ + oZ;
+    h.B = B; h.H = H; h.Z = Z; h.residual = residual_posterior;
+    h.beta = beta; h.inv_beta = 1.f / beta; h.sd_eps = sd_eps;
+    LAUNCH_NW(head_stage_kernel, pick_nw(H, 4), dim3(Z / 16, rt), s, h);
+  }
+  BLVM_CHECK_LAUNCH("srnn_latent_fwd");
+  return BLVM_OK;
+}
+
+extern "C" int blvm_srnn_latent_bwd(const BlvmSrnnWeights* w, const float* d, const float* a, const float* eps,
+                                    const float* zs, const float* mu_q, const float* sd_q, const float* mu_p,
+                                    const float* sd_p, const float* reserve, const float* d_z, const int32_t* x_sl,
+                                    const float* c_raw, const float* c_fn, int stride, float fn_floor, int Tp, int B,
+                                    int H, int Z, int R, int residual_posterior, float sd_eps, float slope, float* d_d,
+                                    float* d_a, float* d_z0, const BlvmSrnnGrads* gr, float* workspace, void* stream_) {
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  int rc = check_srnn(Tp, B, H, Z, R);
+  if (rc) return rc;
+  BLVM_REQUIRE(w && d && a && eps && zs && mu_q && sd_q && mu_p && sd_p && reserve && d_z && workspace && gr, "srnn_bwd: null pointer");
+  BLVM_REQUIRE((c_fn == nullptr && c_raw == nullptr) || x_sl != nullptr, "srnn_bwd: KL coefficients need x_sl");
+  BLVM_REQUIRE(aligned16(workspace) && aligned16(reserve), "srnn_bwd: buffers must be 16-byte aligned");
+  SrnnReserve rs;
+  carve_srnn(const_cast<float*>(reserve), Tp, B, H, Z, &rs);
+  SrnnWs ws;
+  carve_srnn_ws(workspace, Tp, B, H, Z, &ws);
+  const size_t n = (size_t)Tp * B;
+  const int ldw0 = R + Z;
+  const float beta = (float)(0.6931471805599453 / (1.0 - (double)sd_eps));
+#define TRY(x) do { rc = (x); if (rc) return rc; } while (0)
+  TRY(transpose_f32(H, Z, w->prior_w[0] + R, ldw0, ws.pzT, H, s));
+  TRY(transpose_f32(H, Z, w->post_w[0] + R, ldw0, ws.qzT, H, s));
+  for (int k = 1; k < 3; ++k) {
+    TRY(transpose_f32(H, H, w->prior_w[k], H, ws.pT[k], H, s));
+    TRY(transpose_f32(H, H, w->post_w[k], H, ws.qT[k], H, s));
+  }
+  TRY(transpose_f32(2 * Z, H, w->prior_hw, H, ws.phT, 2 * Z, s));
+  TRY(transpose_f32(2 * Z, H, w->post_hw, H, ws.qhT, 2 * Z, s));
+  const int rt = (B + 15) / 16;
+  for (int t = Tp - 1; t >= 0; --t) {
+    const size_t oH = (size_t)t * B * H, oZ = (size_t)t * B * Z, o2Z = (size_t)t * B * 2 * Z;
+    // B1: dz_t = decoder gradient + the two first layers of step t+1, then rsample / residual / KL / softplus heads
+    DzArgs dz;
+    dz.has_gemm = t < Tp - 1;
+    dz.D = ws.DP[0] + (dz.has_gemm ? oH + (size_t)B * H : 0); dz.WT = ws.pzT;
+    dz.D2 = ws.DQ[0] + (dz.has_gemm ? oH + (size_t)B * H : 0); dz.WT2 = ws.qzT;
+    dz.dz_add = d_z + oZ; dz.ld_add = Z;
+    dz.mu_q = mu_q + oZ; dz.sd_q = sd_q + oZ; dz.mu_p = mu_p + oZ; dz.sd_p = sd_p + oZ; dz.eps = eps + oZ;
+    dz.raw_q = rs.RAWQ + oZ; dz.raw_p = rs.RAWP + oZ;
+    dz.x_sl = x_sl; dz.c_raw = c_raw; dz.c_fn = c_fn;
+    dz.dqh = ws.DQH + o2Z; dz.dph = ws.DPH + o2Z;
+    dz.B = B; dz.H = H; dz.Z = Z; dz.residual = residual_posterior; dz.t = t; dz.stride = stride;
+    dz.fn_floor = fn_floor; dz.beta = beta;
+    LAUNCH_NW(dz_stage_kernel, pick_nw(H, 2), dim3(Z / 16, rt), s, dz);
+    // B2: heads -> third layers;  B3, B4: down to the first layers (LeakyReLU derivatives fused)
+    LinLaunch l;
+    l.B = B; l.slope = slope; l.nseg = 2;
+    l.seg[0] = seg(ws.DPH + o2Z, 2 * Z, ws.phT, 2 * Z, nullptr, nullptr, 0, rs.P[2] + oH, H, ws.DP[2] + oH, H, H, 2 * Z, 0);
+    l.seg[1] = seg(ws.DQH + o2Z, 2 * Z, ws.qhT, 2 * Z, nullptr, nullptr, 0, rs.Q[2] + oH, H, ws.DQ[2] + oH, H, H, 2 * Z, 0);
+    launch_lin(l, s);
+    for (int k = 2; k >= 1; --k) {
+      l.seg[0] = seg(ws.DP[k] + oH, H, ws.pT[k], H, nullptr, nullptr, 0, rs.P[k - 1] + oH, H, ws.DP[k - 1] + oH, H, H, H, 0);
+      l.seg[1] = seg(ws.DQ[k] + oH, H, ws.qT[k], H, nullptr, nullptr, 0, rs.Q[k - 1] + oH, H, ws.DQ[k - 1] + oH, H, H, H, 0);
+      launch_lin(l, s);
+    }
+  }
+  BLVM_CHECK_LAUNCH("srnn_latent_bwd");
+  if (d_z0) {  // gradient wrt the initial latent: both first layers of step 0
+    LinLaunch l;
+    l.B = B; l.slope = 0.f; l.nseg = 1;
+    l.seg[0] = seg(ws.DP[0], H, ws.pzT, H, nullptr, nullptr, 0, nullptr, 0, d_z0, Z, Z, H, 0);
+    launch_lin(l, s);
+    l.seg[0] = seg(ws.DQ[0], H, ws.qzT, H, nullptr, d_z0, Z, nullptr, 0, d_z0, Z, Z, H, 0);
+    launch_lin(l, s);
+  }
+  // batched, state-independent part
+  if (d_d) TRY(gemm_f32(0, 1, (int)n, R, H, ws.DP[0], H, w->prior_w[0], ldw0, d_d, R, nullptr, 0, 0.f, nullptr, 0, 0, 1, s));
+  if (d_a) TRY(gemm_f32(0, 1, (int)n, R, H, ws.DQ[0], H, w->post_w[0], ldw0, d_a, R, nullptr, 0, 0.f, nullptr, 0, 0, 1, s));
+  TRY(wgrad(ws.DP[0], H, H, d, R, R, gr->prior_w[0], ldw0, n, s));
+  TRY(wgrad(ws.DP[0], H, H, zs, Z, Z, gr->prior_w[0] ? gr->prior_w[0] + R : nullptr, ldw0, n, s));
+  TRY(bgrad(ws.DP[0], H, H, gr->prior_b[0], n, s));
+  TRY(wgrad(ws.DQ[0], H, H, a, R, R, gr->post_w[0], ldw0, n, s));
+  TRY(wgrad(ws.DQ[0], H, H, zs, Z, Z, gr->post_w[0] ? gr->post_w[0] + R : nullptr, ldw0, n, s));
+  TRY(bgrad(ws.DQ[0], H, H, gr->post_b[0], n, s));
+  for (int k = 1; k < 3; ++k) {
+    TRY(wgrad(ws.DP[k], H, H, rs.P[k - 1], H, H, gr->prior_w[k], H, n, s));
+    TRY(bgrad(ws.DP[k], H, H, gr->prior_b[k], n, s));
+    TRY(wgrad(ws.DQ[k], H, H, rs.Q[k - 1], H, H, gr->post_w[k], H, n, s));
+    TRY(bgrad(ws.DQ[k], H, H, gr->post_b[k], n, s));
+  }
+  TRY(wgrad(ws.DPH, 2 * Z, 2 * Z, rs.P[2], H, H, gr->prior_hw, H, n, s));
+  TRY(bgrad(ws.DPH, 2 * Z, 2 * Z, gr->prior_hb, n, s));
+  TRY(wgrad(ws.DQH, 2 * Z, 2 * Z, rs.Q[2], H, H, gr->post_hw, H, n, s));
+  TRY(bgrad(ws.DQH, 2 * Z, 2 * Z, gr->post_hb, n, s));
+#undef TRY
+  return BLVM_OK;
+}

@@ -19,114 +19,7 @@
 namespace blvm {
 namespace {
 
-// ---------------------------------------------------------------------------------------------------------------
-// Launch-latency notes (measured, profiles/r01_*): a link of the chain costs the kernel boundary (~1.5 us) plus every
-// DEPENDENT memory round trip inside the kernel.  So: (1) no dynamically indexed kernel arguments (each would be a
-// dependent scalar load) — segments are selected with scalar selects on values that arrive with the first kernarg
-// fetch; (2) every epilogue operand (bias, addend, gate, saved activations) is loaded BEFORE the K loop so it
-// travels with the operand loads; (3) the K split is as wide as the reduction allows (NW = 4/8/16 waves) so a
-// wave's dependent MFMA chain is <= 24 instructions.
-// ---------------------------------------------------------------------------------------------------------------
-
-// generic multi-segment linear stage:  out = gate( act( A W^T + bias + add ) )
-// Struct-of-arrays + scalar selects: every field is a plain kernarg scalar (s_load -> SGPR -> s_cselect); absent
-// operands are replaced on the host by a valid dummy pointer (W) plus a flag bit, so all prefetches are unconditional.
-enum { LF_BIAS = 1, LF_ADD = 2, LF_GATE = 4, LF_RELU = 8 };
-
-template <int NSEG>
-struct LinArgs {
-  const float* A[NSEG];     // [B,K]
-  const float* W[NSEG];     // [ncols,K], k contiguous
-  const float* bias[NSEG];  // [ncols]
-  const float* add[NSEG];   // [B,ncols] (may alias out)
-  const float* gate[NSEG];  // [B,ncols]: result *= (gate > 0)
-  float* out[NSEG];         // [B,ncols]
-  int lda[NSEG], ldw[NSEG], ldadd[NSEG], ldgate[NSEG], ldo[NSEG], tiles[NSEG], flags[NSEG];
-  int B, K;
-};
-
-#define PICK(f) (NSEG == 1 ? a.f[0] : (s == 0 ? a.f[0] : (NSEG == 2 || s == 1 ? a.f[NSEG > 1 ? 1 : 0] : a.f[NSEG > 2 ? 2 : 0])))
-
-template <int NW, int NSEG>
-__global__ __launch_bounds__(NW * 64) void lin_stage_kernel(LinArgs<NSEG> a) {
-  __shared__ float red[NW * 256];
-  int ct = blockIdx.x, s = 0;
-  if (NSEG > 1) {
-    const int t0 = a.tiles[0], t1 = a.tiles[NSEG > 1 ? 1 : 0];
-    s = (ct >= t0 ? 1 : 0) + ((NSEG > 2 && ct >= t0 + t1) ? 1 : 0);
-    ct -= (s >= 1 ? t0 : 0) + (s >= 2 ? t1 : 0);
-  }
-  const float* A = PICK(A);
-  const float* W = PICK(W);
-  const float* bias = PICK(bias);
-  const float* add = PICK(add);
-  const float* gate = PICK(gate);
-  float* out = PICK(out);
-  const int lda = PICK(lda), ldw = PICK(ldw), ldadd = PICK(ldadd), ldgate = PICK(ldgate), ldo = PICK(ldo);
-  const int flags = PICK(flags);
-  const int r0 = blockIdx.y * 16, c0 = ct * 16;
-  const int t = threadIdx.x & 255;
-  const int row = r0 + (t >> 4), col = c0 + (t & 15);
-  const bool own = threadIdx.x < 256 && row < a.B;
-  const int rowc = row < a.B ? row : r0;  // clamped row: the prefetches below are unconditional
-  // epilogue operands first: they travel with the operand loads instead of after the reduction
-  const float e_bias = bias[(flags & LF_BIAS) ? col : 0];
-  const float e_add = add[(flags & LF_ADD) ? (size_t)rowc * ldadd + col : 0];
-  const float e_gate = gate[(flags & LF_GATE) ? (size_t)rowc * ldgate + col : 0];
-  f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-  acc[0] = wave_gemm16<NW>(A, lda, r0, a.B, W, ldw, c0, a.K, threadIdx.x >> 6, acc[0]);
-  float v[1];
-  reduce_tiles<1, NW>(acc, red, v);
-  if (!own) return;
-  float x = v[0] + ((flags & LF_BIAS) ? e_bias : 0.f) + ((flags & LF_ADD) ? e_add : 0.f);
-  if (flags & LF_RELU) x = x > 0.f ? x : 0.f;
-  if (flags & LF_GATE) x = e_gate > 0.f ? x : 0.f;
-  out[(size_t)row * ldo + col] = x;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// F4: both Gaussian heads + residual mean + reparameterised sample
-// ---------------------------------------------------------------------------------------------------------------
-struct HeadArgs {
-  const float *P, *Q;                 // [B,H] last hidden of prior / posterior MLP
-  const float *Wp, *bp, *Wq, *bq;     // [2Z,H], [2Z]
-  const float* eps;                   // [B,Z]
-  float *mu_p, *sd_p, *mu_q, *sd_q, *z, *raw_p, *raw_q;  // [B,Z]
-  int B, H, Z, residual;
-  float beta, inv_beta, sd_eps;
-};
-
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void head_stage_kernel(HeadArgs a) {
-  __shared__ float red[4 * NW * 256];
-  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, wave = threadIdx.x >> 6;
-  const int t = threadIdx.x & 255;
-  const int row = r0 + (t >> 4), col = c0 + (t & 15);
-  const bool own = threadIdx.x < 256 && row < a.B;
-  const size_t o = (size_t)row * a.Z + col;
-  const size_t oc = (size_t)(row < a.B ? row : r0) * a.Z + col;  // clamped: unconditional prefetch
-  const float b0 = a.bp[col], b1 = a.bp[a.Z + col], b2 = a.bq[col], b3 = a.bq[a.Z + col], e = a.eps[oc];
-  f32x4 acc[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  acc[0] = wave_gemm16<NW>(a.P, a.H, r0, a.B, a.Wp, a.H, c0, a.H, wave, acc[0]);
-  acc[1] = wave_gemm16<NW>(a.P, a.H, r0, a.B, a.Wp, a.H, a.Z + c0, a.H, wave, acc[1]);
-  acc[2] = wave_gemm16<NW>(a.Q, a.H, r0, a.B, a.Wq, a.H, c0, a.H, wave, acc[2]);
-  acc[3] = wave_gemm16<NW>(a.Q, a.H, r0, a.B, a.Wq, a.H, a.Z + c0, a.H, wave, acc[3]);
-  float v[4];
-  reduce_tiles<4, NW>(acc, red, v);
-  if (!own) return;
-  const float mp = v[0] + b0;
-  const float rp = v[1] + b1;
-  float mq = v[2] + b2;
-  const float rq = v[3] + b3;
-  const float sp = softplus_beta(rp, a.beta, a.inv_beta) + a.sd_eps;
-  const float sq = softplus_beta(rq, a.beta, a.inv_beta) + a.sd_eps;
-  if (a.residual) mq += mp;
-  a.mu_p[o] = mp; a.sd_p[o] = sp; a.mu_q[o] = mq; a.sd_q[o] = sq;
-  a.raw_p[o] = rp; a.raw_q[o] = rq;
-  a.z[o] = e * sq + mq;  // randn_like(mu).mul(sd).add(mu)
-}
+#include "stages.h"
 
 // ---------------------------------------------------------------------------------------------------------------
 // F9: GRU input projection of phi + gates + state update
@@ -169,61 +62,6 @@ __global__ __launch_bounds__(NW * 64) void gru_stage_kernel(GruArgs a) {
   a.decin_next[(size_t)row * ldd + a.H + col] = (1.f - u) * n + u * hp;
   const size_t o = (size_t)row * a.R + col;
   a.rg[o] = r; a.ug[o] = u; a.ng[o] = n;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// B6: dz = dphi0 W_phi0, then through rsample / residual / KL(+free nats) / softplus heads
-// ---------------------------------------------------------------------------------------------------------------
-struct DzArgs {
-  const float* D;    // [B,H] grad wrt pre-activation of phi layer 0
-  const float* WT;   // [Z,H] = phi_w[0]^T
-  const float *mu_q, *sd_q, *mu_p, *sd_p, *eps, *raw_q, *raw_p;  // [B,Z] (step t)
-  const int32_t* x_sl;
-  const float *c_raw, *c_fn;  // [B] or null
-  float *dqh, *dph;   // [B,2Z] grads wrt the heads' Linear outputs
-  int B, H, Z, residual, t, stride;
-  float fn_floor, beta;
-};
-
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void dz_stage_kernel(DzArgs a) {
-  __shared__ float red[NW * 256];
-  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16;
-  const int t = threadIdx.x & 255;
-  const int row = r0 + (t >> 4), col = c0 + (t & 15);
-  const bool own = threadIdx.x < 256 && row < a.B;
-  const int rowc = row < a.B ? row : r0;  // clamped: unconditional prefetch
-  const size_t o = (size_t)rowc * a.Z + col;
-  const float mq = a.mu_q[o], sq = a.sd_q[o], mp = a.mu_p[o], sp = a.sd_p[o], e = a.eps[o], rq = a.raw_q[o], rp = a.raw_p[o];
-  float c_raw = 0.f, c_fn = 0.f;
-  if (a.c_fn != nullptr || a.c_raw != nullptr) {  // wave-uniform
-    const bool live = (long long)a.t * a.stride < a.x_sl[rowc];
-    const float cr = a.c_raw != nullptr ? a.c_raw[rowc] : 0.f;
-    const float cf = a.c_fn != nullptr ? a.c_fn[rowc] : 0.f;
-    c_raw = live ? cr : 0.f;
-    c_fn = live ? cf : 0.f;
-  }
-  f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-  acc[0] = wave_gemm16<NW>(a.D, a.H, r0, a.B, a.WT, a.H, c0, a.H, threadIdx.x >> 6, acc[0]);
-  float v[1];
-  reduce_tiles<1, NW>(acc, red, v);
-  if (!own) return;
-  const float dz = v[0];
-  const float d = mq - mp, ip2 = 1.f / (sp * sp);
-  float coef = c_raw;
-  if (c_fn != 0.f) {
-    const float k = logf(sp) - logf(sq) + (sq * sq + d * d) * 0.5f * ip2 - 0.5f;
-    if (!(a.fn_floor > 0.f) || k > a.fn_floor) coef += c_fn;
-  }
-  const float g_muq = dz + coef * d * ip2;
-  const float g_sdq = dz * e + coef * (sq * ip2 - 1.f / sq);
-  const float g_mup = -coef * d * ip2 + (a.residual ? g_muq : 0.f);
-  const float g_sdp = coef * (1.f / sp - (sq * sq + d * d) * ip2 / sp);
-  const size_t o2 = (size_t)row * 2 * a.Z + col;
-  a.dqh[o2] = g_muq;
-  a.dqh[o2 + a.Z] = g_sdq * sigmoidf_(a.beta * rq);
-  a.dph[o2] = g_mup;
-  a.dph[o2 + a.Z] = g_sdp * sigmoidf_(a.beta * rp);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -277,21 +115,6 @@ __global__ __launch_bounds__(NW * 64) void dh_stage_kernel(DhArgs a) {
   a.dgh[o3] = dr_pre; a.dgh[o3 + a.R] = du_pre; a.dgh[o3 + 2 * a.R] = dn_pre * r;
   a.G[o] = g * u + dd;
 }
-
-// number of waves for a K-deep reduction: <= 4 chunks of 16 per wave where possible
-inline int pick_nw(int K, int groups) {
-  const int chunks = (K / 16) * groups;
-  if (chunks > 32) return 16;
-  if (chunks > 16) return 8;
-  return 4;
-}
-
-#define LAUNCH_NW(kernel, nw, grid, stream, args)                                          \
-  do {                                                                                     \
-    if ((nw) == 16) hipLaunchKernelGGL((kernel<16>), grid, dim3(1024), 0, stream, args);   \
-    else if ((nw) == 8) hipLaunchKernelGGL((kernel<8>), grid, dim3(512), 0, stream, args); \
-    else hipLaunchKernelGGL((kernel<4>), grid, dim3(256), 0, stream, args);                \
-  } while (0)
 
 // ---------------------------------------------------------------------------------------------------------------
 // reserve / workspace carving
@@ -352,71 +175,6 @@ int check_dims(int Tp, int B, int X, int H, int Z, int R) {
                "vrnn: X,H,Z,R must be positive multiples of 16 (got %d,%d,%d,%d)", X, H, Z, R);
   BLVM_REQUIRE((B + 15) / 16 <= 65535, "vrnn: batch too large");
   return BLVM_OK;
-}
-
-struct LinSegH {  // host-side description of one segment
-  const float* A; int lda; const float* W; int ldw; const float* bias; const float* add; int ldadd;
-  const float* gate; int ldgate; float* out; int ldo; int ncols, K, relu;
-};
-
-inline LinSegH seg(const float* A, int lda, const float* W, int ldw, const float* bias, const float* add, int ldadd,
-                   const float* gate, int ldgate, float* out, int ldo, int ncols, int K, int relu) {
-  return LinSegH{A, lda, W, ldw, bias, add, ldadd, gate, ldgate, out, ldo, ncols, K, relu};
-}
-
-struct LinLaunch {
-  LinSegH seg[3];
-  int nseg, B;
-};
-
-template <int NSEG>
-inline void launch_lin_n(const LinLaunch& l, hipStream_t s) {
-  LinArgs<NSEG> a{};
-  int tiles = 0;
-  for (int i = 0; i < NSEG; ++i) {
-    const LinSegH& g = l.seg[i];
-    a.A[i] = g.A; a.W[i] = g.W; a.out[i] = g.out;
-    a.bias[i] = g.bias ? g.bias : g.W;   // valid dummy for absent operands
-    a.add[i] = g.add ? g.add : g.W;
-    a.gate[i] = g.gate ? g.gate : g.W;
-    a.lda[i] = g.lda; a.ldw[i] = g.ldw; a.ldadd[i] = g.ldadd; a.ldgate[i] = g.ldgate; a.ldo[i] = g.ldo;
-    a.tiles[i] = g.ncols / 16;
-    a.flags[i] = (g.bias ? LF_BIAS : 0) | (g.add ? LF_ADD : 0) | (g.gate ? LF_GATE : 0) | (g.relu ? LF_RELU : 0);
-    tiles += g.ncols / 16;
-  }
-  a.B = l.B; a.K = l.seg[0].K;  // all segments of one launch share K
-  const int nw = pick_nw(a.K, 1);
-  const dim3 grid(tiles, (l.B + 15) / 16);
-  if (nw == 16) hipLaunchKernelGGL((lin_stage_kernel<16, NSEG>), grid, dim3(1024), 0, s, a);
-  else if (nw == 8) hipLaunchKernelGGL((lin_stage_kernel<8, NSEG>), grid, dim3(512), 0, s, a);
-  else hipLaunchKernelGGL((lin_stage_kernel<4, NSEG>), grid, dim3(256), 0, s, a);
-}
-
-inline void launch_lin(const LinLaunch& l, hipStream_t s) {
-  if (l.nseg == 1) launch_lin_n<1>(l, s);
-  else if (l.nseg == 2) launch_lin_n<2>(l, s);
-  else launch_lin_n<3>(l, s);
-}
-
-int pick_split(int M, int N, int K) {
-  const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
-  int s = (int)((768 + tiles - 1) / tiles);
-  const int kmax = (K + 255) / 256;  // at least 256 k per slice
-  if (s > kmax) s = kmax;
-  return s < 1 ? 1 : s;
-}
-
-// dW (+)= D^T Act over all rows
-int wgrad(const float* D, int ldd, int n_out, const float* Act, int lda, int k_in, float* dW, int ldw, size_t rows,
-          hipStream_t s) {
-  if (!dW) return BLVM_OK;
-  return gemm_f32(1, 1, n_out, k_in, (int)rows, D, ldd, Act, lda, dW, ldw, nullptr, 0, 0.f, nullptr, 0, 1,
-                  pick_split(n_out, k_in, (int)rows), s);
-}
-
-int bgrad(const float* D, int ldd, int n_out, float* db, size_t rows, hipStream_t s) {
-  if (!db) return BLVM_OK;
-  return colsum_f32((int)rows, n_out, D, ldd, db, 1, s);
 }
 
 }  // namespace
@@ -585,7 +343,7 @@ extern "C" int blvm_vrnn_seq_bwd(const BlvmVrnnWeights* w, const float* enc, con
     }
     // B6: dz and the heads
     DzArgs d;
-    d.D = ws.DPHI[0] + oH; d.WT = ws.fT[0];
+    d.D = ws.DPHI[0] + oH; d.WT = ws.fT[0]; d.D2 = nullptr; d.WT2 = nullptr; d.dz_add = nullptr; d.ld_add = 0; d.has_gemm = 1;
     d.mu_q = mu_q + oZ; d.sd_q = sd_q + oZ; d.mu_p = mu_p + oZ; d.sd_p = sd_p + oZ; d.eps = eps + oZ;
     d.raw_q = rs.RAWQ + oZ; d.raw_p = rs.RAWP + oZ;
     d.x_sl = x_sl; d.c_raw = c_raw; d.c_fn = c_fn;

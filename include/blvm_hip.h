@@ -179,6 +179,39 @@ int blvm_gru_seq_bwd(const float* Wih, const float* Whh, const float* in, int ld
                      int R, float* d_in, int ld_din, int accumulate_din, float* d_h0, float* dWih, float* dWhh,
                      float* dbih, float* dbhh, float* workspace, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * K3  SRNN latent chain over a sequence (forward + BPTT).  Replaces the Python loop `blvm/models/srnn.py:224-253`
+ *     (prior / posterior MLPs `srnn.py:92-111` on cat[d_t, z_{t-1}] / cat[a_t, z_{t-1}], residual posterior, rsample)
+ *     and its autograd backward; the non-gated ("Elman") stochastic transfer that SRNNAudio builds.
+ *   d, a [Tp,B,R]: deterministic forward state (shifted) and smoothing state; eps [Tp,B,Z]; z0 [B,Z] or NULL.
+ *   zs [Tp+1,B,Z]: row 0 = z0, row t+1 = z_t.  slope: LeakyReLU slope of the MLPs (0.01).
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct BlvmSrnnWeights {
+  const float *prior_w[3], *prior_b[3]; /* [H,R+Z] (input order cat[d,z]), [H,H], [H,H] */
+  const float *prior_hw, *prior_hb;     /* [2Z,H] */
+  const float *post_w[3], *post_b[3];   /* [H,R+Z] (input order cat[a,z]), [H,H], [H,H] */
+  const float *post_hw, *post_hb;       /* [2Z,H] */
+} BlvmSrnnWeights;
+
+typedef struct BlvmSrnnGrads { /* same shapes; ACCUMULATED into (caller zeroes) */
+  float *prior_w[3], *prior_b[3], *prior_hw, *prior_hb;
+  float *post_w[3], *post_b[3], *post_hw, *post_hb;
+} BlvmSrnnGrads;
+
+size_t blvm_srnn_reserve_floats(int Tp, int B, int H, int Z, int R);
+size_t blvm_srnn_bwd_workspace_floats(int Tp, int B, int H, int Z, int R);
+int blvm_srnn_latent_fwd(const BlvmSrnnWeights* w, const float* d, const float* a, const float* z0, const float* eps,
+                         int Tp, int B, int H, int Z, int R, int residual_posterior, float sd_eps, float slope,
+                         float* zs, float* mu_q, float* sd_q, float* mu_p, float* sd_p, float* reserve, void* stream);
+/*   d_z [Tp,B,Z]: gradient wrt z_t from outside the chain (the decoder).  KL folded in as for blvm_vrnn_seq_bwd.
+ *   Outputs d_d, d_a [Tp,B,R], d_z0 [B,Z] (each may be NULL); grads accumulated. */
+int blvm_srnn_latent_bwd(const BlvmSrnnWeights* w, const float* d, const float* a, const float* eps, const float* zs,
+                         const float* mu_q, const float* sd_q, const float* mu_p, const float* sd_p,
+                         const float* reserve, const float* d_z, const int32_t* x_sl, const float* c_raw,
+                         const float* c_fn, int stride, float fn_floor, int Tp, int B, int H, int Z, int R,
+                         int residual_posterior, float sd_eps, float slope, float* d_d, float* d_a, float* d_z0,
+                         const BlvmSrnnGrads* grads, float* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

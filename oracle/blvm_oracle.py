@@ -371,3 +371,77 @@ def lstm_audio_forward(sd, x, x_sl, stack=64, num_mix=10, num_bins=256, s_0=None
     log_prob = (ll * mask).sum(1)
     loss = -log_prob.sum() / x_sl.sum()
     return dict(loss=loss, ll=log_prob, z=out, h_n=h_n, c_n=c_n, bpd=float((-log_prob.detach() / LN2).sum() / x_sl.sum()))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# SRNN (blvm/models/srnn.py)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def gru_sequence(x, h0, w_ih, w_hh, b_ih, b_hh):
+    """nn.GRU over a time-major sequence [T,B,I] (no packing, srnn.py:196): returns (out [T,B,R], h_n)."""
+    h, outs = h0, []
+    for t in range(x.size(0)):
+        h = gru_cell(x[t], h, w_ih, w_hh, b_ih, b_hh)
+        outs.append(h)
+    return torch.stack(outs, 0), h
+
+
+def reverse_sequences_diff(x, x_sl):
+    """reverse_sequences (operations.py:56-87) as a differentiable gather."""
+    T = int(x_sl.max())
+    t = torch.arange(T).unsqueeze(1)
+    sl = x_sl.unsqueeze(0)
+    idx = torch.where(t < sl, sl - 1 - t, t)
+    idx = idx.view(T, -1, *([1] * (x.ndim - 2))).expand(-1, -1, *x.shape[2:])
+    return torch.gather(x, 0, idx)
+
+
+def srnn_audio_forward(sd, x, x_sl, eps, beta=1.0, free_nats=0.0, d_0=None, a_0=None, z_0=None, stack=64,
+                       residual_posterior=True, smoothing=True, num_bins=2**16):
+    """SRNNAudio(likelihood="DMoL").forward (srnn.py:162-302, 456-513) with explicit noise eps [T',B,z].
+    `kl` is the RAW KL (srnn.py:156-160); the loss uses the free-nats-clamped one."""
+    B, T = x.shape
+    y = x.unsqueeze(-1)
+    xs, _ = stack_tensor(x, stack)
+    enc = _mlp(xs, sd, "srnn.encoder", (2, 4, 6), F.leaky_relu).permute(1, 0, 2)  # [T',B,h]
+    Tp = enc.size(0)
+    stride = math.ceil(T / Tp)
+    x_sl_strided = (x_sl / stride).ceil().long()
+    R = sd["srnn.d_forward_recurrent.weight_hh_l0"].size(1)
+    Z = sd["srnn.prior.6.params.weight"].size(0) // 2
+    u = torch.cat([torch.zeros_like(enc[:1]), enc[:-1]], 0)
+    d0 = torch.zeros(B, R, dtype=x.dtype) if d_0 is None else d_0
+    g = "srnn.d_forward_recurrent"
+    d_seq, d_n = gru_sequence(u, d0, sd[f"{g}.weight_ih_l0"], sd[f"{g}.weight_hh_l0"], sd[f"{g}.bias_ih_l0"], sd[f"{g}.bias_hh_l0"])
+    d = torch.cat([d0.unsqueeze(0), d_seq[:-1]], 0)
+    cat_xd = torch.cat([enc, d], -1)
+    if smoothing:
+        a0 = torch.zeros(B, R, dtype=x.dtype) if a_0 is None else a_0
+        g = "srnn.a_backward_recurrent"
+        a_rev, a_n = gru_sequence(reverse_sequences_diff(cat_xd, x_sl_strided), a0, sd[f"{g}.weight_ih_l0"],
+                                  sd[f"{g}.weight_hh_l0"], sd[f"{g}.bias_ih_l0"], sd[f"{g}.bias_hh_l0"])
+        a = reverse_sequences_diff(a_rev, x_sl_strided)
+    else:
+        a, a_n = _mlp(cat_xd, sd, "srnn.a_mlp", (0, 2), F.leaky_relu), None
+    z_t = torch.zeros(B, Z, dtype=x.dtype) if z_0 is None else z_0
+    zs, mq, sq, mp, sp = [], [], [], [], []
+    for t in range(Tp):
+        hp = _mlp(torch.cat([d[t], z_t], -1), sd, "srnn.prior", (0, 2, 4), F.leaky_relu)
+        mu_p, sd_p = gaussian_head(hp, sd["srnn.prior.6.params.weight"], sd["srnn.prior.6.params.bias"])
+        hq = _mlp(torch.cat([a[t], z_t], -1), sd, "srnn.posterior", (0, 2, 4), F.leaky_relu)
+        mu_q, sd_q = gaussian_head(hq, sd["srnn.posterior.6.params.weight"], sd["srnn.posterior.6.params.bias"])
+        if residual_posterior:
+            mu_q = mu_q + mu_p
+        z_t = eps[t] * sd_q + mu_q
+        zs.append(z_t); mq.append(mu_q); sq.append(sd_q); mp.append(mu_p); sp.append(sd_p)  # noqa: E702
+    st = lambda v: torch.stack(v, 1)  # noqa: E731
+    z = st(zs)
+    dec = _mlp(torch.cat([z, d.permute(1, 0, 2)], -1), sd, "srnn.decoder", (0, 2, 4), F.leaky_relu)
+    dec = dec.reshape(B, Tp * stack, -1)[:, : int(x_sl.max())]
+    logits, locs, log_scales = dmol_head(dec, sd["srnn.likelihood.params.weight"], sd["srnn.likelihood.params.bias"])
+    ll = dmol_ll(y[:, : dec.size(1)], logits, locs, log_scales, num_bins)
+    kld_twise = kl_gaussian(st(mq), st(sq), st(mp), st(sp))
+    loss, elbo, log_prob, kld, kld_fn = elbo_terms(ll, kld_twise, x_sl, stride, beta, free_nats)
+    return dict(loss=loss, elbo=elbo, log_prob=log_prob, kl=kld, kl_fn=kld_fn, z=z, d_n=d_n, a_n=a_n, z_n=zs[-1],
+                bpd=float((-elbo.detach() / LN2).sum() / x_sl.sum()))

@@ -179,6 +179,59 @@ def gen_vrnn_full():
     save("vrnn_full.npz", **arrays)
 
 
+def gen_srnn():
+    """SRNNAudio: reduced size (full tensors, ragged, smoothing on/off, carried states) + full C3 dims by checksum."""
+    arrays = {}
+    x, _ = O.synth_batch(3, 76, seed=7)
+    x_sl = torch.tensor([76, 53, 30])
+    x = x * (torch.arange(76).unsqueeze(0) < x_sl.unsqueeze(1))
+    arrays.update(x=x, x_sl=x_sl)
+    for tag, smoothing, beta, fn in (("sm", True, 1.0, 2.0), ("ns", False, 0.5, 0.0)):
+        torch.manual_seed(31)
+        m = RM.SRNNAudio(likelihood="DMoL", input_size=8, hidden_size=32, latent_size=16, residual_posterior=True, smoothing=smoothing)
+        eps = replay_eps(321, 10, 3, 16)
+        torch.manual_seed(321)
+        loss, metrics, o = m(x, x_sl, beta=beta, free_nats=fn)
+        loss.backward()
+        arrays.update({f"{tag}_loss": loss, f"{tag}_elbo": o.elbo, f"{tag}_log_prob": o.log_prob, f"{tag}_kl": o.kl,
+                       f"{tag}_z": o.z, f"{tag}_d_n": o.d_n, f"{tag}_z_n": o.z_n, f"{tag}_eps": eps})
+        if smoothing:
+            arrays[f"{tag}_a_n"] = o.a_n
+        arrays[f"{tag}_metric_names"] = np.array([mm.name for mm in metrics])
+        arrays[f"{tag}_metric_values"] = np.array([mm.value for mm in metrics], dtype=np.float64)
+        for k, v in m.state_dict().items():
+            arrays[f"{tag}_sd.{k}"] = v
+        for k, p in m.named_parameters():
+            arrays[f"{tag}_grad.{k}"] = p.grad
+        if smoothing:  # second split with carried states d_0, a_0, z_0 (experiment_srnn_audio.py:261-269)
+            m.zero_grad()
+            eps2 = replay_eps(99, 10, 3, 16)
+            torch.manual_seed(99)
+            loss2, _, o2 = m(x, x_sl, beta=beta, free_nats=fn, d_0=o.d_n.detach(), a_0=o.a_n.detach(), z_0=o.z_n.detach())
+            arrays.update(c_loss=loss2, c_elbo=o2.elbo, c_eps=eps2, c_z=o2.z)
+
+    torch.manual_seed(0)
+    m = RM.SRNNAudio(likelihood="DMoL", input_size=64, hidden_size=256, latent_size=256, residual_posterior=True, smoothing=True)
+    names = []
+    for k, v in m.state_dict().items():
+        names.append(k)
+        arrays[f"cks.{k}"] = np.array([v.double().sum().item(), v.double().abs().sum().item(), *v.shape], dtype=np.float64)
+    arrays["param_names"] = np.array(names)
+    xf, xf_sl = O.synth_batch(4, 1280, seed=0, ragged=True)
+    eps = replay_eps(123, 20, 4, 256)
+    torch.manual_seed(123)
+    loss, metrics, o = m(xf, xf_sl, beta=1.0, free_nats=2.0)
+    loss.backward()
+    arrays.update(f_x_sl=xf_sl, f_loss=loss, f_elbo=o.elbo, f_log_prob=o.log_prob, f_kl=o.kl)
+    arrays["f_metric_names"] = np.array([mm.name for mm in metrics])
+    arrays["f_metric_values"] = np.array([mm.value for mm in metrics], dtype=np.float64)
+    arrays["f_grad_norms"] = np.array([p.grad.double().norm().item() for _, p in m.named_parameters()])
+    arrays["f_grad_names"] = np.array([k for k, _ in m.named_parameters()])
+    arrays["f_grad.srnn.a_backward_recurrent.bias_hh_l0"] = m.srnn.a_backward_recurrent.bias_hh_l0.grad.clone()
+    arrays["f_grad.srnn.encoder.2.bias"] = m.srnn.encoder[2].bias.grad.clone()
+    save("srnn.npz", **arrays)
+
+
 def gen_lstm():
     """LSTMAudio: reduced size with full tensors, and BASELINE config C1 ([8,4000], h=256, s=64) pinned by checksums."""
     arrays = {}
@@ -223,6 +276,6 @@ def gen_lstm():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm"]
+    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn"]
     for w in which:
         globals()[f"gen_{w}"]()

@@ -402,3 +402,67 @@ def test_lstm_audio_c1_vs_reference_golden(tag, ragged):
         assert grads[name].grad.double().norm().item() == pytest.approx(ref, rel=1e-3), name
     for k in ("lstm.bias_hh_l0", "likelihood.params.weight"):
         assert rel_l2(grads[k].grad, T(g[f"{tag}_grad.{k}"])) < 1e-3, k
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# K3 + SRNNAudio (BASELINE config C3) against the reference's own outputs
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("tag,smoothing,beta,fn_", [("sm", True, 1.0, 2.0), ("ns", False, 0.5, 0.0)])
+def test_srnn_small_vs_reference_golden(tag, smoothing, beta, fn_):
+    from blvm.models import SRNNAudio
+
+    g = np.load(os.path.join(GOLDEN, "srnn.npz"))
+    m = SRNNAudio(likelihood="DMoL", input_size=8, hidden_size=32, latent_size=16, residual_posterior=True, smoothing=smoothing)
+    pre = f"{tag}_sd."
+    m.load_state_dict({k[len(pre):]: T(g[k]) for k in g.files if k.startswith(pre)})
+    m.to(DEV)
+    x, x_sl, eps = T(g["x"]), T(g["x_sl"]), T(g[f"{tag}_eps"])
+    loss, metrics, out = m(x.to(DEV), x_sl, beta=beta, free_nats=fn_, eps=eps.to(DEV))
+    loss.backward()
+    assert loss.dtype == torch.float64
+    assert float(loss) == pytest.approx(float(g[f"{tag}_loss"]), rel=1e-5)
+    torch.testing.assert_close(out.elbo.cpu(), T(g[f"{tag}_elbo"]), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(out.log_prob.cpu(), T(g[f"{tag}_log_prob"]), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(out.kl.cpu(), T(g[f"{tag}_kl"]), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(out.z.cpu(), T(g[f"{tag}_z"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(out.d_n.cpu(), T(g[f"{tag}_d_n"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(out.z_n.cpu(), T(g[f"{tag}_z_n"]), rtol=1e-4, atol=1e-5)
+    if smoothing:
+        torch.testing.assert_close(out.a_n.cpu(), T(g[f"{tag}_a_n"]), rtol=1e-4, atol=1e-5)
+    vals = {mm.name: mm.value for mm in metrics}
+    for name, val in zip(g[f"{tag}_metric_names"].tolist(), g[f"{tag}_metric_values"].tolist()):
+        assert vals[name] == pytest.approx(val, rel=1e-5, abs=1e-7), name
+    for k, p in m.named_parameters():
+        assert rel_l2(p.grad, T(g[f"{tag}_grad.{k}"])) < 1e-3, k
+    if smoothing:  # split evaluation: states carried into the next call (experiment_srnn_audio.py:261-269)
+        with torch.no_grad():
+            loss2, _, out2 = m(x.to(DEV), x_sl, beta=beta, free_nats=fn_, eps=T(g["c_eps"]).to(DEV), d_0=out.d_n.detach(),
+                               a_0=out.a_n.detach(), z_0=out.z_n.detach())
+        assert float(loss2) == pytest.approx(float(g["c_loss"]), rel=1e-5)
+        torch.testing.assert_close(out2.z.cpu(), T(g["c_z"]), rtol=1e-4, atol=1e-5)
+
+
+def test_srnn_full_dims_vs_reference_golden():
+    from blvm.models import SRNNAudio
+
+    g = np.load(os.path.join(GOLDEN, "srnn.npz"))
+    torch.manual_seed(0)
+    m = SRNNAudio(likelihood="DMoL", input_size=64, hidden_size=256, latent_size=256, residual_posterior=True, smoothing=True).to(DEV)
+    x, x_sl = O.synth_batch(4, 1280, seed=0, ragged=True)
+    torch.manual_seed(123)
+    eps = torch.stack([torch.randn(4, 256) for _ in range(20)], 0)
+    loss, metrics, out = m(x.to(DEV), x_sl, beta=1.0, free_nats=2.0, eps=eps.to(DEV))
+    loss.backward()
+    assert float(loss) == pytest.approx(float(g["f_loss"]), rel=1e-5)
+    torch.testing.assert_close(out.elbo.cpu(), T(g["f_elbo"]), rtol=1e-5, atol=0)
+    torch.testing.assert_close(out.kl.cpu(), T(g["f_kl"]), rtol=1e-5, atol=0)
+    vals = {mm.name: mm.value for mm in metrics}
+    for name, val in zip(g["f_metric_names"].tolist(), g["f_metric_values"].tolist()):
+        assert vals[name] == pytest.approx(val, rel=1e-5), name
+    grads = dict(m.named_parameters())
+    for name, ref in zip(g["f_grad_names"].tolist(), g["f_grad_norms"].tolist()):
+        assert grads[name].grad.double().norm().item() == pytest.approx(ref, rel=1e-3), name
+    for k in [f[7:] for f in g.files if f.startswith("f_grad.")]:
+        assert rel_l2(grads[k].grad, T(g[f"f_grad.{k}"])) < 1e-3, k

@@ -145,3 +145,37 @@ def test_lstm_audio_init_matches_reference_and_oracle_c1():
         out["loss"].backward()
         for name, ref in zip(g["grad_names"].tolist(), g[f"{tag}_grad_norms"].tolist()):
             assert sd[name].grad.double().norm().item() == pytest.approx(ref, rel=2e-4), name
+
+
+def test_srnn_audio_init_matches_reference_and_oracle_full_dims():
+    from blvm.models import SRNNAudio
+
+    g = np.load(os.path.join(GOLDEN, "srnn.npz"))
+    torch.manual_seed(0)
+    m = SRNNAudio(likelihood="DMoL", input_size=64, hidden_size=256, latent_size=256, residual_posterior=True, smoothing=True)
+    sd0 = m.state_dict()
+    assert list(sd0.keys()) == g["param_names"].tolist()
+    for k, v in sd0.items():
+        cks = g[f"cks.{k}"]
+        assert list(v.shape) == [int(s) for s in cks[2:]], k
+        assert v.double().abs().sum().item() == pytest.approx(cks[1], rel=1e-12), k
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+    x, x_sl = O.synth_batch(4, 1280, seed=0, ragged=True)
+    torch.manual_seed(123)
+    eps = torch.stack([torch.randn(4, 256) for _ in range(20)], 0)
+    out = O.srnn_audio_forward(sd, x, x_sl, eps, beta=1.0, free_nats=2.0, stack=64)
+    np.testing.assert_allclose(out["loss"].item(), g["f_loss"], rtol=1e-7)
+    np.testing.assert_allclose(out["elbo"].detach().numpy(), g["f_elbo"], rtol=1e-7)
+    out["loss"].backward()
+    for name, ref in zip(g["f_grad_names"].tolist(), g["f_grad_norms"].tolist()):
+        assert sd[name].grad.double().norm().item() == pytest.approx(ref, rel=2e-4), name
+
+
+def test_padding_helpers():
+    from blvm.utils.padding import get_modulo_length, get_modulo_padding, get_same_padding
+
+    assert get_modulo_length(1000, 64, kernel_size=64) == 1024 and get_modulo_length(1024, 64, 64) == 1024
+    assert get_modulo_padding(10, 4, 2) == 0 and get_modulo_padding(11, 4, 2) == 3
+    assert get_same_padding(16000, 64, 64) == 0 and get_same_padding(16001, 64, 64) == 63
+    with pytest.raises(ValueError):
+        get_modulo_padding(3, 4, 8)

@@ -129,3 +129,30 @@ def test_lstm_small_forward_backward():
     for k, p in sd.items():
         ref = T(g[f"s_grad.{k}"])
         assert (p.grad - ref).norm() / (ref.norm() + 1e-12) < 2e-5, k
+
+
+@pytest.mark.parametrize("tag,smoothing,beta,fn_", [("sm", True, 1.0, 2.0), ("ns", False, 0.5, 0.0)])
+def test_srnn_small_forward_backward(tag, smoothing, beta, fn_):
+    g = np.load(os.path.join(GOLDEN, "srnn.npz"))
+    pre = f"{tag}_sd."
+    sd = {k[len(pre):]: T(g[k]).clone().requires_grad_(True) for k in g.files if k.startswith(pre)}
+    x, x_sl, eps = T(g["x"]), T(g["x_sl"]), T(g[f"{tag}_eps"])
+    out = O.srnn_audio_forward(sd, x, x_sl, eps, beta=beta, free_nats=fn_, stack=8, smoothing=smoothing)
+    close(out["z"], g[f"{tag}_z"], 1e-5, 1e-6)
+    close(out["loss"], g[f"{tag}_loss"], 1e-7, 0)
+    close(out["elbo"], g[f"{tag}_elbo"], 1e-7, 0)
+    close(out["kl"], g[f"{tag}_kl"], 1e-6, 1e-6)  # raw KL
+    close(out["d_n"], g[f"{tag}_d_n"][0], 1e-5, 1e-6)
+    close(out["z_n"], g[f"{tag}_z_n"], 1e-5, 1e-6)
+    if smoothing:
+        close(out["a_n"], g[f"{tag}_a_n"][0], 1e-5, 1e-6)
+    out["loss"].backward()
+    for k, p in sd.items():
+        ref = T(g[f"{tag}_grad.{k}"])
+        assert (p.grad - ref).norm() / (ref.norm() + 1e-12) < 2e-5, k
+    if smoothing:  # carried states of a second split
+        sd2 = {k: v.detach() for k, v in sd.items()}
+        out2 = O.srnn_audio_forward(sd2, x, x_sl, T(g["c_eps"]), beta=beta, free_nats=fn_, stack=8, d_0=out["d_n"].detach(),
+                                    a_0=out["a_n"].detach(), z_0=out["z_n"].detach())
+        close(out2["loss"], g["c_loss"], 1e-6, 0)
+        close(out2["z"], g["c_z"], 1e-5, 1e-6)
