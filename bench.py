@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU (reference benchmark: --batch_len 64 s of audio)")
     ap.add_argument("--length", type=int, default=16000, help="samples per utterance (1 s at 16 kHz)")
+    ap.add_argument("--model", default="vrnn", choices=["vrnn", "srnn", "lstm"], help="vrnn = BASELINE headline (configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=10)
@@ -95,14 +96,19 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from blvm import _hip, ops
-    from blvm.models import VRNNAudio
+    from blvm.models import LSTMAudio, SRNNAudio, VRNNAudio
     from blvm.training.ddp import FlatGradAllReduce
 
     assert _hip.load().blvm_device_ok() == 1, "libblvm_hip: no gfx950 device"
     B, T, S, H, Z = args.batch, args.length, 64, 256, 256
     Tp = math.ceil(T / S)
     torch.manual_seed(0)  # identical weights on every rank
-    model = VRNNAudio(likelihood="DMoL", input_size=S, hidden_size=H, latent_size=Z, residual_posterior=True).to(dev)
+    if args.model == "vrnn":
+        model = VRNNAudio(likelihood="DMoL", input_size=S, hidden_size=H, latent_size=Z, residual_posterior=True).to(dev)
+    elif args.model == "srnn":
+        model = SRNNAudio(likelihood="DMoL", input_size=S, hidden_size=H, latent_size=Z, residual_posterior=True, smoothing=True).to(dev)
+    else:
+        model = LSTMAudio(stack_size=S, hidden_size=H, num_layers=1, num_mix=10, num_bins=2**16).to(dev)
     params = list(model.parameters())
     opt = torch.optim.Adam(params, lr=3e-4)
     reducer = FlatGradAllReduce(params) if world > 1 else None
@@ -136,7 +142,7 @@ def main():
 
     def step():
         opt.zero_grad(set_to_none=True)
-        loss, metrics, out = model(x, x_sl, beta=1.0, free_nats=2.0)
+        loss, metrics, out = model(x, x_sl, beta=1.0, free_nats=2.0) if args.model != "lstm" else model(x, x_sl)
         loss.backward()
         if reducer is not None:
             reducer(float(B * T))
@@ -175,17 +181,29 @@ def main():
     log(f"timed {args.steps} steps: {ms_step:.2f} ms/step; host enqueue per step: seq_fwd {host['fwd'] / args.steps * 1e3:.2f} ms, "
         f"seq_bwd {host['bwd'] / args.steps * 1e3:.2f} ms")
     frames = world * B * T * args.steps
-    cell_ms = [(e[0].elapsed_time(e[1]), e[2].elapsed_time(e[3])) for e in ev]
-    fwd_ms = sum(c[0] for c in cell_ms) / len(cell_ms)
-    bwd_ms = sum(c[1] for c in cell_ms) / len(cell_ms)
-    macs = cell_macs(H, H, Z, 2 * H) * B * Tp
+    if args.model == "lstm":  # no hooked recurrent-cell call: report the whole step against the model's matmul FLOPs
+        fwd_ms, bwd_ms = ms_step / 3, 2 * ms_step / 3
+    else:
+        cell_ms = [(e[0].elapsed_time(e[1]), e[2].elapsed_time(e[3])) for e in ev]
+        fwd_ms = sum(c[0] for c in cell_ms) / len(cell_ms)
+        bwd_ms = sum(c[1] for c in cell_ms) / len(cell_ms)
+    R = 2 * H
+    if args.model == "vrnn":
+        macs = cell_macs(H, H, Z, R) * B * Tp
+        kname = "VRNN recurrent cell, forward+BPTT (blvm_vrnn_seq_fwd + blvm_vrnn_seq_bwd: stage-kernel chain + hoisted MFMA GEMMs)"
+    elif args.model == "srnn":
+        macs = 2 * ((R + Z) * H + 2 * H * H + 2 * Z * H) * B * Tp
+        kname = "SRNN latent chain, forward+BPTT (blvm_srnn_latent_fwd + blvm_srnn_latent_bwd)"
+    else:
+        macs = (S * H + 2 * H * H + 8 * H * H + 2 * H * H + H * 30 * S + 900 * S) * B * (Tp - 1)
+        kname = "LSTMAudio whole train step (matmul FLOPs of embedding + LSTM + decoder + DMoL Linear)"
     flops_fb = 3 * 2 * macs  # forward + dgrad + wgrad
     achieved = flops_fb / ((fwd_ms + bwd_ms) * 1e-3) / 1e12
     bpd = {m.name: m.value for m in last["metrics"]}["bpd"]
 
     if rank == 0:
         res = {
-            "metric": "audio frames/sec training (VRNN, 16 kHz mu-law)",
+            "metric": f"audio frames/sec training ({args.model.upper()}, 16 kHz mu-law)",
             "value": frames / dt,
             "unit": "frames/s",
             "n_gpus": world,
@@ -199,12 +217,12 @@ def main():
             "data": "synthetic",
             "bits_per_dim": bpd,
             "config": {
-                "workload": f"experiment_vrnn_audio.py: VRNNAudio DMoL s=64 h=256 z=256, synthetic mu-law [{B},1,{T}] per GPU "
+                "workload": f"experiment_{args.model}_audio.py: {type(model).__name__} DMoL s=64 h=256 z=256, synthetic mu-law [{B},1,{T}] per GPU "
                             f"(T'={Tp} recurrent steps), full train step fwd+bwd+clip+Adam, random init",
                 "batch_per_gpu": B, "global_batch": world * B, "samples_per_utterance": T, "parallelism": f"dp{world}",
             },
             "roofline": {
-                "kernel": "VRNN recurrent cell, forward+BPTT (blvm_vrnn_seq_fwd + blvm_vrnn_seq_bwd: stage-kernel chain + hoisted MFMA GEMMs)",
+                "kernel": kname,
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": PEAK_F32_MFMA_TFLOPS,
@@ -216,7 +234,7 @@ def main():
                 "bwd_ms": bwd_ms,
             },
         }  # fmt: skip
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == "vrnn":
             # the box's CPU share for one GPU is 16 cores (more threads than that only thrash the cgroup quota)
             threads = max(1, min(16, os.cpu_count() or 1, len(os.sched_getaffinity(0))))
             res["cpu_baseline"] = cpu_baseline(args.cpu_batch, T, args.cpu_steps, threads)
