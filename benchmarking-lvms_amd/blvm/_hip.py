@@ -80,6 +80,14 @@ _SIGNATURES = {
                              + [c_void_p] * 7),
     "blvm_srnn_latent_bwd": (c_int, [ctypes.POINTER(SrnnWeights)] + [c_void_p] * 13 + [c_int, c_float] + [c_int] * 6
                              + [c_float, c_float] + [c_void_p] * 3 + [ctypes.POINTER(SrnnWeights), c_void_p, c_void_p]),
+    "blvm_scale_act_f32": (c_int, [c_void_p, c_float, c_float, c_void_p, c_size_t, c_void_p]),
+    "blvm_conv1d_k2_workspace_floats": (c_size_t, [c_int] * 2),
+    "blvm_conv1d_k2_fwd": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p] * 3),
+    "blvm_conv1d_k2_bwd": (c_int, [c_void_p] * 3 + [c_int] * 5 + [c_void_p] * 5),
+    "blvm_wavenet_block_reserve_floats": (c_size_t, [c_int] * 4),
+    "blvm_wavenet_block_workspace_floats": (c_size_t, [c_int] * 5),
+    "blvm_wavenet_block_fwd": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_float] + [c_void_p] * 5),
+    "blvm_wavenet_block_bwd": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_float] + [c_void_p] * 7),
 }  # fmt: skip
 
 EXPORTS = tuple(_SIGNATURES)

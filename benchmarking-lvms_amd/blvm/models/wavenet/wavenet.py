@@ -1,0 +1,138 @@
+"""WaveNet with the reference's construction API and state_dict layout (blvm/models/wavenet/wavenet.py:29-293).
+
+forward: left-pad by the receptive field -> causal conv -> in_transform -> 50 gated residual blocks (K10, one autograd
+node) -> sum of skips * variance_scale -> ReLU-Linear-ReLU -> likelihood Linear (K6) -> DMoL log-likelihood (K7).
+Loss in fp32 like the reference: -sum(ll * mask) / sum(x_sl) (wavenet.py:128-146).
+"""
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from blvm import ops
+from blvm.evaluation import BitsPerDimMetric, DeferredScalars, LLMetric, LossMetric
+from blvm.models.base_model import BaseModel
+from blvm.models.vrnn import LazyNamespace
+from blvm.modules.distributions import DiscretizedLogisticMixtureDense
+from blvm.utils.operations import split_sequence
+from blvm.utils.padding import get_modulo_length
+
+from .wavenet_modules import CausalConv1d, PointwiseTransform, ResidualStack
+
+
+class InputSizeError(Exception):
+    def __init__(self, input_size, receptive_field):
+        message = "Input size has to be larger than receptive_field\n"
+        message += f"Input size: {input_size}, Receptive fields size: {receptive_field}"
+        super().__init__(message)
+
+
+class WaveNet(BaseModel):
+    def __init__(self, likelihood: nn.Module, in_channels: int = 1, embedding_dim: int = None, num_bins: int = 256,
+                 n_layers: int = 10, n_stacks: int = 5, res_channels: int = 512, skip_channels: Optional[int] = None,
+                 gate_channels: Optional[int] = None, kernel_size: int = 2, base_dilation: int = 2, n_stack_frames: int = 1,
+                 activation: nn.Module = nn.ReLU):  # fmt: skip
+        super().__init__()
+        if embedding_dim is not None:
+            raise NotImplementedError("libblvm_hip: the embedding input variant of WaveNet is not built (audio runs feed floats)")
+        self.n_layers, self.n_stacks, self.in_channels, self.embedding_dim = n_layers, n_stacks, in_channels, embedding_dim
+        self.res_channels, self.skip_channels, self.gate_channels = res_channels, skip_channels, gate_channels
+        self.kernel_size, self.base_dilation, self.num_bins = kernel_size, base_dilation, num_bins
+        self.n_stack_frames, self.activation = n_stack_frames, activation
+        self.variance_scale = math.sqrt(1 / self.n_stacks * self.n_layers)
+        self.embedding = None
+        self.causal = CausalConv1d(in_channels=in_channels * n_stack_frames, out_channels=res_channels, kernel_size=kernel_size)
+        self.res_stack = ResidualStack(n_layers=n_layers, n_stacks=n_stacks, res_channels=res_channels, kernel_size=kernel_size,
+                                       base_dilation=base_dilation)  # fmt: skip
+        self.receptive_field = self.res_stack.receptive_field + self.causal.kernel_size - 1
+        self.out_transform = PointwiseTransform(res_channels, res_channels * n_stack_frames)
+        self.likelihood = likelihood
+
+    def forward(self, x, x_sl, y=None, pad_causal: bool = True, pad_receptive_field: bool = True):
+        lik, nsf, rf = self.likelihood, self.n_stack_frames, self.receptive_field
+        if not isinstance(lik, DiscretizedLogisticMixtureDense):
+            raise NotImplementedError("libblvm_hip: WaveNet is built with the DMoL likelihood head")
+        if x.ndim == 3:
+            x = x.squeeze(-1)
+        dev = x.device
+        x = x.to(torch.float32)
+        x_sl_host = x_sl.detach().cpu().to(torch.int64)
+        if y is None:
+            y = x.detach()
+            if not pad_receptive_field:
+                y = y[:, rf * nsf :]
+        y = y.reshape(y.size(0), -1).contiguous()
+        x_sl_strided = (x_sl_host / nsf).ceil().int()
+        B = x.size(0)
+        if nsf > 1:
+            T = x.size(1)
+            Tp = (T + nsf - 1) // nsf
+            x = torch.nn.functional.pad(x, (0, Tp * nsf - T)).view(B, Tp, nsf)
+        else:
+            x = x.unsqueeze(-1)
+        xt = x.transpose(0, 1).contiguous()  # time-major [T',B,C_in]
+        if pad_receptive_field:
+            skip_size = xt.size(0)
+            xt = torch.cat([torch.zeros(rf, B, xt.size(2), device=dev), xt], 0)
+        else:
+            skip_size = xt.size(0) - rf
+            x_sl_host = x_sl_host - rf
+        if xt.size(0) - int(pad_causal) < rf:
+            raise InputSizeError(xt.size(0), rf)
+
+        out = self.causal.forward_tm(xt, pad_causal=pad_causal)
+        skip_sum = self.res_stack.forward_tm(out, skip_size)  # [skip_size,B,C]
+        C = self.res_channels
+        logits = self.out_transform.forward_rows(skip_sum.view(skip_size * B, C), self.variance_scale)  # [skip*B, C*nsf]
+        par = ops.linear(logits.view(skip_size * B * nsf, C), lik.params.weight, lik.params.bias)  # [skip*B*nsf, 3K]
+
+        T_y = y.size(1)
+        mask_len = x_sl_host.clamp(min=0, max=T_y).to(device=dev, dtype=torch.int32)
+        log_prob = ops.dmol_log_prob(par.view(skip_size * B, nsf * lik.out_features), None, None, y, mask_len,
+                                     ops.LAYOUT_TIME_MAJOR, B, T_y, skip_size, nsf, lik.num_mix, lik.num_bins,
+                                     lik.log_epsilon).to(torch.float32)  # fmt: skip
+        n_frames = float(x_sl_host.sum())
+        loss = -log_prob.sum() / n_frames
+
+        sums = DeferredScalars(torch.stack([loss.detach().double(), log_prob.detach().double().sum()]))
+        metrics = [
+            LossMetric(sums[0], weight_by=B),
+            LLMetric(sums[1], reduce_by=B),
+            BitsPerDimMetric(sums[1], reduce_by=n_frames),
+        ]
+        F = lik.out_features
+
+        def parameters():
+            p = par.detach().view(skip_size, B, nsf, F).permute(1, 0, 2, 3).reshape(B, skip_size * nsf, F)[:, :T_y]
+            logits_, rest = p[..., : lik.num_mix], p[..., lik.num_mix :].reshape(B, -1, 1, 2 * lik.num_mix)
+            locs, log_scales = rest.chunk(2, dim=-1)
+            return logits_, locs, log_scales.clamp(min=lik.log_epsilon)
+
+        def ll_twise():
+            ll, _ = ops.dmol_ll_twise(par.detach().view(skip_size * B, nsf * F), None, None, y, mask_len, ops.LAYOUT_TIME_MAJOR, B,
+                                      T_y, skip_size, nsf, lik.num_mix, lik.num_bins, lik.log_epsilon)  # fmt: skip
+            return ll
+
+        lazy = dict(
+            parameters=parameters,
+            log_prob_twise=ll_twise,
+            predictions=lambda: lik.sample(output.parameters),
+            predictions_mode=lambda: lik.mode(output.parameters),
+        )
+        output = LazyNamespace(lazy, loss=loss, log_prob=log_prob, z=[skip_sum.detach().transpose(0, 1)], z_sl=x_sl_strided,
+                               y=y.unsqueeze(-1))  # fmt: skip
+        return loss, metrics, output
+
+    def split_sequence(self, x, x_sl, length: int):
+        """Overlap = receptive field (wavenet.py:230-242)."""
+        overlap = self.receptive_field * self.n_stack_frames
+        length = get_modulo_length(length, stride=self.n_stack_frames)
+        mode = "extend" if overlap >= length else "consume"
+        splits_x, splits_x_sl = split_sequence(x, x_sl, length=length, overlap=overlap, mode=mode)
+        if mode == "extend":
+            splits_x = [torch.nn.functional.pad(s, (max(overlap + length - s.size(1), 0), 0)) if s.ndim == 2 else s for s in splits_x]
+        return splits_x, splits_x_sl
+
+    def forward_split(self, x, x_sl, i_split: int, y=None):
+        return self.forward(x, x_sl, y=y, pad_causal=True, pad_receptive_field=(i_split == 0))

@@ -126,6 +126,11 @@ def mlp(x2d: torch.Tensor, layers: Sequence[torch.nn.Linear], act: int = ACT_LEA
     return _MLPFunction.apply(x2d, act, slope, *params)
 
 
+def linear(x2d: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, act: int = ACT_NONE, slope: float = 0.0):
+    """act(x W^T + b) for a raw [out,in] weight (e.g. a 1x1 Conv1d weight viewed as a matrix)."""
+    return _MLPFunction.apply(x2d, act, slope, weight, bias)
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # K7: DMoL head (Linear + log-likelihood + masked per-utterance sums)
 # ----------------------------------------------------------------------------------------------------------------------
@@ -134,25 +139,28 @@ def mlp(x2d: torch.Tensor, layers: Sequence[torch.nn.Linear], act: int = ACT_LEA
 class _DMoLFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dec, W, b, y, x_sl_dev, layout, B, T, Tp, S, num_mix, num_bins, log_eps):
-        dec, W, b, y = _f32c(dec), _f32c(W), _f32c(b), _f32c(y)
+        dec, y = _f32c(dec), _f32c(y)
+        W, b = (_f32c(W), _f32c(b)) if W is not None else (None, None)
         log_prob = torch.zeros(B, device=dec.device, dtype=torch.float64)
         check(
             load().blvm_dmol_fwd(ptr(dec), layout, ptr(W), ptr(b), ptr(y), ptr(x_sl_dev), B, T, Tp, S, num_mix, num_bins,
                                  log_eps, ptr(log_prob), None, stream_ptr()),
             "blvm_dmol_fwd",
         )  # fmt: skip
-        ctx.save_for_backward(dec, W, b, y, x_sl_dev)
+        ctx.has_linear = W is not None
+        ctx.save_for_backward(dec, y, x_sl_dev, *((W, b) if W is not None else ()))
         ctx.cfg = (layout, B, T, Tp, S, num_mix, num_bins, log_eps)
         return log_prob
 
     @staticmethod
     def backward(ctx, g):
-        dec, W, b, y, x_sl_dev = ctx.saved_tensors
+        dec, y, x_sl_dev, *lin = ctx.saved_tensors
+        W, b = lin if ctx.has_linear else (None, None)
         layout, B, T, Tp, S, num_mix, num_bins, log_eps = ctx.cfg
         g32 = g.to(torch.float32).contiguous()
         F = 3 * num_mix
         d_dec = torch.empty_like(dec)
-        d_par = torch.empty_like(dec)
+        d_par = torch.empty_like(dec) if ctx.has_linear else None
         check(
             load().blvm_dmol_bwd(ptr(dec), layout, ptr(W), ptr(b), ptr(y), ptr(x_sl_dev), ptr(g32), B, T, Tp, S, num_mix,
                                  num_bins, log_eps, ptr(d_dec), ptr(d_par), stream_ptr()),
@@ -160,10 +168,10 @@ class _DMoLFunction(torch.autograd.Function):
         )  # fmt: skip
         n_frames = dec.numel() // F
         dW = db = None
-        if ctx.needs_input_grad[1]:
+        if ctx.has_linear and ctx.needs_input_grad[1]:
             dW = torch.zeros_like(W)
             gemm(1, 1, F, F, n_frames, d_par, F, dec, F, dW, F, accumulate=True, split_k=256)
-        if ctx.needs_input_grad[2]:
+        if ctx.has_linear and ctx.needs_input_grad[2]:
             db = torch.empty_like(b)
             colsum(d_par.view(n_frames, F), db)
         return (d_dec if ctx.needs_input_grad[0] else None, dW, db) + (None,) * 10
@@ -177,7 +185,8 @@ def dmol_log_prob(dec, W, b, y, x_sl_dev, layout, B, T, Tp, S, num_mix=10, num_b
 
 def dmol_ll_twise(dec, W, b, y, x_sl_dev, layout, B, T, Tp, S, num_mix=10, num_bins=256, log_eps=-7.0):
     """Masked frame-wise log-likelihood [B,T] (no autograd)."""
-    dec, W, b, y = _f32c(dec), _f32c(W), _f32c(b), _f32c(y)
+    dec, y = _f32c(dec), _f32c(y)
+    W, b = (_f32c(W), _f32c(b)) if W is not None else (None, None)
     lp = torch.zeros(B, device=dec.device, dtype=torch.float64)
     ll = torch.zeros(B, T, device=dec.device, dtype=torch.float32)
     check(
@@ -525,3 +534,135 @@ def srnn_latent_chain(d, a, z0, eps, x_sl_dev, params, H, Z, R, residual_posteri
     fn_floor = float(free_nats) / Z if free_nats else 0.0
     cfg = (Tp, B, H, Z, R, bool(residual_posterior), float(sd_eps), float(slope), int(stride), fn_floor)
     return _SRNNLatentFunction.apply(d, a, z0, eps, x_sl_dev, cfg, *params)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# K10: WaveNet — dilated causal convolution (k=2) and the gated residual stack
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+class _ScaleActFunction(torch.autograd.Function):
+    """y = act(scale * x) (ReLU / LeakyReLU) element-wise."""
+
+    @staticmethod
+    def forward(ctx, x, scale, slope):
+        x = _f32c(x)
+        y = torch.empty_like(x)
+        check(load().blvm_scale_act_f32(ptr(x), scale, slope, ptr(y), x.numel(), stream_ptr()), "blvm_scale_act_f32")
+        ctx.save_for_backward(y)
+        ctx.cfg = (scale, slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        scale, slope = ctx.cfg
+        dy = _f32c(dy)
+        dz = torch.empty_like(dy)
+        check(load().blvm_act_bwd_f32(ptr(dy), ptr(y), slope, ptr(dz), dz.numel(), stream_ptr()), "blvm_act_bwd_f32")
+        if scale != 1.0:  # chain rule through the scale: one more streaming pass over dz
+            dx = torch.empty_like(dz)
+            check(load().blvm_scale_act_f32(ptr(dz), scale, 1.0, ptr(dx), dz.numel(), stream_ptr()), "blvm_scale_act_f32")
+            dz = dx
+        return dz, None, None
+
+
+def scale_act(x, scale: float = 1.0, slope: float = 0.0):
+    return _ScaleActFunction.apply(x, float(scale), float(slope))
+
+
+class _Conv1dK2Function(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, b, dilation):
+        x, W, b = _f32c(x), _f32c(W), _f32c(b)
+        L, B, Cin = x.shape
+        Cout = W.shape[0]
+        lib = load()
+        f32 = dict(device=x.device, dtype=torch.float32)
+        out = torch.empty(L - dilation, B, Cout, **f32)
+        ws = torch.empty(lib.blvm_conv1d_k2_workspace_floats(Cin, Cout), **f32)
+        check(lib.blvm_conv1d_k2_fwd(ptr(x), ptr(W), ptr(b), L, B, Cin, Cout, dilation, ptr(out), ptr(ws), stream_ptr()),
+              "blvm_conv1d_k2_fwd")  # fmt: skip
+        ctx.save_for_backward(x, W)
+        ctx.dims = (L, B, Cin, Cout, dilation)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, W = ctx.saved_tensors
+        L, B, Cin, Cout, dilation = ctx.dims
+        lib = load()
+        f32 = dict(device=x.device, dtype=torch.float32)
+        d_out = _f32c(d_out)
+        d_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW, db = torch.zeros_like(W), torch.zeros(Cout, **f32)
+        ws = torch.empty(lib.blvm_conv1d_k2_workspace_floats(Cin, Cout), **f32)
+        check(lib.blvm_conv1d_k2_bwd(ptr(x), ptr(W), ptr(d_out), L, B, Cin, Cout, dilation, ptr(d_x), ptr(dW), ptr(db), ptr(ws),
+                                     stream_ptr()), "blvm_conv1d_k2_bwd")  # fmt: skip
+        return d_x, dW, db, None
+
+
+def conv1d_k2(x, weight, bias, dilation: int = 1):
+    """Time-major dilated convolution with kernel size 2: x [L,B,Cin], weight [Cout,Cin,2] -> [L-dilation,B,Cout]."""
+    return _Conv1dK2Function.apply(x, weight, bias, int(dilation))
+
+
+class _WaveNetStackFunction(torch.autograd.Function):
+    """All gated residual blocks of a WaveNet stack in one autograd node: x [L,B,C] -> sum of skips [T_skip,B,S].
+    params: (conv.weight [2C,C,2], conv.bias, conv1x1rs.weight [C+S,C,1], conv1x1rs.bias) per block."""
+
+    @staticmethod
+    def forward(ctx, x, dilations, T_skip, inv_std, S, *params):
+        x = _f32c(x)
+        params = tuple(_f32c(p) for p in params)
+        L, B, C = x.shape
+        lib = load()
+        f32 = dict(device=x.device, dtype=torch.float32)
+        skip = torch.zeros(T_skip, B, S, **f32)
+        ws = torch.empty(lib.blvm_wavenet_block_workspace_floats(L, B, C, S, 1), **f32)
+        acts, reserves = [x], []
+        n = len(dilations)
+        for i, d in enumerate(dilations):
+            cw, cb, rw, rb = params[4 * i : 4 * i + 4]
+            xi = acts[-1]
+            Li = xi.shape[0]
+            res = torch.empty(lib.blvm_wavenet_block_reserve_floats(Li, B, C, d), **f32)
+            o = torch.empty(Li - d, B, C, **f32) if i + 1 < n else None  # the last block's residual output is never used
+            check(lib.blvm_wavenet_block_fwd(ptr(xi), ptr(cw), ptr(cb), ptr(rw), ptr(rb), Li, B, C, S, d, T_skip, inv_std, ptr(o),
+                                             ptr(skip), ptr(res), ptr(ws), stream_ptr()), "blvm_wavenet_block_fwd")  # fmt: skip
+            reserves.append(res)
+            if o is not None:
+                acts.append(o)
+        ctx.cfg = (tuple(dilations), T_skip, inv_std, S, L, B, C)
+        ctx.n_acts = len(acts)
+        ctx.save_for_backward(*acts, *reserves, *params)
+        return skip
+
+    @staticmethod
+    def backward(ctx, d_skip):
+        dilations, T_skip, inv_std, S, L, B, C = ctx.cfg
+        n = len(dilations)
+        saved = ctx.saved_tensors
+        acts, reserves, params = saved[: ctx.n_acts], saved[ctx.n_acts : ctx.n_acts + n], saved[ctx.n_acts + n :]
+        lib = load()
+        f32 = dict(device=d_skip.device, dtype=torch.float32)
+        d_skip = _f32c(d_skip)
+        ws = torch.empty(lib.blvm_wavenet_block_workspace_floats(L, B, C, S, 1), **f32)
+        grads = [torch.zeros_like(p) for p in params]
+        d_o = None
+        for i in range(n - 1, -1, -1):
+            cw, _, rw, _ = params[4 * i : 4 * i + 4]
+            xi = acts[i]
+            d_x = torch.empty_like(xi)
+            check(lib.blvm_wavenet_block_bwd(ptr(xi), ptr(cw), ptr(rw), ptr(reserves[i]), ptr(d_o), ptr(d_skip), xi.shape[0], B, C,
+                                             S, dilations[i], T_skip, inv_std, ptr(d_x), ptr(grads[4 * i]), ptr(grads[4 * i + 1]),
+                                             ptr(grads[4 * i + 2]), ptr(grads[4 * i + 3]), ptr(ws), stream_ptr()),
+                  "blvm_wavenet_block_bwd")  # fmt: skip
+            d_o = d_x
+        return (d_o, None, None, None, None, *grads)
+
+
+def wavenet_stack(x, blocks_params, dilations, T_skip: int, inv_std: float, S: int):
+    """x [L,B,C] -> sum over blocks of the last T_skip frames of each block's skip output [T_skip,B,S]."""
+    flat = [p for blk in blocks_params for p in blk]
+    return _WaveNetStackFunction.apply(x, tuple(int(d) for d in dilations), int(T_skip), float(inv_std), int(S), *flat)

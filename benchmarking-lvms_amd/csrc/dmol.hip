@@ -187,14 +187,19 @@ __global__ __launch_bounds__(256) void dmol_kernel(DmolArgs a) {
 #pragma unroll
   for (int i = 0; i < F_MAX; ++i) d[i] = lds[threadIdx.x * (F_MAX + 1) + i];
 
-  // p = W d + bias   (weights are wave-uniform -> scalar operands)
+  // p = W d + bias   (weights are wave-uniform -> scalar operands); W == NULL: the parameters ARE the input
   float p[F_MAX];
+  if (a.W != nullptr) {
 #pragma unroll
-  for (int o = 0; o < F_MAX; ++o) {
-    float s = a.bias[o];
+    for (int o = 0; o < F_MAX; ++o) {
+      float s = a.bias[o];
 #pragma unroll
-    for (int i = 0; i < F_MAX; ++i) s = fmaf(a.W[o * F_MAX + i], d[i], s);
-    p[o] = s;
+      for (int i = 0; i < F_MAX; ++i) s = fmaf(a.W[o * F_MAX + i], d[i], s);
+      p[o] = s;
+    }
+  } else {
+#pragma unroll
+    for (int o = 0; o < F_MAX; ++o) p[o] = d[o];
   }
   const float yv = fc.valid ? a.y[(size_t)fc.b * a.T + fc.tau] : 0.f;
   const float ll = dmol_frame<BWD>(a, yv, p);
@@ -226,29 +231,37 @@ __global__ __launch_bounds__(256) void dmol_kernel(DmolArgs a) {
     for (int o = 0; o < F_MAX; ++o) p[o] *= g;
     // d_dec = W^T dp
     float dd[F_MAX];
+    if (a.W != nullptr) {
 #pragma unroll
-    for (int i = 0; i < F_MAX; ++i) dd[i] = 0.f;
+      for (int i = 0; i < F_MAX; ++i) dd[i] = 0.f;
 #pragma unroll
-    for (int o = 0; o < F_MAX; ++o) {
+      for (int o = 0; o < F_MAX; ++o) {
 #pragma unroll
-      for (int i = 0; i < F_MAX; ++i) dd[i] = fmaf(a.W[o * F_MAX + i], p[o], dd[i]);
+        for (int i = 0; i < F_MAX; ++i) dd[i] = fmaf(a.W[o * F_MAX + i], p[o], dd[i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < F_MAX; ++i) dd[i] = p[i];
     }
     __syncthreads();  // everyone has read its frame from lds
 #pragma unroll
     for (int i = 0; i < F_MAX; ++i) lds[threadIdx.x * (F_MAX + 1) + i] = dd[i];
     __syncthreads();
     unstage_frames(a.d_dec, f0, a.n_frames, lds);
-    __syncthreads();
+    if (a.d_par != nullptr) {
+      __syncthreads();
 #pragma unroll
-    for (int i = 0; i < F_MAX; ++i) lds[threadIdx.x * (F_MAX + 1) + i] = p[i];
-    __syncthreads();
-    unstage_frames(a.d_par, f0, a.n_frames, lds);
+      for (int i = 0; i < F_MAX; ++i) lds[threadIdx.x * (F_MAX + 1) + i] = p[i];
+      __syncthreads();
+      unstage_frames(a.d_par, f0, a.n_frames, lds);
+    }
   }
 }
 
 int check_common(const float* dec, const float* W, const float* bias, const float* y, const int32_t* x_sl, int B,
                  int T, int Tp, int S, int num_mix, int num_bins, int layout) {
-  BLVM_REQUIRE(dec && W && bias && y && x_sl, "dmol: null pointer");
+  BLVM_REQUIRE(dec && y && x_sl, "dmol: null pointer");
+  BLVM_REQUIRE((W == nullptr) == (bias == nullptr), "dmol: W and bias must both be given or both be NULL");
   BLVM_REQUIRE(num_mix == NMIX, "dmol: this build supports num_mix == 10 (got %d)", num_mix);
   BLVM_REQUIRE(B > 0 && T > 0 && Tp > 0 && S > 0 && num_bins > 1, "dmol: bad shape B=%d T=%d Tp=%d S=%d", B, T, Tp, S);
   BLVM_REQUIRE((long long)Tp * S >= T, "dmol: Tp*S (%d*%d) < T (%d)", Tp, S, T);
@@ -296,7 +309,7 @@ extern "C" int blvm_dmol_bwd(const float* dec, int layout, const float* W, const
   using namespace blvm;
   int rc = check_common(dec, W, bias, y, x_sl, B, T, Tp, S, num_mix, num_bins, layout);
   if (rc) return rc;
-  BLVM_REQUIRE(g_b && d_dec && d_par, "dmol_bwd: null pointer");
+  BLVM_REQUIRE(g_b && d_dec && (d_par || !W), "dmol_bwd: null pointer");
   DmolArgs a = make_args(dec, layout, W, bias, y, x_sl, B, T, Tp, S, num_bins, log_eps);
   a.g_b = g_b;
   a.d_dec = d_dec;

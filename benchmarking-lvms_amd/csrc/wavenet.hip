@@ -1,0 +1,289 @@
+// wavenet.hip — K10: dilated causal convolution (kernel size 2) and the gated residual WaveNet block, forward + backward.
+//
+// Replaces CausalConv1d (blvm/models/wavenet/wavenet_modules.py:14-50) and Conv1dResidualGLU (:53-117):
+//   pre = Conv1d(C -> 2C, k=2, dilation=d)(x);  act = tanh(pre[:C]) * sigmoid(pre[C:])   (GatedTanhUnit, activations.py:5-13)
+//   rs  = Conv1d(C -> C+S, k=1)(act);  o = (rs[:C] + x[..., d:]) * sqrt(0.5);  skip += rs[C:][..., -T:]
+// Layout: TIME-MAJOR channel-last [L, B, C].  A dilation then is a plain row offset of d*B rows, "the last T frames"
+// and "what the dilated kernel ate" are row suffixes, and every convolution is a dense [rows, C] x [C, N] product:
+// the two taps of the k=2 kernel are two MFMA GEMMs over shifted views of the same buffer (gemm.hip, second one
+// accumulating), the 1x1 convolution is one GEMM.  The element-wise pieces (gate, residual/skip, their derivatives)
+// are 16-byte-vectorised streaming kernels.  Nothing is padded inside the stack: like the reference, block i
+// consumes d_i frames on the left.
+#include "common.h"
+
+namespace blvm {
+namespace {
+
+inline int pick_split(int M, int N, int K) {
+  const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
+  int s = (int)((768 + tiles - 1) / tiles);
+  const int kmax = (K + 255) / 256;
+  if (s > kmax) s = kmax;
+  return s < 1 ? 1 : s;
+}
+
+inline dim3 ew_grid(size_t n_items) {
+  size_t blocks = (n_items + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  return dim3((unsigned)blocks);
+}
+
+// W [N,K,2] (Conv1d weight, taps interleaved) -> W0 [N,K] (tap on x[t]) and W1 [N,K] (tap on x[t+d])
+__global__ __launch_bounds__(256) void split_taps_kernel(const float* __restrict__ W, float* __restrict__ W0,
+                                                         float* __restrict__ W1, size_t nk) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nk; i += (size_t)gridDim.x * 256) {
+    const float2 w = reinterpret_cast<const float2*>(W)[i];
+    W0[i] = w.x;
+    W1[i] = w.y;
+  }
+}
+
+// dW [N,K,2] += (dW0, dW1)
+__global__ __launch_bounds__(256) void merge_taps_kernel(const float* __restrict__ dW0, const float* __restrict__ dW1,
+                                                         float* __restrict__ dW, size_t nk) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nk; i += (size_t)gridDim.x * 256) {
+    float2 w = reinterpret_cast<float2*>(dW)[i];
+    w.x += dW0[i];
+    w.y += dW1[i];
+    reinterpret_cast<float2*>(dW)[i] = w;
+  }
+}
+
+// act[r,c] = tanh(pre[r,c]) * sigmoid(pre[r,C+c]);  one thread per 4 channels
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__ pre, float* __restrict__ act, size_t rows, int C) {
+  const int c4n = C / 4;
+  const size_t n = rows * c4n;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / c4n;
+    const int c = (int)(i - r * c4n) * 4;
+    const float4 a = *reinterpret_cast<const float4*>(pre + r * 2 * C + c);
+    const float4 b = *reinterpret_cast<const float4*>(pre + r * 2 * C + C + c);
+    float4 o;
+    o.x = tanhf(a.x) * sigmoidf_(b.x); o.y = tanhf(a.y) * sigmoidf_(b.y);
+    o.z = tanhf(a.z) * sigmoidf_(b.z); o.w = tanhf(a.w) * sigmoidf_(b.w);
+    *reinterpret_cast<float4*>(act + r * C + c) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ d_act,
+                                                       float* __restrict__ d_pre, size_t rows, int C) {
+  const int c4n = C / 4;
+  const size_t n = rows * c4n;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / c4n;
+    const int c = (int)(i - r * c4n) * 4;
+    const float4 a = *reinterpret_cast<const float4*>(pre + r * 2 * C + c);
+    const float4 b = *reinterpret_cast<const float4*>(pre + r * 2 * C + C + c);
+    const float4 g = *reinterpret_cast<const float4*>(d_act + r * C + c);
+    const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w}, gv[4] = {g.x, g.y, g.z, g.w};
+    float da[4], db[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float ta = tanhf(av[k]), sb = sigmoidf_(bv[k]);
+      da[k] = gv[k] * sb * (1.f - ta * ta);
+      db[k] = gv[k] * ta * sb * (1.f - sb);
+    }
+    *reinterpret_cast<float4*>(d_pre + r * 2 * C + c) = make_float4(da[0], da[1], da[2], da[3]);
+    *reinterpret_cast<float4*>(d_pre + r * 2 * C + C + c) = make_float4(db[0], db[1], db[2], db[3]);
+  }
+}
+
+// o = (rs[:, :C] + xres) * inv_std;  skip[r - off, :] += rs[r, C:] for rows r >= off   (one thread per element)
+__global__ __launch_bounds__(256) void resskip_fwd_kernel(const float* __restrict__ rs, const float* __restrict__ xres,
+                                                          float* __restrict__ o, float* __restrict__ skip, size_t rows,
+                                                          size_t off, int C, int S, float inv_std) {
+  const int W = C + S;
+  const size_t n = rows * W;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / W;
+    const int c = (int)(i - r * W);
+    const float v = rs[i];
+    if (c < C) {
+      if (o != nullptr) o[r * C + c] = (v + xres[r * C + c]) * inv_std;
+    } else if (r >= off) {
+      skip[(r - off) * S + (c - C)] += v;
+    }
+  }
+}
+
+// d_rs[r, :C] = d_o * inv_std (0 if no d_o);  d_rs[r, C:] = d_skip[r - off] for r >= off else 0;  d_xres = d_o * inv_std
+__global__ __launch_bounds__(256) void resskip_bwd_kernel(const float* __restrict__ d_o, const float* __restrict__ d_skip,
+                                                          float* __restrict__ d_rs, float* __restrict__ d_xres, size_t rows,
+                                                          size_t off, int C, int S, float inv_std) {
+  const int W = C + S;
+  const size_t n = rows * W;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / W;
+    const int c = (int)(i - r * W);
+    if (c < C) {
+      const float g = d_o != nullptr ? d_o[r * C + c] * inv_std : 0.f;
+      d_rs[i] = g;
+      d_xres[r * C + c] = g;
+    } else {
+      d_rs[i] = r >= off ? d_skip[(r - off) * S + (c - C)] : 0.f;
+    }
+  }
+}
+
+// y = act(x * scale), act = ReLU / LeakyReLU(slope)
+__global__ __launch_bounds__(256) void scale_act_kernel(const float* __restrict__ x, float scale, float slope,
+                                                        float* __restrict__ y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float v = x[i] * scale;
+    y[i] = v > 0.f ? v : v * slope;
+  }
+}
+
+struct ConvWs { float *W0, *W1, *dW0, *dW1; };
+
+}  // namespace
+
+// out[L_out*B, N] = x[0:L_out*B] W0^T + x[d*B : d*B + L_out*B] W1^T + bias, with (W0, W1) already split
+static int conv_k2_apply(const float* x, int Cin, const float* W0, const float* W1, const float* bias, size_t rows_out,
+                         size_t shift_rows, int N, float* out, hipStream_t s) {
+  int rc = gemm_f32(0, 0, (int)rows_out, N, Cin, x, Cin, W0, Cin, out, N, bias, 0, 0.f, nullptr, 0, 0, 1, s);
+  if (rc) return rc;
+  return gemm_f32(0, 0, (int)rows_out, N, Cin, x + shift_rows * Cin, Cin, W1, Cin, out, N, nullptr, 0, 0.f, nullptr, 0, 1, 1, s);
+}
+
+}  // namespace blvm
+
+using namespace blvm;
+
+extern "C" int blvm_scale_act_f32(const float* x, float scale, float slope, float* y, size_t n, void* stream) {
+  if (n == 0) return BLVM_OK;
+  BLVM_REQUIRE(x && y, "scale_act: null pointer");
+  hipLaunchKernelGGL(scale_act_kernel, ew_grid(n), dim3(256), 0, static_cast<hipStream_t>(stream), x, scale, slope, y, n);
+  BLVM_CHECK_LAUNCH("scale_act_f32");
+  return BLVM_OK;
+}
+
+// ---- plain dilated causal convolution, kernel size 2 ------------------------------------------------------------------
+extern "C" size_t blvm_conv1d_k2_workspace_floats(int Cin, int Cout) { return (size_t)4 * Cin * Cout + 16; }
+
+extern "C" int blvm_conv1d_k2_fwd(const float* x, const float* W, const float* bias, int L_in, int B, int Cin, int Cout,
+                                  int dilation, float* out, float* workspace, void* stream_) {
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  BLVM_REQUIRE(x && W && out && workspace, "conv1d_k2_fwd: null pointer");
+  BLVM_REQUIRE(L_in > dilation && dilation > 0 && B > 0 && Cin > 0 && Cout > 0, "conv1d_k2_fwd: bad shape");
+  const size_t nk = (size_t)Cin * Cout;
+  float *W0 = workspace, *W1 = workspace + ((nk + 3) & ~(size_t)3);
+  hipLaunchKernelGGL(split_taps_kernel, ew_grid(nk), dim3(256), 0, s, W, W0, W1, nk);
+  BLVM_CHECK_LAUNCH("split_taps");
+  return conv_k2_apply(x, Cin, W0, W1, bias, (size_t)(L_in - dilation) * B, (size_t)dilation * B, Cout, out, s);
+}
+
+extern "C" int blvm_conv1d_k2_bwd(const float* x, const float* W, const float* d_out, int L_in, int B, int Cin, int Cout,
+                                  int dilation, float* d_x, float* dW, float* db, float* workspace, void* stream_) {
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  BLVM_REQUIRE(x && W && d_out && workspace, "conv1d_k2_bwd: null pointer");
+  BLVM_REQUIRE(L_in > dilation && dilation > 0 && B > 0 && Cin > 0 && Cout > 0, "conv1d_k2_bwd: bad shape");
+  const size_t nk = (size_t)Cin * Cout, nk4 = (nk + 3) & ~(size_t)3;
+  float *W0 = workspace, *W1 = W0 + nk4, *dW0 = W1 + nk4, *dW1 = dW0 + nk4;
+  const size_t rows = (size_t)(L_in - dilation) * B, shift = (size_t)dilation * B;
+  int rc;
+  if (d_x) {
+    hipLaunchKernelGGL(split_taps_kernel, ew_grid(nk), dim3(256), 0, s, W, W0, W1, nk);
+    BLVM_HIP(hipMemsetAsync(d_x, 0, sizeof(float) * (size_t)L_in * B * Cin, s));
+    rc = gemm_f32(0, 1, (int)rows, Cin, Cout, d_out, Cout, W0, Cin, d_x, Cin, nullptr, 0, 0.f, nullptr, 0, 1, 1, s);
+    if (rc) return rc;
+    rc = gemm_f32(0, 1, (int)rows, Cin, Cout, d_out, Cout, W1, Cin, d_x + shift * Cin, Cin, nullptr, 0, 0.f, nullptr, 0, 1, 1, s);
+    if (rc) return rc;
+  }
+  if (dW) {
+    BLVM_HIP(hipMemsetAsync(dW0, 0, sizeof(float) * 2 * nk4, s));
+    const int sp = pick_split(Cout, Cin, (int)rows);
+    rc = gemm_f32(1, 1, Cout, Cin, (int)rows, d_out, Cout, x, Cin, dW0, Cin, nullptr, 0, 0.f, nullptr, 0, 1, sp, s);
+    if (rc) return rc;
+    rc = gemm_f32(1, 1, Cout, Cin, (int)rows, d_out, Cout, x + shift * Cin, Cin, dW1, Cin, nullptr, 0, 0.f, nullptr, 0, 1, sp, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(merge_taps_kernel, ew_grid(nk), dim3(256), 0, s, dW0, dW1, dW, nk);
+  }
+  if (db) { rc = colsum_f32((int)rows, Cout, d_out, Cout, db, 1, s); if (rc) return rc; }
+  BLVM_CHECK_LAUNCH("conv1d_k2_bwd");
+  return BLVM_OK;
+}
+
+// ---- gated residual block ------------------------------------------------------------------------------------------------
+extern "C" size_t blvm_wavenet_block_reserve_floats(int L_in, int B, int C, int dilation) {
+  return (size_t)(L_in - dilation) * B * 3 * C + 16;  // pre [rows,2C] + act [rows,C]
+}
+extern "C" size_t blvm_wavenet_block_workspace_floats(int L_in, int B, int C, int S, int dilation) {
+  const size_t rows = (size_t)(L_in - dilation) * B;
+  // W0,W1,dW0,dW1 [2C*C each] + rs/d_rs [rows,C+S] + d_act [rows,C] + d_pre [rows,2C]
+  return (size_t)8 * C * C + 64 + rows * (C + S) + rows * C + rows * 2 * C;
+}
+
+extern "C" int blvm_wavenet_block_fwd(const float* x, const float* conv_w, const float* conv_b, const float* rs_w,
+                                      const float* rs_b, int L_in, int B, int C, int S, int dilation, int T_skip,
+                                      float inv_std, float* o, float* skip, float* reserve, float* workspace,
+                                      void* stream_) {
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  BLVM_REQUIRE(x && conv_w && conv_b && rs_w && rs_b && skip && reserve && workspace, "wavenet_block_fwd: null pointer");
+  BLVM_REQUIRE(C > 0 && C % 4 == 0 && S > 0 && L_in > dilation && dilation > 0 && B > 0, "wavenet_block_fwd: bad shape");
+  const int L_out = L_in - dilation;
+  BLVM_REQUIRE(T_skip > 0 && T_skip <= L_out, "wavenet_block_fwd: skip size %d exceeds the block's output length %d", T_skip, L_out);
+  BLVM_REQUIRE(aligned16(x) && aligned16(reserve) && aligned16(workspace), "wavenet_block_fwd: buffers must be 16-byte aligned");
+  const size_t rows = (size_t)L_out * B, shift = (size_t)dilation * B, nk = (size_t)2 * C * C;
+  float *pre = reserve, *act = reserve + rows * 2 * C;
+  float *W0 = workspace, *W1 = W0 + nk, *rs = W1 + 3 * nk + 64;
+  hipLaunchKernelGGL(split_taps_kernel, ew_grid(nk), dim3(256), 0, s, conv_w, W0, W1, nk);
+  int rc = conv_k2_apply(x, C, W0, W1, conv_b, rows, shift, 2 * C, pre, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(gate_fwd_kernel, ew_grid(rows * (C / 4)), dim3(256), 0, s, pre, act, rows, C);
+  rc = gemm_f32(0, 0, (int)rows, C + S, C, act, C, rs_w, C, rs, C + S, rs_b, 0, 0.f, nullptr, 0, 0, 1, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(resskip_fwd_kernel, ew_grid(rows * (C + S)), dim3(256), 0, s, rs, x + shift * C, o, skip, rows,
+                     rows - (size_t)T_skip * B, C, S, inv_std);
+  BLVM_CHECK_LAUNCH("wavenet_block_fwd");
+  return BLVM_OK;
+}
+
+extern "C" int blvm_wavenet_block_bwd(const float* x, const float* conv_w, const float* rs_w, const float* reserve,
+                                      const float* d_o, const float* d_skip, int L_in, int B, int C, int S, int dilation,
+                                      int T_skip, float inv_std, float* d_x, float* dconv_w, float* dconv_b, float* drs_w,
+                                      float* drs_b, float* workspace, void* stream_) {
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  BLVM_REQUIRE(x && conv_w && rs_w && reserve && d_skip && d_x && workspace, "wavenet_block_bwd: null pointer");
+  BLVM_REQUIRE(C > 0 && C % 4 == 0 && S > 0 && L_in > dilation && dilation > 0 && B > 0, "wavenet_block_bwd: bad shape");
+  const int L_out = L_in - dilation;
+  BLVM_REQUIRE(T_skip > 0 && T_skip <= L_out, "wavenet_block_bwd: bad skip size");
+  BLVM_REQUIRE(aligned16(x) && aligned16(reserve) && aligned16(workspace) && aligned16(d_x), "wavenet_block_bwd: alignment");
+  const size_t rows = (size_t)L_out * B, shift = (size_t)dilation * B, nk = (size_t)2 * C * C;
+  const float *pre = reserve, *act = reserve + rows * 2 * C;
+  float *W0 = workspace, *W1 = W0 + nk, *dW0 = W1 + nk, *dW1 = dW0 + nk;
+  float* d_rs = dW1 + nk + 64;
+  float* d_act = d_rs + rows * (C + S);
+  float* d_pre = d_act + rows * C;
+  int rc;
+  hipLaunchKernelGGL(split_taps_kernel, ew_grid(nk), dim3(256), 0, s, conv_w, W0, W1, nk);
+  // d_x: rows [0, d*B) start at zero, rows [d*B, L*B) start with the residual path d_o * inv_std
+  BLVM_HIP(hipMemsetAsync(d_x, 0, sizeof(float) * shift * C, s));
+  hipLaunchKernelGGL(resskip_bwd_kernel, ew_grid(rows * (C + S)), dim3(256), 0, s, d_o, d_skip, d_rs, d_x + shift * C, rows,
+                     rows - (size_t)T_skip * B, C, S, inv_std);
+  // 1x1 convolution
+  rc = gemm_f32(0, 1, (int)rows, C, C + S, d_rs, C + S, rs_w, C, d_act, C, nullptr, 0, 0.f, nullptr, 0, 0, 1, s);
+  if (rc) return rc;
+  if (drs_w) { rc = gemm_f32(1, 1, C + S, C, (int)rows, d_rs, C + S, act, C, drs_w, C, nullptr, 0, 0.f, nullptr, 0, 1, pick_split(C + S, C, (int)rows), s); if (rc) return rc; }
+  if (drs_b) { rc = colsum_f32((int)rows, C + S, d_rs, C + S, drs_b, 1, s); if (rc) return rc; }
+  // gate
+  hipLaunchKernelGGL(gate_bwd_kernel, ew_grid(rows * (C / 4)), dim3(256), 0, s, pre, d_act, d_pre, rows, C);
+  // dilated convolution: weight gradients of both taps, then the two shifted input gradients
+  if (dconv_w) {
+    BLVM_HIP(hipMemsetAsync(dW0, 0, sizeof(float) * 2 * nk, s));
+    const int sp = pick_split(2 * C, C, (int)rows);
+    rc = gemm_f32(1, 1, 2 * C, C, (int)rows, d_pre, 2 * C, x, C, dW0, C, nullptr, 0, 0.f, nullptr, 0, 1, sp, s);
+    if (rc) return rc;
+    rc = gemm_f32(1, 1, 2 * C, C, (int)rows, d_pre, 2 * C, x + shift * C, C, dW1, C, nullptr, 0, 0.f, nullptr, 0, 1, sp, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(merge_taps_kernel, ew_grid(nk), dim3(256), 0, s, dW0, dW1, dconv_w, nk);
+  }
+  if (dconv_b) { rc = colsum_f32((int)rows, 2 * C, d_pre, 2 * C, dconv_b, 1, s); if (rc) return rc; }
+  rc = gemm_f32(0, 1, (int)rows, C, 2 * C, d_pre, 2 * C, W0, C, d_x, C, nullptr, 0, 0.f, nullptr, 0, 1, 1, s);
+  if (rc) return rc;
+  rc = gemm_f32(0, 1, (int)rows, C, 2 * C, d_pre, 2 * C, W1, C, d_x + shift * C, C, nullptr, 0, 0.f, nullptr, 0, 1, 1, s);
+  if (rc) return rc;
+  BLVM_CHECK_LAUNCH("wavenet_block_bwd");
+  return BLVM_OK;
+}

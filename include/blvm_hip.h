@@ -63,7 +63,8 @@ int blvm_colsum_f32(int M, int N, const float* X, int ldx, float* out, int accum
  *   dec      [rows, S*F] contiguous, F = 3*num_mix features per audio frame (frame f = row*S + j at dec + f*F)
  *   layout   0: rows are batch-major (row = b*Tp + t)   1: rows are time-major (row = t*B + b)
  *   y        [B, T] targets in [-1,1];  x_sl [B] int32 on device;  frame (b, tau=t*S+j) counts iff tau < x_sl[b]
- *   W [F,F], bias [F]: the likelihood's Linear;  log_eps: clamp floor of the log-scales (-7)
+ *   W [F,F], bias [F]: the likelihood's Linear (both NULL: `dec` already holds the F parameters, e.g. WaveNet's
+ *   Linear(C->F) computed by K6);  log_eps: clamp floor of the log-scales (-7)
  *   log_prob [B] double, ACCUMULATED (caller zeroes);  ll_twise optional [B,T] fp32 (masked ll, may be NULL)
  * ------------------------------------------------------------------------------------------------------------- */
 int blvm_dmol_fwd(const float* dec, int layout, const float* W, const float* bias, const float* y,
@@ -211,6 +212,35 @@ int blvm_srnn_latent_bwd(const BlvmSrnnWeights* w, const float* d, const float* 
                          const float* c_fn, int stride, float fn_floor, int Tp, int B, int H, int Z, int R,
                          int residual_posterior, float sd_eps, float slope, float* d_d, float* d_a, float* d_z0,
                          const BlvmSrnnGrads* grads, float* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * K10  WaveNet: dilated causal convolution (kernel size 2) and the gated residual block.  Replaces
+ *      `CausalConv1d` (`blvm/models/wavenet/wavenet_modules.py:14-50`) and `Conv1dResidualGLU` (`:53-117`).
+ *      Activations are TIME-MAJOR channel-last [L, B, C]; weights keep the Conv1d layout [C_out, C_in, k].
+ *      out[t] = W[:,:,0] x[t] + W[:,:,1] x[t+dilation] + bias for t in [0, L_in - dilation)  (no padding: a block
+ *      consumes `dilation` frames on the left, as the reference's stack does).
+ * ------------------------------------------------------------------------------------------------------------- */
+int blvm_scale_act_f32(const float* x, float scale, float slope, float* y, size_t n, void* stream); /* y = act(scale x) */
+size_t blvm_conv1d_k2_workspace_floats(int Cin, int Cout);
+int blvm_conv1d_k2_fwd(const float* x, const float* W, const float* bias, int L_in, int B, int Cin, int Cout,
+                       int dilation, float* out, float* workspace, void* stream);
+/*   d_x [L_in,B,Cin] (=), dW [Cout,Cin,2] (+=), db [Cout] (+=); each may be NULL. */
+int blvm_conv1d_k2_bwd(const float* x, const float* W, const float* d_out, int L_in, int B, int Cin, int Cout,
+                       int dilation, float* d_x, float* dW, float* db, float* workspace, void* stream);
+
+/*   x [L_in,B,C]; conv_w [2C,C,2], conv_b [2C]; rs_w [C+S,C] (the 1x1 conv: first C rows residual, last S rows skip),
+ *   rs_b [C+S]; o [L_in-dilation,B,C] = (res + x[dilation:]) * inv_std (may be NULL for the last block);
+ *   skip [T_skip,B,S] += the last T_skip frames of the skip branch.  reserve keeps pre-activations for backward. */
+size_t blvm_wavenet_block_reserve_floats(int L_in, int B, int C, int dilation);
+size_t blvm_wavenet_block_workspace_floats(int L_in, int B, int C, int S, int dilation);
+int blvm_wavenet_block_fwd(const float* x, const float* conv_w, const float* conv_b, const float* rs_w,
+                           const float* rs_b, int L_in, int B, int C, int S, int dilation, int T_skip, float inv_std,
+                           float* o, float* skip, float* reserve, float* workspace, void* stream);
+/*   d_o may be NULL (last block); d_x [L_in,B,C] (=); weight grads (+=), each may be NULL. */
+int blvm_wavenet_block_bwd(const float* x, const float* conv_w, const float* rs_w, const float* reserve,
+                           const float* d_o, const float* d_skip, int L_in, int B, int C, int S, int dilation,
+                           int T_skip, float inv_std, float* d_x, float* dconv_w, float* dconv_b, float* drs_w,
+                           float* drs_b, float* workspace, void* stream);
 
 #ifdef __cplusplus
 }

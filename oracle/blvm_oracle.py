@@ -445,3 +445,64 @@ def srnn_audio_forward(sd, x, x_sl, eps, beta=1.0, free_nats=0.0, d_0=None, a_0=
     loss, elbo, log_prob, kld, kld_fn = elbo_terms(ll, kld_twise, x_sl, stride, beta, free_nats)
     return dict(loss=loss, elbo=elbo, log_prob=log_prob, kl=kld, kl_fn=kld_fn, z=z, d_n=d_n, a_n=a_n, z_n=zs[-1],
                 bpd=float((-elbo.detach() / LN2).sum() / x_sl.sum()))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# WaveNet (blvm/models/wavenet/wavenet.py, wavenet_modules.py)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def wavenet_dilations(n_layers, n_stacks, base_dilation=2):
+    """[1, b, 2b, 4b, ...] per stack (wavenet_modules.py:178-183)."""
+    if base_dilation > 1:
+        return [1, *[base_dilation * 2**i for i in range(n_layers - 1)]] * n_stacks
+    return [1] * n_layers * n_stacks
+
+
+def wavenet_forward(sd, x, x_sl, n_layers, n_stacks, num_bins=2**16, num_mix=10, base_dilation=2, n_stack_frames=1,
+                    pad_causal=True, pad_receptive_field=True):
+    """WaveNet.forward for float input (embedding=None) and a DMoL head (wavenet.py:148-228): left-pad by the receptive
+    field, causal conv (drop last input, k=2), 1x1 in_transform (always present), gated residual
+    blocks without padding (each eats `dilation` frames; skips take the last `skip_size` frames), sum of skips *
+    sqrt(n_layers/n_stacks), ReLU-Linear-ReLU, likelihood; fp32 loss = -sum(ll * mask) / sum(x_sl)."""
+    dil = wavenet_dilations(n_layers, n_stacks, base_dilation)
+    rf = sum(dil) + 1 + (sd["causal.conv.weight"].size(2) - 1)
+    y = x.detach()
+    if not pad_receptive_field:
+        y = y[:, rf * n_stack_frames :]
+    if n_stack_frames > 1:
+        x, pad = stack_tensor(x, n_stack_frames)
+    else:
+        x = x.unsqueeze(-1)
+    y = y.unsqueeze(-1)
+    h = x.transpose(1, 2)  # [B,C,T]
+    if pad_receptive_field:
+        skip_size = h.size(2)
+        h = F.pad(h, (rf, 0))
+    else:
+        skip_size = h.size(2) - rf
+        x_sl = x_sl - rf
+    if pad_causal:
+        h = h[..., :-1]
+    h = F.conv1d(h, sd["causal.conv.weight"], sd["causal.conv.bias"])
+    h = F.conv1d(h, sd["res_stack.in_transform.weight"], sd["res_stack.in_transform.bias"])
+    C = h.size(1)
+    skips = 0
+    for i, d in enumerate(dil):
+        p = f"res_stack.res_blocks.{i}"
+        pre = F.conv1d(h, sd[f"{p}.conv.weight"], sd[f"{p}.conv.bias"], dilation=d)
+        a, b = pre.chunk(2, 1)
+        rs = F.conv1d(torch.tanh(a) * torch.sigmoid(b), sd[f"{p}.conv1x1rs.weight"], sd[f"{p}.conv1x1rs.bias"])
+        r, s = rs[:, :C], rs[:, C:]
+        skips = skips + s[..., -skip_size:]
+        h = (r + h[..., -r.size(2) :]) * math.sqrt(0.5)
+    out = (skips * math.sqrt(n_layers / n_stacks)).transpose(1, 2)
+    out = F.relu(F.linear(F.relu(out), sd["out_transform.linear.weight"], sd["out_transform.linear.bias"]))
+    if n_stack_frames > 1:
+        out = out.reshape(out.size(0), out.size(1) * n_stack_frames, -1)[:, : y.size(1)]
+    logits, locs, log_scales = dmol_head(out, sd["likelihood.params.weight"], sd["likelihood.params.bias"], num_mix)
+    mask = sequence_mask(x_sl, max_len=y.size(1))
+    ll_twise = dmol_ll(y, logits, locs, log_scales, num_bins) * mask
+    log_prob = ll_twise.sum(1)
+    loss = -log_prob.nansum() / x_sl.nansum()
+    return dict(loss=loss, log_prob=log_prob, log_prob_twise=ll_twise, bpd=float((-log_prob.detach() / LN2).sum() / x_sl.sum()))

@@ -232,6 +232,53 @@ def gen_srnn():
     save("srnn.npz", **arrays)
 
 
+def gen_wavenet():
+    """WaveNet + DMoL: reduced size with full tensors; BASELINE config C5 dims (5x10, C=96) on a short batch by checksum."""
+    arrays = {}
+    torch.manual_seed(41)
+    lik = DiscretizedLogisticMixtureDense(16, 1, num_mix=10, num_bins=2**16)
+    m = RM.WaveNet(likelihood=lik, n_layers=3, n_stacks=2, res_channels=16, kernel_size=2, base_dilation=2, n_stack_frames=1)
+    x, _ = O.synth_batch(3, 50, seed=8)
+    x_sl = torch.tensor([50, 33, 20])
+    x = x * (torch.arange(50).unsqueeze(0) < x_sl.unsqueeze(1))
+    for tag, pad_rf in (("s", True), ("n", False)):
+        m.zero_grad()
+        xr = x.clone().requires_grad_(True)
+        torch.manual_seed(1)
+        loss, metrics, o = m(xr, x_sl, pad_receptive_field=pad_rf)
+        loss.backward()
+        arrays.update({f"{tag}_loss": loss, f"{tag}_log_prob": o.log_prob, f"{tag}_ll_twise": o.log_prob_twise, f"{tag}_dx": xr.grad})
+        arrays[f"{tag}_metric_names"] = np.array([mm.name for mm in metrics])
+        arrays[f"{tag}_metric_values"] = np.array([mm.value for mm in metrics], dtype=np.float64)
+        for k, p in m.named_parameters():
+            arrays[f"{tag}_grad.{k}"] = p.grad
+    arrays.update(s_x=x, s_x_sl=x_sl, s_rf=np.int64(m.receptive_field))
+    for k, v in m.state_dict().items():
+        arrays[f"s_sd.{k}"] = v
+
+    torch.manual_seed(0)
+    lik = DiscretizedLogisticMixtureDense(96, 1, num_mix=10, num_bins=2**16)
+    m = RM.WaveNet(likelihood=lik, n_layers=10, n_stacks=5, res_channels=96, kernel_size=2, base_dilation=2, n_stack_frames=1)
+    names = []
+    for k, v in m.state_dict().items():
+        names.append(k)
+        arrays[f"cks.{k}"] = np.array([v.double().sum().item(), v.double().abs().sum().item(), *v.shape], dtype=np.float64)
+    arrays["param_names"] = np.array(names)
+    xf, xf_sl = O.synth_batch(2, 1500, seed=0, ragged=True)
+    torch.manual_seed(1)
+    loss, metrics, o = m(xf, xf_sl)
+    loss.backward()
+    arrays.update(f_x_sl=xf_sl, f_loss=loss, f_log_prob=o.log_prob, f_rf=np.int64(m.receptive_field))
+    arrays["f_metric_names"] = np.array([mm.name for mm in metrics])
+    arrays["f_metric_values"] = np.array([mm.value for mm in metrics], dtype=np.float64)
+    arrays["f_grad_norms"] = np.array([p.grad.double().norm().item() for _, p in m.named_parameters()])
+    arrays["f_grad_names"] = np.array([k for k, _ in m.named_parameters()])
+    arrays["f_grad.causal.conv.weight"] = m.causal.conv.weight.grad.clone()
+    arrays["f_grad.res_stack.res_blocks.49.conv1x1rs.bias"] = m.res_stack.res_blocks[49].conv1x1rs.bias.grad.clone()
+    arrays["f_grad.res_stack.res_blocks.7.conv.weight"] = m.res_stack.res_blocks[7].conv.weight.grad.clone()
+    save("wavenet.npz", **arrays)
+
+
 def gen_lstm():
     """LSTMAudio: reduced size with full tensors, and BASELINE config C1 ([8,4000], h=256, s=64) pinned by checksums."""
     arrays = {}
@@ -276,6 +323,6 @@ def gen_lstm():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn"]
+    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn", "wavenet"]
     for w in which:
         globals()[f"gen_{w}"]()

@@ -466,3 +466,90 @@ def test_srnn_full_dims_vs_reference_golden():
         assert grads[name].grad.double().norm().item() == pytest.approx(ref, rel=1e-3), name
     for k in [f[7:] for f in g.files if f.startswith("f_grad.")]:
         assert rel_l2(grads[k].grad, T(g[f"f_grad.{k}"])) < 1e-3, k
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# K10 WaveNet (BASELINE config C5)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def test_causal_conv_reference_known_answers():
+    """The reference's own tests/models/wavenet/test_causal_conv.py:41-60: all-ones weights on arange(1..32) [1,2,16]."""
+    from blvm.models.wavenet import CausalConv1d
+
+    x = torch.arange(1, 33, dtype=torch.float32).view(1, 2, 16).to(DEV)
+    for k, expect in ((1, list(range(18, 47, 2))), (2, list(range(38, 91, 4)))):
+        conv = CausalConv1d(2, 1, k).to(DEV)
+        conv.init_weights_for_test()
+        out = conv(x)
+        assert out.shape == (1, 1, len(expect))
+        assert out.cpu().view(-1).tolist() == [float(v) for v in expect]
+
+
+def _small_wavenet(g):
+    from blvm.models import WaveNet
+    from blvm.modules.distributions import DiscretizedLogisticMixtureDense
+
+    lik = DiscretizedLogisticMixtureDense(16, 1, num_mix=10, num_bins=2**16)
+    m = WaveNet(likelihood=lik, n_layers=3, n_stacks=2, res_channels=16, kernel_size=2, base_dilation=2, n_stack_frames=1)
+    m.load_state_dict({k[5:]: T(g[k]) for k in g.files if k.startswith("s_sd.")})
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("tag,pad_rf", [("s", True), ("n", False)])
+def test_wavenet_small_vs_reference_golden(tag, pad_rf):
+    g = np.load(os.path.join(GOLDEN, "wavenet.npz"))
+    m = _small_wavenet(g)
+    assert m.receptive_field == int(g["s_rf"])
+    x = T(g["s_x"]).to(DEV).requires_grad_(True)
+    loss, metrics, out = m(x, T(g["s_x_sl"]), pad_receptive_field=pad_rf)
+    loss.backward()
+    assert float(loss) == pytest.approx(float(g[f"{tag}_loss"]), rel=1e-5)
+    torch.testing.assert_close(out.log_prob.cpu(), T(g[f"{tag}_log_prob"]), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(out.log_prob_twise.cpu(), T(g[f"{tag}_ll_twise"]), rtol=1e-4, atol=1e-4)
+    vals = {mm.name: mm.value for mm in metrics}
+    for name, val in zip(g[f"{tag}_metric_names"].tolist(), g[f"{tag}_metric_values"].tolist()):
+        assert vals[name] == pytest.approx(val, rel=1e-5), name
+    assert rel_l2(x.grad, T(g[f"{tag}_dx"])) < 1e-3
+    for k, p in m.named_parameters():
+        assert rel_l2(p.grad, T(g[f"{tag}_grad.{k}"])) < 1e-3, k
+    assert out.predictions.shape == out.predictions_mode.shape == (3, 50 if pad_rf else 50 - m.receptive_field, 1)
+
+
+def test_wavenet_causality_by_input_gradient_and_short_input():
+    """The reference's test strategy for the stack (tests/models/wavenet/test_wavenet.py:65-102): the loss on frames
+    < s must not depend on inputs >= s - 1 ... checked through d(loss)/d(x); too-short inputs raise InputSizeError."""
+    from blvm.models.wavenet import InputSizeError
+
+    g = np.load(os.path.join(GOLDEN, "wavenet.npz"))
+    m = _small_wavenet(g)
+    rf = m.receptive_field
+    x = (torch.rand(1, rf + 1, generator=torch.Generator().manual_seed(3)) - 0.5).to(DEV).requires_grad_(True)
+    x_sl = torch.tensor([rf + 1])
+    loss, _, _ = m(x, x_sl)
+    loss.backward()
+    assert (x.grad[:, :-1] != 0).all() and (x.grad[:, -1] == 0).all()
+    with pytest.raises(InputSizeError):
+        m(x.detach()[:, :rf], torch.tensor([rf]), pad_receptive_field=False)
+    _, _, o = m(x.detach(), x_sl, pad_receptive_field=False)
+    assert o.predictions.shape == (1, 1, 1)
+
+
+def test_wavenet_c5_dims_vs_reference_golden():
+    from blvm.models import WaveNet
+    from blvm.modules.distributions import DiscretizedLogisticMixtureDense
+
+    g = np.load(os.path.join(GOLDEN, "wavenet.npz"))
+    torch.manual_seed(0)
+    lik = DiscretizedLogisticMixtureDense(96, 1, num_mix=10, num_bins=2**16)
+    m = WaveNet(likelihood=lik, n_layers=10, n_stacks=5, res_channels=96, kernel_size=2, base_dilation=2, n_stack_frames=1).to(DEV)
+    x, x_sl = O.synth_batch(2, 1500, seed=0, ragged=True)
+    loss, metrics, out = m(x.to(DEV), x_sl)
+    loss.backward()
+    assert float(loss) == pytest.approx(float(g["f_loss"]), rel=1e-5)
+    torch.testing.assert_close(out.log_prob.cpu(), T(g["f_log_prob"]), rtol=1e-5, atol=0)
+    grads = dict(m.named_parameters())
+    for name, ref in zip(g["f_grad_names"].tolist(), g["f_grad_norms"].tolist()):
+        assert grads[name].grad.double().norm().item() == pytest.approx(ref, rel=2e-3), name
+    for k in [f[7:] for f in g.files if f.startswith("f_grad.")]:
+        assert rel_l2(grads[k].grad, T(g[f"f_grad.{k}"])) < 2e-3, k

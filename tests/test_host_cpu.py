@@ -179,3 +179,28 @@ def test_padding_helpers():
     assert get_same_padding(16000, 64, 64) == 0 and get_same_padding(16001, 64, 64) == 63
     with pytest.raises(ValueError):
         get_modulo_padding(3, 4, 8)
+
+
+def test_wavenet_init_matches_reference_and_oracle_c5_dims():
+    from blvm.models import WaveNet
+    from blvm.modules.distributions import DiscretizedLogisticMixtureDense
+
+    g = np.load(os.path.join(GOLDEN, "wavenet.npz"))
+    torch.manual_seed(0)
+    lik = DiscretizedLogisticMixtureDense(96, 1, num_mix=10, num_bins=2**16)
+    m = WaveNet(likelihood=lik, n_layers=10, n_stacks=5, res_channels=96, kernel_size=2, base_dilation=2, n_stack_frames=1)
+    assert m.receptive_field == int(g["f_rf"]) == 5117
+    sd0 = m.state_dict()
+    assert list(sd0.keys()) == g["param_names"].tolist()
+    for k, v in sd0.items():
+        cks = g[f"cks.{k}"]
+        assert list(v.shape) == [int(s) for s in cks[2:]], k
+        assert v.double().abs().sum().item() == pytest.approx(cks[1], rel=1e-12), k
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+    x, x_sl = O.synth_batch(2, 1500, seed=0, ragged=True)
+    out = O.wavenet_forward(sd, x, x_sl, n_layers=10, n_stacks=5)
+    np.testing.assert_allclose(out["loss"].item(), g["f_loss"], rtol=2e-6)
+    np.testing.assert_allclose(out["log_prob"].detach().numpy(), g["f_log_prob"], rtol=2e-6)
+    out["loss"].backward()
+    for name, ref in zip(g["f_grad_names"].tolist(), g["f_grad_norms"].tolist()):
+        assert sd[name].grad.double().norm().item() == pytest.approx(ref, rel=5e-4), name

@@ -156,3 +156,19 @@ def test_srnn_small_forward_backward(tag, smoothing, beta, fn_):
                                     a_0=out["a_n"].detach(), z_0=out["z_n"].detach())
         close(out2["loss"], g["c_loss"], 1e-6, 0)
         close(out2["z"], g["c_z"], 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("tag,pad_rf", [("s", True), ("n", False)])
+def test_wavenet_small_forward_backward(tag, pad_rf):
+    g = np.load(os.path.join(GOLDEN, "wavenet.npz"))
+    sd = {k[5:]: T(g[k]).clone().requires_grad_(True) for k in g.files if k.startswith("s_sd.")}
+    x = T(g["s_x"]).clone().requires_grad_(True)
+    out = O.wavenet_forward(sd, x, T(g["s_x_sl"]), n_layers=3, n_stacks=2, pad_receptive_field=pad_rf)
+    close(out["loss"], g[f"{tag}_loss"], 1e-6, 0)
+    close(out["log_prob"], g[f"{tag}_log_prob"], 1e-6, 1e-4)
+    close(out["log_prob_twise"], g[f"{tag}_ll_twise"], 1e-5, 1e-5)
+    out["loss"].backward()
+    close(x.grad, g[f"{tag}_dx"], 1e-4, 1e-7)
+    for k, p in sd.items():
+        ref = T(g[f"{tag}_grad.{k}"])
+        assert (p.grad - ref).norm() / (ref.norm() + 1e-12) < 2e-5, k
