@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU (reference benchmark: --batch_len 64 s of audio)")
     ap.add_argument("--length", type=int, default=16000, help="samples per utterance (1 s at 16 kHz)")
-    ap.add_argument("--model", default="vrnn", choices=["vrnn", "srnn", "lstm"], help="vrnn = BASELINE headline (configs[1])")
+    ap.add_argument("--model", default="vrnn", choices=["vrnn", "srnn", "lstm", "wavenet"], help="vrnn = BASELINE headline (configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=10)
@@ -96,7 +96,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from blvm import _hip, ops
-    from blvm.models import LSTMAudio, SRNNAudio, VRNNAudio
+    from blvm.models import LSTMAudio, SRNNAudio, VRNNAudio, WaveNet
+    from blvm.modules.distributions import DiscretizedLogisticMixtureDense
     from blvm.training.ddp import FlatGradAllReduce
 
     assert _hip.load().blvm_device_ok() == 1, "libblvm_hip: no gfx950 device"
@@ -107,6 +108,9 @@ def main():
         model = VRNNAudio(likelihood="DMoL", input_size=S, hidden_size=H, latent_size=Z, residual_posterior=True).to(dev)
     elif args.model == "srnn":
         model = SRNNAudio(likelihood="DMoL", input_size=S, hidden_size=H, latent_size=Z, residual_posterior=True, smoothing=True).to(dev)
+    elif args.model == "wavenet":
+        lik = DiscretizedLogisticMixtureDense(96, 1, num_mix=10, num_bins=2**16)
+        model = WaveNet(likelihood=lik, n_layers=10, n_stacks=5, res_channels=96, kernel_size=2, base_dilation=2, n_stack_frames=1).to(dev)
     else:
         model = LSTMAudio(stack_size=S, hidden_size=H, num_layers=1, num_mix=10, num_bins=2**16).to(dev)
     params = list(model.parameters())
@@ -142,7 +146,7 @@ def main():
 
     def step():
         opt.zero_grad(set_to_none=True)
-        loss, metrics, out = model(x, x_sl, beta=1.0, free_nats=2.0) if args.model != "lstm" else model(x, x_sl)
+        loss, metrics, out = model(x, x_sl, beta=1.0, free_nats=2.0) if args.model in ("vrnn", "srnn") else model(x, x_sl)
         loss.backward()
         if reducer is not None:
             reducer(float(B * T))
@@ -181,7 +185,7 @@ def main():
     log(f"timed {args.steps} steps: {ms_step:.2f} ms/step; host enqueue per step: seq_fwd {host['fwd'] / args.steps * 1e3:.2f} ms, "
         f"seq_bwd {host['bwd'] / args.steps * 1e3:.2f} ms")
     frames = world * B * T * args.steps
-    if args.model == "lstm":  # no hooked recurrent-cell call: report the whole step against the model's matmul FLOPs
+    if args.model in ("lstm", "wavenet"):  # no hooked recurrent-cell call: whole step against the model's matmul FLOPs
         fwd_ms, bwd_ms = ms_step / 3, 2 * ms_step / 3
     else:
         cell_ms = [(e[0].elapsed_time(e[1]), e[2].elapsed_time(e[3])) for e in ev]
@@ -194,6 +198,9 @@ def main():
     elif args.model == "srnn":
         macs = 2 * ((R + Z) * H + 2 * H * H + 2 * Z * H) * B * Tp
         kname = "SRNN latent chain, forward+BPTT (blvm_srnn_latent_fwd + blvm_srnn_latent_bwd)"
+    elif args.model == "wavenet":
+        macs = 2777088 * B * T  # algorithmic MAC per frame, 5x10 blocks, C=96, k=2
+        kname = "WaveNet whole train step (conv/MFMA path: 50 gated residual blocks as shifted-view GEMMs)"
     else:
         macs = (S * H + 2 * H * H + 8 * H * H + 2 * H * H + H * 30 * S + 900 * S) * B * (Tp - 1)
         kname = "LSTMAudio whole train step (matmul FLOPs of embedding + LSTM + decoder + DMoL Linear)"

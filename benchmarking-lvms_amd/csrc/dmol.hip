@@ -23,6 +23,12 @@ constexpr int F_MAX = 30;   // 3 * num_mix, num_mix = 10
 constexpr int NMIX = 10;
 constexpr int FPB = 256;    // frames per block
 
+// The 30x30 head weights are read-only for the whole launch and wave-uniform: reading them through the CONSTANT
+// address space makes hipcc keep them on the scalar path (s_load -> SGPR operands of v_pk_fma) even inside loops that
+// also store to global memory (otherwise it falls back to 900 vector loads of a uniform address per iteration).
+typedef const __attribute__((address_space(4))) float cfloat;
+__device__ __forceinline__ cfloat* as_const(const float* p) { return (cfloat*)(uintptr_t)p; }
+
 struct DmolArgs {
   const float* dec;
   const float* W;
@@ -107,8 +113,21 @@ __device__ __forceinline__ FrameCoord frame_coord(const DmolArgs& a, long long f
   return c;
 }
 
+// Hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp): the kernel has a budget of ~1700 vector
+// instructions per frame before it stops being HBM-bound; libm-accurate expf/logf/log1pf/division cost 4x that.
+__device__ __forceinline__ float fexp(float x) { return __expf(x); }
+__device__ __forceinline__ float flog(float x) { return __logf(x); }
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 // Per-frame DMoL math.  p[0..9] logits, p[10..19] locs, p[20..29] raw log-scales.
 // Returns ll; if BWD, overwrites p with dll/dp.
+//
+// Same quantities as blvm/utils/log_likelihoods.py:170-231, evaluated without the fp32 cancellation of
+// sigmoid(plus) - sigmoid(minus):  with m = (y - loc)/s, w = half_bin/s, t = exp(-|m|)
+//     delta = sigma(m+w) - sigma(m-w) = sinh(w) / (cosh(m) + cosh(w)) = 2 t sinh(w) / (1 + t^2 + 2 t cosh(w))
+//     log_pdf_mid = m - log s - 2 softplus(m),  softplus(m) = max(m,0) + log(1 + t)
+//     d log(delta)/dm = -sinh(m)/(cosh(m)+cosh(w)) = -sign(m)(1 - t^2)/(1 + t^2 + 2 t cosh(w)),   1 - 2 sigma(m) = -sign(m)(1-t)/(1+t)
+// (2 exp + 1 log + 2 rcp per component).  The edge bins (|y| > 1 - 2/bins) are rare and take the libm path.
 template <bool BWD>
 __device__ __forceinline__ float dmol_frame(const DmolArgs& a, float yv, float (&p)[F_MAX]) {
   float mx = p[0];
@@ -116,59 +135,78 @@ __device__ __forceinline__ float dmol_frame(const DmolArgs& a, float yv, float (
   for (int m = 1; m < NMIX; ++m) mx = fmaxf(mx, p[m]);
   float se = 0.f;
 #pragma unroll
-  for (int m = 0; m < NMIX; ++m) se += exp_(p[m] - mx);
-  const float lse_logits = mx + log_(se);
+  for (int m = 0; m < NMIX; ++m) se += fexp(p[m] - mx);
+  const float lse_logits = mx + flog(se);
 
   float lp[NMIX], dloc[NMIX], dls[NMIX];
   const bool is_low = yv < a.low_edge, is_high = yv > a.high_edge;
+  const bool any_edge = __any(is_low || is_high);  // wave-uniform
   float tmax = -INFINITY;
 #pragma unroll
   for (int m = 0; m < NMIX; ++m) {
     const float loc = p[NMIX + m];
     const float raw = p[2 * NMIX + m];
     const float ls = fmaxf(raw, a.log_eps);
-    const float c = yv - loc;
-    const float inv = exp_(-ls);
-    const float plus = inv * (c + a.half_bin);
-    const float minus = inv * (c - a.half_bin);
-    const float sp = sigmoidf_(plus), sm = sigmoidf_(minus);
-    const float delta = sp - sm;
-    float v, gl, gs;  // value, d/dloc, d/dls
-    if (is_high) {
-      v = -softplusf_(minus);
-      if (BWD) { gl = inv * sm; gs = minus * sm; }
-    } else if (is_low) {
-      v = plus - softplusf_(plus);
-      if (BWD) { const float q = 1.f - sp; gl = -inv * q; gs = -plus * q; }
-    } else if (delta > 1e-5f) {
-      v = log_(fmaxf(delta, 1e-10f));
-      if (BWD) {
-        const float dp = sp * (1.f - sp), dm = sm * (1.f - sm), rd = 1.f / delta;
-        gl = -inv * (dp - dm) * rd;
-        gs = -(plus * dp - minus * dm) * rd;
-      }
+    const float inv = fexp(-ls);
+    const float mm = inv * (yv - loc);
+    const float w = inv * a.half_bin;
+    const float t = fexp(-fabsf(mm));
+    float sh, ch;  // sinh(w), cosh(w); w > 0
+    if (w < 0.25f) {
+      const float w2 = w * w;
+      sh = w * (1.f + w2 * (1.f / 6.f + w2 * (1.f / 120.f)));
+      ch = 1.f + w2 * (0.5f + w2 * (1.f / 24.f + w2 * (1.f / 720.f)));
     } else {
-      const float mid = inv * c;
-      v = mid - ls - 2.f * softplusf_(mid) - a.log_half_bins;
-      if (BWD) { const float q = 1.f - 2.f * sigmoidf_(mid); gl = -inv * q; gs = -mid * q - 1.f; }
+      const float ew = fexp(w), iw = frcp(ew);
+      sh = 0.5f * (ew - iw);
+      ch = 0.5f * (ew + iw);
+    }
+    const float rden = frcp(1.f + t * t + 2.f * t * ch);
+    const float delta = 2.f * t * sh * rden;
+    const bool big = delta > 1e-5f;
+    const float L = flog(big ? fmaxf(delta, 1e-10f) : 1.f + t);
+    float v = big ? L : mm - ls - 2.f * fmaxf(mm, 0.f) - 2.f * L - a.log_half_bins;
+    float gl = 0.f, gs = 0.f;
+    if (BWD) {
+      const float sgn = mm < 0.f ? -1.f : 1.f;
+      if (big) {
+        const float s_over = sgn * (1.f - t * t) * rden;  // sinh(m) / (cosh(m) + cosh(w))
+        gl = inv * s_over;
+        gs = mm * s_over - w * ch * frcp(sh) + w * delta;
+      } else {
+        const float q = -sgn * (1.f - t) * frcp(1.f + t);  // 1 - 2 sigmoid(m)
+        gl = -inv * q;
+        gs = -mm * q - 1.f;
+      }
+    }
+    if (any_edge) {
+      const float plus = mm + w, minus = mm - w;
+      if (is_high) {
+        v = -softplusf_(minus);
+        if (BWD) { const float sm = sigmoidf_(minus); gl = inv * sm; gs = minus * sm; }
+      } else if (is_low) {
+        v = plus - softplusf_(plus);
+        if (BWD) { const float q = 1.f - sigmoidf_(plus); gl = -inv * q; gs = -plus * q; }
+      }
     }
     lp[m] = v + (p[m] - lse_logits);
     tmax = fmaxf(tmax, lp[m]);
     if (BWD) { dloc[m] = gl; dls[m] = (raw >= a.log_eps) ? gs : 0.f; }
   }
   float s = 0.f;
+  float e[NMIX];
 #pragma unroll
-  for (int m = 0; m < NMIX; ++m) s += exp_(lp[m] - tmax);
-  const float ll = tmax + log_(s);
+  for (int m = 0; m < NMIX; ++m) { e[m] = fexp(lp[m] - tmax); s += e[m]; }
+  const float ll = tmax + flog(s);
   if (BWD) {
-    const float rs = 1.f / s, rse = 1.f / se;
+    const float rs = frcp(s), rse = frcp(se);
 #pragma unroll
     for (int m = 0; m < NMIX; ++m) {
-      const float w = exp_(lp[m] - tmax) * rs;            // responsibility of component m
-      const float pm = exp_(p[m] - mx) * rse;             // softmax(logits)_m
-      p[m] = w - pm;
-      p[NMIX + m] = w * dloc[m];
-      p[2 * NMIX + m] = w * dls[m];
+      const float wgt = e[m] * rs;                     // responsibility of component m
+      const float pm = fexp(p[m] - mx) * rse;          // softmax(logits)_m
+      p[m] = wgt - pm;
+      p[NMIX + m] = wgt * dloc[m];
+      p[2 * NMIX + m] = wgt * dls[m];
     }
   }
   return ll;
@@ -188,13 +226,15 @@ __global__ __launch_bounds__(256) void dmol_kernel(DmolArgs a) {
   for (int i = 0; i < F_MAX; ++i) d[i] = lds[threadIdx.x * (F_MAX + 1) + i];
 
   // p = W d + bias   (weights are wave-uniform -> scalar operands); W == NULL: the parameters ARE the input
+  cfloat* Wc = as_const(a.W);
+  cfloat* bc = as_const(a.bias);
   float p[F_MAX];
   if (a.W != nullptr) {
 #pragma unroll
     for (int o = 0; o < F_MAX; ++o) {
-      float s = a.bias[o];
+      float s = bc[o];
 #pragma unroll
-      for (int i = 0; i < F_MAX; ++i) s = fmaf(a.W[o * F_MAX + i], d[i], s);
+      for (int i = 0; i < F_MAX; ++i) s = fmaf(Wc[o * F_MAX + i], d[i], s);
       p[o] = s;
     }
   } else {
@@ -237,7 +277,7 @@ __global__ __launch_bounds__(256) void dmol_kernel(DmolArgs a) {
 #pragma unroll
       for (int o = 0; o < F_MAX; ++o) {
 #pragma unroll
-        for (int i = 0; i < F_MAX; ++i) dd[i] = fmaf(a.W[o * F_MAX + i], p[o], dd[i]);
+        for (int i = 0; i < F_MAX; ++i) dd[i] = fmaf(Wc[o * F_MAX + i], p[o], dd[i]);
       }
     } else {
 #pragma unroll
@@ -256,6 +296,154 @@ __global__ __launch_bounds__(256) void dmol_kernel(DmolArgs a) {
       unstage_frames(a.d_par, f0, a.n_frames, lds);
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row-wise variant for stack sizes that are multiples of 64 (the VRNN / SRNN / LSTM decoders, S = 64 or 256).
+// A workgroup owns ONE utterance and a chunk of its 64-frame units, each wave stages its own unit through a private
+// LDS image (no inter-wave traffic), the per-utterance sum is carried in registers across the chunk and costs ONE fp64
+// atomic per workgroup (the flat kernel above issues one per wave: 250 serialised atomics per utterance address at
+// [64,16000]).  Integer divisions are 32-bit and wave-uniform.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void stage_unit(const float* __restrict__ src, float* __restrict__ lds, int lane) {
+  // 64 frames x 30 floats = 480 float4, contiguous and 16-byte aligned in HBM -> LDS [64][31]
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int q = lane + 64 * k;
+    if (q < 480) {
+      const float4 v = reinterpret_cast<const float4*>(src)[q];
+      const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int idx = 4 * q + c, fr = (idx * 2185) >> 16;  // idx / 30, exact for idx < 1920
+        lds[fr * (F_MAX + 1) + (idx - fr * F_MAX)] = e[c];
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void unstage_unit(float* __restrict__ dst, const float* __restrict__ lds, int lane) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int q = lane + 64 * k;
+    if (q < 480) {
+      float e[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int idx = 4 * q + c, fr = (idx * 2185) >> 16;
+        e[c] = lds[fr * (F_MAX + 1) + (idx - fr * F_MAX)];
+      }
+      reinterpret_cast<float4*>(dst)[q] = make_float4(e[0], e[1], e[2], e[3]);
+    }
+  }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void dmol_rows_kernel(DmolArgs a, int units, int nchunks) {
+  __shared__ __attribute__((aligned(16))) float lds_all[4 * 64 * (F_MAX + 1)];
+  __shared__ double wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* lds = lds_all + wave * 64 * (F_MAX + 1);
+  const int b = blockIdx.x / nchunks, c = blockIdx.x - b * nchunks;
+  const int u_begin = (int)((long long)c * units / nchunks), u_end = (int)((long long)(c + 1) * units / nchunks);
+  cfloat* Wc = as_const(a.W);
+  cfloat* bc = as_const(a.bias);
+  const int upr = a.S >> 6;  // 64-frame units per row
+  const int len = min(a.x_sl[b], a.T);
+  const float g = BWD ? a.g_b[b] : 0.f;
+  double acc = 0.0;
+  for (int u0 = u_begin; u0 < u_end; u0 += 4) {
+    const int u = u0 + wave;
+    const bool active = u < u_end;  // wave-uniform
+    const int t = active ? u / upr : 0;
+    const int j0 = active ? (u - t * upr) * 64 : 0;
+    const long long row = a.layout == 0 ? (long long)b * a.Tp + t : (long long)t * a.B + b;
+    const size_t base = ((size_t)row * a.S + j0) * F_MAX;
+    if (active) stage_unit(a.dec + base, lds, lane);
+    __syncthreads();
+    const int tau = t * a.S + j0 + lane;
+    const bool valid = active && tau < len;
+    float d[F_MAX];
+#pragma unroll
+    for (int i = 0; i < F_MAX; ++i) d[i] = lds[lane * (F_MAX + 1) + i];
+    float p[F_MAX];
+    if (a.W != nullptr) {
+#pragma unroll
+      for (int o = 0; o < F_MAX; ++o) {
+        float s = bc[o];
+#pragma unroll
+        for (int i = 0; i < F_MAX; ++i) s = fmaf(Wc[o * F_MAX + i], d[i], s);
+        p[o] = s;
+      }
+    } else {
+#pragma unroll
+      for (int o = 0; o < F_MAX; ++o) p[o] = d[o];
+    }
+    const float yv = valid ? a.y[(size_t)b * a.T + tau] : 0.f;
+    const float ll = dmol_frame<BWD>(a, yv, p);
+    if (!BWD) {
+      if (valid) {
+        acc += (double)ll;
+        if (a.ll_twise != nullptr) a.ll_twise[(size_t)b * a.T + tau] = ll;
+      }
+      __syncthreads();
+    } else {
+      const float gv = valid ? g : 0.f;
+#pragma unroll
+      for (int o = 0; o < F_MAX; ++o) p[o] *= gv;
+      float dd[F_MAX];
+      if (a.W != nullptr) {
+#pragma unroll
+        for (int i = 0; i < F_MAX; ++i) dd[i] = 0.f;
+#pragma unroll
+        for (int o = 0; o < F_MAX; ++o) {
+#pragma unroll
+          for (int i = 0; i < F_MAX; ++i) dd[i] = fmaf(Wc[o * F_MAX + i], p[o], dd[i]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < F_MAX; ++i) dd[i] = p[i];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < F_MAX; ++i) lds[lane * (F_MAX + 1) + i] = dd[i];
+      __syncthreads();
+      if (active) unstage_unit(a.d_dec + base, lds, lane);
+      if (a.d_par != nullptr) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < F_MAX; ++i) lds[lane * (F_MAX + 1) + i] = p[i];
+        __syncthreads();
+        if (active) unstage_unit(a.d_par + base, lds, lane);
+      }
+      __syncthreads();
+    }
+  }
+  if (!BWD) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) wsum[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(a.log_prob + b, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+  }
+}
+
+template <bool BWD>
+int launch_dmol(DmolArgs& a, hipStream_t s) {
+  if (a.S % 64 == 0 && aligned16(a.dec) && (!BWD || (aligned16(a.d_dec) && (a.d_par == nullptr || aligned16(a.d_par))))) {
+    const long long units = (long long)a.Tp * (a.S / 64);
+    BLVM_REQUIRE(units < (1ll << 31), "dmol: too many frames");
+    int nchunks = (int)((units + 3) / 4);
+    const int cap = (2048 + a.B - 1) / a.B;
+    if (nchunks > cap) nchunks = cap;
+    if (nchunks < 1) nchunks = 1;
+    hipLaunchKernelGGL((dmol_rows_kernel<BWD>), dim3((unsigned)(a.B * nchunks)), dim3(256), 0, s, a, (int)units, nchunks);
+  } else {
+    const long long blocks = (a.n_frames + FPB - 1) / FPB;
+    BLVM_REQUIRE(blocks < (1ll << 31), "dmol: too many frames");
+    hipLaunchKernelGGL((dmol_kernel<BWD>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+  }
+  return BLVM_OK;
 }
 
 int check_common(const float* dec, const float* W, const float* bias, const float* y, const int32_t* x_sl, int B,
@@ -296,9 +484,8 @@ extern "C" int blvm_dmol_fwd(const float* dec, int layout, const float* W, const
   DmolArgs a = make_args(dec, layout, W, bias, y, x_sl, B, T, Tp, S, num_bins, log_eps);
   a.log_prob = log_prob;
   a.ll_twise = ll_twise;
-  const long long blocks = (a.n_frames + FPB - 1) / FPB;
-  BLVM_REQUIRE(blocks < (1ll << 31), "dmol_fwd: too many frames");
-  hipLaunchKernelGGL((dmol_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  rc = launch_dmol<false>(a, static_cast<hipStream_t>(stream));
+  if (rc) return rc;
   BLVM_CHECK_LAUNCH("dmol_fwd");
   return BLVM_OK;
 }
@@ -314,9 +501,8 @@ extern "C" int blvm_dmol_bwd(const float* dec, int layout, const float* W, const
   a.g_b = g_b;
   a.d_dec = d_dec;
   a.d_par = d_par;
-  const long long blocks = (a.n_frames + FPB - 1) / FPB;
-  BLVM_REQUIRE(blocks < (1ll << 31), "dmol_bwd: too many frames");
-  hipLaunchKernelGGL((dmol_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  rc = launch_dmol<true>(a, static_cast<hipStream_t>(stream));
+  if (rc) return rc;
   BLVM_CHECK_LAUNCH("dmol_bwd");
   return BLVM_OK;
 }
