@@ -1,0 +1,125 @@
+"""Shared body of the experiment entry points: synthetic length-bucketed data, one process per GPU, and the reference's
+loop order (experiments/experiment_vrnn_audio.py:213-298): forward -> zero_grad -> backward -> [gradient all-reduce] ->
+clip by value -> clip by norm -> optimizer step; lr_scheduler.step() per epoch; evaluation every `test_every` epochs,
+optionally on split sequences with carried state; checkpoint when the test metric improves."""
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "benchmarking-lvms_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from blvm.data.transforms import MuLawEncode  # noqa: E402
+from blvm.evaluation import Tracker  # noqa: E402
+from blvm.training.ddp import FlatGradAllReduce  # noqa: E402
+
+
+class SyntheticUtterances:
+    """Batches of synthetic mu-law waveforms with the shape of the reference's collated batches: x [B,T] float32 in
+    (-1,1) zero-padded on the right, x_sl [B] int64 on the host, longest first (batchers.py:145-151)."""
+
+    def __init__(self, n_utterances, max_length, batch_size, batch_len, bits, seed, rank=0, world=1, min_frac=0.5):
+        g = torch.Generator().manual_seed(seed)
+        lens = (torch.rand(n_utterances, generator=g) * (1 - min_frac) + min_frac) * max_length
+        lens = lens.long().clamp(min=1).sort(descending=True).values.tolist()
+        self.batches, cur = [], []
+        for n in lens:  # greedy buckets bounded by examples or by total samples (LengthTrainSampler idea)
+            cur.append(n)
+            full = len(cur) >= batch_size if batch_size else sum(cur) + n > batch_len
+            if full:
+                self.batches.append(cur)
+                cur = []
+        if cur:
+            self.batches.append(cur)
+        self.batches = [b[rank::world] for b in self.batches if len(b[rank::world]) > 0]  # utterances shard by rank
+        self.mulaw, self.seed, self.rank = MuLawEncode(bits), seed, rank
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        for i, lens in enumerate(self.batches):
+            g = torch.Generator().manual_seed(self.seed * 7919 + i * 31 + self.rank)
+            T = max(lens)
+            x = self.mulaw((torch.rand(len(lens), T, generator=g) * 2 - 1) * 0.5)
+            x_sl = torch.tensor(lens, dtype=torch.int64)
+            yield (x * (torch.arange(T).unsqueeze(0) < x_sl.unsqueeze(1))), x_sl
+
+
+def setup(args):
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local_rank if args.device == "auto" else int(args.device))
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", args.ddp_master_addr or "127.0.0.1")
+        if args.ddp_master_port:
+            os.environ.setdefault("MASTER_PORT", args.ddp_master_port)
+        dist.init_process_group("nccl", device_id=dev)
+    torch.manual_seed(args.seed)  # same weights on every rank
+    if args.use_amp and rank == 0:
+        print("note: --use_amp is accepted for CLI parity; libblvm_hip computes in fp32", file=sys.stderr)
+    if isinstance(args.batch_len, float):
+        args.batch_len = int(16000 * args.batch_len)
+    return rank, world, dev
+
+
+def run(args, model, forward_train, forward_eval, best_metric, num_bits, split_eval_fn=None, clip=True):
+    """forward_train(model, x, x_sl) / forward_eval(model, x, x_sl) -> (loss, metrics, outputs)."""
+    rank, world, dev = setup(args)
+    model = model.to(dev)
+    params = [p for p in model.parameters() if p.requires_grad]
+    optimizer = getattr(torch.optim, args.optimizer or "Adam")(params, lr=args.lr, **args.optimizer_kwargs)
+    scheduler = getattr(torch.optim.lr_scheduler, args.lr_scheduler)(optimizer, **args.lr_scheduler_kwargs)
+    reducer = FlatGradAllReduce(params) if world > 1 else None
+    bs, bl = args.batch_size, (args.batch_len or (0 if args.batch_size else 64 * 16000))
+    train = SyntheticUtterances(args.synthetic_utterances, args.synthetic_length, bs, bl, num_bits, args.seed, rank, world)
+    test = SyntheticUtterances(max(args.synthetic_utterances // 8, 1), args.synthetic_length, bs, bl, num_bits, args.seed + 1, rank, world)
+    tracker = Tracker()
+    best = None
+    for epoch in tracker.epochs(args.epochs):
+        model.train()
+        t0, frames = time.time(), 0
+        for x, x_sl in tracker.steps(train, source="train"):
+            x = x.to(dev, non_blocking=True)
+            loss, metrics, _ = forward_train(model, x, x_sl)
+            optimizer.zero_grad(set_to_none=True)
+            loss.backward()
+            if reducer is not None:
+                reducer(float(x_sl.sum()))
+            if clip:
+                torch.nn.utils.clip_grad_value_(params, args.max_grad_value)
+                torch.nn.utils.clip_grad_norm_(params, args.max_grad_norm)
+            optimizer.step()
+            tracker.update(metrics)
+            frames += int(x_sl.sum())
+        scheduler.step()
+        torch.cuda.synchronize()
+        if rank == 0:
+            vals = ", ".join(f"{k} {v:.4f}" for k, v in tracker.values("train").items())
+            print(f"epoch {epoch:4d} | {frames * world / (time.time() - t0):.3e} frames/s | {vals}", flush=True)
+        if (epoch - 1) % args.test_every == 0:
+            model.eval()
+            with torch.no_grad():
+                for x, x_sl in tracker.steps(test, source="test"):
+                    x = x.to(dev, non_blocking=True)
+                    if split_eval_fn is not None:
+                        split_eval_fn(model, x, x_sl, tracker)
+                    else:
+                        tracker.update(forward_eval(model, x, x_sl)[1])
+            value = tracker.values("test").get(best_metric)
+            if rank == 0 and value is not None:
+                print(f"           test {best_metric} {value:.4f}", flush=True)
+                improved = best is None or (value > best if best_metric.startswith("elbo") else value < best)
+                if improved:
+                    best = value
+                    if args.save_checkpoints and args.checkpoint_dir:
+                        model.save(args.checkpoint_dir)
+        tracker.log()
+    if world > 1:
+        dist.destroy_process_group()
+    return tracker
