@@ -14,6 +14,8 @@
 // first layer and of the GRU input projection before the loop; all weight gradients and d(enc) after it.
 //
 // Numerics: fp32 operands, fp32 MFMA accumulation (an exact fma chain), so a sequence is reproducible run-to-run.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace blvm {
@@ -169,6 +171,35 @@ size_t carve_ws(float* base, int Tp, int B, int X, int H, int Z, int R, BwdWs* w
   return off;
 }
 
+// A second stream for work that is independent of the recurrent chain (lazily created, one per process).
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t ready = nullptr, done = nullptr;
+  int ensure() {
+    if (stream) return BLVM_OK;
+    BLVM_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    BLVM_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    BLVM_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    return BLVM_OK;
+  }
+};
+inline SideStream& side_stream() {
+  static thread_local SideStream s;
+  return s;
+}
+// Steps per side-stream range; 0 (default) keeps the batched GEMMs behind the chain on the caller's stream.
+// Measured on MI355X at [64,16000]: 24.3 ms/step without overlap, 26.1 / 25.3 / 27.2 ms with ranges of 50 / 25 / 125
+// steps — the big GEMM workgroups take CU slots and memory-pipeline share from the latency-bound chain links, which
+// costs more than the 2.5 ms of GEMMs it hides.  Kept as an experiment switch (env BLVM_WGRAD_OVERLAP_STEPS).
+inline int overlap_chunk_steps() {
+  static int v = [] {
+    const char* e = getenv("BLVM_WGRAD_OVERLAP_STEPS");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
+
 int check_dims(int Tp, int B, int X, int H, int Z, int R) {
   BLVM_REQUIRE(Tp > 0 && B > 0, "vrnn: bad Tp=%d B=%d", Tp, B);
   BLVM_REQUIRE(X > 0 && H > 0 && Z > 0 && R > 0 && X % 16 == 0 && H % 16 == 0 && Z % 16 == 0 && R % 16 == 0,
@@ -323,6 +354,60 @@ extern "C" int blvm_vrnn_seq_bwd(const BlvmVrnnWeights* w, const float* enc, con
     LAUNCH_NW(dh_stage_kernel, pick_nw(H, 2), dim3(R / 16, rt), s, d);
   };
 
+  // ---- batched, state-independent part: d(enc) and every weight gradient as large MFMA GEMMs over a row range ----
+  // Rows [r0, r0+nr) of every per-step gradient buffer are final once the chain has passed step r0/B, so the range
+  // can be processed on a second stream UNDER the latency-bound BPTT chain (which leaves most CUs idle).
+  const float* hprev_all = decin + H;  // [n rows, ld = H+R]
+  auto batched = [&](size_t r0, size_t nr, hipStream_t st) -> int {
+    int rc2 = BLVM_OK;
+#define TRY(x) do { rc2 = (x); if (rc2) return rc2; } while (0)
+    const float* DGI = ws.DGI + r0 * 3 * R; const float* DGH = ws.DGH + r0 * 3 * R;
+    const float* encr = enc + r0 * X; const float* decr = decin + r0 * ldd; const float* hpr = hprev_all + r0 * ldd;
+    if (d_enc) {
+      TRY(gemm_f32(0, 1, (int)nr, X, H, ws.DQ[0] + r0 * H, H, w->post_w[0] + R, R + X, d_enc + r0 * X, X, nullptr, 0, 0.f, nullptr, 0, 0, 1, st));
+      TRY(gemm_f32(0, 1, (int)nr, X, 3 * R, DGI, 3 * R, w->gru_wih, X + H, d_enc + r0 * X, X, nullptr, 0, 0.f, nullptr, 0, 1, 1, st));
+    }
+    TRY(wgrad(DGI, 3 * R, 3 * R, encr, X, X, gr->gru_wih, X + H, nr, st));
+    TRY(wgrad(DGI, 3 * R, 3 * R, decr, ldd, H, gr->gru_wih ? gr->gru_wih + X : nullptr, X + H, nr, st));
+    TRY(wgrad(DGH, 3 * R, 3 * R, hpr, ldd, R, gr->gru_whh, R, nr, st));
+    TRY(bgrad(DGI, 3 * R, 3 * R, gr->gru_bih, nr, st));
+    TRY(bgrad(DGH, 3 * R, 3 * R, gr->gru_bhh, nr, st));
+    TRY(wgrad(ws.DPHI[0] + r0 * H, H, H, z + r0 * Z, Z, Z, gr->phi_w[0], Z, nr, st));
+    TRY(bgrad(ws.DPHI[0] + r0 * H, H, H, gr->phi_b[0], nr, st));
+    for (int l = 1; l < 4; ++l) {
+      TRY(wgrad(ws.DPHI[l] + r0 * H, H, H, rs.FZ[l - 1] + r0 * H, H, H, gr->phi_w[l], H, nr, st));
+      TRY(bgrad(ws.DPHI[l] + r0 * H, H, H, gr->phi_b[l], nr, st));
+    }
+    TRY(wgrad(ws.DPH + r0 * 2 * Z, 2 * Z, 2 * Z, rs.P[2] + r0 * H, H, H, gr->prior_hw, H, nr, st));
+    TRY(bgrad(ws.DPH + r0 * 2 * Z, 2 * Z, 2 * Z, gr->prior_hb, nr, st));
+    TRY(wgrad(ws.DQH + r0 * 2 * Z, 2 * Z, 2 * Z, rs.Q[2] + r0 * H, H, H, gr->post_hw, H, nr, st));
+    TRY(bgrad(ws.DQH + r0 * 2 * Z, 2 * Z, 2 * Z, gr->post_hb, nr, st));
+    for (int l = 2; l >= 1; --l) {
+      TRY(wgrad(ws.DP[l] + r0 * H, H, H, rs.P[l - 1] + r0 * H, H, H, gr->prior_w[l], H, nr, st));
+      TRY(bgrad(ws.DP[l] + r0 * H, H, H, gr->prior_b[l], nr, st));
+      TRY(wgrad(ws.DQ[l] + r0 * H, H, H, rs.Q[l - 1] + r0 * H, H, H, gr->post_w[l], H, nr, st));
+      TRY(bgrad(ws.DQ[l] + r0 * H, H, H, gr->post_b[l], nr, st));
+    }
+    TRY(wgrad(ws.DP[0] + r0 * H, H, H, hpr, ldd, R, gr->prior_w[0], R, nr, st));
+    TRY(bgrad(ws.DP[0] + r0 * H, H, H, gr->prior_b[0], nr, st));
+    TRY(wgrad(ws.DQ[0] + r0 * H, H, H, hpr, ldd, R, gr->post_w[0], R + X, nr, st));
+    TRY(wgrad(ws.DQ[0] + r0 * H, H, H, encr, X, X, gr->post_w[0] ? gr->post_w[0] + R : nullptr, R + X, nr, st));
+    TRY(bgrad(ws.DQ[0] + r0 * H, H, H, gr->post_b[0], nr, st));
+#undef TRY
+    return BLVM_OK;
+  };
+  const int chunk = overlap_chunk_steps();
+  const bool overlap = chunk > 0 && Tp >= 2 * chunk;
+  SideStream& side = side_stream();
+  if (overlap) {
+    rc = side.ensure();
+    if (rc) return rc;
+    // the side stream must not start before the caller's stream has produced this call's inputs / zeroed grads
+    BLVM_HIP(hipEventRecord(side.ready, s));
+    BLVM_HIP(hipStreamWaitEvent(side.stream, side.ready, 0));
+  }
+  int chunk_hi = Tp;  // steps [chunk_lo, chunk_hi) form the next range handed to the side stream
+
   launch_dh(-1, Tp - 1);  // G(T') = 0: gate derivatives of the last step, G <- d_decin h-part of row T'-1
   for (int t = Tp - 1; t >= 0; --t) {
     const size_t oH = (size_t)t * B * H, oZ = (size_t)t * B * Z, o3R = (size_t)t * B * 3 * R, o2Z = (size_t)t * B * 2 * Z;
@@ -364,45 +449,23 @@ extern "C" int blvm_vrnn_seq_bwd(const BlvmVrnnWeights* w, const float* enc, con
     }
     // B10 (+ gate derivatives of step t-1)
     launch_dh(t, t - 1);
+    if (overlap && (chunk_hi - t >= chunk || t == 0)) {  // every per-step gradient of steps >= t is final now
+      BLVM_HIP(hipEventRecord(side.ready, s));
+      BLVM_HIP(hipStreamWaitEvent(side.stream, side.ready, 0));
+      rc = batched((size_t)t * B, (size_t)(chunk_hi - t) * B, side.stream);
+      if (rc) return rc;
+      chunk_hi = t;
+    }
   }
   BLVM_CHECK_LAUNCH("vrnn_seq_bwd");
   if (d_h0) BLVM_HIP(hipMemcpyAsync(d_h0, ws.G, sizeof(float) * (size_t)B * R, hipMemcpyDeviceToDevice, s));
 
-  // ---- batched, state-independent part: d(enc) and every weight gradient as large MFMA GEMMs -------------------
-  if (d_enc) {
-    rc = gemm_f32(0, 1, (int)n, X, H, ws.DQ[0], H, w->post_w[0] + R, R + X, d_enc, X, nullptr, 0, 0.f, nullptr, 0, 0, 1, s);
+  if (overlap) {  // join the side stream: everything queued after this call sees the weight gradients
+    BLVM_HIP(hipEventRecord(side.done, side.stream));
+    BLVM_HIP(hipStreamWaitEvent(s, side.done, 0));
+  } else {
+    rc = batched(0, n, s);
     if (rc) return rc;
-    rc = gemm_f32(0, 1, (int)n, X, 3 * R, ws.DGI, 3 * R, w->gru_wih, X + H, d_enc, X, nullptr, 0, 0.f, nullptr, 0, 1, 1, s);
-    if (rc) return rc;
   }
-  const float* hprev_all = decin + H;  // [n rows, ld = H+R]
-#define TRY(x) do { rc = (x); if (rc) return rc; } while (0)
-  TRY(wgrad(ws.DGI, 3 * R, 3 * R, enc, X, X, gr->gru_wih, X + H, n, s));
-  TRY(wgrad(ws.DGI, 3 * R, 3 * R, decin, ldd, H, gr->gru_wih ? gr->gru_wih + X : nullptr, X + H, n, s));
-  TRY(wgrad(ws.DGH, 3 * R, 3 * R, hprev_all, ldd, R, gr->gru_whh, R, n, s));
-  TRY(bgrad(ws.DGI, 3 * R, 3 * R, gr->gru_bih, n, s));
-  TRY(bgrad(ws.DGH, 3 * R, 3 * R, gr->gru_bhh, n, s));
-  TRY(wgrad(ws.DPHI[0], H, H, z, Z, Z, gr->phi_w[0], Z, n, s));
-  TRY(bgrad(ws.DPHI[0], H, H, gr->phi_b[0], n, s));
-  for (int l = 1; l < 4; ++l) {
-    TRY(wgrad(ws.DPHI[l], H, H, rs.FZ[l - 1], H, H, gr->phi_w[l], H, n, s));
-    TRY(bgrad(ws.DPHI[l], H, H, gr->phi_b[l], n, s));
-  }
-  TRY(wgrad(ws.DPH, 2 * Z, 2 * Z, rs.P[2], H, H, gr->prior_hw, H, n, s));
-  TRY(bgrad(ws.DPH, 2 * Z, 2 * Z, gr->prior_hb, n, s));
-  TRY(wgrad(ws.DQH, 2 * Z, 2 * Z, rs.Q[2], H, H, gr->post_hw, H, n, s));
-  TRY(bgrad(ws.DQH, 2 * Z, 2 * Z, gr->post_hb, n, s));
-  for (int l = 2; l >= 1; --l) {
-    TRY(wgrad(ws.DP[l], H, H, rs.P[l - 1], H, H, gr->prior_w[l], H, n, s));
-    TRY(bgrad(ws.DP[l], H, H, gr->prior_b[l], n, s));
-    TRY(wgrad(ws.DQ[l], H, H, rs.Q[l - 1], H, H, gr->post_w[l], H, n, s));
-    TRY(bgrad(ws.DQ[l], H, H, gr->post_b[l], n, s));
-  }
-  TRY(wgrad(ws.DP[0], H, H, hprev_all, ldd, R, gr->prior_w[0], R, n, s));
-  TRY(bgrad(ws.DP[0], H, H, gr->prior_b[0], n, s));
-  TRY(wgrad(ws.DQ[0], H, H, hprev_all, ldd, R, gr->post_w[0], R + X, n, s));
-  TRY(wgrad(ws.DQ[0], H, H, enc, X, X, gr->post_w[0] ? gr->post_w[0] + R : nullptr, R + X, n, s));
-  TRY(bgrad(ws.DQ[0], H, H, gr->post_b[0], n, s));
-#undef TRY
   return BLVM_OK;
 }
