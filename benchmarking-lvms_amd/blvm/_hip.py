@@ -39,6 +39,17 @@ class SrnnWeights(ctypes.Structure):
     ]  # fmt: skip
 
 
+class RssmWeights(ctypes.Structure):
+    """struct BlvmRssmWeights / BlvmRssmGrads."""
+
+    _fields_ = [
+        ("gin_w", c_void_p), ("gin_b", c_void_p), ("gru_wih", c_void_p), ("gru_whh", c_void_p), ("gru_bih", c_void_p),
+        ("gru_bhh", c_void_p),
+        ("prior_w", c_void_p * 3), ("prior_b", c_void_p * 3), ("prior_hw", c_void_p), ("prior_hb", c_void_p),
+        ("post_w", c_void_p * 3), ("post_b", c_void_p * 3), ("post_hw", c_void_p), ("post_hb", c_void_p),
+    ]  # fmt: skip
+
+
 _SIGNATURES = {
     "blvm_version": (c_int, []),
     "blvm_last_error": (ctypes.c_char_p, []),
@@ -88,6 +99,11 @@ _SIGNATURES = {
     "blvm_wavenet_block_workspace_floats": (c_size_t, [c_int] * 5),
     "blvm_wavenet_block_fwd": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_float] + [c_void_p] * 5),
     "blvm_wavenet_block_bwd": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_float] + [c_void_p] * 7),
+    "blvm_rssm_reserve_floats": (c_size_t, [c_int] * 4),
+    "blvm_rssm_bwd_workspace_floats": (c_size_t, [c_int] * 4),
+    "blvm_rssm_seq_fwd": (c_int, [ctypes.POINTER(RssmWeights)] + [c_void_p] * 5 + [c_int] * 7 + [c_float] + [c_void_p] * 8),
+    "blvm_rssm_seq_bwd": (c_int, [ctypes.POINTER(RssmWeights)] + [c_void_p] * 15 + [c_int, c_float] + [c_int] * 7 + [c_float]
+                          + [c_void_p] * 4 + [ctypes.POINTER(RssmWeights), c_void_p, c_void_p]),
 }  # fmt: skip
 
 EXPORTS = tuple(_SIGNATURES)

@@ -666,3 +666,102 @@ def wavenet_stack(x, blocks_params, dilations, T_skip: int, inv_std: float, S: i
     """x [L,B,C] -> sum over blocks of the last T_skip frames of each block's skip output [T_skip,B,S]."""
     flat = [p for blk in blocks_params for p in blk]
     return _WaveNetStackFunction.apply(x, tuple(int(d) for d in dilations), int(T_skip), float(inv_std), int(S), *flat)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# K5: RSSM cell (Clockwork-VAE) over a sequence
+# ----------------------------------------------------------------------------------------------------------------------
+
+_RSSM_PARAM_ORDER = (
+    ["gin_w", "gin_b", "gru_wih", "gru_whh", "gru_bih", "gru_bhh"]
+    + ["prior_w0", "prior_b0", "prior_w1", "prior_b1", "prior_w2", "prior_b2", "prior_hw", "prior_hb"]
+    + ["post_w0", "post_b0", "post_w1", "post_b1", "post_w2", "post_b2", "post_hw", "post_hb"]
+)
+RSSM_PLAIN, RSSM_RESIDUAL, RSSM_PRECISION = 0, 1, 2
+
+
+def _pack_rssm(ts):
+    d = dict(zip(_RSSM_PARAM_ORDER, ts))
+    w = _hip.RssmWeights()
+    for k in ("gin_w", "gin_b", "gru_wih", "gru_whh", "gru_bih", "gru_bhh", "prior_hw", "prior_hb", "post_hw", "post_hb"):
+        setattr(w, k, ptr(d[k]))
+    for i in range(3):
+        w.prior_w[i], w.prior_b[i] = ptr(d[f"prior_w{i}"]), ptr(d[f"prior_b{i}"])
+        w.post_w[i], w.post_b[i] = ptr(d[f"post_w{i}"]), ptr(d[f"post_b{i}"])
+    return w
+
+
+class _RSSMSeqFunction(torch.autograd.Function):
+    """(enc, ctx, z0, h0, eps, 22 params) -> zs [T+1,B,Z], hs [T+1,B,H], kld [B], kld_fn [B] (+ non-diff. mu/sd)."""
+
+    @staticmethod
+    def forward(ctx_, enc, ctx, z0, h0, eps, x_sl_dev, cfg, *params):
+        T, B, H, Z, C, E, mode, sd_eps, stride, fn_floor = cfg
+        enc, eps = _f32c(enc), _f32c(eps)
+        ctx = _f32c(ctx) if ctx is not None else None
+        params = tuple(_f32c(p) for p in params)
+        lib = load()
+        f32 = dict(device=enc.device, dtype=torch.float32)
+        zs, hs = torch.empty(T + 1, B, Z, **f32), torch.empty(T + 1, B, H, **f32)
+        mu_q, sd_q, mu_p, sd_p = (torch.empty(T, B, Z, **f32) for _ in range(4))
+        reserve = torch.empty(lib.blvm_rssm_reserve_floats(T, B, H, Z), **f32)
+        check(
+            lib.blvm_rssm_seq_fwd(_pack_rssm(params), ptr(enc), ptr(ctx), ptr(_f32c(z0)) if z0 is not None else None,
+                                  ptr(_f32c(h0)) if h0 is not None else None, ptr(eps), T, B, H, Z, C, E, mode, sd_eps, ptr(zs),
+                                  ptr(hs), ptr(mu_q), ptr(sd_q), ptr(mu_p), ptr(sd_p), ptr(reserve), stream_ptr()),
+            "blvm_rssm_seq_fwd",
+        )  # fmt: skip
+        kld = torch.zeros(B, device=enc.device, dtype=torch.float64)
+        kld_fn = torch.zeros(B, device=enc.device, dtype=torch.float64)
+        check(
+            lib.blvm_kl_fwd(ptr(mu_q), ptr(sd_q), ptr(mu_p), ptr(sd_p), LAYOUT_TIME_MAJOR, ptr(x_sl_dev), B, T, Z, stride,
+                            fn_floor, ptr(kld), ptr(kld_fn), stream_ptr()),
+            "blvm_kl_fwd",
+        )  # fmt: skip
+        ctx_.cfg = cfg
+        ctx_.has = (ctx is not None, z0 is not None, h0 is not None)
+        saved = [enc, eps, x_sl_dev, zs, hs, mu_q, sd_q, mu_p, sd_p, reserve] + ([ctx] if ctx is not None else [])
+        ctx_.n_fixed = len(saved)
+        ctx_.save_for_backward(*saved, *params)
+        ctx_.mark_non_differentiable(mu_q, sd_q, mu_p, sd_p)
+        return zs, hs, kld, kld_fn, mu_q, sd_q, mu_p, sd_p
+
+    @staticmethod
+    def backward(ctx_, d_zs, d_hs, g_kld, g_kld_fn, *_unused):
+        T, B, H, Z, C, E, mode, sd_eps, stride, fn_floor = ctx_.cfg
+        has_ctx, has_z0, has_h0 = ctx_.has
+        saved = ctx_.saved_tensors
+        enc, eps, x_sl_dev, zs, hs, mu_q, sd_q, mu_p, sd_p, reserve = saved[:10]
+        ctx = saved[10] if has_ctx else None
+        params = saved[ctx_.n_fixed :]
+        lib = load()
+        f32 = dict(device=enc.device, dtype=torch.float32)
+        d_zs = _f32c(d_zs) if d_zs is not None else torch.zeros_like(zs)
+        d_hs = _f32c(d_hs) if d_hs is not None else torch.zeros_like(hs)
+        c_raw = g_kld.to(torch.float32).contiguous() if g_kld is not None else None
+        c_fn = g_kld_fn.to(torch.float32).contiguous() if g_kld_fn is not None else None
+        grads = [torch.zeros_like(p) for p in params]
+        d_enc = torch.empty_like(enc)
+        d_ctx = torch.empty_like(ctx) if has_ctx else None
+        d_z0 = torch.empty(B, Z, **f32) if has_z0 else None
+        d_h0 = torch.empty(B, H, **f32) if has_h0 else None
+        ws = torch.empty(lib.blvm_rssm_bwd_workspace_floats(T, B, H, Z), **f32)
+        check(
+            lib.blvm_rssm_seq_bwd(_pack_rssm(params), ptr(enc), ptr(ctx), ptr(eps), ptr(zs), ptr(hs), ptr(mu_q), ptr(sd_q),
+                                  ptr(mu_p), ptr(sd_p), ptr(reserve), ptr(d_zs), ptr(d_hs), ptr(x_sl_dev), ptr(c_raw), ptr(c_fn),
+                                  stride, fn_floor, T, B, H, Z, C, E, mode, sd_eps, ptr(d_enc), ptr(d_ctx), ptr(d_z0), ptr(d_h0),
+                                  _pack_rssm(grads), ptr(ws), stream_ptr()),
+            "blvm_rssm_seq_bwd",
+        )  # fmt: skip
+        if d_h0 is not None:
+            d_h0 = d_h0 + d_hs[0]  # the direct gradient wrt the carried state (tiny [B,H] add)
+        return (d_enc, d_ctx, d_z0, d_h0, None, None, None, *grads)
+
+
+def rssm_sequence(enc, ctx, z0, h0, eps, x_sl_dev, params, H, Z, mode, stride, free_nats=0.0, sd_eps=1e-6):
+    """enc [T,B,E], ctx [T,B,C] or None -> (zs [T+1,B,Z], hs [T+1,B,H], kld [B], kld_fn [B], mu_q, sd_q, mu_p, sd_p)."""
+    T, B, E = enc.shape
+    C = ctx.shape[2] if ctx is not None else 0
+    fn_floor = float(free_nats) / Z if free_nats else 0.0
+    cfg = (T, B, H, Z, C, E, int(mode), float(sd_eps), int(stride), fn_floor)
+    return _RSSMSeqFunction.apply(enc, ctx, z0, h0, eps, x_sl_dev, cfg, *params)

@@ -1,0 +1,337 @@
+// rssm.hip — K5: the recurrent state-space cell of the Clockwork-VAE over a whole sequence, forward + BPTT.
+//
+// Replaces the per-level time loop `clockwork_vae.py:272-281` over the scripted `RSSMCell.forward`
+// (blvm/modules/rssm.py:79-104):
+//   g = ReLU(Linear(cat[z_{t-1}, context_t]));  h_t = GRUCell(g, h_{t-1})
+//   posterior = MLP(cat[h_t, enc_t]) -> (mu_q, sd_q);  prior = MLP(h_t) -> (mu_p, sd_p)
+//   residual / precision-weighted combination (variational.py:125-138);  z_t = rsample
+// Six dependent links per step in each direction (stages.h kernels + the two GRU links below); the context / encoding
+// halves of the concatenated-input layers, every weight gradient and d(context), d(enc) are batched MFMA GEMMs
+// outside the loop.  Same design and numerics as vrnn.hip.
+#include "common.h"
+
+namespace blvm {
+namespace {
+
+#include "stages.h"
+
+// ---- GRU link: gi = A Wih^T + bih (3 gate tiles) ; gates with the precomputed hidden projection ; state update ------
+struct GruCellArgs {
+  const float* A;      int lda;   // [B,K] GRU input
+  const float* Wih;    int ldw;   // [3H,K]
+  const float* bih;               // [3H]
+  const float* gh;                // [B,3H] hidden projection incl. b_hh
+  const float* hprev;  int ldh;   // [B,H]
+  float* hnext;        int ldn;   // [B,H]
+  float *rg, *ug, *ng;            // [B,H]
+  int B, H, K;
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void gru_cell_stage_kernel(GruCellArgs a) {
+  __shared__ float red[3 * NW * 256];
+  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, wave = threadIdx.x >> 6, H = a.H;
+  const int t = threadIdx.x & 255;
+  const int row = r0 + (t >> 4), col = c0 + (t & 15);
+  const bool own = threadIdx.x < 256 && row < a.B;
+  const int rowc = row < a.B ? row : r0;
+  const size_t o3 = (size_t)rowc * 3 * H + col;
+  const float b0 = a.bih[col], b1 = a.bih[H + col], b2 = a.bih[2 * H + col];
+  const float hr = a.gh[o3], hz = a.gh[o3 + H], hn = a.gh[o3 + 2 * H];
+  const float hp = a.hprev[(size_t)rowc * a.ldh + col];
+  f32x4 acc[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[g] = wave_gemm16<NW>(a.A, a.lda, r0, a.B, a.Wih, a.ldw, g * H + c0, a.K, wave, acc[g]);
+  }
+  float v[3];
+  reduce_tiles<3, NW>(acc, red, v);
+  if (!own) return;
+  const float r = sigmoidf_(v[0] + b0 + hr);
+  const float u = sigmoidf_(v[1] + b1 + hz);
+  const float n = tanhf(v[2] + b2 + r * hn);
+  a.hnext[(size_t)row * a.ldn + col] = (1.f - u) * n + u * hp;
+  const size_t o = (size_t)row * H + col;
+  a.rg[o] = r; a.ug[o] = u; a.ng[o] = n;
+}
+
+// ---- backward GRU link: complete dL/dh_t, then the gate derivatives of step t -------------------------------------------
+struct RssmDhArgs {
+  const float *DQ0, *DP0;   // [B,H] grads wrt the first posterior / prior layer pre-activations of step t
+  const float *WqT, *WpT;   // [H,H] h-part of post_w0 / prior_w0, transposed
+  const float* dh_add;      // [B,H] direct gradient wrt h_t (from the level below / the decoder) or null
+  float* G;                 // [B,H] running gradient wrt h (in: from step t+1; out: towards step t-1 through the u gate)
+  const float *rg, *ug, *ng, *gh;  // step t saves; gh [B,3H]
+  const float* hprev;       // [B,H] h_{t-1}
+  float *dgi, *dgh;         // [B,3H]
+  int B, H;
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void rssm_dh_stage_kernel(RssmDhArgs a) {
+  __shared__ float red[2 * NW * 256];
+  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, wave = threadIdx.x >> 6, H = a.H;
+  const int t = threadIdx.x & 255;
+  const int row = r0 + (t >> 4), col = c0 + (t & 15);
+  const bool own = threadIdx.x < 256 && row < a.B;
+  const int rowc = row < a.B ? row : r0;
+  const size_t o = (size_t)rowc * H + col, o3 = (size_t)rowc * 3 * H + col;
+  const float g0 = a.G[o] + (a.dh_add != nullptr ? a.dh_add[o] : 0.f);
+  const float r = a.rg[o], u = a.ug[o], n = a.ng[o], hn = a.gh[o3 + 2 * H], hp = a.hprev[o];
+  f32x4 acc[2];
+  acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  acc[0] = wave_gemm16<NW>(a.DQ0, H, r0, a.B, a.WqT, H, c0, H, wave, acc[0]);
+  acc[1] = wave_gemm16<NW>(a.DP0, H, r0, a.B, a.WpT, H, c0, H, wave, acc[1]);
+  float v[2];
+  reduce_tiles<2, NW>(acc, red, v);
+  if (!own) return;
+  const float g = g0 + v[0] + v[1];
+  const float dn_pre = g * (1.f - u) * (1.f - n * n);
+  const float du_pre = g * (hp - n) * u * (1.f - u);
+  const float dr_pre = dn_pre * hn * r * (1.f - r);
+  a.dgi[o3] = dr_pre; a.dgi[o3 + H] = du_pre; a.dgi[o3 + 2 * H] = dn_pre;
+  a.dgh[o3] = dr_pre; a.dgh[o3 + H] = du_pre; a.dgh[o3 + 2 * H] = dn_pre * r;
+  a.G[o] = g * u;
+}
+
+struct RssmReserve { float *GIN, *GHb, *RG, *UG, *NG, *Q[3], *P[3], *RAWQ, *RAWP, *MUQR, *XGIN, *XQ; };
+size_t carve_rssm(float* base, int T, int B, int H, int Z, RssmReserve* r) {
+  const size_t n = (size_t)T * B;
+  size_t off = 0;
+  auto take = [&](size_t cnt) { float* p = base ? base + off : nullptr; off += (cnt + 3) & ~(size_t)3; return p; };
+  RssmReserve t;
+  t.GIN = take(n * H); t.GHb = take(n * 3 * H);
+  t.RG = take(n * H); t.UG = take(n * H); t.NG = take(n * H);
+  for (int i = 0; i < 3; ++i) t.Q[i] = take(n * H);
+  for (int i = 0; i < 3; ++i) t.P[i] = take(n * H);
+  t.RAWQ = take(n * Z); t.RAWP = take(n * Z); t.MUQR = take(n * Z);
+  t.XGIN = take(n * H); t.XQ = take(n * H);
+  if (r) *r = t;
+  return off;
+}
+
+struct RssmWs { float *gzT, *wihT, *whhT, *qT[3], *pT[3], *qhT, *phT, *DGIN, *DGI, *DGH, *DQH, *DPH, *DQ[3], *DP[3], *G; };
+size_t carve_rssm_ws(float* base, int T, int B, int H, int Z, RssmWs* w) {
+  const size_t n = (size_t)T * B;
+  size_t off = 0;
+  auto take = [&](size_t cnt) { float* p = base ? base + off : nullptr; off += (cnt + 3) & ~(size_t)3; return p; };
+  RssmWs t;
+  t.gzT = take((size_t)Z * H); t.wihT = take((size_t)H * 3 * H); t.whhT = take((size_t)H * 3 * H);
+  for (int i = 0; i < 3; ++i) { t.qT[i] = take((size_t)H * H); t.pT[i] = take((size_t)H * H); }
+  t.qhT = take((size_t)H * 2 * Z); t.phT = take((size_t)H * 2 * Z);
+  t.DGIN = take(n * H); t.DGI = take(n * 3 * H); t.DGH = take(n * 3 * H);
+  t.DQH = take(n * 2 * Z); t.DPH = take(n * 2 * Z);
+  for (int i = 0; i < 3; ++i) { t.DQ[i] = take(n * H); t.DP[i] = take(n * H); }
+  t.G = take((size_t)B * H);
+  if (w) *w = t;
+  return off;
+}
+
+int check_rssm(int T, int B, int H, int Z, int C, int E) {
+  BLVM_REQUIRE(T > 0 && B > 0, "rssm: bad T=%d B=%d", T, B);
+  BLVM_REQUIRE(H > 0 && Z > 0 && H % 16 == 0 && Z % 16 == 0, "rssm: H, Z must be positive multiples of 16 (got %d, %d)", H, Z);
+  BLVM_REQUIRE(C >= 0 && E > 0 && C % 4 == 0 && E % 4 == 0, "rssm: context / encoding sizes must be multiples of 4 (got %d, %d)", C, E);
+  BLVM_REQUIRE((B + 15) / 16 <= 65535, "rssm: batch too large");
+  return BLVM_OK;
+}
+
+}  // namespace
+}  // namespace blvm
+
+using namespace blvm;
+
+extern "C" size_t blvm_rssm_reserve_floats(int T, int B, int H, int Z) { return carve_rssm(nullptr, T, B, H, Z, nullptr); }
+extern "C" size_t blvm_rssm_bwd_workspace_floats(int T, int B, int H, int Z) { return carve_rssm_ws(nullptr, T, B, H, Z, nullptr); }
+
+extern "C" int blvm_rssm_seq_fwd(const BlvmRssmWeights* w, const float* enc, const float* ctx, const float* z0,
+                                 const float* h0, const float* eps, int T, int B, int H, int Z, int C, int E, int mode,
+                                 float sd_eps, float* zs, float* hs, float* mu_q, float* sd_q, float* mu_p, float* sd_p,
+                                 float* reserve, void* stream_) {
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  int rc = check_rssm(T, B, H, Z, C, E);
+  if (rc) return rc;
+  BLVM_REQUIRE(w && enc && eps && zs && hs && mu_q && sd_q && mu_p && sd_p && reserve, "rssm_fwd: null pointer");
+  BLVM_REQUIRE(C == 0 || ctx != nullptr, "rssm_fwd: context missing");
+  BLVM_REQUIRE(mode >= 0 && mode <= 2, "rssm_fwd: mode must be 0 (plain), 1 (residual) or 2 (precision-weighted)");
+  BLVM_REQUIRE(aligned16(zs) && aligned16(hs) && aligned16(reserve), "rssm_fwd: buffers must be 16-byte aligned");
+  RssmReserve rs;
+  carve_rssm(reserve, T, B, H, Z, &rs);
+  const size_t n = (size_t)T * B;
+  const int ldg = Z + C, ldq = H + E;
+  const float beta = (float)(0.6931471805599453 / (1.0 - (double)sd_eps));
+  if (C > 0) {
+    rc = gemm_f32(0, 0, (int)n, H, C, ctx, C, w->gin_w + Z, ldg, rs.XGIN, H, w->gin_b, 0, 0.f, nullptr, 0, 0, 1, s);
+    if (rc) return rc;
+  }
+  rc = gemm_f32(0, 0, (int)n, H, E, enc, E, w->post_w[0] + H, ldq, rs.XQ, H, w->post_b[0], 0, 0.f, nullptr, 0, 0, 1, s);
+  if (rc) return rc;
+  if (z0) BLVM_HIP(hipMemcpyAsync(zs, z0, sizeof(float) * (size_t)B * Z, hipMemcpyDeviceToDevice, s));
+  else BLVM_HIP(hipMemsetAsync(zs, 0, sizeof(float) * (size_t)B * Z, s));
+  if (h0) BLVM_HIP(hipMemcpyAsync(hs, h0, sizeof(float) * (size_t)B * H, hipMemcpyDeviceToDevice, s));
+  else BLVM_HIP(hipMemsetAsync(hs, 0, sizeof(float) * (size_t)B * H, s));
+  const int rt = (B + 15) / 16;
+  for (int t = 0; t < T; ++t) {
+    const size_t oH = (size_t)t * B * H, oZ = (size_t)t * B * Z, o3 = (size_t)t * B * 3 * H;
+    const float* zprev = zs + oZ;
+    const float* hprev = hs + oH;
+    float* hnew = hs + oH + (size_t)B * H;
+    LinLaunch l;
+    l.B = B; l.nseg = 2;
+    // L1: GRU input layer (z half; context half hoisted) | hidden projection of the GRU
+    l.seg[0] = seg(zprev, Z, w->gin_w, ldg, C > 0 ? nullptr : w->gin_b, C > 0 ? rs.XGIN + oH : nullptr, H, nullptr, 0, rs.GIN + oH, H, H, Z, 1);
+    l.seg[1] = seg(hprev, H, w->gru_whh, H, w->gru_bhh, nullptr, 0, nullptr, 0, rs.GHb + o3, 3 * H, 3 * H, H, 0);
+    launch_lin(l, s);
+    // L2: GRU
+    GruCellArgs g;
+    g.A = rs.GIN + oH; g.lda = H; g.Wih = w->gru_wih; g.ldw = H; g.bih = w->gru_bih; g.gh = rs.GHb + o3;
+    g.hprev = hprev; g.ldh = H; g.hnext = hnew; g.ldn = H;
+    g.rg = rs.RG + oH; g.ug = rs.UG + oH; g.ng = rs.NG + oH; g.B = B; g.H = H; g.K = H;
+    LAUNCH_NW(gru_cell_stage_kernel, pick_nw(H, 3), dim3(H / 16, rt), s, g);
+    // L3..L5: posterior | prior MLPs on h_t
+    l.seg[0] = seg(hnew, H, w->post_w[0], ldq, nullptr, rs.XQ + oH, H, nullptr, 0, rs.Q[0] + oH, H, H, H, 1);
+    l.seg[1] = seg(hnew, H, w->prior_w[0], H, w->prior_b[0], nullptr, 0, nullptr, 0, rs.P[0] + oH, H, H, H, 1);
+    launch_lin(l, s);
+    for (int k = 1; k < 3; ++k) {
+      l.seg[0] = seg(rs.Q[k - 1] + oH, H, w->post_w[k], H, w->post_b[k], nullptr, 0, nullptr, 0, rs.Q[k] + oH, H, H, H, 1);
+      l.seg[1] = seg(rs.P[k - 1] + oH, H, w->prior_w[k], H, w->prior_b[k], nullptr, 0, nullptr, 0, rs.P[k] + oH, H, H, H, 1);
+      launch_lin(l, s);
+    }
+    // L6: heads, combination, sample
+    HeadArgs h;
+    h.P = rs.P[2] + oH; h.Q = rs.Q[2] + oH;
+    h.Wp = w->prior_hw; h.bp = w->prior_hb; h.Wq = w->post_hw; h.bq = w->post_hb;
+    h.eps = eps + oZ;
+    h.mu_p = mu_p + oZ; h.sd_p = sd_p + oZ; h.mu_q = mu_q + oZ; h.sd_q = sd_q + oZ;
+    h.z = zs + oZ + (size_t)B * Z;
+    h.raw_p = rs.RAWP + oZ; h.raw_q = rs.RAWQ + oZ; h.muq_raw = rs.MUQR + oZ;
+    h.B = B; h.H = H; h.Z = Z; h.residual = mode;
+    h.beta = beta; h.inv_beta = 1.f / beta; h.sd_eps = sd_eps;
+    LAUNCH_NW(head_stage_kernel, pick_nw(H, 4), dim3(Z / 16, rt), s, h);
+  }
+  BLVM_CHECK_LAUNCH("rssm_seq_fwd");
+  return BLVM_OK;
+}
+
+extern "C" int blvm_rssm_seq_bwd(const BlvmRssmWeights* w, const float* enc, const float* ctx, const float* eps,
+                                 const float* zs, const float* hs, const float* mu_q, const float* sd_q,
+                                 const float* mu_p, const float* sd_p, const float* reserve, const float* d_zs,
+                                 const float* d_hs, const int32_t* x_sl, const float* c_raw, const float* c_fn, int stride,
+                                 float fn_floor, int T, int B, int H, int Z, int C, int E, int mode, float sd_eps,
+                                 float* d_enc, float* d_ctx, float* d_z0, float* d_h0, const BlvmRssmGrads* gr,
+                                 float* workspace, void* stream_) {
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  int rc = check_rssm(T, B, H, Z, C, E);
+  if (rc) return rc;
+  BLVM_REQUIRE(w && enc && eps && zs && hs && mu_q && sd_q && mu_p && sd_p && reserve && d_zs && d_hs && gr && workspace,
+               "rssm_bwd: null pointer");
+  BLVM_REQUIRE((c_fn == nullptr && c_raw == nullptr) || x_sl != nullptr, "rssm_bwd: KL coefficients need x_sl");
+  BLVM_REQUIRE(aligned16(workspace) && aligned16(reserve), "rssm_bwd: buffers must be 16-byte aligned");
+  RssmReserve rs;
+  carve_rssm(const_cast<float*>(reserve), T, B, H, Z, &rs);
+  RssmWs ws;
+  carve_rssm_ws(workspace, T, B, H, Z, &ws);
+  const size_t n = (size_t)T * B, bh = (size_t)B * H, bz = (size_t)B * Z;
+  const int ldg = Z + C, ldq = H + E;
+  const float beta = (float)(0.6931471805599453 / (1.0 - (double)sd_eps));
+#define TRY(x) do { rc = (x); if (rc) return rc; } while (0)
+  TRY(transpose_f32(H, Z, w->gin_w, ldg, ws.gzT, H, s));
+  TRY(transpose_f32(3 * H, H, w->gru_wih, H, ws.wihT, 3 * H, s));
+  TRY(transpose_f32(3 * H, H, w->gru_whh, H, ws.whhT, 3 * H, s));
+  TRY(transpose_f32(H, H, w->post_w[0], ldq, ws.qT[0], H, s));
+  TRY(transpose_f32(H, H, w->prior_w[0], H, ws.pT[0], H, s));
+  for (int k = 1; k < 3; ++k) {
+    TRY(transpose_f32(H, H, w->post_w[k], H, ws.qT[k], H, s));
+    TRY(transpose_f32(H, H, w->prior_w[k], H, ws.pT[k], H, s));
+  }
+  TRY(transpose_f32(2 * Z, H, w->post_hw, H, ws.qhT, 2 * Z, s));
+  TRY(transpose_f32(2 * Z, H, w->prior_hw, H, ws.phT, 2 * Z, s));
+  BLVM_HIP(hipMemsetAsync(ws.G, 0, sizeof(float) * bh, s));
+  const int rt = (B + 15) / 16;
+  for (int t = T - 1; t >= 0; --t) {
+    const size_t oH = (size_t)t * B * H, oZ = (size_t)t * B * Z, o3 = (size_t)t * B * 3 * H, o2Z = (size_t)t * B * 2 * Z;
+    const bool last = t == T - 1;
+    // B1: dz_t (direct + through the GRU input layer of step t+1), then rsample / combination / KL / softplus heads
+    DzArgs dz;
+    dz.has_gemm = !last;
+    dz.D = ws.DGIN + (last ? 0 : oH + bh); dz.WT = ws.gzT; dz.D2 = nullptr; dz.WT2 = nullptr;
+    dz.dz_add = d_zs + oZ + bz; dz.ld_add = Z;
+    dz.mu_q = mu_q + oZ; dz.sd_q = sd_q + oZ; dz.mu_p = mu_p + oZ; dz.sd_p = sd_p + oZ; dz.eps = eps + oZ;
+    dz.raw_q = rs.RAWQ + oZ; dz.raw_p = rs.RAWP + oZ; dz.muq_raw = rs.MUQR + oZ;
+    dz.x_sl = x_sl; dz.c_raw = c_raw; dz.c_fn = c_fn;
+    dz.dqh = ws.DQH + o2Z; dz.dph = ws.DPH + o2Z;
+    dz.B = B; dz.H = H; dz.Z = Z; dz.residual = mode; dz.t = t; dz.stride = stride;
+    dz.fn_floor = fn_floor; dz.beta = beta; dz.sd_eps = sd_eps;
+    LAUNCH_NW(dz_stage_kernel, pick_nw(H, 1), dim3(Z / 16, rt), s, dz);
+    // B2: heads -> third layers | G += DGH[t+1] Whh (the recurrent path of step t+1, off the critical chain)
+    LinLaunch l;
+    l.B = B; l.nseg = last ? 2 : 3;
+    l.seg[0] = seg(ws.DQH + o2Z, 2 * Z, ws.qhT, 2 * Z, nullptr, nullptr, 0, rs.Q[2] + oH, H, ws.DQ[2] + oH, H, H, 2 * Z, 0);
+    l.seg[1] = seg(ws.DPH + o2Z, 2 * Z, ws.phT, 2 * Z, nullptr, nullptr, 0, rs.P[2] + oH, H, ws.DP[2] + oH, H, H, 2 * Z, 0);
+    if (!last) l.seg[2] = seg(ws.DGH + o3 + (size_t)B * 3 * H, 3 * H, ws.whhT, 3 * H, nullptr, ws.G, H, nullptr, 0, ws.G, H, H, 3 * H, 0);
+    launch_lin(l, s);
+    // B3, B4
+    l.nseg = 2;
+    for (int k = 2; k >= 1; --k) {
+      l.seg[0] = seg(ws.DQ[k] + oH, H, ws.qT[k], H, nullptr, nullptr, 0, rs.Q[k - 1] + oH, H, ws.DQ[k - 1] + oH, H, H, H, 0);
+      l.seg[1] = seg(ws.DP[k] + oH, H, ws.pT[k], H, nullptr, nullptr, 0, rs.P[k - 1] + oH, H, ws.DP[k - 1] + oH, H, H, H, 0);
+      launch_lin(l, s);
+    }
+    // B5: complete dL/dh_t and the gate derivatives of step t
+    RssmDhArgs d;
+    d.DQ0 = ws.DQ[0] + oH; d.DP0 = ws.DP[0] + oH; d.WqT = ws.qT[0]; d.WpT = ws.pT[0];
+    d.dh_add = d_hs + oH + bh; d.G = ws.G;
+    d.rg = rs.RG + oH; d.ug = rs.UG + oH; d.ng = rs.NG + oH; d.gh = rs.GHb + o3; d.hprev = hs + oH;
+    d.dgi = ws.DGI + o3; d.dgh = ws.DGH + o3; d.B = B; d.H = H;
+    LAUNCH_NW(rssm_dh_stage_kernel, pick_nw(H, 2), dim3(H / 16, rt), s, d);
+    // B6: through the GRU input projection to the (ReLU) GRU input layer
+    l.nseg = 1;
+    l.seg[0] = seg(ws.DGI + o3, 3 * H, ws.wihT, 3 * H, nullptr, nullptr, 0, rs.GIN + oH, H, ws.DGIN + oH, H, H, 3 * H, 0);
+    launch_lin(l, s);
+  }
+  BLVM_CHECK_LAUNCH("rssm_seq_bwd");
+  // gradients wrt the initial state: z0 through the GRU input layer of step 0 (+ its direct gradient), h0 through the
+  // GRU of step 0 (the caller adds the direct gradient d_hs[0])
+  if (d_z0) {
+    LinLaunch l;
+    l.B = B; l.nseg = 1;
+    l.seg[0] = seg(ws.DGIN, H, ws.gzT, H, nullptr, d_zs, Z, nullptr, 0, d_z0, Z, Z, H, 0);
+    launch_lin(l, s);
+  }
+  if (d_h0) {
+    LinLaunch l;
+    l.B = B; l.nseg = 1;
+    l.seg[0] = seg(ws.DGH, 3 * H, ws.whhT, 3 * H, nullptr, ws.G, H, nullptr, 0, d_h0, H, H, 3 * H, 0);
+    launch_lin(l, s);
+  }
+  BLVM_CHECK_LAUNCH("rssm_seq_bwd tail");
+  // batched, state-independent part
+  const float* hnew_all = hs + bh;  // h_1..h_T
+  if (d_ctx && C > 0) TRY(gemm_f32(0, 1, (int)n, C, H, ws.DGIN, H, w->gin_w + Z, ldg, d_ctx, C, nullptr, 0, 0.f, nullptr, 0, 0, 1, s));
+  if (d_enc) TRY(gemm_f32(0, 1, (int)n, E, H, ws.DQ[0], H, w->post_w[0] + H, ldq, d_enc, E, nullptr, 0, 0.f, nullptr, 0, 0, 1, s));
+  TRY(wgrad(ws.DGIN, H, H, zs, Z, Z, gr->gin_w, ldg, n, s));
+  if (C > 0) TRY(wgrad(ws.DGIN, H, H, ctx, C, C, gr->gin_w ? gr->gin_w + Z : nullptr, ldg, n, s));
+  TRY(bgrad(ws.DGIN, H, H, gr->gin_b, n, s));
+  TRY(wgrad(ws.DGI, 3 * H, 3 * H, rs.GIN, H, H, gr->gru_wih, H, n, s));
+  TRY(wgrad(ws.DGH, 3 * H, 3 * H, hs, H, H, gr->gru_whh, H, n, s));
+  TRY(bgrad(ws.DGI, 3 * H, 3 * H, gr->gru_bih, n, s));
+  TRY(bgrad(ws.DGH, 3 * H, 3 * H, gr->gru_bhh, n, s));
+  TRY(wgrad(ws.DQ[0], H, H, hnew_all, H, H, gr->post_w[0], ldq, n, s));
+  TRY(wgrad(ws.DQ[0], H, H, enc, E, E, gr->post_w[0] ? gr->post_w[0] + H : nullptr, ldq, n, s));
+  TRY(bgrad(ws.DQ[0], H, H, gr->post_b[0], n, s));
+  TRY(wgrad(ws.DP[0], H, H, hnew_all, H, H, gr->prior_w[0], H, n, s));
+  TRY(bgrad(ws.DP[0], H, H, gr->prior_b[0], n, s));
+  for (int k = 1; k < 3; ++k) {
+    TRY(wgrad(ws.DQ[k], H, H, rs.Q[k - 1], H, H, gr->post_w[k], H, n, s));
+    TRY(bgrad(ws.DQ[k], H, H, gr->post_b[k], n, s));
+    TRY(wgrad(ws.DP[k], H, H, rs.P[k - 1], H, H, gr->prior_w[k], H, n, s));
+    TRY(bgrad(ws.DP[k], H, H, gr->prior_b[k], n, s));
+  }
+  TRY(wgrad(ws.DQH, 2 * Z, 2 * Z, rs.Q[2], H, H, gr->post_hw, H, n, s));
+  TRY(bgrad(ws.DQH, 2 * Z, 2 * Z, gr->post_hb, n, s));
+  TRY(wgrad(ws.DPH, 2 * Z, 2 * Z, rs.P[2], H, H, gr->prior_hw, H, n, s));
+  TRY(bgrad(ws.DPH, 2 * Z, 2 * Z, gr->prior_hb, n, s));
+#undef TRY
+  return BLVM_OK;
+}

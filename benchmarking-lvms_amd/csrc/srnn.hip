@@ -109,7 +109,7 @@ extern "C" int blvm_srnn_latent_fwd(const BlvmSrnnWeights* w, const float* d, co
     h.z = zs + (size_t)(t + 1) * B * Z;
     h.raw_p = rs.RAWP + oZ; h.raw_q = rs.RAWQ + oZ;
     h.B = B; h.H = H; h.Z = Z; h.residual = residual_posterior;
-    h.beta = beta; h.inv_beta = 1.f / beta; h.sd_eps = sd_eps;
+    h.beta = beta; h.inv_beta = 1.f / beta; h.sd_eps = sd_eps; h.muq_raw = nullptr;
     LAUNCH_NW(head_stage_kernel, pick_nw(H, 4), dim3(Z / 16, rt), s, h);
   }
   BLVM_CHECK_LAUNCH("srnn_latent_fwd");
@@ -158,7 +158,7 @@ extern "C" int blvm_srnn_latent_bwd(const BlvmSrnnWeights* w, const float* d, co
     dz.x_sl = x_sl; dz.c_raw = c_raw; dz.c_fn = c_fn;
     dz.dqh = ws.DQH + o2Z; dz.dph = ws.DPH + o2Z;
     dz.B = B; dz.H = H; dz.Z = Z; dz.residual = residual_posterior; dz.t = t; dz.stride = stride;
-    dz.fn_floor = fn_floor; dz.beta = beta;
+    dz.fn_floor = fn_floor; dz.beta = beta; dz.sd_eps = sd_eps; dz.muq_raw = nullptr;
     LAUNCH_NW(dz_stage_kernel, pick_nw(H, 2), dim3(Z / 16, rt), s, dz);
     // B2: heads -> third layers;  B3, B4: down to the first layers (LeakyReLU derivatives fused)
     LinLaunch l;

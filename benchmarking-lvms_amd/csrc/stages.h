@@ -25,8 +25,8 @@ struct LinArgs {
   const float* add[NSEG];   // [B,ncols] (may alias out)
   const float* gate[NSEG];  // [B,ncols]: result *= (gate > 0)
   float* out[NSEG];         // [B,ncols]
-  int lda[NSEG], ldw[NSEG], ldadd[NSEG], ldgate[NSEG], ldo[NSEG], tiles[NSEG], flags[NSEG];
-  int B, K;
+  int lda[NSEG], ldw[NSEG], ldadd[NSEG], ldgate[NSEG], ldo[NSEG], tiles[NSEG], flags[NSEG], K[NSEG];
+  int B;
   float slope;  // negative-side slope of the activation AND of the gate (0 = ReLU, 0.01 = LeakyReLU)
 };
 
@@ -49,6 +49,7 @@ __global__ __launch_bounds__(NW * 64) void lin_stage_kernel(LinArgs<NSEG> a) {
   float* out = PICK(out);
   const int lda = PICK(lda), ldw = PICK(ldw), ldadd = PICK(ldadd), ldgate = PICK(ldgate), ldo = PICK(ldo);
   const int flags = PICK(flags);
+  const int K = PICK(K);
   const int r0 = blockIdx.y * 16, c0 = ct * 16;
   const int t = threadIdx.x & 255;
   const int row = r0 + (t >> 4), col = c0 + (t & 15);
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(NW * 64) void lin_stage_kernel(LinArgs<NSEG> a) {
   const float e_add = add[(flags & LF_ADD) ? (size_t)rowc * ldadd + col : 0];
   const float e_gate = gate[(flags & LF_GATE) ? (size_t)rowc * ldgate + col : 0];
   f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-  acc[0] = wave_gemm16<NW>(A, lda, r0, a.B, W, ldw, c0, a.K, threadIdx.x >> 6, acc[0]);
+  acc[0] = wave_gemm16<NW>(A, lda, r0, a.B, W, ldw, c0, K, threadIdx.x >> 6, acc[0]);
   float v[1];
   reduce_tiles<1, NW>(acc, red, v);
   if (!own) return;
@@ -77,7 +78,8 @@ struct HeadArgs {
   const float *Wp, *bp, *Wq, *bq;     // [2Z,H], [2Z]
   const float* eps;                   // [B,Z]
   float *mu_p, *sd_p, *mu_q, *sd_q, *z, *raw_p, *raw_q;  // [B,Z]
-  int B, H, Z, residual;
+  float* muq_raw;  // [B,Z] posterior mean BEFORE the combination with the prior (needed by backward in mode 2), or null
+  int B, H, Z, residual;  // residual: 0 plain, 1 mu_q += mu_p, 2 precision-weighted product of q and p (variational.py:125-138)
   float beta, inv_beta, sd_eps;
 };
 
@@ -107,10 +109,19 @@ __global__ __launch_bounds__(NW * 64) void head_stage_kernel(HeadArgs a) {
   const float rq = v[3] + b3;
   const float sp = softplus_beta(rp, a.beta, a.inv_beta) + a.sd_eps;
   const float sq = softplus_beta(rq, a.beta, a.inv_beta) + a.sd_eps;
-  if (a.residual) mq += mp;
-  a.mu_p[o] = mp; a.sd_p[o] = sp; a.mu_q[o] = mq; a.sd_q[o] = sq;
+  if (a.muq_raw != nullptr) a.muq_raw[o] = mq;
+  float sqc = sq;
+  if (a.residual == 1) {
+    mq += mp;
+  } else if (a.residual == 2) {
+    const float pq = 1.f / (sq * sq), pp = 1.f / (sp * sp);
+    const float var = 1.f / (pq + pp);
+    mq = var * (mq * pq + mp * pp);
+    sqc = sqrtf(var);
+  }
+  a.mu_p[o] = mp; a.sd_p[o] = sp; a.mu_q[o] = mq; a.sd_q[o] = sqc;
   a.raw_p[o] = rp; a.raw_q[o] = rq;
-  a.z[o] = e * sq + mq;  // randn_like(mu).mul(sd).add(mu)
+  a.z[o] = e * sqc + mq;  // randn_like(mu).mul(sd).add(mu)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -124,11 +135,12 @@ struct DzArgs {
   const float* dz_add;  // optional [B,Z] (row stride ld_add) direct gradient wrt z (SRNN: from the decoder), or null
   int ld_add, has_gemm;
   const float *mu_q, *sd_q, *mu_p, *sd_p, *eps, *raw_q, *raw_p;  // [B,Z] (step t)
+  const float* muq_raw;  // [B,Z] un-combined posterior mean (mode 2 only)
   const int32_t* x_sl;
   const float *c_raw, *c_fn;  // [B] or null
   float *dqh, *dph;   // [B,2Z] grads wrt the heads' Linear outputs
   int B, H, Z, residual, t, stride;
-  float fn_floor, beta;
+  float fn_floor, beta, sd_eps;
 };
 
 template <int NW>
@@ -167,10 +179,27 @@ __global__ __launch_bounds__(NW * 64) void dz_stage_kernel(DzArgs a) {
     const float k = logf(sp) - logf(sq) + (sq * sq + d * d) * 0.5f * ip2 - 0.5f;
     if (!(a.fn_floor > 0.f) || k > a.fn_floor) coef += c_fn;
   }
-  const float g_muq = dz + coef * d * ip2;
-  const float g_sdq = dz * e + coef * (sq * ip2 - 1.f / sq);
-  const float g_mup = -coef * d * ip2 + (a.residual ? g_muq : 0.f);
-  const float g_sdp = coef * (1.f / sp - (sq * sq + d * d) * ip2 / sp);
+  // gradients wrt the (combined) posterior (mq, sq) and the prior (mp, sp) of: rsample + KL(+free nats)
+  float g_muq = dz + coef * d * ip2;
+  float g_sdq = dz * e + coef * (sq * ip2 - 1.f / sq);
+  float g_mup = -coef * d * ip2;
+  float g_sdp = coef * (1.f / sp - (sq * sq + d * d) * ip2 / sp);
+  if (a.residual == 1) {
+    g_mup += g_muq;  // mu_q = mu_q' + mu_p
+  } else if (a.residual == 2) {
+    // (mq, sq) = precision-weighted product of q' = (muq_raw, softplus(raw_q)+eps) and p: var = 1/(pq+pp),
+    // mq = var (mq' pq + mp pp), sq = sqrt(var)
+    const float mqr = a.muq_raw[o];
+    const float sqr = softplus_beta(rq, a.beta, 1.f / a.beta) + a.sd_eps;
+    const float pq = 1.f / (sqr * sqr), pp = ip2, var = sq * sq;
+    const float half_s3 = 0.5f * var * sq;
+    const float g_pq = g_muq * var * (mqr - mq) - g_sdq * half_s3;
+    const float g_pp = g_muq * var * (mp - mq) - g_sdq * half_s3;
+    g_mup += g_muq * var * pp;
+    g_sdp += g_pp * (-2.f * pp / sp);
+    g_sdq = g_pq * (-2.f * pq / sqr);
+    g_muq = g_muq * var * pq;
+  }
   const size_t o2 = (size_t)row * 2 * a.Z + col;
   a.dqh[o2] = g_muq;
   a.dqh[o2 + a.Z] = g_sdq * sigmoidf_(a.beta * rq);
@@ -213,7 +242,7 @@ struct LinLaunch {
 template <int NSEG>
 inline void launch_lin_n(const LinLaunch& l, hipStream_t s) {
   LinArgs<NSEG> a{};
-  int tiles = 0;
+  int tiles = 0, kmax = 0;
   for (int i = 0; i < NSEG; ++i) {
     const LinSegH& g = l.seg[i];
     a.A[i] = g.A; a.W[i] = g.W; a.out[i] = g.out;
@@ -223,11 +252,13 @@ inline void launch_lin_n(const LinLaunch& l, hipStream_t s) {
     a.lda[i] = g.lda; a.ldw[i] = g.ldw; a.ldadd[i] = g.ldadd; a.ldgate[i] = g.ldgate; a.ldo[i] = g.ldo;
     a.tiles[i] = g.ncols / 16;
     a.flags[i] = (g.bias ? LF_BIAS : 0) | (g.add ? LF_ADD : 0) | (g.gate ? LF_GATE : 0) | (g.relu ? LF_RELU : 0);
+    a.K[i] = g.K;
+    kmax = g.K > kmax ? g.K : kmax;
     tiles += g.ncols / 16;
   }
-  a.B = l.B; a.K = l.seg[0].K;  // all segments of one launch share K
+  a.B = l.B;
   a.slope = l.slope;
-  const int nw = pick_nw(a.K, 1);
+  const int nw = pick_nw(kmax, 1);
   const dim3 grid(tiles, (l.B + 15) / 16);
   if (nw == 16) hipLaunchKernelGGL((lin_stage_kernel<16, NSEG>), grid, dim3(1024), 0, s, a);
   else if (nw == 8) hipLaunchKernelGGL((lin_stage_kernel<8, NSEG>), grid, dim3(512), 0, s, a);

@@ -277,7 +277,7 @@ extern "C" int blvm_vrnn_seq_fwd(const BlvmVrnnWeights* w, const float* enc, con
     h.mu_p = mu_p + oZ; h.sd_p = sd_p + oZ; h.mu_q = mu_q + oZ; h.sd_q = sd_q + oZ; h.z = z + oZ;
     h.raw_p = rs.RAWP + oZ; h.raw_q = rs.RAWQ + oZ;
     h.B = B; h.H = H; h.Z = Z; h.residual = residual_posterior;
-    h.beta = beta; h.inv_beta = 1.f / beta; h.sd_eps = sd_eps;
+    h.beta = beta; h.inv_beta = 1.f / beta; h.sd_eps = sd_eps; h.muq_raw = nullptr;
     LAUNCH_NW(head_stage_kernel, pick_nw(H, 4), dim3(Z / 16, rt), s, h);
     // F5..F8: phi_z MLP (last layer writes phi into decin row t)
     a.nseg = 1;
@@ -434,7 +434,7 @@ extern "C" int blvm_vrnn_seq_bwd(const BlvmVrnnWeights* w, const float* enc, con
     d.x_sl = x_sl; d.c_raw = c_raw; d.c_fn = c_fn;
     d.dqh = ws.DQH + o2Z; d.dph = ws.DPH + o2Z;
     d.B = B; d.H = H; d.Z = Z; d.residual = residual_posterior; d.t = t; d.stride = stride;
-    d.fn_floor = fn_floor; d.beta = beta;
+    d.fn_floor = fn_floor; d.beta = beta; d.sd_eps = sd_eps; d.muq_raw = nullptr;
     LAUNCH_NW(dz_stage_kernel, pick_nw(H, 1), dim3(Z / 16, rt), s, d);
     // B7: heads -> last hidden layers
     a.nseg = 2;

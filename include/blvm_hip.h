@@ -242,6 +242,46 @@ int blvm_wavenet_block_bwd(const float* x, const float* conv_w, const float* rs_
                            int T_skip, float inv_std, float* d_x, float* dconv_w, float* dconv_b, float* drs_w,
                            float* drs_b, float* workspace, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * K5  RSSM cell of the Clockwork-VAE over a sequence (forward + BPTT).  Replaces the per-level time loop
+ *     `blvm/models/clockwork_vae/clockwork_vae.py:272-281` over `RSSMCell.forward` (`blvm/modules/rssm.py:79-104`).
+ *   enc [T,B,E] encodings of this level; ctx [T,B,C] context from the level above (C may be 0, ctx NULL);
+ *   z0 [B,Z], h0 [B,H] or NULL (zeros); eps [T,B,Z];
+ *   mode: 0 plain, 1 residual posterior (mu_q += mu_p), 2 precision-weighted posterior (`variational.py:125-138`).
+ *   zs [T+1,B,Z], hs [T+1,B,H]: row 0 = initial state, row t+1 = state after step t (the context for the level below
+ *   is cat[zs[1:], hs[1:]]).  mu_q/sd_q are the COMBINED posterior parameters the KL is taken against.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct BlvmRssmWeights {
+  const float *gin_w, *gin_b;           /* [H, Z+C] (input order cat[z, context]), [H] */
+  const float *gru_wih, *gru_whh;       /* [3H,H] each, rows [r|z|n] */
+  const float *gru_bih, *gru_bhh;       /* [3H] */
+  const float *prior_w[3], *prior_b[3]; /* [H,H] x3 */
+  const float *prior_hw, *prior_hb;     /* [2Z,H] */
+  const float *post_w[3], *post_b[3];   /* [H,H+E] (input order cat[h, enc]), [H,H], [H,H] */
+  const float *post_hw, *post_hb;       /* [2Z,H] */
+} BlvmRssmWeights;
+
+typedef struct BlvmRssmGrads { /* same shapes; ACCUMULATED into (caller zeroes) */
+  float *gin_w, *gin_b, *gru_wih, *gru_whh, *gru_bih, *gru_bhh;
+  float *prior_w[3], *prior_b[3], *prior_hw, *prior_hb;
+  float *post_w[3], *post_b[3], *post_hw, *post_hb;
+} BlvmRssmGrads;
+
+size_t blvm_rssm_reserve_floats(int T, int B, int H, int Z);
+size_t blvm_rssm_bwd_workspace_floats(int T, int B, int H, int Z);
+int blvm_rssm_seq_fwd(const BlvmRssmWeights* w, const float* enc, const float* ctx, const float* z0, const float* h0,
+                      const float* eps, int T, int B, int H, int Z, int C, int E, int mode, float sd_eps, float* zs,
+                      float* hs, float* mu_q, float* sd_q, float* mu_p, float* sd_p, float* reserve, void* stream);
+/*   d_zs [T+1,B,Z], d_hs [T+1,B,H]: gradients wrt zs / hs from outside the chain (rows 1.. = the states, row 0 = the
+ *   initial state).  KL folded in as for blvm_vrnn_seq_bwd (stride = level stride in audio frames).
+ *   Outputs (each may be NULL): d_enc [T,B,E], d_ctx [T,B,C], d_z0 [B,Z] (complete), d_h0 [B,H] (WITHOUT d_hs[0]). */
+int blvm_rssm_seq_bwd(const BlvmRssmWeights* w, const float* enc, const float* ctx, const float* eps, const float* zs,
+                      const float* hs, const float* mu_q, const float* sd_q, const float* mu_p, const float* sd_p,
+                      const float* reserve, const float* d_zs, const float* d_hs, const int32_t* x_sl,
+                      const float* c_raw, const float* c_fn, int stride, float fn_floor, int T, int B, int H, int Z,
+                      int C, int E, int mode, float sd_eps, float* d_enc, float* d_ctx, float* d_z0, float* d_h0,
+                      const BlvmRssmGrads* grads, float* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

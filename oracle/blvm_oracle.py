@@ -506,3 +506,36 @@ def wavenet_forward(sd, x, x_sl, n_layers, n_stacks, num_bins=2**16, num_mix=10,
     log_prob = ll_twise.sum(1)
     loss = -log_prob.nansum() / x_sl.nansum()
     return dict(loss=loss, log_prob=log_prob, log_prob_twise=ll_twise, bpd=float((-log_prob.detach() / LN2).sum() / x_sl.sum()))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# RSSM cell (blvm/modules/rssm.py:79-104)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def rssm_cell_step(sd, enc_t, state, ctx_t, eps_t, residual_posterior=False, precision_posterior=False, prefix=""):
+    """One RSSMCell.forward with explicit noise.  state = (z, h); ctx_t [B,C] (C may be 0)."""
+    z, h = state
+    p = prefix
+    g = F.relu(F.linear(torch.cat([z, ctx_t], -1), sd[f"{p}gru_in.0.weight"], sd[f"{p}gru_in.0.bias"]))
+    h_new = gru_cell(g, h, sd[f"{p}gru_cell.weight_ih"], sd[f"{p}gru_cell.weight_hh"], sd[f"{p}gru_cell.bias_ih"], sd[f"{p}gru_cell.bias_hh"])
+    q = _mlp(torch.cat([h_new, enc_t], -1), sd, f"{p}posterior", (0, 2, 4), F.relu)
+    mu_q, sd_q = gaussian_head(q, sd[f"{p}posterior.6.params.weight"], sd[f"{p}posterior.6.params.bias"])
+    pr = _mlp(h_new, sd, f"{p}prior", (0, 2, 4), F.relu)
+    mu_p, sd_p = gaussian_head(pr, sd[f"{p}prior.6.params.weight"], sd[f"{p}prior.6.params.bias"])
+    if residual_posterior:
+        mu_q = mu_q + mu_p
+    elif precision_posterior:
+        mu_q, sd_q = precision_weighted_gaussian(mu_q, sd_q, mu_p, sd_p)
+    z_new = eps_t * sd_q + mu_q
+    return (z_new, h_new), dict(z=z_new, enc_mu=mu_q, enc_sd=sd_q, prior_mu=mu_p, prior_sd=sd_p)
+
+
+def rssm_sequence(sd, enc, ctx, state0, eps, **kw):
+    """Run the cell over time-major enc [T,B,E] / ctx [T,B,C]; returns stacked (zs, hs [T,B,*]) and distributions."""
+    state, zs, hs, ds = state0, [], [], []
+    for t in range(enc.size(0)):
+        state, d = rssm_cell_step(sd, enc[t], state, ctx[t], eps[t], **kw)
+        zs.append(state[0]); hs.append(state[1]); ds.append(d)  # noqa: E702
+    st = lambda k: torch.stack([d[k] for d in ds], 0)  # noqa: E731
+    return torch.stack(zs, 0), torch.stack(hs, 0), {k: st(k) for k in ("enc_mu", "enc_sd", "prior_mu", "prior_sd")}

@@ -279,6 +279,45 @@ def gen_wavenet():
     save("wavenet.npz", **arrays)
 
 
+def gen_rssm():
+    """Reference RSSMCell stepped over a short sequence in its three posterior modes; scalar test loss
+    sum(z*wz) + sum(h*wh) + 0.7 * sum(KL) so that every gradient path (direct, recurrent, KL) is exercised."""
+    from blvm.modules.rssm import RSSMCell
+
+    arrays = {}
+    T, B, Z, H, C, E = 6, 5, 16, 32, 48, 32
+    g = torch.Generator().manual_seed(17)
+    enc, ctx = torch.randn(T, B, E, generator=g), torch.randn(T, B, C, generator=g)
+    z0, h0 = torch.randn(B, Z, generator=g) * 0.3, torch.randn(B, H, generator=g) * 0.3
+    wz, wh = torch.randn(T, B, Z, generator=g), torch.randn(T, B, H, generator=g)
+    arrays.update(enc=enc, ctx=ctx, z0=z0, h0=h0, wz=wz, wh=wh)
+    for tag, kw, c_dim in (("plain", {}, C), ("res", dict(residual_posterior=True), C), ("prec", dict(precision_posterior=True), C),
+                           ("top", dict(precision_posterior=True), 0)):
+        torch.manual_seed(51)
+        cell = RSSMCell(z_dim=Z, h_dim=H, c_dim=c_dim, e_dim=E, **kw)
+        eps = replay_eps(77, T, B, Z)
+        torch.manual_seed(77)
+        z0r, h0r = z0.clone().requires_grad_(True), h0.clone().requires_grad_(True)
+        encr, ctxr = enc.clone().requires_grad_(True), ctx[..., :c_dim].clone().requires_grad_(True)
+        state, zs, hs, kls = (z0r, h0r), [], [], []
+        for t in range(T):
+            state, d = cell(encr[t], state, ctxr[t])
+            zs.append(state[0]); hs.append(state[1])
+            kls.append(RV.kl_divergence_gaussian(d.enc_mu, d.enc_sd, d.prior_mu, d.prior_sd))
+        zs, hs, kl = torch.stack(zs), torch.stack(hs), torch.stack(kls)
+        loss = (zs * wz).sum() + (hs * wh).sum() + 0.7 * kl.sum()
+        loss.backward()
+        arrays.update({f"{tag}_eps": eps, f"{tag}_zs": zs, f"{tag}_hs": hs, f"{tag}_kl": kl.sum((0, 2)), f"{tag}_loss": loss,
+                       f"{tag}_d_enc": encr.grad, f"{tag}_d_z0": z0r.grad, f"{tag}_d_h0": h0r.grad})
+        if c_dim:
+            arrays[f"{tag}_d_ctx"] = ctxr.grad
+        for k, v in cell.state_dict().items():
+            arrays[f"{tag}_sd.{k}"] = v
+        for k, p in cell.named_parameters():
+            arrays[f"{tag}_grad.{k}"] = p.grad
+    save("rssm.npz", **arrays)
+
+
 def gen_lstm():
     """LSTMAudio: reduced size with full tensors, and BASELINE config C1 ([8,4000], h=256, s=64) pinned by checksums."""
     arrays = {}
@@ -323,6 +362,6 @@ def gen_lstm():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn", "wavenet"]
+    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn", "wavenet", "rssm"]
     for w in which:
         globals()[f"gen_{w}"]()

@@ -553,3 +553,39 @@ def test_wavenet_c5_dims_vs_reference_golden():
         assert grads[name].grad.double().norm().item() == pytest.approx(ref, rel=2e-3), name
     for k in [f[7:] for f in g.files if f.startswith("f_grad.")]:
         assert rel_l2(grads[k].grad, T(g[f"f_grad.{k}"])) < 2e-3, k
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# K5 RSSM cell (Clockwork-VAE) against the reference cell stepped on the CPU
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("tag,kw,c_dim", [("plain", {}, 48), ("res", dict(residual_posterior=True), 48),
+                                          ("prec", dict(precision_posterior=True), 48), ("top", dict(precision_posterior=True), 0)])
+def test_rssm_sequence_vs_reference_golden(tag, kw, c_dim):
+    from blvm.modules.rssm import RSSMCell
+
+    g = np.load(os.path.join(GOLDEN, "rssm.npz"))
+    T_, B, Z, H, E = 6, 5, 16, 32, 32
+    cell = RSSMCell(z_dim=Z, h_dim=H, c_dim=c_dim, e_dim=E, **kw)
+    pre = f"{tag}_sd."
+    cell.load_state_dict({k[len(pre):]: T(g[k]) for k in g.files if k.startswith(pre)})
+    cell.to(DEV)
+    enc = T(g["enc"]).to(DEV).requires_grad_(True)
+    ctx = T(g["ctx"])[..., :c_dim].contiguous().to(DEV).requires_grad_(True) if c_dim else None
+    z0, h0 = T(g["z0"]).to(DEV).requires_grad_(True), T(g["h0"]).to(DEV).requires_grad_(True)
+    x_sl = torch.full((B,), T_, dtype=torch.int32, device=DEV)
+    zs, hs, kld, kld_fn, mq, sq, mp, sp = cell.sequence(enc, ctx, (z0, h0), T(g[f"{tag}_eps"]).to(DEV), x_sl, 1, 0.0)
+    torch.testing.assert_close(zs[1:].cpu(), T(g[f"{tag}_zs"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(hs[1:].cpu(), T(g[f"{tag}_hs"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(kld.cpu().float(), T(g[f"{tag}_kl"]), rtol=1e-4, atol=1e-4)
+    loss = (zs[1:] * T(g["wz"]).to(DEV)).sum() + (hs[1:] * T(g["wh"]).to(DEV)).sum() + 0.7 * kld.sum()
+    assert float(loss) == pytest.approx(float(g[f"{tag}_loss"]), rel=1e-4)
+    loss.backward()
+    assert rel_l2(enc.grad, T(g[f"{tag}_d_enc"])) < 1e-3
+    assert rel_l2(z0.grad, T(g[f"{tag}_d_z0"])) < 1e-3
+    assert rel_l2(h0.grad, T(g[f"{tag}_d_h0"])) < 1e-3
+    if c_dim:
+        assert rel_l2(ctx.grad, T(g[f"{tag}_d_ctx"])) < 1e-3
+    for k, p in cell.named_parameters():
+        assert rel_l2(p.grad, T(g[f"{tag}_grad.{k}"])) < 1e-3, k

@@ -172,3 +172,26 @@ def test_wavenet_small_forward_backward(tag, pad_rf):
     for k, p in sd.items():
         ref = T(g[f"{tag}_grad.{k}"])
         assert (p.grad - ref).norm() / (ref.norm() + 1e-12) < 2e-5, k
+
+
+@pytest.mark.parametrize("tag,kw,c_dim", [("plain", {}, 48), ("res", dict(residual_posterior=True), 48),
+                                          ("prec", dict(precision_posterior=True), 48), ("top", dict(precision_posterior=True), 0)])
+def test_rssm_cell_sequence(tag, kw, c_dim):
+    g = np.load(os.path.join(GOLDEN, "rssm.npz"))
+    pre = f"{tag}_sd."
+    sd = {k[len(pre):]: T(g[k]).clone().requires_grad_(True) for k in g.files if k.startswith(pre)}
+    enc, ctx = T(g["enc"]).clone().requires_grad_(True), T(g["ctx"])[..., :c_dim].clone().requires_grad_(True)
+    z0, h0 = T(g["z0"]).clone().requires_grad_(True), T(g["h0"]).clone().requires_grad_(True)
+    zs, hs, d = O.rssm_sequence(sd, enc, ctx, (z0, h0), T(g[f"{tag}_eps"]), **kw)
+    close(zs, g[f"{tag}_zs"], 1e-5, 1e-6)
+    close(hs, g[f"{tag}_hs"], 1e-5, 1e-6)
+    kl = O.kl_gaussian(d["enc_mu"], d["enc_sd"], d["prior_mu"], d["prior_sd"])
+    loss = (zs * T(g["wz"])).sum() + (hs * T(g["wh"])).sum() + 0.7 * kl.sum()
+    close(loss, g[f"{tag}_loss"], 1e-5, 1e-4)
+    loss.backward()
+    close(enc.grad, g[f"{tag}_d_enc"], 1e-4, 1e-6)
+    close(z0.grad, g[f"{tag}_d_z0"], 1e-4, 1e-6)
+    close(h0.grad, g[f"{tag}_d_h0"], 1e-4, 1e-6)
+    for k, p in sd.items():
+        ref = T(g[f"{tag}_grad.{k}"])
+        assert (p.grad - ref).norm() / (ref.norm() + 1e-12) < 2e-5, k
