@@ -1,6 +1,7 @@
 from .metrics import (  # noqa: F401
     BitsPerDimMetric,
     DeferredScalars,
+    EMAMetric,
     KLMetric,
     LatestMeanMetric,
     LLMetric,

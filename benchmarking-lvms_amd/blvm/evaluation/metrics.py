@@ -130,6 +130,38 @@ class LatestMeanMetric(Metric):
         self._latest = metric.latest
 
 
+class EMAMetric(Metric):
+    """Exponential moving average of a mean (blvm/evaluation/metrics.py:160-206): `weight_by` is the weight of the NEW value
+    on update."""
+
+    def __init__(self, values, name: str, tags: Set[str] = None, reduce_by=None, weight_by=None, get_best: str = None,
+                 log_to_console: bool = True, log_to_framework: bool = True):  # fmt: skip
+        super().__init__(name, tags, get_best, log_to_console, log_to_framework)
+        numel = values.numel() if isinstance(values, torch.Tensor) else 1
+        self._num = _total(values)
+        self._den = _total(reduce_by) or numel
+        self._w = _total(weight_by)
+        self._ema = None
+
+    @property
+    def weight_by(self):
+        return float(self._w) if self._w is not None and float(self._w) != 0 else float(self._den)
+
+    @property
+    def ema(self):
+        if self._ema is None:
+            self._ema = float(self._num) / float(self._den)
+        return self._ema
+
+    @property
+    def value(self):
+        return self.ema
+
+    def update(self, metric: "EMAMetric"):
+        avg_weight = (self.weight_by + metric.weight_by) / 2
+        self._ema = avg_weight * metric.ema + (1 - avg_weight) * self.ema
+
+
 class RunningMeanMetric(Metric):
     def __init__(self, values, name: str, tags: Set[str] = None, reduce_by=None, weight_by=None, get_best: str = None,
                  log_to_console: bool = True, log_to_framework: bool = True):  # fmt: skip

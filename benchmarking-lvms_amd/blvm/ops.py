@@ -77,7 +77,8 @@ class _MLPFunction(torch.autograd.Function):
             M, K = inp.shape
             N = W.shape[0]
             out = torch.empty(M, N, device=x.device, dtype=torch.float32)
-            gemm(0, 0, M, N, K, inp, inp.stride(0), _f32c(W), K, out, N, bias=_f32c(b), act=act, slope=slope)
+            gemm(0, 0, M, N, K, inp, inp.stride(0), _f32c(W), K, out, N, bias=_f32c(b) if b is not None else None, act=act,
+                 slope=slope)
             acts.append(out)
         ctx.act, ctx.slope, ctx.n_layers = act, slope, n_layers
         ctx.save_for_backward(*acts, *params)
@@ -106,7 +107,7 @@ class _MLPFunction(torch.autograd.Function):
                 dW = torch.zeros_like(W, dtype=torch.float32)
                 gemm(1, 1, N, K, M, dz, N, inp, inp.stride(0), dW, K, accumulate=True, split_k=_pick_split(N, K, M))
                 grads[2 * l] = dW
-            if ctx.needs_input_grad[4 + 2 * l]:
+            if b is not None and ctx.needs_input_grad[4 + 2 * l]:
                 db = torch.empty(N, device=dz.device, dtype=torch.float32)
                 colsum(dz, db)
                 grads[2 * l + 1] = db
@@ -765,3 +766,197 @@ def rssm_sequence(enc, ctx, z0, h0, eps, x_sl_dev, params, H, Z, mode, stride, f
     fn_floor = float(free_nats) / Z if free_nats else 0.0
     cfg = (T, B, H, Z, C, E, int(mode), float(sd_eps), int(stride), fn_floor)
     return _RSSMSeqFunction.apply(enc, ctx, z0, h0, eps, x_sl_dev, cfg, *params)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# K11: Clockwork-VAE convolutional coders — time-major channel-last [L,B,C]
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def _norm_ws(N, device):
+    return torch.empty(load().blvm_chan_norm_workspace_doubles(N), device=device, dtype=torch.float64)
+
+
+def _chan_norm_fwd(x, gamma, beta, eps):
+    L, B, C = x.shape
+    y, mr = torch.empty_like(x), torch.empty(2, B * C, device=x.device, dtype=torch.float32)
+    check(load().blvm_chan_norm_fwd(ptr(x), L, B * C, C, ptr(gamma), ptr(beta), eps, ptr(y), ptr(mr), ptr(_norm_ws(B * C, x.device)),
+                                    stream_ptr()), "blvm_chan_norm_fwd")  # fmt: skip
+    return y, mr
+
+
+def _chan_norm_bwd(x, dy, mr, gamma, relu_mask, dgamma, dbeta):
+    L, B, C = x.shape
+    dx = torch.empty_like(x)
+    check(load().blvm_chan_norm_bwd(ptr(x), ptr(dy), ptr(mr), ptr(gamma), L, B * C, C, int(relu_mask), ptr(dx), ptr(dgamma),
+                                    ptr(dbeta), ptr(_norm_ws(B * C, x.device)), stream_ptr()), "blvm_chan_norm_bwd")  # fmt: skip
+    return dx
+
+
+def _dwconv_fwd(x, w, bias, stride, dilation, transposed, relu):
+    L, B, C = x.shape
+    k = w.shape[-1]
+    L_out = load().blvm_dwconv_out_length(L, k, stride, dilation, int(transposed))
+    if L_out <= 0:
+        raise _hip.BlvmHipError(f"depthwise conv: input length {L} is shorter than the kernel ({k=}, {dilation=})")
+    y = torch.empty(L_out, B, C, device=x.device, dtype=torch.float32)
+    check(load().blvm_dwconv_fwd(ptr(x), ptr(w), ptr(bias), L, B * C, C, k, stride, dilation, int(transposed), int(relu), ptr(y),
+                                 stream_ptr()), "blvm_dwconv_fwd")  # fmt: skip
+    return y
+
+
+def _dwconv_bwd(x, w, y, dy, stride, dilation, transposed, relu, need_dx, dw, dbias):
+    L, B, C = x.shape
+    k = w.shape[-1]
+    dx = torch.empty_like(x) if need_dx else None
+    check(load().blvm_dwconv_bwd(ptr(x), ptr(w), ptr(y), ptr(dy), L, B * C, C, k, stride, dilation, int(transposed), int(relu),
+                                 ptr(dx), ptr(dw), ptr(dbias), stream_ptr()), "blvm_dwconv_bwd")  # fmt: skip
+    return dx
+
+
+class _ChanNormFunction(torch.autograd.Function):
+    """nn.GroupNorm(num_groups=C, C) on [L,B,C]: per-(sample, channel) normalisation over time."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x, gamma, beta = _f32c(x), _f32c(gamma), _f32c(beta)
+        y, mr = _chan_norm_fwd(x, gamma, beta, eps)
+        ctx.save_for_backward(x, mr, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mr, gamma = ctx.saved_tensors
+        dgamma, dbeta = torch.zeros_like(gamma), torch.zeros_like(gamma)
+        dx = _chan_norm_bwd(x, _f32c(dy), mr, gamma, False, dgamma, dbeta)
+        return dx, dgamma, dbeta, None
+
+
+def chan_norm(x, gamma, beta, eps: float = 1e-5):
+    return _ChanNormFunction.apply(x, gamma, beta, eps)
+
+
+class _DwConvFunction(torch.autograd.Function):
+    """Depthwise Conv1d / ConvTranspose1d (groups = channels, no padding) on [L,B,C], optional fused ReLU."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, dilation, transposed, relu):
+        x, w = _f32c(x), _f32c(w)
+        bias = _f32c(bias) if bias is not None else None
+        y = _dwconv_fwd(x, w, bias, stride, dilation, transposed, relu)
+        ctx.cfg = (stride, dilation, transposed, relu, bias is not None)
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        stride, dilation, transposed, relu, has_bias = ctx.cfg
+        x, w, y = ctx.saved_tensors
+        dw = torch.zeros_like(w)
+        db = torch.zeros(w.shape[0], device=w.device, dtype=torch.float32) if has_bias else None
+        dx = _dwconv_bwd(x, w, y, _f32c(dy), stride, dilation, transposed, relu, ctx.needs_input_grad[0], dw, db)
+        return dx, dw, db, None, None, None, None
+
+
+def dwconv(x, weight, bias, stride=1, dilation=1, transposed=False, relu=False):
+    return _DwConvFunction.apply(x, weight, bias, int(stride), int(dilation), bool(transposed), bool(relu))
+
+
+class _ResampleAddFunction(torch.autograd.Function):
+    """TemporalResidual: y + nearest-resampled x (convolutional_coders.py:15-26); y [Ly,B,C], x [Lx,B,C]."""
+
+    @staticmethod
+    def forward(ctx, y, x):
+        y, x = _f32c(y), _f32c(x)
+        Ly, B, C = y.shape
+        out = torch.empty_like(y)
+        check(load().blvm_resample_add_fwd(ptr(y), ptr(x), Ly, x.shape[0], B * C, ptr(out), stream_ptr()), "blvm_resample_add_fwd")
+        ctx.Lx = x.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _f32c(dout)
+        Ly, B, C = dout.shape
+        if ctx.Lx == Ly:
+            return dout, dout
+        dx = torch.zeros(ctx.Lx, B, C, device=dout.device, dtype=torch.float32)
+        check(load().blvm_resample_add_bwd(ptr(dout), Ly, ctx.Lx, B * C, ptr(dx), stream_ptr()), "blvm_resample_add_bwd")
+        return dout, dx
+
+
+def resample_add(y, x):
+    return _ResampleAddFunction.apply(y, x)
+
+
+class _SepBlockFunction(torch.autograd.Function):
+    """One `BlockSeparable` (convolutional_coders.py:29-66) as a single autograd node on [L,B,C]:
+    1x1 conv C->4C + ReLU (K6 epilogue) -> channel norm -> depthwise (transposed) conv k, stride s + ReLU -> channel norm
+    -> 1x1 conv 4C->C (no bias) -> + nearest-resampled input.  params: w1 [4C,C], b1, g1, be1, wd [4C,k], bd, g2, be2,
+    wp [C,4C]."""
+
+    @staticmethod
+    def forward(ctx, x, cfg, w1, b1, g1, be1, wd, bd, g2, be2, wp):
+        stride, dilation, transposed, eps = cfg
+        x = _f32c(x)
+        w1, b1, g1, be1, wd, bd, g2, be2, wp = (_f32c(p) for p in (w1, b1, g1, be1, wd, bd, g2, be2, wp))
+        L, B, C = x.shape
+        Cb = w1.shape[0]
+        a1 = torch.empty(L, B, Cb, device=x.device, dtype=torch.float32)
+        gemm(0, 0, L * B, Cb, C, x, C, w1, C, a1, Cb, bias=b1, act=ACT_RELU)
+        n1, mr1 = _chan_norm_fwd(a1, g1, be1, eps)
+        d = _dwconv_fwd(n1, wd, bd, stride, dilation, transposed, True)
+        n2, mr2 = _chan_norm_fwd(d, g2, be2, eps)
+        L2 = d.shape[0]
+        r = torch.empty(L2, B, C, device=x.device, dtype=torch.float32)
+        gemm(0, 0, L2 * B, C, Cb, n2, Cb, wp, Cb, r, C)
+        out = torch.empty_like(r)
+        check(load().blvm_resample_add_fwd(ptr(r), ptr(x), L2, L, B * C, ptr(out), stream_ptr()), "blvm_resample_add_fwd")
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, a1, mr1, n1, d, mr2, n2, w1, g1, wd, g2, wp)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        stride, dilation, transposed, eps = ctx.cfg
+        x, a1, mr1, n1, d, mr2, n2, w1, g1, wd, g2, wp = ctx.saved_tensors
+        dout = _f32c(dout)
+        L, B, C = x.shape
+        L2, Cb = d.shape[0], w1.shape[0]
+        M, M2 = L * B, L2 * B
+        dev = x.device
+        # pointwise 4C->C
+        dwp = torch.zeros_like(wp)
+        gemm(1, 1, C, Cb, M2, dout, C, n2, Cb, dwp, Cb, accumulate=True, split_k=_pick_split(C, Cb, M2))
+        dn2 = torch.empty(L2, B, Cb, device=dev, dtype=torch.float32)
+        gemm(0, 1, M2, Cb, C, dout, C, wp, Cb, dn2, Cb)
+        # norm 2 (+ the ReLU in front of it: d > 0 <=> pre-activation > 0)
+        dg2, dbe2 = torch.zeros_like(g2), torch.zeros_like(g2)
+        dd = _chan_norm_bwd(d, dn2, mr2, g2, True, dg2, dbe2)
+        del dn2
+        # depthwise conv
+        dwd, dbd = torch.zeros_like(wd), torch.zeros(Cb, device=dev, dtype=torch.float32)
+        dn1 = _dwconv_bwd(n1, wd, None, dd, stride, dilation, transposed, False, True, dwd, dbd)
+        del dd
+        # norm 1 (+ ReLU of the 1x1 conv)
+        dg1, dbe1 = torch.zeros_like(g1), torch.zeros_like(g1)
+        da1 = _chan_norm_bwd(a1, dn1, mr1, g1, True, dg1, dbe1)
+        del dn1
+        # 1x1 conv C->4C
+        dw1 = torch.zeros_like(w1)
+        gemm(1, 1, Cb, C, M, da1, Cb, x, C, dw1, C, accumulate=True, split_k=_pick_split(Cb, C, M))
+        db1 = torch.empty(Cb, device=dev, dtype=torch.float32)
+        colsum(da1.view(M, Cb), db1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if L2 == L:
+                dx = dout.clone()
+            else:
+                dx = torch.zeros_like(x)
+                check(load().blvm_resample_add_bwd(ptr(dout), L2, L, B * C, ptr(dx), stream_ptr()), "blvm_resample_add_bwd")
+            gemm(0, 1, M, C, Cb, da1, Cb, w1, C, dx, C, accumulate=True)
+        return dx, None, dw1, db1, dg1, dbe1, dwd, dbd, dg2, dbe2, dwp
+
+
+def sep_block(x, stride, dilation, transposed, w1, b1, g1, be1, wd, bd, g2, be2, wp, eps: float = 1e-5):
+    return _SepBlockFunction.apply(x, (int(stride), int(dilation), bool(transposed), float(eps)), w1, b1, g1, be1, wd, bd, g2, be2, wp)
