@@ -137,11 +137,24 @@ def linear(x2d: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, act: int
 # ----------------------------------------------------------------------------------------------------------------------
 
 
+def _dmol_check_shapes(dec, W, y, B, T, Tp, S, num_mix):
+    """The fused head is the per-frame [F,F] Linear of the stacked-frame models (F = 3 * num_mix); a head with another
+    input width (e.g. CW-VAE's h -> F) runs as a K6 GEMM in front and the kernel gets W = None."""
+    F = 3 * num_mix
+    if dec.dim() != 2 or dec.shape[0] != B * Tp or dec.shape[1] != S * F:
+        raise _hip.BlvmHipError(f"DMoL: activations must be [B*T'={B * Tp}, S*3*num_mix={S * F}], got {tuple(dec.shape)}")
+    if W is not None and tuple(W.shape) != (F, F):
+        raise _hip.BlvmHipError(f"DMoL: fused head weight must be [{F},{F}], got {tuple(W.shape)}")
+    if tuple(y.shape) != (B, T) or Tp * S < T:
+        raise _hip.BlvmHipError(f"DMoL: targets must be [B={B}, T={T}] with T <= T'*S={Tp * S}, got {tuple(y.shape)}")
+
+
 class _DMoLFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dec, W, b, y, x_sl_dev, layout, B, T, Tp, S, num_mix, num_bins, log_eps):
         dec, y = _f32c(dec), _f32c(y)
         W, b = (_f32c(W), _f32c(b)) if W is not None else (None, None)
+        _dmol_check_shapes(dec, W, y, B, T, Tp, S, num_mix)
         log_prob = torch.zeros(B, device=dec.device, dtype=torch.float64)
         check(
             load().blvm_dmol_fwd(ptr(dec), layout, ptr(W), ptr(b), ptr(y), ptr(x_sl_dev), B, T, Tp, S, num_mix, num_bins,
@@ -188,6 +201,7 @@ def dmol_ll_twise(dec, W, b, y, x_sl_dev, layout, B, T, Tp, S, num_mix=10, num_b
     """Masked frame-wise log-likelihood [B,T] (no autograd)."""
     dec, y = _f32c(dec), _f32c(y)
     W, b = (_f32c(W), _f32c(b)) if W is not None else (None, None)
+    _dmol_check_shapes(dec, W, y, B, T, Tp, S, num_mix)
     lp = torch.zeros(B, device=dec.device, dtype=torch.float64)
     ll = torch.zeros(B, T, device=dec.device, dtype=torch.float32)
     check(

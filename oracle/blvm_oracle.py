@@ -539,3 +539,135 @@ def rssm_sequence(sd, enc, ctx, state0, eps, **kw):
         zs.append(state[0]); hs.append(state[1]); ds.append(d)  # noqa: E702
     st = lambda k: torch.stack([d[k] for d in ds], 0)  # noqa: E731
     return torch.stack(zs, 0), torch.stack(hs, 0), {k: st(k) for k in ("enc_mu", "enc_sd", "prior_mu", "prior_sd")}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Clockwork VAE (blvm/models/clockwork_vae/clockwork_vae.py, convolutional_coders.py)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def get_same_padding(length, stride, kernel_size, dilation=1):
+    """blvm/utils/padding.py:100-117."""
+    return max(0, dilation * (kernel_size - 1) - (length - 1) % stride)
+
+
+def coder_block_strides(strides, num_blocks, stride_per_block):
+    """Stride of every block per level: `stride_per_block` until the level's stride is used up, then 1
+    (convolutional_coders.py:178-191)."""
+    out = []
+    for s in strides:
+        rem, lvl = s, []
+        for _ in range(num_blocks):
+            if rem >= stride_per_block:
+                lvl.append(stride_per_block)
+                rem //= stride_per_block
+            else:
+                assert rem == 1
+                lvl.append(1)
+        out.append(lvl)
+    return out
+
+
+def coder_receptive_fields(block_strides, kernel_size=5):
+    """Per-level receptive field r += (k-1)*s_in, s_in *= s (blvm/utils/convolutions.py:117-119)."""
+    out = []
+    for lvl in block_strides:
+        s_in, r = 1, 1
+        for s in lvl:
+            r += (kernel_size - 1) * s_in
+            s_in *= s
+        out.append(r)
+    return out
+
+
+def separable_block(sd, p, x, stride, transposed):
+    """BlockSeparable (convolutional_coders.py:29-66) on [B,C,T]: 1x1 conv -> ReLU -> GroupNorm(groups=C) -> depthwise
+    (transposed) conv -> ReLU -> GroupNorm -> 1x1 conv (no bias), + input (nearest-resampled when the length changed,
+    :15-26)."""
+    m = f"{p}.block.module"
+    h = F.relu(F.conv1d(x, sd[f"{m}.0.weight"], sd[f"{m}.0.bias"]))
+    C = h.size(1)
+    h = F.group_norm(h, C, sd[f"{m}.2.weight"], sd[f"{m}.2.bias"])
+    conv = F.conv_transpose1d if transposed else F.conv1d
+    h = F.relu(conv(h, sd[f"{m}.3.depthwise_conv.weight"], sd[f"{m}.3.depthwise_conv.bias"], stride=stride, groups=C))
+    h = F.group_norm(h, C, sd[f"{m}.3.norm.weight"], sd[f"{m}.3.norm.bias"])
+    h = F.conv1d(h, sd[f"{m}.3.pointwise_conv.weight"])
+    if h.size(-1) == x.size(-1):
+        return h + x
+    return h + F.interpolate(x, size=h.size(-1), mode="nearest")
+
+
+def coder_level(sd, p, hidden, level, block_strides, transposed, pad_right=0):
+    """ConvCoder1d.forward_level (convolutional_coders.py:277-291): in-projection, right zero padding BEFORE the blocks
+    (encoder) or cropping AFTER them (transposed decoder), out-projection.  Transposed coders hold their blocks in
+    mirrored order (:227-231)."""
+    if f"{p}.in_projs.{level}.0.weight" in sd:
+        hidden = F.relu(F.conv1d(hidden, sd[f"{p}.in_projs.{level}.0.weight"], sd[f"{p}.in_projs.{level}.0.bias"]))
+    if not transposed and pad_right:
+        hidden = F.pad(hidden, [0, pad_right])
+    strides = block_strides[level][::-1] if transposed else block_strides[level]
+    for b, s in enumerate(strides):
+        hidden = separable_block(sd, f"{p}.levels.{level}.{b}", hidden, s, transposed)
+    if transposed and pad_right:
+        hidden = F.pad(hidden, [0, -pad_right])
+    enc = hidden
+    if f"{p}.out_projs.{level}.0.weight" in sd:
+        enc = F.relu(F.conv1d(hidden, sd[f"{p}.out_projs.{level}.0.weight"], sd[f"{p}.out_projs.{level}.0.bias"]))
+    return hidden, enc
+
+
+def cwvae_audio_forward(sd, x, x_sl, eps, strides, num_level_layers, stride_per_layer, beta=1.0, free_nats=0.0, state0=None,
+                        residual_posterior=False, precision_posterior=False, num_mix=10, num_bins=256, prefix="cwvae"):
+    """CWVAE.forward with pad_same=True (clockwork_vae.py:200-338) for CWVAEAudio (:396-529).  x [B,T] float, x_sl [B];
+    eps[l] [T_l,B,z_l].  Levels run top-down; level l's context is the decoded cat(z, h) of level l+1; the KL of level l
+    is masked by ceil(x_sl / overall_stride_l) with free nats scaled by overall_stride_l / overall_stride_0 (:147-153);
+    reductions in fp32 as the reference (bool masks)."""
+    NL = len(strides)
+    os_ = [int(v) for v in torch.tensor(strides).cumprod(0)]
+    bs = coder_block_strides(strides, num_level_layers, stride_per_layer)
+    rfs = coder_receptive_fields(bs)
+    B, T = x.shape
+    y = x.detach().unsqueeze(-1)
+    same = []
+    for l in range(NL):
+        length = math.ceil(T / strides[l - 1]) if l > 0 else T  # (sic) clockwork_vae.py:245
+        same.append(get_same_padding(length, kernel_size=rfs[l], stride=strides[l]))
+
+    hidden, encs = x.unsqueeze(1), []
+    for l in range(NL):
+        hidden, e = coder_level(sd, f"{prefix}.encoder", hidden, l, bs, False, same[l])
+        encs.append(e)
+
+    ctx = None
+    kld_l, kld_fn_l, zs_l, hs_l, mus, state_n = [None] * NL, [None] * NL, [None] * NL, [None] * NL, [None] * NL, [None] * NL
+    for l in range(NL - 1, -1, -1):
+        enc = encs[l].permute(2, 0, 1)  # [T_l,B,E]
+        T_l = enc.size(0)
+        c = torch.zeros(T_l, B, 0, dtype=x.dtype) if ctx is None else ctx.permute(2, 0, 1)
+        cell_sd = {k[len(f"{prefix}.cells.{l}."):]: v for k, v in sd.items() if k.startswith(f"{prefix}.cells.{l}.")}
+        Z, H = cell_sd["prior.6.params.weight"].size(0) // 2, cell_sd["gru_cell.weight_hh"].size(1)
+        st0 = (torch.zeros(B, Z, dtype=x.dtype), torch.zeros(B, H, dtype=x.dtype)) if state0 is None else state0[l]
+        zs, hs, d = rssm_sequence(cell_sd, enc, c, st0, eps[l], residual_posterior=residual_posterior,
+                                  precision_posterior=precision_posterior)
+        kl = kl_gaussian(d["enc_mu"], d["enc_sd"], d["prior_mu"], d["prior_sd"])  # [T_l,B,Z]
+        sl = torch.ceil(x_sl / os_[l]).to(torch.int64)
+        mask = sequence_mask(sl, max_len=T_l).t().unsqueeze(-1)  # [T_l,B,1]
+        fn = free_nats * os_[l] / os_[0]
+        kld_l[l] = (kl * mask).sum((0, 2))
+        kld_fn_l[l] = (discount_free_nats(kl, fn) * mask).sum((0, 2))
+        stop = (sl - 1).clamp(0)
+        state_n[l] = (torch.stack([zs[t, b] for b, t in enumerate(stop)]), torch.stack([hs[t, b] for b, t in enumerate(stop)]))
+        zs_l[l], hs_l[l], mus[l] = zs, hs, (d["enc_mu"], d["prior_mu"])
+        _, ctx = coder_level(sd, f"{prefix}.decoder", torch.cat([zs, hs], -1).permute(1, 2, 0), l, bs, True, same[l])
+
+    dec = ctx.permute(0, 2, 1)  # [B,T,h]
+    # the head is registered on CWVAEAudio first (`likelihood.*`) and again inside CWVAE (`cwvae.likelihood.*`, same tensor)
+    logits, locs, log_scales = dmol_head(dec, sd["likelihood.params.weight"], sd["likelihood.params.bias"], num_mix)
+    seq_mask = sequence_mask(x_sl, max_len=T)
+    ll_twise = dmol_ll(y, logits, locs, log_scales, num_bins) * seq_mask
+    log_prob = ll_twise.view(B, -1).sum(1)
+    kld, kld_fn = sum(kld_l), sum(kld_fn_l)
+    elbo = log_prob - kld
+    loss = -(log_prob - beta * kld_fn).sum() / x_sl.sum()
+    return dict(loss=loss, elbo=elbo, log_prob=log_prob, kld=kld, kld_l=kld_l, z=zs_l, h=hs_l, mus=mus, state_n=state_n,
+                dec=dec, encodings=encs, bpd=float((-elbo.detach() / LN2).sum() / x_sl.sum()))

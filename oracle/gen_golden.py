@@ -318,6 +318,97 @@ def gen_rssm():
     save("rssm.npz", **arrays)
 
 
+def replay_eps_levels(seed, T_levels, B, z_sizes):
+    """CWVAE runs its levels top-down, one randn_like(mu) per step (clockwork_vae.py:265-279): replay that order."""
+    torch.manual_seed(seed)
+    eps = [None] * len(T_levels)
+    for l in range(len(T_levels) - 1, -1, -1):
+        eps[l] = torch.stack([torch.randn(B, z_sizes[l]) for _ in range(T_levels[l])], 0)
+    return eps
+
+
+def gen_cwvae():
+    """CWVAEAudio: reduced size with full tensors (precision-weighted and residual posteriors, ragged lengths, free nats,
+    carried state) and BASELINE config C4 dims (h=192, z=[128,64,32], strides [64,16,16], 8 blocks/level) on a short batch
+    pinned by checksums."""
+    arrays = {}
+    cfg = dict(z_size=[32, 16, 16], h_size=16, strides=[4, 2, 2], num_level_layers=2, stride_per_layer=2, likelihood="DMoL",
+               num_mix=10, num_bins=2**16)
+    B, T = 3, 150
+    x, _ = O.synth_batch(B, T, seed=17)
+    x_sl = torch.tensor([150, 97, 41])
+    x = x * (torch.arange(T).unsqueeze(0) < x_sl.unsqueeze(1))
+    arrays.update(x=x, x_sl=x_sl)
+    for tag, kw, beta, fn in (("pw", dict(precision_posterior=True), 1.0, 0.5), ("rs", dict(residual_posterior=True), 0.7, 0.0)):
+        torch.manual_seed(51)
+        m = RM.CWVAEAudio(**cfg, **kw)
+        # level lengths under same padding: ceil(previous / stride)
+        T_l, n = [], T
+        for s in cfg["strides"]:
+            n = math.ceil(n / s)
+            T_l.append(n)
+        eps = replay_eps_levels(77, T_l, B, cfg["z_size"])
+        torch.manual_seed(77)
+        loss, metrics, o = m(x, x_sl, beta=beta, free_nats=fn)
+        loss.backward()
+        arrays.update({f"{tag}_loss": loss, f"{tag}_elbo": o.elbo, f"{tag}_log_prob": o.log_prob, f"{tag}_kld": o.kld,
+                       f"{tag}_T_l": np.array(T_l)})
+        for l in range(3):
+            arrays.update({f"{tag}_eps{l}": eps[l], f"{tag}_z{l}": o.z[l], f"{tag}_enc_mu{l}": o.enc_mus[l],
+                           f"{tag}_prior_mu{l}": o.prior_mus[l], f"{tag}_z_sl{l}": o.z_sl[l],
+                           f"{tag}_state_z{l}": o.state_n[l][0], f"{tag}_state_h{l}": o.state_n[l][1]})
+        arrays[f"{tag}_params"] = o.reconstructions_parameters[0]  # logits of the DMoL head, [B,T,1,10]
+        arrays[f"{tag}_metric_names"] = np.array([mm.name for mm in metrics])
+        arrays[f"{tag}_metric_values"] = np.array([mm.value for mm in metrics], dtype=np.float64)
+        for k, v in m.state_dict().items():
+            arrays[f"{tag}_sd.{k}"] = v
+        for k, p in m.named_parameters():
+            arrays[f"{tag}_grad.{k}"] = p.grad
+        if tag == "pw":  # second call with the carried per-level state (experiment_clockwork_audio.py:263-271)
+            m.zero_grad()
+            eps2 = replay_eps_levels(5, T_l, B, cfg["z_size"])
+            state0 = [(z.detach(), h.detach()) for z, h in o.state_n]
+            torch.manual_seed(5)
+            loss2, _, o2 = m(x, x_sl, state0=state0, beta=beta, free_nats=fn)
+            arrays.update(c_loss=loss2, c_elbo=o2.elbo)
+            for l in range(3):
+                arrays[f"c_eps{l}"] = eps2[l]
+                arrays[f"c_z{l}"] = o2.z[l]
+
+    # BASELINE config C4 dimensions, short batch
+    torch.manual_seed(0)
+    full = dict(z_size=[128, 64, 32], h_size=192, strides=[64, 16, 16], num_level_layers=8, stride_per_layer=2,
+                precision_posterior=True, likelihood="DMoL", num_bins=2**16)
+    m = RM.CWVAEAudio(**full)
+    names = []
+    for k, v in m.state_dict().items():
+        names.append(k)
+        arrays[f"cks.{k}"] = np.array([v.double().sum().item(), v.double().abs().sum().item(), *v.shape], dtype=np.float64)
+    arrays["param_names"] = np.array(names)
+    Bf, Tf = 2, 16384  # lengths where the (sic) same-padding arithmetic of clockwork_vae.py:245 is consistent
+    xf, _ = O.synth_batch(Bf, Tf, seed=0)
+    xf_sl = torch.tensor([16384, 12000])
+    T_l, n = [], Tf
+    for s in full["strides"]:
+        n = math.ceil(n / s)
+        T_l.append(n)
+    eps = replay_eps_levels(123, T_l, Bf, full["z_size"])
+    torch.manual_seed(123)
+    loss, metrics, o = m(xf, xf_sl, beta=1.0, free_nats=4.0)
+    loss.backward()
+    arrays.update(f_x_sl=xf_sl, f_loss=loss, f_elbo=o.elbo, f_log_prob=o.log_prob, f_kld=o.kld, f_T_l=np.array(T_l))
+    for l in range(3):
+        arrays[f"f_z{l}"] = o.z[l]
+    arrays["f_metric_names"] = np.array([mm.name for mm in metrics])
+    arrays["f_metric_values"] = np.array([mm.value for mm in metrics], dtype=np.float64)
+    # No gradients are stored at these dimensions: at random init the C4 network is chaotic in fp32 (the reference's own
+    # fp32 activations differ by tens of percent from a float64 evaluation, and a single top-level step makes every
+    # per-channel norm of the top decoder degenerate), so its gradients are not a usable fixture.  Gradient parity is
+    # pinned on the reduced model above and per kernel at C4 widths (tests/test_gpu_convcoder.py, test_gpu_cwvae.py).
+    arrays["f_grad_names"] = np.array([k for k, _ in m.named_parameters()])
+    save("cwvae.npz", **arrays)
+
+
 def gen_lstm():
     """LSTMAudio: reduced size with full tensors, and BASELINE config C1 ([8,4000], h=256, s=64) pinned by checksums."""
     arrays = {}
@@ -362,6 +453,6 @@ def gen_lstm():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn", "wavenet", "rssm"]
+    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn", "wavenet", "rssm", "cwvae"]
     for w in which:
         globals()[f"gen_{w}"]()

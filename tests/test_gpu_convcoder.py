@@ -120,11 +120,11 @@ def _randomise_norms(module, g):
 
 
 @pytest.mark.parametrize("transposed", [False, True])
-@pytest.mark.parametrize("stride", [1, 2, 4])
-def test_separable_block_matches_torch(transposed, stride):
+@pytest.mark.parametrize("stride,C,B,L", [(1, 24, 3, 61), (2, 24, 3, 61), (4, 24, 3, 61), (2, 192, 2, 777), (1, 192, 2, 300)])
+def test_separable_block_matches_torch(transposed, stride, C, B, L):
+    """Last two cases: BASELINE C4 widths (192 -> 768 channels)."""
     torch.manual_seed(stride + 10 * transposed)
     g = torch.Generator().manual_seed(1)
-    C, B, L = 24, 3, 61
     block = BlockSeparable(C, 5, stride, 1, nn.ReLU, transposed, bias=True)
     _randomise_norms(block, g)
     ref = BlockSeparable(C, 5, stride, 1, nn.ReLU, transposed, bias=True).double()
