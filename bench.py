@@ -38,6 +38,29 @@ def cell_macs(X, H, Z, R):
     return prior + post + phi + gru  # 2,686,976 at X=H=Z=256, R=512
 
 
+def cwvae_macs(model, T):
+    """Multiply-accumulates per utterance of one CW-VAE forward: 1x1 convs + depthwise taps of every block at its own rate,
+    projections, RSSM cells (gru_in, GRU, 2x3-layer MLP + heads per step), DMoL head."""
+    cw = model.cwvae
+    h, macs = cw.h_size[0], 0
+    lens = [T]
+    for s in cw.strides:
+        lens.append(math.ceil(lens[-1] / s))
+    for coder in (cw.encoder, cw.decoder):
+        for l, level in enumerate(coder.levels):
+            n = lens[l] if not coder.transposed else lens[l + 1]
+            for blk in level:  # lengths ignore the (small) same-padding
+                n_out = n * blk.stride if coder.transposed else math.ceil(n / blk.stride)
+                macs += n * h * 4 * h + n_out * (5 * 4 * h + 4 * h * h)
+                n = n_out
+    macs += T * h + T * h * h + T * h * 30  # encoder in-projection, decoder out-projection, DMoL Linear
+    for l, cell in enumerate(cw.cells):
+        Z, C, E = cell.z_dim, cell.c_dim, cell.e_dim
+        per_step = (Z + C) * h + 6 * h * h + (h * h + 2 * h * h + 2 * Z * h) + ((h + E) * h + 2 * h * h + 2 * Z * h)
+        macs += lens[l + 1] * (per_step + (Z + h) * h)  # + decoder in-projection of cat(z, h)
+    return macs
+
+
 def cpu_baseline(B, T, steps, threads):
     """The CPU oracle (a restatement of the reference's PyTorch path, pinned to it by golden vectors) timed on the
     host cores: forward + backward + Adam on a bounded sample of the same workload."""
@@ -76,9 +99,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU (reference benchmark: --batch_len 64 s of audio)")
-    ap.add_argument("--length", type=int, default=16000, help="samples per utterance (1 s at 16 kHz)")
-    ap.add_argument("--model", default="vrnn", choices=["vrnn", "srnn", "lstm", "wavenet"], help="vrnn = BASELINE headline (configs[1])")
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default 64 = the reference's --batch_len 64 s of audio; cwvae: 8)")
+    ap.add_argument("--length", type=int, default=None, help="samples per utterance (default 16000 = 1 s at 16 kHz; cwvae: 49152)")
+    ap.add_argument("--model", default="vrnn", choices=["vrnn", "srnn", "lstm", "wavenet", "cwvae"], help="vrnn = BASELINE headline (configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=10)
@@ -96,11 +119,15 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from blvm import _hip, ops
-    from blvm.models import LSTMAudio, SRNNAudio, VRNNAudio, WaveNet
+    from blvm.models import CWVAEAudio, LSTMAudio, SRNNAudio, VRNNAudio, WaveNet
     from blvm.modules.distributions import DiscretizedLogisticMixtureDense
     from blvm.training.ddp import FlatGradAllReduce
 
     assert _hip.load().blvm_device_ok() == 1, "libblvm_hip: no gfx950 device"
+    if args.batch is None:
+        args.batch = 8 if args.model == "cwvae" else 64  # SURVEY §8d shapes per config (C4: [8, 49152] per GPU)
+    if args.length is None:
+        args.length = 49152 if args.model == "cwvae" else 16000
     B, T, S, H, Z = args.batch, args.length, 64, 256, 256
     Tp = math.ceil(T / S)
     torch.manual_seed(0)  # identical weights on every rank
@@ -111,6 +138,9 @@ def main():
     elif args.model == "wavenet":
         lik = DiscretizedLogisticMixtureDense(96, 1, num_mix=10, num_bins=2**16)
         model = WaveNet(likelihood=lik, n_layers=10, n_stacks=5, res_channels=96, kernel_size=2, base_dilation=2, n_stack_frames=1).to(dev)
+    elif args.model == "cwvae":  # BASELINE config C4
+        model = CWVAEAudio(z_size=[128, 64, 32], h_size=192, strides=[64, 16, 16], num_level_layers=8, stride_per_layer=2,
+                           precision_posterior=True, likelihood="DMoL", num_bins=2**16).to(dev)  # fmt: skip
     else:
         model = LSTMAudio(stack_size=S, hidden_size=H, num_layers=1, num_mix=10, num_bins=2**16).to(dev)
     params = list(model.parameters())
@@ -146,7 +176,12 @@ def main():
 
     def step():
         opt.zero_grad(set_to_none=True)
-        loss, metrics, out = model(x, x_sl, beta=1.0, free_nats=2.0) if args.model in ("vrnn", "srnn") else model(x, x_sl)
+        if args.model in ("vrnn", "srnn"):
+            loss, metrics, out = model(x, x_sl, beta=1.0, free_nats=2.0)
+        elif args.model == "cwvae":
+            loss, metrics, out = model(x, x_sl, beta=1.0, free_nats=4.0)  # experiment_clockwork_audio.py:64 default
+        else:
+            loss, metrics, out = model(x, x_sl)
         loss.backward()
         if reducer is not None:
             reducer(float(B * T))
@@ -185,7 +220,7 @@ def main():
     log(f"timed {args.steps} steps: {ms_step:.2f} ms/step; host enqueue per step: seq_fwd {host['fwd'] / args.steps * 1e3:.2f} ms, "
         f"seq_bwd {host['bwd'] / args.steps * 1e3:.2f} ms")
     frames = world * B * T * args.steps
-    if args.model in ("lstm", "wavenet"):  # no hooked recurrent-cell call: whole step against the model's matmul FLOPs
+    if args.model in ("lstm", "wavenet", "cwvae"):  # no hooked recurrent-cell call: whole step against the model's matmul FLOPs
         fwd_ms, bwd_ms = ms_step / 3, 2 * ms_step / 3
     else:
         cell_ms = [(e[0].elapsed_time(e[1]), e[2].elapsed_time(e[3])) for e in ev]
@@ -201,12 +236,15 @@ def main():
     elif args.model == "wavenet":
         macs = 2777088 * B * T  # algorithmic MAC per frame, 5x10 blocks, C=96, k=2
         kname = "WaveNet whole train step (conv/MFMA path: 50 gated residual blocks as shifted-view GEMMs)"
+    elif args.model == "cwvae":
+        macs = cwvae_macs(model, T) * B
+        kname = "CW-VAE whole train step (1x1-conv GEMMs of 48 separable blocks + 3 RSSM levels; the depthwise/norm passes are HBM-bound)"
     else:
         macs = (S * H + 2 * H * H + 8 * H * H + 2 * H * H + H * 30 * S + 900 * S) * B * (Tp - 1)
         kname = "LSTMAudio whole train step (matmul FLOPs of embedding + LSTM + decoder + DMoL Linear)"
     flops_fb = 3 * 2 * macs  # forward + dgrad + wgrad
     achieved = flops_fb / ((fwd_ms + bwd_ms) * 1e-3) / 1e12
-    bpd = {m.name: m.value for m in last["metrics"]}["bpd"]
+    bpd = {m.name: m.value for m in last["metrics"]}["elbo (bpt)" if args.model == "cwvae" else "bpd"]
 
     if rank == 0:
         res = {
@@ -224,7 +262,9 @@ def main():
             "data": "synthetic",
             "bits_per_dim": bpd,
             "config": {
-                "workload": f"experiment_{args.model}_audio.py: {type(model).__name__} DMoL s=64 h=256 z=256, synthetic mu-law [{B},1,{T}] per GPU "
+                "workload": (f"experiment_clockwork_audio.py: CWVAEAudio DMoL h=192 z=[128,64,32] strides [64,16,16] 8 blocks/level precision posterior, "
+                             f"synthetic mu-law [{B},1,{T}] per GPU, full train step fwd+bwd+clip+Adam, random init") if args.model == "cwvae" else
+                            f"experiment_{args.model}_audio.py: {type(model).__name__} DMoL s=64 h=256 z=256, synthetic mu-law [{B},1,{T}] per GPU "
                             f"(T'={Tp} recurrent steps), full train step fwd+bwd+clip+Adam, random init",
                 "batch_per_gpu": B, "global_batch": world * B, "samples_per_utterance": T, "parallelism": f"dp{world}",
             },

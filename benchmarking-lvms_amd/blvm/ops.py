@@ -51,7 +51,23 @@ def colsum(X2d: torch.Tensor, out: torch.Tensor, accumulate=False):
     check(load().blvm_colsum_f32(M, N, ptr(X2d), X2d.stride(0), ptr(out), int(accumulate), stream_ptr()), "blvm_colsum_f32")
 
 
+def _zeros_like_many(tensors):
+    """Zero-initialised gradient buffers for `tensors` carved out of ONE allocation (one fill launch instead of one per
+    tensor; offsets kept 16-byte aligned)."""
+    sizes = [(t.numel() + 3) // 4 * 4 for t in tensors]
+    flat = torch.zeros(sum(sizes), device=tensors[0].device, dtype=torch.float32)
+    out, off = [], 0
+    for t, n in zip(tensors, sizes):
+        out.append(flat[off : off + t.numel()].view(t.shape))
+        off += n
+    return out
+
+
 def _pick_split(M, N, K):
+    """Split-K factor of a weight-gradient GEMM [M,N] += A^T B over K rows: enough workgroups to fill 256 CUs."""
+    if K >= 65536 and M >= 128 and N >= 128:  # conv-coder wgrads: K = L*B ~ 4e5 rows, 128x128 tiles, ~4 workgroups per CU
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        return max(1, min((1024 + tiles - 1) // tiles, K // 2048))
     tiles = ((M + 63) // 64) * ((N + 63) // 64)
     s = (768 + tiles - 1) // tiles
     return max(1, min(s, (K + 255) // 256))
@@ -326,7 +342,7 @@ class _VRNNSeqFunction(torch.autograd.Function):
         d_decin = _f32c(d_decin) if d_decin is not None else torch.zeros_like(decin)
         c_raw = g_kld.to(torch.float32).contiguous() if g_kld is not None else None
         c_fn = g_kld_fn.to(torch.float32).contiguous() if g_kld_fn is not None else None
-        grads = [torch.zeros_like(p) for p in params]
+        grads = _zeros_like_many(params)
         d_enc = torch.empty_like(enc)
         d_h0 = torch.empty(B, R, **f32) if ctx.has_h0 else None
         ws = torch.empty(lib.blvm_vrnn_bwd_workspace_floats(Tp, B, X, H, Z, R), **f32)
@@ -524,7 +540,7 @@ class _SRNNLatentFunction(torch.autograd.Function):
         d_z = d_zs[1:]  # rows 1.. are the sampled latents; row 0 is z0 (its direct gradient is added below)
         c_raw = g_kld.to(torch.float32).contiguous() if g_kld is not None else None
         c_fn = g_kld_fn.to(torch.float32).contiguous() if g_kld_fn is not None else None
-        grads = [torch.zeros_like(p) for p in params]
+        grads = _zeros_like_many(params)
         d_d, d_a = torch.empty_like(d), torch.empty_like(a)
         d_z0 = torch.empty(B, Z, **f32) if ctx.has_z0 else None
         ws = torch.empty(lib.blvm_srnn_bwd_workspace_floats(Tp, B, H, Z, R), **f32)
@@ -663,7 +679,7 @@ class _WaveNetStackFunction(torch.autograd.Function):
         f32 = dict(device=d_skip.device, dtype=torch.float32)
         d_skip = _f32c(d_skip)
         ws = torch.empty(lib.blvm_wavenet_block_workspace_floats(L, B, C, S, 1), **f32)
-        grads = [torch.zeros_like(p) for p in params]
+        grads = _zeros_like_many(params)
         d_o = None
         for i in range(n - 1, -1, -1):
             cw, _, rw, _ = params[4 * i : 4 * i + 4]
@@ -755,7 +771,7 @@ class _RSSMSeqFunction(torch.autograd.Function):
         d_hs = _f32c(d_hs) if d_hs is not None else torch.zeros_like(hs)
         c_raw = g_kld.to(torch.float32).contiguous() if g_kld is not None else None
         c_fn = g_kld_fn.to(torch.float32).contiguous() if g_kld_fn is not None else None
-        grads = [torch.zeros_like(p) for p in params]
+        grads = _zeros_like_many(params)
         d_enc = torch.empty_like(enc)
         d_ctx = torch.empty_like(ctx) if has_ctx else None
         d_z0 = torch.empty(B, Z, **f32) if has_z0 else None
@@ -940,24 +956,20 @@ class _SepBlockFunction(torch.autograd.Function):
         M, M2 = L * B, L2 * B
         dev = x.device
         # pointwise 4C->C
-        dwp = torch.zeros_like(wp)
+        dwp, dg2, dbe2, dwd, dbd, dg1, dbe1, dw1 = _zeros_like_many([wp, g2, g2, wd, g2, g1, g1, w1])
         gemm(1, 1, C, Cb, M2, dout, C, n2, Cb, dwp, Cb, accumulate=True, split_k=_pick_split(C, Cb, M2))
         dn2 = torch.empty(L2, B, Cb, device=dev, dtype=torch.float32)
         gemm(0, 1, M2, Cb, C, dout, C, wp, Cb, dn2, Cb)
         # norm 2 (+ the ReLU in front of it: d > 0 <=> pre-activation > 0)
-        dg2, dbe2 = torch.zeros_like(g2), torch.zeros_like(g2)
         dd = _chan_norm_bwd(d, dn2, mr2, g2, True, dg2, dbe2)
         del dn2
         # depthwise conv
-        dwd, dbd = torch.zeros_like(wd), torch.zeros(Cb, device=dev, dtype=torch.float32)
         dn1 = _dwconv_bwd(n1, wd, None, dd, stride, dilation, transposed, False, True, dwd, dbd)
         del dd
         # norm 1 (+ ReLU of the 1x1 conv)
-        dg1, dbe1 = torch.zeros_like(g1), torch.zeros_like(g1)
         da1 = _chan_norm_bwd(a1, dn1, mr1, g1, True, dg1, dbe1)
         del dn1
         # 1x1 conv C->4C
-        dw1 = torch.zeros_like(w1)
         gemm(1, 1, Cb, C, M, da1, Cb, x, C, dw1, C, accumulate=True, split_k=_pick_split(Cb, C, M))
         db1 = torch.empty(Cb, device=dev, dtype=torch.float32)
         colsum(da1.view(M, Cb), db1)

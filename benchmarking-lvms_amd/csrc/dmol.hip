@@ -247,7 +247,15 @@ __global__ __launch_bounds__(256) void dmol_kernel(DmolArgs a) {
   if (!BWD) {
     const float llm = fc.valid ? ll : 0.f;
     if (a.ll_twise != nullptr && fc.valid) a.ll_twise[(size_t)fc.b * a.T + fc.tau] = llm;
-    // per-utterance fp64 sums
+    // per-utterance fp64 sums: wave-uniform utterance -> shuffle reduction + one atomic per wave; otherwise (time-major
+    // single-frame rows interleave the whole batch inside a wave) reduce per utterance in LDS first, so that the global
+    // fp64 atomics are one per (workgroup, utterance) instead of one per frame on B hot addresses.
+    __shared__ double part[256];
+    const bool lds_path = a.B <= 256;
+    if (lds_path) {
+      part[threadIdx.x] = 0.0;
+      __syncthreads();
+    }
     const int b0 = __builtin_amdgcn_readfirstlane(fc.b);
     const bool uniform = __all((fc.b == b0) || !fc.valid);
     if (uniform) {
@@ -259,10 +267,18 @@ __global__ __launch_bounds__(256) void dmol_kernel(DmolArgs a) {
       if (vm != 0ull) {
         const int src = __ffsll((long long)vm) - 1;
         const int bb = __shfl(fc.b, src, 64);
-        if ((threadIdx.x & 63) == 0) atomicAdd(a.log_prob + bb, v);
+        if ((threadIdx.x & 63) == 0) {
+          if (lds_path) atomicAdd(&part[bb], v);
+          else atomicAdd(a.log_prob + bb, v);
+        }
       }
     } else if (fc.valid) {
-      atomicAdd(a.log_prob + fc.b, (double)llm);
+      if (lds_path) atomicAdd(&part[fc.b], (double)llm);
+      else atomicAdd(a.log_prob + fc.b, (double)llm);
+    }
+    if (lds_path) {
+      __syncthreads();
+      if ((int)threadIdx.x < a.B && part[threadIdx.x] != 0.0) atomicAdd(a.log_prob + threadIdx.x, part[threadIdx.x]);
     }
   } else {
     const float g = fc.valid ? a.g_b[fc.b] : 0.f;

@@ -254,7 +254,12 @@ int gemm_f32(int op_a, int op_b, int M, int N, int K, const float* A, int lda, c
   g.b_vec = aligned16(B) && (ldb % 4 == 0);
   if (split_k < 1) split_k = 1;
   const bool big = (M >= 128 && N >= 128 && (size_t)((M + 127) / 128) * ((N + 127) / 128) * split_k >= 192);
-  const int bm = big ? 128 : 64;
+  // 192-wide tiles for the conv coders' channel counts (192 = 1.5 x 128 would waste a quarter of a 128-tile pair and
+  // re-read the other operand): N % 192 == 0 -> 128x192, else M % 192 == 0 -> 192x128
+  const bool n192 = big && N % 192 == 0 && N % 128 != 0;
+  const bool m192 = big && !n192 && M % 192 == 0 && M % 128 != 0;
+  const int bm = big ? (m192 ? 192 : 128) : 64;
+  const int bn = big ? (n192 ? 192 : 128) : 64;
   int ksteps = (K + BK - 1) / BK;
   if (split_k > ksteps) split_k = ksteps > 0 ? ksteps : 1;
   g.k_per_split = ((ksteps + split_k - 1) / split_k) * BK;
@@ -262,11 +267,13 @@ int gemm_f32(int op_a, int op_b, int M, int N, int K, const float* A, int lda, c
   split_k = (K + g.k_per_split - 1) / g.k_per_split;
   if (split_k < 1) split_k = 1;
   BLVM_REQUIRE(split_k == 1 || (act == 0 && gate == nullptr), "gemm: split-K needs a linear epilogue");
-  dim3 grid((N + bm - 1) / bm, (M + bm - 1) / bm, split_k);
+  dim3 grid((N + bn - 1) / bn, (M + bm - 1) / bm, split_k);
   BLVM_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
   if (split_k > 1 && !accumulate)  // atomic accumulation needs a zeroed destination
     BLVM_HIP(hipMemset2DAsync(C, sizeof(float) * (size_t)ldc, 0, sizeof(float) * (size_t)N, (size_t)M, stream));
-  if (big) launch_gemm<128, 128>(g, op_a, op_b, grid, stream);
+  if (n192) launch_gemm<128, 192>(g, op_a, op_b, grid, stream);
+  else if (m192) launch_gemm<192, 128>(g, op_a, op_b, grid, stream);
+  else if (big) launch_gemm<128, 128>(g, op_a, op_b, grid, stream);
   else launch_gemm<64, 64>(g, op_a, op_b, grid, stream);
   BLVM_CHECK_LAUNCH("gemm_f32");
   return BLVM_OK;

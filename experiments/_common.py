@@ -114,7 +114,7 @@ def run(args, model, forward_train, forward_eval, best_metric, num_bits, split_e
             value = tracker.values("test").get(best_metric)
             if rank == 0 and value is not None:
                 print(f"           test {best_metric} {value:.4f}", flush=True)
-                improved = best is None or (value > best if best_metric.startswith("elbo") else value < best)
+                improved = best is None or (value > best if best_metric == "elbo" else value < best)  # "elbo" in nats: max; bits / loss: min
                 if improved:
                     best = value
                     if args.save_checkpoints and args.checkpoint_dir:

@@ -145,7 +145,7 @@ def test_separable_block_matches_torch(transposed, stride, C, B, L):
     pr = dict(ref.named_parameters())
     for n, p in block.named_parameters():
         assert p.grad is not None, n
-        assert rel_l2(p.grad, pr[n].grad) < 1e-4, n
+        assert rel_l2(p.grad, pr[n].grad) < 3e-4, n  # fp32 GEMM weight gradients over L*B rows vs float64
 
 
 @pytest.mark.parametrize("transposed", [False, True])

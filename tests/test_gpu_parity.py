@@ -73,6 +73,19 @@ def test_gemm_split_k_gate_accumulate_and_strides():
     assert rel_l2(C2, ref * torch.where(gate > 0, 1.0, 0.01)) < 2e-6
 
 
+@pytest.mark.parametrize("op_a,op_b,M,N,K,split", [(0, 0, 16400, 192, 200, 1), (0, 1, 16385, 576, 192, 1), (1, 1, 192, 768, 30000, 40),
+                                                    (1, 0, 384, 130, 20001, 24), (0, 0, 12290, 384, 100, 1)])
+def test_gemm_192_wide_tiles(op_a, op_b, M, N, K, split):
+    """Conv-coder channel counts (192 / 576 / 384 = odd multiples of 64...) take the 128x192 / 192x128 tile variants."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(*((K, M) if op_a else (M, K)), generator=g)
+    Bm = torch.randn(*((K, N) if op_b else (N, K)), generator=g)
+    ref = (A.t() if op_a else A).double() @ (Bm if op_b else Bm.t()).double()
+    C = torch.full((M, N), 2.0, device=DEV)
+    ops.gemm(op_a, op_b, M, N, K, A.to(DEV), A.shape[1], Bm.to(DEV), Bm.shape[1], C, N, accumulate=True, split_k=split)
+    assert rel_l2(C, ref + 2) < 3e-6
+
+
 def test_mlp_function_forward_backward_vs_torch():
     torch.manual_seed(3)
     lins = [torch.nn.Linear(24, 64), torch.nn.Linear(64, 64), torch.nn.Linear(64, 48)]
