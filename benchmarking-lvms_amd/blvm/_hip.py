@@ -105,11 +105,12 @@ _SIGNATURES = {
     "blvm_rssm_seq_bwd": (c_int, [ctypes.POINTER(RssmWeights)] + [c_void_p] * 15 + [c_int, c_float] + [c_int] * 7 + [c_float]
                           + [c_void_p] * 4 + [ctypes.POINTER(RssmWeights), c_void_p, c_void_p]),
     "blvm_chan_norm_workspace_doubles": (c_size_t, [c_int]),
+    "blvm_chan_norm_stats": (c_int, [c_void_p] + [c_int] * 3 + [c_void_p] * 2 + [c_float] + [c_void_p] * 4),
     "blvm_chan_norm_fwd": (c_int, [c_void_p] + [c_int] * 3 + [c_void_p] * 2 + [c_float] + [c_void_p] * 4),
-    "blvm_chan_norm_bwd": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p] * 5),
+    "blvm_chan_norm_bwd": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p] * 6),
     "blvm_dwconv_out_length": (c_int, [c_int] * 5),
-    "blvm_dwconv_fwd": (c_int, [c_void_p] * 3 + [c_int] * 8 + [c_void_p] * 2),
-    "blvm_dwconv_bwd": (c_int, [c_void_p] * 4 + [c_int] * 8 + [c_void_p] * 4),
+    "blvm_dwconv_fwd": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p] * 2),
+    "blvm_dwconv_bwd": (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_void_p] * 4),
     "blvm_resample_add_fwd": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p] * 2),
     "blvm_resample_add_bwd": (c_int, [c_void_p] + [c_int] * 3 + [c_void_p] * 2),
 }  # fmt: skip

@@ -815,32 +815,44 @@ def _chan_norm_fwd(x, gamma, beta, eps):
     return y, mr
 
 
-def _chan_norm_bwd(x, dy, mr, gamma, relu_mask, dgamma, dbeta):
+def _chan_norm_stats(x, gamma, beta, eps):
+    """Statistics only: mr [2,N] = [mean | rstd] and the column affine ss [2,N] with norm(x) = x * ss[0] + ss[1]."""
+    L, B, C = x.shape
+    mr, ss = (torch.empty(2, B * C, device=x.device, dtype=torch.float32) for _ in range(2))
+    check(load().blvm_chan_norm_stats(ptr(x), L, B * C, C, ptr(gamma), ptr(beta), eps, ptr(mr), ptr(ss),
+                                      ptr(_norm_ws(B * C, x.device)), stream_ptr()), "blvm_chan_norm_stats")  # fmt: skip
+    return mr, ss
+
+
+def _chan_norm_bwd(x, dy, mr, gamma, relu_mask, dgamma, dbeta, dx_chan_sum=None):
     L, B, C = x.shape
     dx = torch.empty_like(x)
     check(load().blvm_chan_norm_bwd(ptr(x), ptr(dy), ptr(mr), ptr(gamma), L, B * C, C, int(relu_mask), ptr(dx), ptr(dgamma),
-                                    ptr(dbeta), ptr(_norm_ws(B * C, x.device)), stream_ptr()), "blvm_chan_norm_bwd")  # fmt: skip
+                                    ptr(dbeta), ptr(dx_chan_sum), ptr(_norm_ws(B * C, x.device)), stream_ptr()),
+          "blvm_chan_norm_bwd")  # fmt: skip
     return dx
 
 
-def _dwconv_fwd(x, w, bias, stride, dilation, transposed, relu):
+def _dwconv_fwd(x, w, bias, stride, dilation, transposed, relu, in_affine=None):
     L, B, C = x.shape
     k = w.shape[-1]
     L_out = load().blvm_dwconv_out_length(L, k, stride, dilation, int(transposed))
     if L_out <= 0:
         raise _hip.BlvmHipError(f"depthwise conv: input length {L} is shorter than the kernel ({k=}, {dilation=})")
     y = torch.empty(L_out, B, C, device=x.device, dtype=torch.float32)
-    check(load().blvm_dwconv_fwd(ptr(x), ptr(w), ptr(bias), L, B * C, C, k, stride, dilation, int(transposed), int(relu), ptr(y),
-                                 stream_ptr()), "blvm_dwconv_fwd")  # fmt: skip
+    sc, sh = (in_affine[0], in_affine[1]) if in_affine is not None else (None, None)
+    check(load().blvm_dwconv_fwd(ptr(x), ptr(sc), ptr(sh), ptr(w), ptr(bias), L, B * C, C, k, stride, dilation, int(transposed),
+                                 int(relu), ptr(y), stream_ptr()), "blvm_dwconv_fwd")  # fmt: skip
     return y
 
 
-def _dwconv_bwd(x, w, y, dy, stride, dilation, transposed, relu, need_dx, dw, dbias):
+def _dwconv_bwd(x, w, y, dy, stride, dilation, transposed, relu, need_dx, dw, dbias, in_affine=None):
     L, B, C = x.shape
     k = w.shape[-1]
     dx = torch.empty_like(x) if need_dx else None
-    check(load().blvm_dwconv_bwd(ptr(x), ptr(w), ptr(y), ptr(dy), L, B * C, C, k, stride, dilation, int(transposed), int(relu),
-                                 ptr(dx), ptr(dw), ptr(dbias), stream_ptr()), "blvm_dwconv_bwd")  # fmt: skip
+    sc, sh = (in_affine[0], in_affine[1]) if in_affine is not None else (None, None)
+    check(load().blvm_dwconv_bwd(ptr(x), ptr(sc), ptr(sh), ptr(w), ptr(y), ptr(dy), L, B * C, C, k, stride, dilation,
+                                 int(transposed), int(relu), ptr(dx), ptr(dw), ptr(dbias), stream_ptr()), "blvm_dwconv_bwd")  # fmt: skip
     return dx
 
 
@@ -934,8 +946,8 @@ class _SepBlockFunction(torch.autograd.Function):
         Cb = w1.shape[0]
         a1 = torch.empty(L, B, Cb, device=x.device, dtype=torch.float32)
         gemm(0, 0, L * B, Cb, C, x, C, w1, C, a1, Cb, bias=b1, act=ACT_RELU)
-        n1, mr1 = _chan_norm_fwd(a1, g1, be1, eps)
-        d = _dwconv_fwd(n1, wd, bd, stride, dilation, transposed, True)
+        mr1, ss1 = _chan_norm_stats(a1, g1, be1, eps)  # norm 1 is applied inside the stencil's loads: never materialised
+        d = _dwconv_fwd(a1, wd, bd, stride, dilation, transposed, True, in_affine=ss1)
         n2, mr2 = _chan_norm_fwd(d, g2, be2, eps)
         L2 = d.shape[0]
         r = torch.empty(L2, B, C, device=x.device, dtype=torch.float32)
@@ -943,20 +955,20 @@ class _SepBlockFunction(torch.autograd.Function):
         out = torch.empty_like(r)
         check(load().blvm_resample_add_fwd(ptr(r), ptr(x), L2, L, B * C, ptr(out), stream_ptr()), "blvm_resample_add_fwd")
         ctx.cfg = cfg
-        ctx.save_for_backward(x, a1, mr1, n1, d, mr2, n2, w1, g1, wd, g2, wp)
+        ctx.save_for_backward(x, a1, mr1, ss1, d, mr2, n2, w1, g1, wd, g2, wp)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         stride, dilation, transposed, eps = ctx.cfg
-        x, a1, mr1, n1, d, mr2, n2, w1, g1, wd, g2, wp = ctx.saved_tensors
+        x, a1, mr1, ss1, d, mr2, n2, w1, g1, wd, g2, wp = ctx.saved_tensors
         dout = _f32c(dout)
         L, B, C = x.shape
         L2, Cb = d.shape[0], w1.shape[0]
         M, M2 = L * B, L2 * B
         dev = x.device
         # pointwise 4C->C
-        dwp, dg2, dbe2, dwd, dbd, dg1, dbe1, dw1 = _zeros_like_many([wp, g2, g2, wd, g2, g1, g1, w1])
+        dwp, dg2, dbe2, dwd, dbd, dg1, dbe1, dw1, db1 = _zeros_like_many([wp, g2, g2, wd, g2, g1, g1, w1, g1])
         gemm(1, 1, C, Cb, M2, dout, C, n2, Cb, dwp, Cb, accumulate=True, split_k=_pick_split(C, Cb, M2))
         dn2 = torch.empty(L2, B, Cb, device=dev, dtype=torch.float32)
         gemm(0, 1, M2, Cb, C, dout, C, wp, Cb, dn2, Cb)
@@ -964,15 +976,13 @@ class _SepBlockFunction(torch.autograd.Function):
         dd = _chan_norm_bwd(d, dn2, mr2, g2, True, dg2, dbe2)
         del dn2
         # depthwise conv
-        dn1 = _dwconv_bwd(n1, wd, None, dd, stride, dilation, transposed, False, True, dwd, dbd)
+        dn1 = _dwconv_bwd(a1, wd, None, dd, stride, dilation, transposed, False, True, dwd, dbd, in_affine=ss1)
         del dd
         # norm 1 (+ ReLU of the 1x1 conv)
-        da1 = _chan_norm_bwd(a1, dn1, mr1, g1, True, dg1, dbe1)
+        da1 = _chan_norm_bwd(a1, dn1, mr1, g1, True, dg1, dbe1, dx_chan_sum=db1)  # db1 = column sums of da1, same pass
         del dn1
         # 1x1 conv C->4C
         gemm(1, 1, Cb, C, M, da1, Cb, x, C, dw1, C, accumulate=True, split_k=_pick_split(Cb, C, M))
-        db1 = torch.empty(Cb, device=dev, dtype=torch.float32)
-        colsum(da1.view(M, Cb), db1)
         dx = None
         if ctx.needs_input_grad[0]:
             if L2 == L:

@@ -292,23 +292,33 @@ int blvm_rssm_seq_bwd(const BlvmRssmWeights* w, const float* enc, const float* c
  * chan_norm: nn.GroupNorm(num_groups=C, C) == per-(sample,channel) normalisation over time, biased variance, eps;
  *   y = (x-mean)*rstd*gamma_c + beta_c;  mr [2,N] receives [mean | rstd] (kept for backward);
  *   workspace: blvm_chan_norm_workspace_doubles(N) float64.
- *   bwd: dx (relu_mask=1 multiplies by (x>0): a ReLU feeding the norm), dgamma/dbeta ACCUMULATED (may be NULL).
+ *   blvm_chan_norm_stats: statistics only — mr and the column affine scale_shift [2,N] = [rstd*gamma | beta - mean*rstd*gamma]
+ *   for consumers that normalise on load (blvm_dwconv_*'s in_scale / in_shift), so the normalised tensor never hits HBM.
+ *   bwd: dx (relu_mask=1 multiplies by (x>0): a ReLU feeding the norm), dgamma/dbeta ACCUMULATED (may be NULL),
+ *   dx_chan_sum [C] (may be NULL) += sum over rows and samples of dx (the bias gradient of the layer that produced x).
  * dwconv: depthwise Conv1d (transposed=0: L_out=(L_in-k_eff)/stride+1) or ConvTranspose1d (transposed=1:
  *   L_out=(L_in-1)*stride+k_eff), k<=8, no padding (callers pad), weights [C,k] (= torch [C,1,k]), bias [C] or NULL,
- *   relu=1 fuses a ReLU on the output (bwd then needs y).  bwd: dx (may be NULL), dw/dbias ACCUMULATED (may be NULL).
+ *   relu=1 fuses a ReLU on the output (bwd then needs y).  in_scale/in_shift ([N] each, or both NULL): the convolution
+ *   runs on x*in_scale + in_shift (column-wise).  bwd: dx = gradient wrt that transformed input (may be NULL),
+ *   dw/dbias ACCUMULATED (may be NULL).
  * resample_add: out[t] = y[t] + x[nearest(t)], nearest(t)=min(floor(t*float(L_in)/L_out), L_in-1) (F.interpolate
  *   mode='nearest');  bwd ACCUMULATES dout into dx [L_in,N] (dy is dout itself).
  * ------------------------------------------------------------------------------------------------------------- */
 size_t blvm_chan_norm_workspace_doubles(int N);
+int blvm_chan_norm_stats(const float* x, int L, int N, int C, const float* gamma, const float* beta, float eps, float* mr,
+                         float* scale_shift, double* workspace, void* stream);
 int blvm_chan_norm_fwd(const float* x, int L, int N, int C, const float* gamma, const float* beta, float eps, float* y,
                        float* mr, double* workspace, void* stream);
 int blvm_chan_norm_bwd(const float* x, const float* dy, const float* mr, const float* gamma, int L, int N, int C,
-                       int relu_mask, float* dx, float* dgamma, float* dbeta, double* workspace, void* stream);
+                       int relu_mask, float* dx, float* dgamma, float* dbeta, float* dx_chan_sum, double* workspace,
+                       void* stream);
 int blvm_dwconv_out_length(int L_in, int k, int stride, int dilation, int transposed);
-int blvm_dwconv_fwd(const float* x, const float* w, const float* bias, int L_in, int N, int C, int k, int stride,
-                    int dilation, int transposed, int relu, float* y, void* stream);
-int blvm_dwconv_bwd(const float* x, const float* w, const float* y, const float* dy, int L_in, int N, int C, int k,
-                    int stride, int dilation, int transposed, int relu, float* dx, float* dw, float* dbias, void* stream);
+int blvm_dwconv_fwd(const float* x, const float* in_scale, const float* in_shift, const float* w, const float* bias,
+                    int L_in, int N, int C, int k, int stride, int dilation, int transposed, int relu, float* y,
+                    void* stream);
+int blvm_dwconv_bwd(const float* x, const float* in_scale, const float* in_shift, const float* w, const float* y,
+                    const float* dy, int L_in, int N, int C, int k, int stride, int dilation, int transposed, int relu,
+                    float* dx, float* dw, float* dbias, void* stream);
 int blvm_resample_add_fwd(const float* y, const float* x, int L_out, int L_in, int N, float* out, void* stream);
 int blvm_resample_add_bwd(const float* dout, int L_out, int L_in, int N, float* dx, void* stream);
 
