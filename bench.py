@@ -61,6 +61,18 @@ def cwvae_macs(model, T):
     return macs
 
 
+def pmc_traffic(model, B, T):
+    """HBM-side bytes per train step of the dominant kernel, from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE in separate runs, FETCH_SIZE doubled on gfx950 per MI355X_MICROARCH.md) — counters cannot be read from inside
+    the timed process, so this is the profile of the same command, valid for the workload it was taken on only."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_vrnn_pmc_traffic.json")
+    if model != "vrnn" or (B, T) != (64, 16000) or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    return d["cell_stage_kernels_read_bytes_per_step"] + d["cell_stage_kernels_write_bytes_per_step"]
+
+
 def cpu_baseline(B, T, steps, threads):
     """The CPU oracle (a restatement of the reference's PyTorch path, pinned to it by golden vectors) timed on the
     host cores: forward + backward + Adam on a bounded sample of the same workload."""
@@ -275,7 +287,7 @@ def main():
                 "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                "traffic": None,
+                "traffic": pmc_traffic(args.model, B, T),
                 "flops_per_call": flops_fb,
                 "fwd_ms": fwd_ms,
                 "bwd_ms": bwd_ms,
