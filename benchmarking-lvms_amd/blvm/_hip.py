@@ -104,6 +104,8 @@ _SIGNATURES = {
     "blvm_rssm_seq_fwd": (c_int, [ctypes.POINTER(RssmWeights)] + [c_void_p] * 5 + [c_int] * 7 + [c_float] + [c_void_p] * 8),
     "blvm_rssm_seq_bwd": (c_int, [ctypes.POINTER(RssmWeights)] + [c_void_p] * 15 + [c_int, c_float] + [c_int] * 7 + [c_float]
                           + [c_void_p] * 4 + [ctypes.POINTER(RssmWeights), c_void_p, c_void_p]),
+    "blvm_gauss_latent_fwd": (c_int, [c_void_p] * 5 + [c_size_t] + [c_float] * 3 + [c_int] + [c_void_p] * 5),
+    "blvm_gauss_latent_bwd": (c_int, [c_void_p] * 9 + [c_size_t] + [c_float] * 3 + [c_int] + [c_void_p] * 5),
     "blvm_chan_norm_workspace_doubles": (c_size_t, [c_int]),
     "blvm_chan_norm_stats": (c_int, [c_void_p] + [c_int] * 3 + [c_void_p] * 2 + [c_float] + [c_void_p] * 4),
     "blvm_chan_norm_fwd": (c_int, [c_void_p] + [c_int] * 3 + [c_void_p] * 2 + [c_float] + [c_void_p] * 4),

@@ -100,15 +100,16 @@ class ResidualStack(nn.Module):
             out.append(r)
         return out
 
-    def forward_tm(self, x: torch.Tensor, skip_size: int):
+    def forward_tm(self, x: torch.Tensor, skip_size: int, groups=None):
         """x [L,B,C_in] -> sum of the blocks' skip outputs [skip_size,B,S] (the reference returns the list and sums it
-        in WaveNet.forward, wavenet.py:197-198)."""
+        in WaveNet.forward, wavenet.py:197-198).  `groups` (one entry per block: output index or -1) instead returns a
+        tuple of partial sums — STCN reads only the last skip of every stack (stcn.py:299)."""
         L, B, C = x.shape
         t = self.in_transform
         o = ops.linear(x.reshape(L * B, C), t.weight.view(t.out_channels, C), t.bias).view(L, B, -1)
         blk = self.res_blocks[0]
         return ops.wavenet_stack(o, [b.kernel_params() for b in self.res_blocks], self.dilations, skip_size, blk.inv_std,
-                                 blk.skip_channels)  # fmt: skip
+                                 blk.skip_channels, groups=groups)  # fmt: skip
 
 
 class PointwiseTransform(nn.Module):

@@ -281,6 +281,37 @@ _VRNN_PARAM_ORDER = (
 )
 
 
+class _GaussLatentFunction(torch.autograd.Function):
+    """(mu_p, sd_p_raw, mu_q_raw, sd_q_raw, eps) -> (sd_p, mu_q, sd_q, z): softplus heads, posterior combination and the
+    reparameterised sample of one STCN latent level, elementwise (K8b)."""
+
+    @staticmethod
+    def forward(ctx, mu_p, sp_raw, mq, sq_raw, eps, cfg):
+        mu_p, sp_raw, mq, sq_raw, eps = (_f32c(t) for t in (mu_p, sp_raw, mq, sq_raw, eps))
+        beta_p, beta_q, sd_eps, mode = cfg
+        outs = [torch.empty_like(mu_p) for _ in range(4)]
+        check(load().blvm_gauss_latent_fwd(ptr(mu_p), ptr(sp_raw), ptr(mq), ptr(sq_raw), ptr(eps), mu_p.numel(), beta_p, beta_q,
+                                           sd_eps, mode, *(ptr(o) for o in outs), stream_ptr()), "blvm_gauss_latent_fwd")  # fmt: skip
+        ctx.cfg = cfg
+        ctx.save_for_backward(mu_p, sp_raw, mq, sq_raw, eps)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_sd_p, g_mu_q, g_sd_q, g_z):
+        mu_p, sp_raw, mq, sq_raw, eps = ctx.saved_tensors
+        beta_p, beta_q, sd_eps, mode = ctx.cfg
+        gs = [_f32c(g) if g is not None else None for g in (g_sd_p, g_mu_q, g_sd_q, g_z)]
+        outs = [torch.empty_like(mu_p) for _ in range(4)]
+        check(load().blvm_gauss_latent_bwd(ptr(mu_p), ptr(sp_raw), ptr(mq), ptr(sq_raw), ptr(eps), *(ptr(g) for g in gs),
+                                           mu_p.numel(), beta_p, beta_q, sd_eps, mode, *(ptr(o) for o in outs), stream_ptr()),
+              "blvm_gauss_latent_bwd")  # fmt: skip
+        return (*outs, None, None)
+
+
+def gauss_latent(mu_p, sd_p_raw, mu_q_raw, sd_q_raw, eps, beta_p: float, beta_q: float, sd_eps: float, mode: int):
+    return _GaussLatentFunction.apply(mu_p, sd_p_raw, mu_q_raw, sd_q_raw, eps, (float(beta_p), float(beta_q), float(sd_eps), int(mode)))
+
+
 def _pack_weights(ts: Sequence[Optional[torch.Tensor]]) -> VrnnWeights:
     d = dict(zip(_VRNN_PARAM_ORDER, ts))
     p = lambda k: ptr(d[k]) if d[k] is not None else None  # noqa: E731
@@ -639,45 +670,51 @@ def conv1d_k2(x, weight, bias, dilation: int = 1):
 
 
 class _WaveNetStackFunction(torch.autograd.Function):
-    """All gated residual blocks of a WaveNet stack in one autograd node: x [L,B,C] -> sum of skips [T_skip,B,S].
+    """All gated residual blocks of a residual stack in one autograd node: x [L,B,C] -> G skip tensors [T_skip,B,S].
+    `groups[i]` names the output that block i's skip branch is accumulated into; -1 = the block's skip is not used at all
+    (its skip half of the 1x1 convolution is not computed; the weight rows get a zero gradient).
     params: (conv.weight [2C,C,2], conv.bias, conv1x1rs.weight [C+S,C,1], conv1x1rs.bias) per block."""
 
     @staticmethod
-    def forward(ctx, x, dilations, T_skip, inv_std, S, *params):
+    def forward(ctx, x, dilations, groups, T_skip, inv_std, S, *params):
         x = _f32c(x)
         params = tuple(_f32c(p) for p in params)
         L, B, C = x.shape
         lib = load()
         f32 = dict(device=x.device, dtype=torch.float32)
-        skip = torch.zeros(T_skip, B, S, **f32)
+        n_out = max(groups) + 1
+        skips = [torch.zeros(T_skip, B, S, **f32) for _ in range(n_out)]
         ws = torch.empty(lib.blvm_wavenet_block_workspace_floats(L, B, C, S, 1), **f32)
         acts, reserves = [x], []
         n = len(dilations)
-        for i, d in enumerate(dilations):
+        last_used = max(i for i in range(n) if groups[i] >= 0)
+        for i, d in enumerate(dilations[: last_used + 1]):  # blocks after the last used skip cannot influence any output
             cw, cb, rw, rb = params[4 * i : 4 * i + 4]
             xi = acts[-1]
             Li = xi.shape[0]
             res = torch.empty(lib.blvm_wavenet_block_reserve_floats(Li, B, C, d), **f32)
-            o = torch.empty(Li - d, B, C, **f32) if i + 1 < n else None  # the last block's residual output is never used
-            check(lib.blvm_wavenet_block_fwd(ptr(xi), ptr(cw), ptr(cb), ptr(rw), ptr(rb), Li, B, C, S, d, T_skip, inv_std, ptr(o),
-                                             ptr(skip), ptr(res), ptr(ws), stream_ptr()), "blvm_wavenet_block_fwd")  # fmt: skip
+            o = torch.empty(Li - d, B, C, **f32) if i < last_used else None  # the last block's residual output is never used
+            Si = S if groups[i] >= 0 else 0
+            check(lib.blvm_wavenet_block_fwd(ptr(xi), ptr(cw), ptr(cb), ptr(rw), ptr(rb), Li, B, C, Si, d, T_skip, inv_std, ptr(o),
+                                             ptr(skips[groups[i]]) if Si else None, ptr(res), ptr(ws), stream_ptr()),
+                  "blvm_wavenet_block_fwd")  # fmt: skip
             reserves.append(res)
             if o is not None:
                 acts.append(o)
-        ctx.cfg = (tuple(dilations), T_skip, inv_std, S, L, B, C)
+        ctx.cfg = (tuple(dilations), tuple(groups), T_skip, inv_std, S, L, B, C, last_used)
         ctx.n_acts = len(acts)
         ctx.save_for_backward(*acts, *reserves, *params)
-        return skip
+        return tuple(skips)
 
     @staticmethod
-    def backward(ctx, d_skip):
-        dilations, T_skip, inv_std, S, L, B, C = ctx.cfg
-        n = len(dilations)
+    def backward(ctx, *d_skips):
+        dilations, groups, T_skip, inv_std, S, L, B, C, last_used = ctx.cfg
+        n = last_used + 1
         saved = ctx.saved_tensors
         acts, reserves, params = saved[: ctx.n_acts], saved[ctx.n_acts : ctx.n_acts + n], saved[ctx.n_acts + n :]
         lib = load()
-        f32 = dict(device=d_skip.device, dtype=torch.float32)
-        d_skip = _f32c(d_skip)
+        f32 = dict(device=acts[0].device, dtype=torch.float32)
+        d_skips = [_f32c(g) if g is not None else torch.zeros(T_skip, B, S, **f32) for g in d_skips]
         ws = torch.empty(lib.blvm_wavenet_block_workspace_floats(L, B, C, S, 1), **f32)
         grads = _zeros_like_many(params)
         d_o = None
@@ -685,18 +722,22 @@ class _WaveNetStackFunction(torch.autograd.Function):
             cw, _, rw, _ = params[4 * i : 4 * i + 4]
             xi = acts[i]
             d_x = torch.empty_like(xi)
-            check(lib.blvm_wavenet_block_bwd(ptr(xi), ptr(cw), ptr(rw), ptr(reserves[i]), ptr(d_o), ptr(d_skip), xi.shape[0], B, C,
-                                             S, dilations[i], T_skip, inv_std, ptr(d_x), ptr(grads[4 * i]), ptr(grads[4 * i + 1]),
-                                             ptr(grads[4 * i + 2]), ptr(grads[4 * i + 3]), ptr(ws), stream_ptr()),
-                  "blvm_wavenet_block_bwd")  # fmt: skip
+            Si = S if groups[i] >= 0 else 0
+            check(lib.blvm_wavenet_block_bwd(ptr(xi), ptr(cw), ptr(rw), ptr(reserves[i]), ptr(d_o),
+                                             ptr(d_skips[groups[i]]) if Si else None, xi.shape[0], B, C, Si, dilations[i], T_skip,
+                                             inv_std, ptr(d_x), ptr(grads[4 * i]), ptr(grads[4 * i + 1]), ptr(grads[4 * i + 2]),
+                                             ptr(grads[4 * i + 3]), ptr(ws), stream_ptr()), "blvm_wavenet_block_bwd")  # fmt: skip
             d_o = d_x
-        return (d_o, None, None, None, None, *grads)
+        return (d_o, None, None, None, None, None, *grads)
 
 
-def wavenet_stack(x, blocks_params, dilations, T_skip: int, inv_std: float, S: int):
-    """x [L,B,C] -> sum over blocks of the last T_skip frames of each block's skip output [T_skip,B,S]."""
+def wavenet_stack(x, blocks_params, dilations, T_skip: int, inv_std: float, S: int, groups=None):
+    """x [L,B,C] -> skip output(s) [T_skip,B,S]: the sum over blocks of the last T_skip frames of each block's skip branch
+    (groups=None: one sum over all blocks, returned as a tensor; otherwise a tuple, see _WaveNetStackFunction)."""
     flat = [p for blk in blocks_params for p in blk]
-    return _WaveNetStackFunction.apply(x, tuple(int(d) for d in dilations), int(T_skip), float(inv_std), int(S), *flat)
+    g = tuple(0 for _ in dilations) if groups is None else tuple(int(v) for v in groups)
+    out = _WaveNetStackFunction.apply(x, tuple(int(d) for d in dilations), g, int(T_skip), float(inv_std), int(S), *flat)
+    return out[0] if groups is None else out
 
 
 # ----------------------------------------------------------------------------------------------------------------------

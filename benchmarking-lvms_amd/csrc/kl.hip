@@ -93,8 +93,106 @@ int check(const float* mu_q, const float* sd_q, const float* mu_p, const float* 
   return BLVM_OK;
 }
 
+// ---- Gaussian latent head: softplus heads, posterior combination, reparameterised sample (elementwise) ---------------
+struct LatentArgs {
+  const float *mu_p, *sp_raw, *mq, *sq_raw, *eps;
+  float *sd_p, *mu_q, *sd_q, *z;                          // forward outputs
+  const float *g_sd_p, *g_mu_q, *g_sd_q, *g_z;            // backward: upstream gradients (each may be null)
+  float *d_mu_p, *d_sp_raw, *d_mq, *d_sq_raw;             // backward outputs
+  size_t n;
+  float beta_p, beta_q, sd_eps;
+  int mode;  // 0 plain, 1 residual (mu_q += mu_p), 2 precision-weighted
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void latent_head_kernel(LatentArgs a) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
+    const float mu_p = a.mu_p[i], mq = a.mq[i], rp = a.sp_raw[i], rq = a.sq_raw[i], e = a.eps[i];
+    const float sp = softplus_beta(rp, a.beta_p, 1.f / a.beta_p) + a.sd_eps;
+    const float sq0 = softplus_beta(rq, a.beta_q, 1.f / a.beta_q) + a.sd_eps;
+    float mu_q, sd_q, pr_p = 0.f, pr_q = 0.f, var = 0.f;
+    if (a.mode == 2) {
+      pr_p = 1.f / (sp * sp);
+      pr_q = 1.f / (sq0 * sq0);
+      var = 1.f / (pr_p + pr_q);
+      mu_q = var * (mu_p * pr_p + mq * pr_q);
+      sd_q = sqrtf(var);
+    } else {
+      mu_q = a.mode == 1 ? mq + mu_p : mq;
+      sd_q = sq0;
+    }
+    if (!BWD) {
+      a.sd_p[i] = sp;
+      a.mu_q[i] = mu_q;
+      a.sd_q[i] = sd_q;
+      a.z[i] = fmaf(sd_q, e, mu_q);
+    } else {
+      const float gz = a.g_z ? a.g_z[i] : 0.f;
+      const float gm = (a.g_mu_q ? a.g_mu_q[i] : 0.f) + gz;
+      const float gs = (a.g_sd_q ? a.g_sd_q[i] : 0.f) + gz * e;
+      float d_sp = a.g_sd_p ? a.g_sd_p[i] : 0.f, d_sq0, d_mu_p, d_mq;
+      if (a.mode == 2) {
+        const float dvar = gm * (mu_p * pr_p + mq * pr_q) + gs / (2.f * sd_q);
+        const float d_pr_p = gm * var * mu_p - dvar * var * var;
+        const float d_pr_q = gm * var * mq - dvar * var * var;
+        d_mu_p = gm * var * pr_p;
+        d_mq = gm * var * pr_q;
+        d_sp += d_pr_p * (-2.f * pr_p / sp);
+        d_sq0 = d_pr_q * (-2.f * pr_q / sq0);
+      } else {
+        d_mu_p = a.mode == 1 ? gm : 0.f;
+        d_mq = gm;
+        d_sq0 = gs;
+      }
+      a.d_mu_p[i] = d_mu_p;
+      a.d_mq[i] = d_mq;
+      a.d_sp_raw[i] = d_sp * sigmoidf_(a.beta_p * rp);   // d softplus_beta(x)/dx = sigmoid(beta x)
+      a.d_sq_raw[i] = d_sq0 * sigmoidf_(a.beta_q * rq);
+    }
+  }
+}
+
 }  // namespace
 }  // namespace blvm
+
+extern "C" int blvm_gauss_latent_fwd(const float* mu_p, const float* sd_p_raw, const float* mu_q_raw, const float* sd_q_raw,
+                                     const float* eps, size_t n, float beta_p, float beta_q, float sd_eps, int mode,
+                                     float* sd_p, float* mu_q, float* sd_q, float* z, void* stream) {
+  using namespace blvm;
+  BLVM_REQUIRE(mu_p && sd_p_raw && mu_q_raw && sd_q_raw && eps && sd_p && mu_q && sd_q && z, "gauss_latent_fwd: null pointer");
+  BLVM_REQUIRE(mode >= 0 && mode <= 2 && beta_p > 0.f && beta_q > 0.f, "gauss_latent_fwd: bad mode / beta");
+  if (n == 0) return BLVM_OK;
+  LatentArgs a{};
+  a.mu_p = mu_p; a.sp_raw = sd_p_raw; a.mq = mu_q_raw; a.sq_raw = sd_q_raw; a.eps = eps;
+  a.sd_p = sd_p; a.mu_q = mu_q; a.sd_q = sd_q; a.z = z;
+  a.n = n; a.beta_p = beta_p; a.beta_q = beta_q; a.sd_eps = sd_eps; a.mode = mode;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL((latent_head_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  BLVM_CHECK_LAUNCH("gauss_latent_fwd");
+  return BLVM_OK;
+}
+
+extern "C" int blvm_gauss_latent_bwd(const float* mu_p, const float* sd_p_raw, const float* mu_q_raw, const float* sd_q_raw,
+                                     const float* eps, const float* g_sd_p, const float* g_mu_q, const float* g_sd_q,
+                                     const float* g_z, size_t n, float beta_p, float beta_q, float sd_eps, int mode,
+                                     float* d_mu_p, float* d_sd_p_raw, float* d_mu_q_raw, float* d_sd_q_raw, void* stream) {
+  using namespace blvm;
+  BLVM_REQUIRE(mu_p && sd_p_raw && mu_q_raw && sd_q_raw && eps && d_mu_p && d_sd_p_raw && d_mu_q_raw && d_sd_q_raw,
+               "gauss_latent_bwd: null pointer");
+  BLVM_REQUIRE(mode >= 0 && mode <= 2 && beta_p > 0.f && beta_q > 0.f, "gauss_latent_bwd: bad mode / beta");
+  if (n == 0) return BLVM_OK;
+  LatentArgs a{};
+  a.mu_p = mu_p; a.sp_raw = sd_p_raw; a.mq = mu_q_raw; a.sq_raw = sd_q_raw; a.eps = eps;
+  a.g_sd_p = g_sd_p; a.g_mu_q = g_mu_q; a.g_sd_q = g_sd_q; a.g_z = g_z;
+  a.d_mu_p = d_mu_p; a.d_sp_raw = d_sd_p_raw; a.d_mq = d_mu_q_raw; a.d_sq_raw = d_sd_q_raw;
+  a.n = n; a.beta_p = beta_p; a.beta_q = beta_q; a.sd_eps = sd_eps; a.mode = mode;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL((latent_head_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  BLVM_CHECK_LAUNCH("gauss_latent_bwd");
+  return BLVM_OK;
+}
 
 extern "C" int blvm_kl_fwd(const float* mu_q, const float* sd_q, const float* mu_p, const float* sd_p, int layout,
                            const int32_t* x_sl, int B, int Tp, int Z, int stride, float fn_floor, double* kld,

@@ -177,7 +177,9 @@ struct SideStream {
   hipEvent_t ready = nullptr, done = nullptr;
   int ensure() {
     if (stream) return BLVM_OK;
-    BLVM_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    int least = 0, greatest = 0;  // lowest priority: the batched GEMMs must not take dispatch slots from the chain's links
+    BLVM_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    BLVM_HIP(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, least));
     BLVM_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
     BLVM_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
     return BLVM_OK;

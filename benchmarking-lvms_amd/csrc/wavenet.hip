@@ -220,8 +220,8 @@ extern "C" int blvm_wavenet_block_fwd(const float* x, const float* conv_w, const
                                       float inv_std, float* o, float* skip, float* reserve, float* workspace,
                                       void* stream_) {
   hipStream_t s = static_cast<hipStream_t>(stream_);
-  BLVM_REQUIRE(x && conv_w && conv_b && rs_w && rs_b && skip && reserve && workspace, "wavenet_block_fwd: null pointer");
-  BLVM_REQUIRE(C > 0 && C % 4 == 0 && S > 0 && L_in > dilation && dilation > 0 && B > 0, "wavenet_block_fwd: bad shape");
+  BLVM_REQUIRE(x && conv_w && conv_b && rs_w && rs_b && (skip || S == 0) && reserve && workspace, "wavenet_block_fwd: null pointer");
+  BLVM_REQUIRE(C > 0 && C % 4 == 0 && S >= 0 && L_in > dilation && dilation > 0 && B > 0, "wavenet_block_fwd: bad shape");
   const int L_out = L_in - dilation;
   BLVM_REQUIRE(T_skip > 0 && T_skip <= L_out, "wavenet_block_fwd: skip size %d exceeds the block's output length %d", T_skip, L_out);
   BLVM_REQUIRE(aligned16(x) && aligned16(reserve) && aligned16(workspace), "wavenet_block_fwd: buffers must be 16-byte aligned");
@@ -245,8 +245,8 @@ extern "C" int blvm_wavenet_block_bwd(const float* x, const float* conv_w, const
                                       int T_skip, float inv_std, float* d_x, float* dconv_w, float* dconv_b, float* drs_w,
                                       float* drs_b, float* workspace, void* stream_) {
   hipStream_t s = static_cast<hipStream_t>(stream_);
-  BLVM_REQUIRE(x && conv_w && rs_w && reserve && d_skip && d_x && workspace, "wavenet_block_bwd: null pointer");
-  BLVM_REQUIRE(C > 0 && C % 4 == 0 && S > 0 && L_in > dilation && dilation > 0 && B > 0, "wavenet_block_bwd: bad shape");
+  BLVM_REQUIRE(x && conv_w && rs_w && reserve && (d_skip || S == 0) && d_x && workspace, "wavenet_block_bwd: null pointer");
+  BLVM_REQUIRE(C > 0 && C % 4 == 0 && S >= 0 && L_in > dilation && dilation > 0 && B > 0, "wavenet_block_bwd: bad shape");
   const int L_out = L_in - dilation;
   BLVM_REQUIRE(T_skip > 0 && T_skip <= L_out, "wavenet_block_bwd: bad skip size");
   BLVM_REQUIRE(aligned16(x) && aligned16(reserve) && aligned16(workspace) && aligned16(d_x), "wavenet_block_bwd: alignment");

@@ -92,6 +92,19 @@ int blvm_kl_bwd(const float* mu_q, const float* sd_q, const float* mu_p, const f
                 const int32_t* x_sl, const float* c_raw, const float* c_fn, int B, int Tp, int Z, int stride,
                 float fn_floor, float* d_mu_q, float* d_sd_q, float* d_mu_p, float* d_sd_p, void* stream);
 
+/* K8b  Gaussian latent head, elementwise over n = rows*Z: sd = softplus_beta(raw) + sd_eps for prior and posterior
+ * (`DiagonalGaussianDenseSTCN.forward`, `blvm/models/stcn/stcn.py:32-76`), posterior combination (mode 0 plain, 1 residual
+ * mu_q += mu_p, 2 precision-weighted `variational.py:125-138`) and the reparameterised sample z = mu_q + sd_q*eps
+ * (`variational.py:141-152`) — the per-level body of `STCN.infer` (`stcn.py:297-327`).  bwd: upstream gradients wrt the four
+ * outputs (each may be NULL) -> gradients wrt mu_p, sd_p_raw, mu_q_raw, sd_q_raw. */
+int blvm_gauss_latent_fwd(const float* mu_p, const float* sd_p_raw, const float* mu_q_raw, const float* sd_q_raw,
+                          const float* eps, size_t n, float beta_p, float beta_q, float sd_eps, int mode, float* sd_p,
+                          float* mu_q, float* sd_q, float* z, void* stream);
+int blvm_gauss_latent_bwd(const float* mu_p, const float* sd_p_raw, const float* mu_q_raw, const float* sd_q_raw,
+                          const float* eps, const float* g_sd_p, const float* g_mu_q, const float* g_sd_q, const float* g_z,
+                          size_t n, float beta_p, float beta_q, float sd_eps, int mode, float* d_mu_p, float* d_sd_p_raw,
+                          float* d_mu_q_raw, float* d_sd_q_raw, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * K1  VRNN recurrent cell over a whole sequence (forward and BPTT).  Replaces the scripted per-step loop
  *     `blvm/models/vrnn.py:305-308` over `VRNNCell.forward` (`vrnn.py:109-141`) and its autograd backward.
@@ -230,7 +243,8 @@ int blvm_conv1d_k2_bwd(const float* x, const float* W, const float* d_out, int L
 
 /*   x [L_in,B,C]; conv_w [2C,C,2], conv_b [2C]; rs_w [C+S,C] (the 1x1 conv: first C rows residual, last S rows skip),
  *   rs_b [C+S]; o [L_in-dilation,B,C] = (res + x[dilation:]) * inv_std (may be NULL for the last block);
- *   skip [T_skip,B,S] += the last T_skip frames of the skip branch.  reserve keeps pre-activations for backward. */
+ *   skip [T_skip,B,S] += the last T_skip frames of the skip branch; S == 0 (skip NULL, rs_w = the first C rows): a block
+ *   whose skip output is unused (STCN reads only every n-th block's skip, `stcn.py:301`).  reserve keeps pre-activations. */
 size_t blvm_wavenet_block_reserve_floats(int L_in, int B, int C, int dilation);
 size_t blvm_wavenet_block_workspace_floats(int L_in, int B, int C, int S, int dilation);
 int blvm_wavenet_block_fwd(const float* x, const float* conv_w, const float* conv_b, const float* rs_w,

@@ -671,3 +671,83 @@ def cwvae_audio_forward(sd, x, x_sl, eps, strides, num_level_layers, stride_per_
     loss = -(log_prob - beta * kld_fn).sum() / x_sl.sum()
     return dict(loss=loss, elbo=elbo, log_prob=log_prob, kld=kld, kld_l=kld_l, z=zs_l, h=hs_l, mus=mus, state_n=state_n,
                 dec=dec, encodings=encs, bpd=float((-elbo.detach() / LN2).sum() / x_sl.sum()))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# STCN (blvm/models/stcn/stcn.py)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def residual_stack_skips(sd, p, h, dilations, skip_size):
+    """ResidualStack.forward (wavenet_modules.py:195-215): 1x1 in_transform, then gated residual blocks without padding;
+    returns the LIST of skip tensors, each cut to its last `skip_size` frames.  h [B,C,T]."""
+    h = F.conv1d(h, sd[f"{p}.in_transform.weight"], sd[f"{p}.in_transform.bias"])
+    C = sd[f"{p}.res_blocks.0.conv.weight"].size(1)
+    skips = []
+    for i, d in enumerate(dilations):
+        b = f"{p}.res_blocks.{i}"
+        pre = F.conv1d(h, sd[f"{b}.conv.weight"], sd[f"{b}.conv.bias"], dilation=d)
+        a, g = pre.chunk(2, 1)
+        rs = F.conv1d(torch.tanh(a) * torch.sigmoid(g), sd[f"{b}.conv1x1rs.weight"], sd[f"{b}.conv1x1rs.bias"])
+        r, s = rs[:, :C], rs[:, C:]
+        skips.append(s[..., -skip_size:])
+        h = (r + h[..., -r.size(2):]) * math.sqrt(0.5)
+    return skips
+
+
+def stcn_gaussian(sd, p, x, init_sd_mean, epsilon=1e-3):
+    """DiagonalGaussianDenseSTCN.forward (stcn.py:32-76): two 3-layer LeakyReLU MLPs, sd = softplus_beta(.) + epsilon."""
+    def mlp(q):
+        h = F.leaky_relu(F.linear(x, sd[f"{q}.0.weight"], sd[f"{q}.0.bias"]))
+        h = F.leaky_relu(F.linear(h, sd[f"{q}.2.weight"], sd[f"{q}.2.bias"]))
+        return F.linear(h, sd[f"{q}.4.weight"], sd[f"{q}.4.bias"])
+    beta = math.log(2) / (init_sd_mean - epsilon)
+    return mlp(f"{p}.transform_mu"), F.softplus(mlp(f"{p}.transform_sd"), beta=beta) + epsilon
+
+
+def stcn_forward(sd, x, x_sl, eps, n_layers, latent_size, n_stack_frames=1, base_dilation=2, beta=1.0, free_nats=0.0,
+                 precision_posterior=True, dense=True, num_mix=10, num_bins=2**16):
+    """STCN.forward, top-down inference, pad_receptive_field=True, DMoL head (stcn.py:346-431).  x [B,T]; eps[l] [B,T',z_l]
+    (one draw per level, top level first, stcn.py:325).  fp32 reductions with bool masks as the reference."""
+    n = len(latent_size)
+    S = n_stack_frames
+    dil = wavenet_dilations(n_layers, n, base_dilation)
+    rf = sum(dil) + 1 + (sd["causal.conv.weight"].size(2) - 1)
+    y = x.detach().unsqueeze(-1)
+    if S > 1:
+        xs, pad = stack_tensor(x, S)
+    else:
+        xs = x.unsqueeze(-1)
+    h = xs.transpose(1, 2)  # [B,C,T']
+    T = h.size(2)
+    h = F.pad(h, (rf, 0))
+    h = F.conv1d(h, sd["causal.conv.weight"], sd["causal.conv.bias"])
+    d = residual_stack_skips(sd, "res_stack", h, dil, T + 1)[n - 1 :: n]  # the last skip of every stack (stcn.py:299)
+    d_p = [t[..., :-1].permute(0, 2, 1) for t in d]
+    d_q = [t[..., 1:].permute(0, 2, 1) for t in d]
+    mu_p, sd_p, mu_q, sd_q, z = ([None] * n for _ in range(5))
+    for l in reversed(range(n)):
+        in_p, in_q = (d_p[l], d_q[l]) if l == n - 1 else (torch.cat([d_p[l], z[l + 1]], -1), torch.cat([d_q[l], z[l + 1]], -1))
+        mu_p[l], sd_p[l] = stcn_gaussian(sd, f"prior.{l}", in_p, 0.5)
+        mu_q[l], sd_q[l] = stcn_gaussian(sd, f"posterior.{l}", in_q, 0.1)
+        if precision_posterior:
+            mu_q[l], sd_q[l] = precision_weighted_gaussian(mu_p[l], sd_p[l], mu_q[l], sd_q[l])
+        z[l] = eps[l] * sd_q[l] + mu_q[l]
+    logits_in = (torch.cat(z, -1) if dense else z[0]).permute(0, 2, 1)
+    out_dil = [1] * n_layers
+    logits_in = F.pad(logits_in, (sum(out_dil), 0))  # out_transform.receptive_field - 1
+    logits = sum(residual_stack_skips(sd, "out_transform", logits_in, out_dil, T)) * (1 / math.sqrt(n))
+    logits = F.relu(F.linear(logits.permute(0, 2, 1), sd["out_upsample.0.weight"], sd["out_upsample.0.bias"]))
+    if S > 1:
+        logits = logits.reshape(logits.size(0), logits.size(1) * S, -1)[:, : y.size(1)]
+    lg, locs, log_scales = dmol_head(logits, sd["likelihood_module.params.weight"], sd["likelihood_module.params.bias"], num_mix)
+    seq_mask = sequence_mask(x_sl, max_len=y.size(1))
+    log_prob = (dmol_ll(y, lg, locs, log_scales, num_bins) * seq_mask).sum(1)
+    z_mask = seq_mask[:, ::S].unsqueeze(-1)
+    kl = [kl_gaussian(mu_q[l], sd_q[l], mu_p[l], sd_p[l]) * z_mask for l in range(n)]
+    kl_fn = [discount_free_nats(kl[l], free_nats) * z_mask for l in range(n)]
+    kld, kld_fn = torch.cat(kl, -1).sum((1, 2)), torch.cat(kl_fn, -1).sum((1, 2))
+    elbo = log_prob - kld
+    loss = -(log_prob - beta * kld_fn).sum() / x_sl.sum()
+    return dict(loss=loss, elbo=elbo, log_prob=log_prob, kld=kld, klds=[k.sum((1, 2)) for k in kl], z=z, mu_q=mu_q, mu_p=mu_p,
+                bpd=float((-elbo.detach() / LN2).sum() / x_sl.sum()))

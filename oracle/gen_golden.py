@@ -409,6 +409,73 @@ def gen_cwvae():
     save("cwvae.npz", **arrays)
 
 
+def gen_stcn():
+    """STCN (top-down, dense, precision posterior, DMoL): reduced size with full tensors (stacked and single frames, ragged
+    lengths, free nats) and the default configuration (25 blocks, C=256, latents [256..16], 64-frame stacks) by checksum."""
+    from blvm.models import STCN
+
+    arrays = {}
+    for tag, S, T, beta, fn in (("s8", 8, 203, 1.0, 1.5), ("s1", 1, 61, 0.6, 0.0)):
+        cfg = dict(likelihood="DMoL", n_layers=3, latent_size=[16, 16, 32], res_channels=16, n_stack_frames=S)
+        torch.manual_seed(61)
+        m = STCN(**cfg)
+        B = 3
+        x, _ = O.synth_batch(B, T, seed=19)
+        x_sl = torch.tensor([T, int(T * 0.7), int(T * 0.3)])
+        x = x * (torch.arange(T).unsqueeze(0) < x_sl.unsqueeze(1))
+        Tp = math.ceil(T / S)
+        torch.manual_seed(88)  # one randn_like(mu) per level, top level first (stcn.py:309-325)
+        eps = [None] * 3
+        for l in (2, 1, 0):
+            eps[l] = torch.randn(B, Tp, cfg["latent_size"][l])
+        torch.manual_seed(88)
+        loss, metrics, o = m(x, x_sl, beta=beta, free_nats=fn)
+        loss.backward()
+        arrays.update({f"{tag}_x": x, f"{tag}_x_sl": x_sl, f"{tag}_loss": loss, f"{tag}_elbo": o.elbo, f"{tag}_log_prob": o.log_prob})
+        for l in range(3):
+            arrays.update({f"{tag}_eps{l}": eps[l], f"{tag}_z{l}": o.z[l], f"{tag}_enc_mu{l}": o.enc_mus[l],
+                           f"{tag}_prior_mu{l}": o.prior_mus[l], f"{tag}_kld{l}": o.klds[l]})
+        arrays[f"{tag}_metric_names"] = np.array([mm.name for mm in metrics])
+        arrays[f"{tag}_metric_values"] = np.array([mm.value for mm in metrics], dtype=np.float64)
+        for k, v in m.state_dict().items():
+            arrays[f"{tag}_sd.{k}"] = v
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                arrays[f"{tag}_grad.{k}"] = p.grad
+        arrays[f"{tag}_nograd"] = np.array([k for k, p in m.named_parameters() if p.grad is None])
+
+    torch.manual_seed(0)
+    full = dict(likelihood="DMoL", n_layers=5, latent_size=[256, 128, 64, 32, 16], res_channels=256, n_stack_frames=64, dense=True)
+    m = STCN(**full)
+    names = []
+    for k, v in m.state_dict().items():
+        names.append(k)
+        arrays[f"cks.{k}"] = np.array([v.double().sum().item(), v.double().abs().sum().item(), *v.shape], dtype=np.float64)
+    arrays["param_names"] = np.array(names)
+    Bf, Tf = 4, 4000
+    xf, xf_sl = O.synth_batch(Bf, Tf, seed=0, ragged=True)
+    Tp = math.ceil(Tf / 64)
+    torch.manual_seed(123)
+    eps = [None] * 5
+    for l in (4, 3, 2, 1, 0):
+        eps[l] = torch.randn(Bf, Tp, full["latent_size"][l])
+    torch.manual_seed(123)
+    loss, metrics, o = m(xf, xf_sl, beta=1.0, free_nats=2.0)
+    loss.backward()
+    arrays.update(f_x_sl=xf_sl, f_loss=loss, f_elbo=o.elbo, f_log_prob=o.log_prob)
+    for l in range(5):
+        arrays[f"f_kld{l}"] = o.klds[l]
+        arrays[f"f_z{l}"] = o.z[l]
+    arrays["f_metric_names"] = np.array([mm.name for mm in metrics])
+    arrays["f_metric_values"] = np.array([mm.value for mm in metrics], dtype=np.float64)
+    gn = [(k, p.grad.double().norm().item()) for k, p in m.named_parameters() if p.grad is not None]
+    arrays["f_grad_names"] = np.array([k for k, _ in gn])
+    arrays["f_grad_norms"] = np.array([v for _, v in gn])
+    for k in ("causal.conv.weight", "prior.0.transform_sd.4.weight", "out_transform.res_blocks.4.conv1x1rs.weight", "res_stack.res_blocks.12.conv.bias"):
+        arrays[f"f_grad.{k}"] = dict(m.named_parameters())[k].grad.clone()
+    save("stcn.npz", **arrays)
+
+
 def gen_lstm():
     """LSTMAudio: reduced size with full tensors, and BASELINE config C1 ([8,4000], h=256, s=64) pinned by checksums."""
     arrays = {}
@@ -453,6 +520,6 @@ def gen_lstm():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn", "wavenet", "rssm", "cwvae"]
+    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn", "wavenet", "rssm", "cwvae", "stcn"]
     for w in which:
         globals()[f"gen_{w}"]()
