@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default 64 = the reference's --batch_len 64 s of audio; cwvae: 8)")
     ap.add_argument("--length", type=int, default=None, help="samples per utterance (default 16000 = 1 s at 16 kHz; cwvae: 49152)")
-    ap.add_argument("--model", default="vrnn", choices=["vrnn", "srnn", "lstm", "wavenet", "cwvae"], help="vrnn = BASELINE headline (configs[1])")
+    ap.add_argument("--model", default="vrnn", choices=["vrnn", "srnn", "lstm", "wavenet", "cwvae", "stcn"], help="vrnn = BASELINE headline (configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=10)
@@ -131,7 +131,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from blvm import _hip, ops
-    from blvm.models import CWVAEAudio, LSTMAudio, SRNNAudio, VRNNAudio, WaveNet
+    from blvm.models import STCN, CWVAEAudio, LSTMAudio, SRNNAudio, VRNNAudio, WaveNet
     from blvm.modules.distributions import DiscretizedLogisticMixtureDense
     from blvm.training.ddp import FlatGradAllReduce
 
@@ -150,6 +150,8 @@ def main():
     elif args.model == "wavenet":
         lik = DiscretizedLogisticMixtureDense(96, 1, num_mix=10, num_bins=2**16)
         model = WaveNet(likelihood=lik, n_layers=10, n_stacks=5, res_channels=96, kernel_size=2, base_dilation=2, n_stack_frames=1).to(dev)
+    elif args.model == "stcn":  # the reference's default STCN, 64-sample frames
+        model = STCN(likelihood="DMoL", n_layers=5, latent_size=[256, 128, 64, 32, 16], res_channels=256, n_stack_frames=S, dense=True).to(dev)
     elif args.model == "cwvae":  # BASELINE config C4
         model = CWVAEAudio(z_size=[128, 64, 32], h_size=192, strides=[64, 16, 16], num_level_layers=8, stride_per_layer=2,
                            precision_posterior=True, likelihood="DMoL", num_bins=2**16).to(dev)  # fmt: skip
@@ -192,6 +194,8 @@ def main():
             loss, metrics, out = model(x, x_sl, beta=1.0, free_nats=2.0)
         elif args.model == "cwvae":
             loss, metrics, out = model(x, x_sl, beta=1.0, free_nats=4.0)  # experiment_clockwork_audio.py:64 default
+        elif args.model == "stcn":
+            loss, metrics, out = model(x, x_sl, beta=1.0, free_nats=4.0)  # experiment_stcn_audio.py:64 default
         else:
             loss, metrics, out = model(x, x_sl)
         loss.backward()
@@ -232,7 +236,7 @@ def main():
     log(f"timed {args.steps} steps: {ms_step:.2f} ms/step; host enqueue per step: seq_fwd {host['fwd'] / args.steps * 1e3:.2f} ms, "
         f"seq_bwd {host['bwd'] / args.steps * 1e3:.2f} ms")
     frames = world * B * T * args.steps
-    if args.model in ("lstm", "wavenet", "cwvae"):  # no hooked recurrent-cell call: whole step against the model's matmul FLOPs
+    if args.model in ("lstm", "wavenet", "cwvae", "stcn"):  # no hooked recurrent-cell call: whole step against the model's matmul FLOPs
         fwd_ms, bwd_ms = ms_step / 3, 2 * ms_step / 3
     else:
         cell_ms = [(e[0].elapsed_time(e[1]), e[2].elapsed_time(e[3])) for e in ev]
@@ -248,6 +252,14 @@ def main():
     elif args.model == "wavenet":
         macs = 2777088 * B * T  # algorithmic MAC per frame, 5x10 blocks, C=96, k=2
         kname = "WaveNet whole train step (conv/MFMA path: 50 gated residual blocks as shifted-view GEMMs)"
+    elif args.model == "stcn":
+        C, zs = 256, [256, 128, 64, 32, 16]
+        per_step = S * C * 2 + C * C + 25 * (2 * C * 2 * C + C * 2 * C) + sum(zs) * C + 5 * (2 * C * 2 * C + C * 2 * C) + C * 30 * S + 900 * S
+        for l, z in enumerate(zs):  # 4 three-layer MLPs per level (prior / posterior x mean / sd)
+            cin = C + (zs[l + 1] if l + 1 < len(zs) else 0)
+            per_step += 4 * (cin * C + C * C + C * z)
+        macs = per_step * B * Tp
+        kname = "STCN whole train step (time-parallel: 30 gated residual blocks + 20 latent MLPs as MFMA GEMMs, DMoL head)"
     elif args.model == "cwvae":
         macs = cwvae_macs(model, T) * B
         kname = "CW-VAE whole train step (1x1-conv GEMMs of 48 separable blocks + 3 RSSM levels; the depthwise/norm passes are HBM-bound)"
@@ -256,7 +268,7 @@ def main():
         kname = "LSTMAudio whole train step (matmul FLOPs of embedding + LSTM + decoder + DMoL Linear)"
     flops_fb = 3 * 2 * macs  # forward + dgrad + wgrad
     achieved = flops_fb / ((fwd_ms + bwd_ms) * 1e-3) / 1e12
-    bpd = {m.name: m.value for m in last["metrics"]}["elbo (bpt)" if args.model == "cwvae" else "bpd"]
+    bpd = {m.name: m.value for m in last["metrics"]}[{"cwvae": "elbo (bpt)", "stcn": "elbo (bpx)"}.get(args.model, "bpd")]
 
     if rank == 0:
         res = {
