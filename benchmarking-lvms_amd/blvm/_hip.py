@@ -104,6 +104,10 @@ _SIGNATURES = {
     "blvm_rssm_seq_fwd": (c_int, [ctypes.POINTER(RssmWeights)] + [c_void_p] * 5 + [c_int] * 7 + [c_float] + [c_void_p] * 8),
     "blvm_rssm_seq_bwd": (c_int, [ctypes.POINTER(RssmWeights)] + [c_void_p] * 15 + [c_int, c_float] + [c_int] * 7 + [c_float]
                           + [c_void_p] * 4 + [ctypes.POINTER(RssmWeights), c_void_p, c_void_p]),
+    "blvm_gmm_fwd": (c_int, [c_void_p, c_int] + [c_void_p] * 4 + [c_int] * 5 + [c_float] * 2 + [c_void_p] * 3),
+    "blvm_gmm_bwd": (c_int, [c_void_p, c_int] + [c_void_p] * 5 + [c_int] * 5 + [c_float] * 2 + [c_void_p] * 3),
+    "blvm_gauss_head_fwd": (c_int, [c_void_p, c_int] + [c_void_p] * 4 + [c_int] * 4 + [c_float] * 2 + [c_void_p] * 3),
+    "blvm_gauss_head_bwd": (c_int, [c_void_p, c_int] + [c_void_p] * 5 + [c_int] * 4 + [c_float] * 2 + [c_void_p] * 3),
     "blvm_gauss_latent_fwd": (c_int, [c_void_p] * 5 + [c_size_t] + [c_float] * 3 + [c_int] + [c_void_p] * 5),
     "blvm_gauss_latent_bwd": (c_int, [c_void_p] * 9 + [c_size_t] + [c_float] * 3 + [c_int] + [c_void_p] * 5),
     "blvm_chan_norm_workspace_doubles": (c_size_t, [c_int]),

@@ -20,7 +20,7 @@ from blvm.evaluation import (BitsPerDimMetric, DeferredScalars, EMAMetric, KLMet
 from blvm.models.base_model import BaseModel
 from blvm.models.clockwork_vae.convolutional_coders import ConvCoder1d
 from blvm.models.vrnn import LazyNamespace
-from blvm.modules.distributions import DiscretizedLogisticMixtureDense
+from blvm.modules.distributions import DiagonalGaussianDense, DiagonalGaussianMixtureDense, DiscretizedLogisticMixtureDense
 from blvm.modules.rssm import RSSMCell
 from blvm.utils.operations import split_sequence
 from blvm.utils.padding import get_modulo_length, get_modulo_padding, get_same_padding
@@ -38,8 +38,8 @@ class CWVAE(nn.Module):
             raise NotImplementedError("libblvm_hip: with_resets=True (state reset on the parent's tick) is not built yet")
         if not (isinstance(encoder, ConvCoder1d) and isinstance(decoder, ConvCoder1d) and decoder.transposed and not encoder.transposed):
             raise NotImplementedError("libblvm_hip: CWVAE needs ConvCoder1d coders (encoder plain, decoder transposed)")
-        if not isinstance(likelihood, DiscretizedLogisticMixtureDense):
-            raise NotImplementedError("libblvm_hip: the DMoL head is the one built for CWVAE")
+        if not isinstance(likelihood, (DiscretizedLogisticMixtureDense, DiagonalGaussianMixtureDense, DiagonalGaussianDense)):
+            raise NotImplementedError("libblvm_hip: CWVAE is built with the DMoL, GMM and Gaussian likelihood heads")
 
         self.encoder, self.decoder, self.likelihood = encoder, decoder, likelihood
         self.residual_posterior, self.precision_posterior = residual_posterior, precision_posterior
@@ -149,8 +149,7 @@ class CWVAE(nn.Module):
         lik = self.likelihood
         # head: Linear h -> 3*num_mix as a K6 GEMM, then K7 without its fused [F,F] Linear
         par = ops.linear(context.reshape(T * B, -1), lik.params.weight, lik.params.bias)
-        log_prob = ops.dmol_log_prob(par, None, None, y, x_sl_dev, ops.LAYOUT_TIME_MAJOR, B, T, T, 1, lik.num_mix, lik.num_bins,
-                                     lik.log_epsilon)  # fmt: skip
+        log_prob = lik.fused_log_prob(par, y, x_sl_dev, ops.LAYOUT_TIME_MAJOR, B, T, T, 1, fused_linear=False)
 
         kld, kld_fn = sum(kld_l), sum(kld_fn_l)
         n_frames = float(x_sl.sum())
@@ -221,8 +220,10 @@ class CWVAEAudio(BaseModel):
         if isinstance(likelihood, str):
             if likelihood == "DMoL":
                 likelihood = DiscretizedLogisticMixtureDense(x_dim=h_size, y_dim=1, num_mix=num_mix, num_bins=num_bins)
-            elif likelihood in ("Gaussian", "GMM"):
-                raise NotImplementedError(f"libblvm_hip: likelihood '{likelihood}' is not built yet (DMoL is the benchmark head)")
+            elif likelihood == "Gaussian":
+                likelihood = DiagonalGaussianDense(x_dim=h_size, y_dim=1, epsilon=1e-2)
+            elif likelihood == "GMM":
+                likelihood = DiagonalGaussianMixtureDense(x_dim=h_size, y_dim=1, num_mix=num_mix, initial_sd=1, epsilon=1e-2)
             else:
                 raise ValueError(f"Unknown likelihood type {likelihood}")
         self.likelihood = likelihood

@@ -17,9 +17,9 @@ from blvm import ops
 from blvm.data.transforms import StackTensor
 from blvm.evaluation import BitsPerDimMetric, DeferredScalars, KLMetric, LatestMeanMetric, LLMetric, LossMetric
 from blvm.models.base_model import BaseModel
-from blvm.models.vrnn import LazyNamespace, _linears
+from blvm.models.vrnn import LIKELIHOOD_HEADS, LazyNamespace, _linears
 from blvm.modules.convenience import View
-from blvm.modules.distributions import DiagonalGaussianDense, DiscretizedLogisticMixtureDense
+from blvm.modules.distributions import DiagonalGaussianDense, DiagonalGaussianMixtureDense, DiscretizedLogisticMixtureDense
 from blvm.utils.operations import split_sequence
 from blvm.utils.padding import get_modulo_length
 
@@ -76,7 +76,7 @@ class SRNN(nn.Module):
         ok = (
             stack is not None
             and isinstance(dec, nn.Sequential)
-            and isinstance(lik, DiscretizedLogisticMixtureDense)
+            and isinstance(lik, LIKELIHOOD_HEADS)
             and all(isinstance(m, (nn.Linear, nn.LeakyReLU, View, StackTensor)) for m in list(enc) + list(dec))
             and isinstance(dec[-2], nn.LeakyReLU)
         )
@@ -132,8 +132,7 @@ class SRNN(nn.Module):
         )
         z = zs[1:]
         dec = ops.mlp(torch.cat([z, d], -1).view(Tp * B, Z + R), dec_lin, ops.ACT_LEAKY, ops.LEAKY_SLOPE)
-        log_prob = ops.dmol_log_prob(dec, lik.params.weight, lik.params.bias, y, x_sl_dev, ops.LAYOUT_TIME_MAJOR, B, T, Tp, S,
-                                     lik.num_mix, lik.num_bins, lik.log_epsilon)  # fmt: skip
+        log_prob = lik.fused_log_prob(dec, y, x_sl_dev, ops.LAYOUT_TIME_MAJOR, B, T, Tp, S)  # K7 / K7b / K7c
 
         n_frames = float(x_sl_host.sum())
         elbo = log_prob - kld
@@ -191,8 +190,11 @@ class SRNNAudio(BaseModel):
         if likelihood == "DMoL":
             # hard-coded num_mix / num_bins on this branch, as in the reference (srnn.py:433-438)
             likelihood_module = DiscretizedLogisticMixtureDense(x_dim=2 * num_mix + num_mix, y_dim=1, num_mix=10, num_bins=2**16)
-        elif likelihood in ("GMM", "Gaussian"):
-            raise NotImplementedError(f"libblvm_hip: likelihood '{likelihood}' is not built yet (DMoL is the benchmark head)")
+        elif likelihood == "GMM":
+            likelihood_module = DiagonalGaussianMixtureDense(x_dim=2 * num_mix + num_mix, y_dim=1, num_mix=num_mix, initial_sd=1,
+                                                             epsilon=1e-4)  # fmt: skip
+        elif likelihood == "Gaussian":
+            likelihood_module = DiagonalGaussianDense(x_dim=2, y_dim=1, epsilon=1e-4)
         else:
             raise ValueError(f"Unknown likelihood type {likelihood}")
 

@@ -19,7 +19,8 @@ from blvm.models.base_model import BaseModel
 from blvm.models.vrnn import LazyNamespace
 from blvm.models.wavenet.wavenet_modules import CausalConv1d, ResidualStack
 from blvm.modules.convenience import AddConstant
-from blvm.modules.distributions import ConditionalDistribution, DiscretizedLogisticMixtureDense
+from blvm.modules.distributions import (ConditionalDistribution, DiagonalGaussianDense, DiagonalGaussianMixtureDense,
+                                        DiscretizedLogisticMixtureDense)  # fmt: skip
 
 
 class DiagonalGaussianDenseSTCN(ConditionalDistribution):
@@ -94,8 +95,11 @@ class STCN(BaseModel):
         num_mix = 10
         if likelihood == "DMoL":
             likelihood_module = DiscretizedLogisticMixtureDense(x_dim=2 * num_mix + num_mix, y_dim=1, num_mix=num_mix, num_bins=2**16)
-        elif likelihood in ("GMM", "Gaussian"):
-            raise NotImplementedError(f"libblvm_hip: likelihood '{likelihood}' is not built yet (DMoL is the benchmark head)")
+        elif likelihood == "GMM":
+            likelihood_module = DiagonalGaussianMixtureDense(x_dim=2 * num_mix + num_mix, y_dim=1, num_mix=num_mix, initial_sd=1,
+                                                             epsilon=1e-4)  # fmt: skip
+        elif likelihood == "Gaussian":
+            likelihood_module = DiagonalGaussianDense(x_dim=2, y_dim=1, epsilon=1e-4)
         else:
             raise ValueError(f"Unknown likelihood type {likelihood}")
         self.out_upsample = nn.Sequential(nn.Linear(res_channels, likelihood_module.out_features * n_stack_frames), nn.ReLU())
@@ -186,8 +190,7 @@ class STCN(BaseModel):
         h = ops.scale_act(skip_sum.view(T * B, C), self.inv_std, 1.0)  # * inv_std (slope 1: no activation)
         up = self.out_upsample[0]
         dec = ops.linear(h, up.weight, up.bias, ops.ACT_RELU)  # [T*B, S*F]
-        log_prob = ops.dmol_log_prob(dec, lik.params.weight, lik.params.bias, y, mask_len, ops.LAYOUT_TIME_MAJOR, B, T_y, T, S,
-                                     lik.num_mix, lik.num_bins, lik.log_epsilon)  # fmt: skip
+        log_prob = lik.fused_log_prob(dec, y, mask_len, ops.LAYOUT_TIME_MAJOR, B, T_y, T, S)  # K7 / K7b / K7c
 
         kld, kld_fn = sum(klds), sum(klds_fn)
         n_frames = float(x_sl_host.sum())

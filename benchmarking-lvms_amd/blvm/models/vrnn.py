@@ -19,7 +19,10 @@ from blvm.data.transforms import StackTensor
 from blvm.evaluation import BitsPerDimMetric, DeferredScalars, KLMetric, LatestMeanMetric, LLMetric, LossMetric
 from blvm.models.base_model import BaseModel
 from blvm.modules.convenience import View
-from blvm.modules.distributions import DiagonalGaussianDense, DiscretizedLogisticMixtureDense
+from blvm.modules.distributions import (DiagonalGaussianDense, DiagonalGaussianMixtureDense,
+                                        DiscretizedLogisticMixtureDense)  # fmt: skip
+
+LIKELIHOOD_HEADS = (DiscretizedLogisticMixtureDense, DiagonalGaussianMixtureDense, DiagonalGaussianDense)
 
 
 class LazyNamespace(SimpleNamespace):
@@ -138,7 +141,7 @@ class VRNN(nn.Module):
         ok = (
             stack is not None
             and isinstance(dec, nn.Sequential)
-            and isinstance(lik, DiscretizedLogisticMixtureDense)
+            and isinstance(lik, LIKELIHOOD_HEADS)
             and self.condition_h_on_x
             and self.condition_x_on_h
             and all(isinstance(m, (nn.Linear, nn.LeakyReLU, View, StackTensor)) for m in list(enc) + list(dec))
@@ -177,8 +180,7 @@ class VRNN(nn.Module):
         decin, kld, kld_fn, mu_q, sd_q, mu_p, sd_p, z = self.vrnn_cell.sequence(enc, h0, eps, x_sl_dev, stride, free_nats)
 
         dec = ops.mlp(decin[:Tp].view(Tp * B, H + R), dec_lin, ops.ACT_LEAKY, ops.LEAKY_SLOPE)  # [T'*B, S*F]
-        log_prob = ops.dmol_log_prob(dec, lik.params.weight, lik.params.bias, y, x_sl_dev, ops.LAYOUT_TIME_MAJOR, B, T, Tp,
-                                     S, lik.num_mix, lik.num_bins, lik.log_epsilon)  # fmt: skip
+        log_prob = lik.fused_log_prob(dec, y, x_sl_dev, ops.LAYOUT_TIME_MAJOR, B, T, Tp, S)  # K7 / K7b / K7c
 
         # ELBO assembly in float64 as the reference does (mask dtype `float`, vrnn.py:266-279)
         n_frames = float(x_sl_host.sum())
@@ -244,8 +246,11 @@ class VRNNAudio(BaseModel):
             # the reference hard-codes num_mix=10, num_bins=2**16 on this branch whatever the ctor args say
             # (vrnn.py:464-469); x_dim still follows num_mix.
             likelihood_module = DiscretizedLogisticMixtureDense(x_dim=2 * num_mix + num_mix, y_dim=1, num_mix=10, num_bins=2**16)
-        elif likelihood in ("GMM", "Gaussian"):
-            raise NotImplementedError(f"libblvm_hip: likelihood '{likelihood}' is not built yet (DMoL is the benchmark head)")
+        elif likelihood == "GMM":
+            likelihood_module = DiagonalGaussianMixtureDense(x_dim=2 * num_mix + num_mix, y_dim=1, num_mix=num_mix, initial_sd=1,
+                                                             epsilon=1e-4)  # fmt: skip
+        elif likelihood == "Gaussian":
+            likelihood_module = DiagonalGaussianDense(x_dim=2, y_dim=1, epsilon=1e-4)
         else:
             raise ValueError(f"Unknown likelihood type {likelihood}")
 

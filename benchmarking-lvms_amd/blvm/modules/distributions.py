@@ -37,12 +37,24 @@ class DiagonalGaussianDense(ConditionalDistribution):
     def mode(self, params):
         return params[0].contiguous()
 
+    @torch.no_grad()
+    def sample(self, params):
+        return params[0] + params[1] * torch.randn_like(params[0])
+
     def forward(self, x: torch.Tensor):
         lead = x.shape[:-1]
         p = ops.mlp(x.reshape(-1, x.shape[-1]), [self.params], act=ops.ACT_NONE)
         mu, raw = p.view(*lead, -1).chunk(2, dim=-1)
         # softplus on a small [*, y_dim] tensor: torch element-wise (not on the fused hot path)
         return mu, self.sd_activation(raw)
+
+    def fused_log_prob(self, dec, y, x_sl_dev, layout, B, T, Tp, S, fused_linear: bool = True):
+        """Masked per-utterance log-likelihood sums [B] straight from decoder activations (K7c): the head's Linear(2->2),
+        softplus and `gaussian_ll(..., epsilon=0)` (distributions.py:142-149) in one pass."""
+        if self.y_dim != 1:
+            raise NotImplementedError("Gaussian likelihood head: y_dim must be 1 on the audio path")
+        W, b = (self.params.weight, self.params.bias) if fused_linear else (None, None)
+        return ops.gauss_log_prob(dec, W, b, y, x_sl_dev, layout, B, T, Tp, S, self.softplus_beta, self.epsilon)
 
 
 class DiscretizedLogisticMixtureDense(ConditionalDistribution):
@@ -63,6 +75,11 @@ class DiscretizedLogisticMixtureDense(ConditionalDistribution):
         locs, log_scales = p[..., self.num_mix :].reshape(*lead, 1, 2 * self.num_mix).chunk(2, dim=-1)
         return logits, locs, log_scales.clamp(min=self.log_epsilon)
 
+    def fused_log_prob(self, dec, y, x_sl_dev, layout, B, T, Tp, S, fused_linear: bool = True):
+        """Masked per-utterance log-likelihood sums [B] straight from decoder activations (K7)."""
+        W, b = (self.params.weight, self.params.bias) if fused_linear else (None, None)
+        return ops.dmol_log_prob(dec, W, b, y, x_sl_dev, layout, B, T, Tp, S, self.num_mix, self.num_bins, self.log_epsilon)
+
     def mode(self, params):
         idx = params[0].argmax(-1, keepdim=True).unsqueeze(-2)
         return torch.gather(params[1], index=idx, dim=-1).squeeze(-1).contiguous()
@@ -78,3 +95,51 @@ class DiscretizedLogisticMixtureDense(ConditionalDistribution):
         u2 = torch.empty_like(loc).uniform_(1e-8, 1.0 - 1e-8)  # rsample_logistic default bounds (variational.py:281)
         x = loc + torch.exp(ls) * (torch.log(u2) - torch.log(1.0 - u2))
         return x.clamp(-1.0, 1.0)
+
+
+class DiagonalGaussianMixtureDense(ConditionalDistribution):
+    """Gaussian mixture head with the reference's constructor and parameter layout (distributions.py:153-206); note the
+    reference's softplus beta here is ln2 / initial_sd (epsilon is NOT subtracted, :168-171)."""
+
+    def __init__(self, x_dim, y_dim, num_mix: int, initial_sd: float = 1, epsilon: float = 1e-6):
+        super().__init__()
+        self.x_dim, self.y_dim, self.num_mix, self.initial_sd, self.epsilon = x_dim, y_dim, num_mix, initial_sd, epsilon
+        self.out_features = num_mix * (2 * y_dim + 1)
+        self.params = nn.Linear(x_dim, self.out_features)
+        beta = self.softplus_beta
+        self.sd_activation = nn.Sequential(nn.Softplus(beta=beta), AddConstant(epsilon)) if epsilon > 0 else nn.Softplus(beta=beta)
+        self.reset_parameters()
+
+    @property
+    def softplus_beta(self) -> float:
+        return math.log(2) / self.initial_sd if self.epsilon > 0 else math.log(2) / (self.initial_sd - self.epsilon)
+
+    def forward(self, x):
+        """(logits [*,K], means [*,1,K], sds [*,1,K]) as the reference returns them (distributions.py:190-206)."""
+        if self.y_dim != 1:
+            raise NotImplementedError("GMM head: y_dim must be 1 on the audio path")
+        lead = x.shape[:-1]
+        p = ops.mlp(x.reshape(-1, x.shape[-1]), [self.params], act=ops.ACT_NONE).view(*lead, -1)
+        logits = p[..., : self.num_mix]
+        mu, raw = p[..., self.num_mix :].reshape(*lead, 1, 2 * self.num_mix).chunk(2, dim=-1)
+        return logits, mu, self.sd_activation(raw)
+
+    def fused_log_prob(self, dec, y, x_sl_dev, layout, B, T, Tp, S, fused_linear: bool = True):
+        """Masked per-utterance log-likelihood sums [B] straight from decoder activations (K7b)."""
+        W, b = (self.params.weight, self.params.bias) if fused_linear else (None, None)
+        return ops.gmm_log_prob(dec, W, b, y, x_sl_dev, layout, B, T, Tp, S, self.num_mix, self.softplus_beta,
+                                self.epsilon if self.epsilon > 0 else 0.0)  # fmt: skip
+
+    def mode(self, params):
+        idx = params[0].argmax(-1, keepdim=True).unsqueeze(-2)
+        return torch.gather(params[1], index=idx, dim=-1).squeeze(-1).contiguous()
+
+    @torch.no_grad()
+    def sample(self, params, eps: float = 1e-6):
+        """Gumbel-max component pick + Gaussian sample (blvm/utils/variational.py:156-197)."""
+        logits, mu, sd = params
+        u = torch.empty_like(logits).uniform_(eps, 1.0 - eps)
+        idx = (logits - torch.log(-torch.log(u))).argmax(-1, keepdim=True).unsqueeze(-2)
+        m = torch.gather(mu, -1, idx.expand(*mu.shape[:-1], 1)).squeeze(-1)
+        s = torch.gather(sd, -1, idx.expand(*sd.shape[:-1], 1)).squeeze(-1)
+        return m + s * torch.randn_like(m)

@@ -213,6 +213,72 @@ def dmol_log_prob(dec, W, b, y, x_sl_dev, layout, B, T, Tp, S, num_mix=10, num_b
     return _DMoLFunction.apply(dec, W, b, y, x_sl_dev, layout, B, T, Tp, S, num_mix, num_bins, log_eps)
 
 
+class _GaussHeadFunction(torch.autograd.Function):
+    """K7b (kind 1, Gaussian mixture, F = 3*num_mix) / K7c (kind 2, single Gaussian, F = 2): decoder activations -> per-frame
+    Linear(F->F) (optional) -> log-likelihood -> masked per-utterance float64 sums [B]."""
+
+    @staticmethod
+    def forward(ctx, dec, W, b, y, x_sl_dev, kind, layout, B, T, Tp, S, num_mix, sd_beta, sd_eps):
+        dec, y = _f32c(dec), _f32c(y)
+        W, b = (_f32c(W), _f32c(b)) if W is not None else (None, None)
+        F = 3 * num_mix if kind == 1 else 2
+        if dec.dim() != 2 or dec.shape[0] != B * Tp or dec.shape[1] != S * F:
+            raise _hip.BlvmHipError(f"Gaussian head: activations must be [B*T'={B * Tp}, S*F={S * F}], got {tuple(dec.shape)}")
+        if W is not None and tuple(W.shape) != (F, F):
+            raise _hip.BlvmHipError(f"Gaussian head: fused head weight must be [{F},{F}], got {tuple(W.shape)}")
+        if tuple(y.shape) != (B, T) or Tp * S < T:
+            raise _hip.BlvmHipError(f"Gaussian head: targets must be [B={B}, T={T}] with T <= T'*S={Tp * S}, got {tuple(y.shape)}")
+        log_prob = torch.zeros(B, device=dec.device, dtype=torch.float64)
+        lib = load()
+        if kind == 1:
+            rc = lib.blvm_gmm_fwd(ptr(dec), layout, ptr(W), ptr(b), ptr(y), ptr(x_sl_dev), B, T, Tp, S, num_mix, sd_beta, sd_eps,
+                                  ptr(log_prob), None, stream_ptr())  # fmt: skip
+        else:
+            rc = lib.blvm_gauss_head_fwd(ptr(dec), layout, ptr(W), ptr(b), ptr(y), ptr(x_sl_dev), B, T, Tp, S, sd_beta, sd_eps,
+                                         ptr(log_prob), None, stream_ptr())  # fmt: skip
+        check(rc, "blvm_gmm_fwd" if kind == 1 else "blvm_gauss_head_fwd")
+        ctx.has_linear = W is not None
+        ctx.save_for_backward(dec, y, x_sl_dev, *((W, b) if W is not None else ()))
+        ctx.cfg = (kind, layout, B, T, Tp, S, num_mix, sd_beta, sd_eps, F)
+        return log_prob
+
+    @staticmethod
+    def backward(ctx, g):
+        dec, y, x_sl_dev, *lin = ctx.saved_tensors
+        W, b = lin if ctx.has_linear else (None, None)
+        kind, layout, B, T, Tp, S, num_mix, sd_beta, sd_eps, F = ctx.cfg
+        g32 = g.to(torch.float32).contiguous()
+        d_dec = torch.empty_like(dec)
+        d_par = torch.empty_like(dec) if ctx.has_linear else None
+        lib = load()
+        if kind == 1:
+            rc = lib.blvm_gmm_bwd(ptr(dec), layout, ptr(W), ptr(b), ptr(y), ptr(x_sl_dev), ptr(g32), B, T, Tp, S, num_mix, sd_beta,
+                                  sd_eps, ptr(d_dec), ptr(d_par), stream_ptr())  # fmt: skip
+        else:
+            rc = lib.blvm_gauss_head_bwd(ptr(dec), layout, ptr(W), ptr(b), ptr(y), ptr(x_sl_dev), ptr(g32), B, T, Tp, S, sd_beta,
+                                         sd_eps, ptr(d_dec), ptr(d_par), stream_ptr())  # fmt: skip
+        check(rc, "blvm_gmm_bwd" if kind == 1 else "blvm_gauss_head_bwd")
+        n_frames = dec.numel() // F
+        dW = db = None
+        if ctx.has_linear and ctx.needs_input_grad[1]:
+            dW = torch.zeros_like(W)
+            gemm(1, 1, F, F, n_frames, d_par, F, dec, F, dW, F, accumulate=True, split_k=256)
+        if ctx.has_linear and ctx.needs_input_grad[2]:
+            db = torch.empty_like(b)
+            colsum(d_par.view(n_frames, F), db)
+        return (d_dec if ctx.needs_input_grad[0] else None, dW, db) + (None,) * 11
+
+
+def gmm_log_prob(dec, W, b, y, x_sl_dev, layout, B, T, Tp, S, num_mix, sd_beta, sd_eps):
+    """Per-utterance masked Gaussian-mixture log-likelihood sums [B] (float64); dec [rows, S*3*num_mix]."""
+    return _GaussHeadFunction.apply(dec, W, b, y, x_sl_dev, 1, layout, B, T, Tp, S, num_mix, float(sd_beta), float(sd_eps))
+
+
+def gauss_log_prob(dec, W, b, y, x_sl_dev, layout, B, T, Tp, S, sd_beta, sd_eps):
+    """Per-utterance masked Gaussian log-likelihood sums [B] (float64); dec [rows, S*2]."""
+    return _GaussHeadFunction.apply(dec, W, b, y, x_sl_dev, 2, layout, B, T, Tp, S, 10, float(sd_beta), float(sd_eps))
+
+
 def dmol_ll_twise(dec, W, b, y, x_sl_dev, layout, B, T, Tp, S, num_mix=10, num_bins=256, log_eps=-7.0):
     """Masked frame-wise log-likelihood [B,T] (no autograd)."""
     dec, y = _f32c(dec), _f32c(y)

@@ -43,6 +43,8 @@ struct DmolArgs {
   long long n_frames;  // rows * S
   int layout, B, T, Tp, S;
   float half_bin, low_edge, high_edge, log_half_bins, log_eps;
+  int kind;                 // 0 discretized logistic mixture, 1 Gaussian mixture
+  float sd_beta, sd_eps;    // kind 1: sd = softplus_beta(raw) + sd_eps
 };
 
 // Stage 256 frames x 30 floats (contiguous in HBM) into LDS [256][31].
@@ -212,6 +214,56 @@ __device__ __forceinline__ float dmol_frame(const DmolArgs& a, float yv, float (
   return ll;
 }
 
+// Per-frame Gaussian-mixture math (`DiagonalGaussianMixtureDense.forward` blvm/modules/distributions.py:190-206 after its
+// Linear; `gaussian_mixture_ll` blvm/utils/log_likelihoods.py:42-60 with epsilon = 0): p[0..9] logits, p[10..19] means,
+// p[20..29] pre-softplus standard deviations.  Returns ll; if BWD, overwrites p with dll/dp.
+template <bool BWD>
+__device__ __forceinline__ float gmm_frame(const DmolArgs& a, float yv, float (&p)[F_MAX]) {
+  float mx = p[0];
+#pragma unroll
+  for (int m = 1; m < NMIX; ++m) mx = fmaxf(mx, p[m]);
+  float se = 0.f;
+#pragma unroll
+  for (int m = 0; m < NMIX; ++m) se += fexp(p[m] - mx);
+  const float lse_logits = mx + flog(se);
+  float lp[NMIX], dmu[NMIX], dsd[NMIX];
+  float tmax = -INFINITY;
+  const float inv_beta = 1.f / a.sd_beta;
+#pragma unroll
+  for (int m = 0; m < NMIX; ++m) {
+    const float mu = p[NMIX + m], raw = p[2 * NMIX + m];
+    const float sd = softplus_beta(raw, a.sd_beta, inv_beta) + a.sd_eps;
+    const float isd = frcp(sd), d = (yv - mu) * isd;
+    lp[m] = -0.5f * d * d - flog(sd) - 0.91893853320467274f + (p[m] - lse_logits);
+    tmax = fmaxf(tmax, lp[m]);
+    if (BWD) {
+      dmu[m] = d * isd;                                             // d/dmu
+      dsd[m] = (d * d - 1.f) * isd * sigmoidf_(a.sd_beta * raw);    // d/dsd * d sd/d raw
+    }
+  }
+  float s = 0.f, e[NMIX];
+#pragma unroll
+  for (int m = 0; m < NMIX; ++m) { e[m] = fexp(lp[m] - tmax); s += e[m]; }
+  const float ll = tmax + flog(s);
+  if (BWD) {
+    const float rs = frcp(s), rse = frcp(se);
+#pragma unroll
+    for (int m = 0; m < NMIX; ++m) {
+      const float wgt = e[m] * rs;
+      const float pm = fexp(p[m] - mx) * rse;
+      p[m] = wgt - pm;
+      p[NMIX + m] = wgt * dmu[m];
+      p[2 * NMIX + m] = wgt * dsd[m];
+    }
+  }
+  return ll;
+}
+
+template <bool BWD>
+__device__ __forceinline__ float head_frame(const DmolArgs& a, float yv, float (&p)[F_MAX]) {
+  return a.kind == 0 ? dmol_frame<BWD>(a, yv, p) : gmm_frame<BWD>(a, yv, p);  // wave-uniform branch
+}
+
 template <bool BWD>
 __global__ __launch_bounds__(256) void dmol_kernel(DmolArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[FPB * (F_MAX + 1)];
@@ -242,7 +294,7 @@ __global__ __launch_bounds__(256) void dmol_kernel(DmolArgs a) {
     for (int o = 0; o < F_MAX; ++o) p[o] = d[o];
   }
   const float yv = fc.valid ? a.y[(size_t)fc.b * a.T + fc.tau] : 0.f;
-  const float ll = dmol_frame<BWD>(a, yv, p);
+  const float ll = head_frame<BWD>(a, yv, p);
 
   if (!BWD) {
     const float llm = fc.valid ? ll : 0.f;
@@ -396,7 +448,7 @@ __global__ __launch_bounds__(256) void dmol_rows_kernel(DmolArgs a, int units, i
       for (int o = 0; o < F_MAX; ++o) p[o] = d[o];
     }
     const float yv = valid ? a.y[(size_t)b * a.T + tau] : 0.f;
-    const float ll = dmol_frame<BWD>(a, yv, p);
+    const float ll = head_frame<BWD>(a, yv, p);
     if (!BWD) {
       if (valid) {
         acc += (double)ll;
@@ -520,5 +572,129 @@ extern "C" int blvm_dmol_bwd(const float* dec, int layout, const float* W, const
   rc = launch_dmol<true>(a, static_cast<hipStream_t>(stream));
   if (rc) return rc;
   BLVM_CHECK_LAUNCH("dmol_bwd");
+  return BLVM_OK;
+}
+
+namespace blvm {
+namespace {
+
+// ---- single diagonal Gaussian head (`DiagonalGaussianDense` as a likelihood, blvm/modules/distributions.py:105-150;
+// `gaussian_ll` blvm/utils/log_likelihoods.py:17-39 with epsilon = 0): a frame's 2 activations -> Linear(2->2) -> (mu, raw sd),
+// sd = softplus_beta(raw) + eps, ll = -(y-mu)^2/(2 sd^2) - log sd - log(2 pi)/2; masked per-utterance float64 sums.
+// One lane per frame, 8-byte coalesced accesses; frame -> (utterance, sample) map as in dmol_kernel.
+template <bool BWD>
+__global__ __launch_bounds__(256) void gauss_head_kernel(DmolArgs a) {
+  __shared__ double part[256];
+  const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
+  const FrameCoord fc = frame_coord(a, f);
+  const bool lds_path = !BWD && a.B <= 256;
+  if (lds_path) part[threadIdx.x] = 0.0;
+  float2 d = make_float2(0.f, 0.f);
+  if (f < a.n_frames) d = reinterpret_cast<const float2*>(a.dec)[f];
+  float w00 = 1.f, w01 = 0.f, w10 = 0.f, w11 = 1.f, b0 = 0.f, b1 = 0.f;
+  if (a.W != nullptr) { w00 = a.W[0]; w01 = a.W[1]; w10 = a.W[2]; w11 = a.W[3]; b0 = a.bias[0]; b1 = a.bias[1]; }
+  const float mu = fmaf(w00, d.x, fmaf(w01, d.y, b0)), raw = fmaf(w10, d.x, fmaf(w11, d.y, b1));
+  const float sd = softplus_beta(raw, a.sd_beta, 1.f / a.sd_beta) + a.sd_eps;
+  const float yv = fc.valid ? a.y[(size_t)fc.b * a.T + fc.tau] : 0.f;
+  const float isd = 1.f / sd, z = (yv - mu) * isd;
+  if (!BWD) {
+    const float ll = fc.valid ? -0.5f * z * z - logf(sd) - 0.91893853320467274f : 0.f;
+    if (a.ll_twise != nullptr && fc.valid) a.ll_twise[(size_t)fc.b * a.T + fc.tau] = ll;
+    if (lds_path) {
+      __syncthreads();
+      if (fc.valid) atomicAdd(&part[fc.b], (double)ll);
+      __syncthreads();
+      if ((int)threadIdx.x < a.B && part[threadIdx.x] != 0.0) atomicAdd(a.log_prob + threadIdx.x, part[threadIdx.x]);
+    } else if (fc.valid) {
+      atomicAdd(a.log_prob + fc.b, (double)ll);
+    }
+  } else {
+    if (f >= a.n_frames) return;
+    const float g = fc.valid ? a.g_b[fc.b] : 0.f;
+    const float dmu = g * z * isd;
+    const float draw = g * (z * z - 1.f) * isd * sigmoidf_(a.sd_beta * raw);
+    if (a.d_par != nullptr) reinterpret_cast<float2*>(a.d_par)[f] = make_float2(dmu, draw);
+    reinterpret_cast<float2*>(a.d_dec)[f] = make_float2(fmaf(w00, dmu, w10 * draw), fmaf(w01, dmu, w11 * draw));
+  }
+}
+
+template <bool BWD>
+int launch_gauss(const DmolArgs& a, hipStream_t s) {
+  const long long blocks = (a.n_frames + 255) / 256;
+  BLVM_REQUIRE(blocks < (1ll << 31), "gauss_head: too many frames");
+  hipLaunchKernelGGL((gauss_head_kernel<BWD>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+  return BLVM_OK;
+}
+
+}  // namespace
+}  // namespace blvm
+
+extern "C" int blvm_gauss_head_fwd(const float* dec, int layout, const float* W, const float* bias, const float* y,
+                                   const int32_t* x_sl, int B, int T, int Tp, int S, float sd_beta, float sd_eps,
+                                   double* log_prob, float* ll_twise, void* stream) {
+  using namespace blvm;
+  int rc = check_common(dec, W, bias, y, x_sl, B, T, Tp, S, NMIX, 2, layout);
+  if (rc) return rc;
+  BLVM_REQUIRE(log_prob != nullptr && sd_beta > 0.f && aligned16(dec), "gauss_head_fwd: bad arguments");
+  DmolArgs a = make_args(dec, layout, W, bias, y, x_sl, B, T, Tp, S, 2, 0.f);
+  a.kind = 2; a.sd_beta = sd_beta; a.sd_eps = sd_eps;
+  a.log_prob = log_prob;
+  a.ll_twise = ll_twise;
+  rc = launch_gauss<false>(a, static_cast<hipStream_t>(stream));
+  if (rc) return rc;
+  BLVM_CHECK_LAUNCH("gauss_head_fwd");
+  return BLVM_OK;
+}
+
+extern "C" int blvm_gauss_head_bwd(const float* dec, int layout, const float* W, const float* bias, const float* y,
+                                   const int32_t* x_sl, const float* g_b, int B, int T, int Tp, int S, float sd_beta,
+                                   float sd_eps, float* d_dec, float* d_par, void* stream) {
+  using namespace blvm;
+  int rc = check_common(dec, W, bias, y, x_sl, B, T, Tp, S, NMIX, 2, layout);
+  if (rc) return rc;
+  BLVM_REQUIRE(g_b && d_dec && (d_par || !W) && sd_beta > 0.f && aligned16(dec) && aligned16(d_dec), "gauss_head_bwd: bad arguments");
+  DmolArgs a = make_args(dec, layout, W, bias, y, x_sl, B, T, Tp, S, 2, 0.f);
+  a.kind = 2; a.sd_beta = sd_beta; a.sd_eps = sd_eps;
+  a.g_b = g_b;
+  a.d_dec = d_dec;
+  a.d_par = d_par;
+  rc = launch_gauss<true>(a, static_cast<hipStream_t>(stream));
+  if (rc) return rc;
+  BLVM_CHECK_LAUNCH("gauss_head_bwd");
+  return BLVM_OK;
+}
+
+extern "C" int blvm_gmm_fwd(const float* dec, int layout, const float* W, const float* bias, const float* y,
+                            const int32_t* x_sl, int B, int T, int Tp, int S, int num_mix, float sd_beta, float sd_eps,
+                            double* log_prob, float* ll_twise, void* stream) {
+  using namespace blvm;
+  int rc = check_common(dec, W, bias, y, x_sl, B, T, Tp, S, num_mix, 2, layout);
+  if (rc) return rc;
+  BLVM_REQUIRE(log_prob != nullptr && sd_beta > 0.f, "gmm_fwd: bad arguments");
+  DmolArgs a = make_args(dec, layout, W, bias, y, x_sl, B, T, Tp, S, 2, 0.f);
+  a.kind = 1; a.sd_beta = sd_beta; a.sd_eps = sd_eps;
+  a.log_prob = log_prob;
+  a.ll_twise = ll_twise;
+  rc = launch_dmol<false>(a, static_cast<hipStream_t>(stream));
+  if (rc) return rc;
+  BLVM_CHECK_LAUNCH("gmm_fwd");
+  return BLVM_OK;
+}
+
+extern "C" int blvm_gmm_bwd(const float* dec, int layout, const float* W, const float* bias, const float* y,
+                            const int32_t* x_sl, const float* g_b, int B, int T, int Tp, int S, int num_mix, float sd_beta,
+                            float sd_eps, float* d_dec, float* d_par, void* stream) {
+  using namespace blvm;
+  int rc = check_common(dec, W, bias, y, x_sl, B, T, Tp, S, num_mix, 2, layout);
+  if (rc) return rc;
+  BLVM_REQUIRE(g_b && d_dec && (d_par || !W) && sd_beta > 0.f, "gmm_bwd: bad arguments");
+  DmolArgs a = make_args(dec, layout, W, bias, y, x_sl, B, T, Tp, S, 2, 0.f);
+  a.kind = 1; a.sd_beta = sd_beta; a.sd_eps = sd_eps;
+  a.g_b = g_b;
+  a.d_dec = d_dec;
+  a.d_par = d_par;
+  rc = launch_dmol<true>(a, static_cast<hipStream_t>(stream));
+  if (rc) return rc;
+  BLVM_CHECK_LAUNCH("gmm_bwd");
   return BLVM_OK;
 }

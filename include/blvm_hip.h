@@ -77,6 +77,26 @@ int blvm_dmol_bwd(const float* dec, int layout, const float* W, const float* bia
                   const int32_t* x_sl, const float* g_b, int B, int T, int Tp, int S, int num_mix, int num_bins,
                   float log_eps, float* d_dec, float* d_par, void* stream);
 
+/* K7b / K7c  Gaussian output heads, same calling convention, frame layout, masks and float64 per-utterance sums as K7:
+ *   gmm: `DiagonalGaussianMixtureDense.forward` + `.log_prob` (`blvm/modules/distributions.py:153-206`,
+ *        `gaussian_mixture_ll` `blvm/utils/log_likelihoods.py:42-60`): dec [rows, S*3*num_mix] -> Linear(30->30) (W NULL:
+ *        dec ARE the parameters) -> logits | means | pre-softplus sds, sd = softplus_beta(raw) + sd_eps.
+ *   gauss_head: `DiagonalGaussianDense.forward` + `.log_prob` (`distributions.py:105-150`, `gaussian_ll`
+ *        `log_likelihoods.py:17-39`): dec [rows, S*2] -> Linear(2->2) (W NULL: none) -> mean | pre-softplus sd.
+ *   bwd: d_dec (gradient wrt dec) and d_par (gradient wrt the Linear's output; dW = d_par^T dec, db = colsum(d_par)). */
+int blvm_gmm_fwd(const float* dec, int layout, const float* W, const float* bias, const float* y, const int32_t* x_sl,
+                 int B, int T, int Tp, int S, int num_mix, float sd_beta, float sd_eps, double* log_prob, float* ll_twise,
+                 void* stream);
+int blvm_gmm_bwd(const float* dec, int layout, const float* W, const float* bias, const float* y, const int32_t* x_sl,
+                 const float* g_b, int B, int T, int Tp, int S, int num_mix, float sd_beta, float sd_eps, float* d_dec,
+                 float* d_par, void* stream);
+int blvm_gauss_head_fwd(const float* dec, int layout, const float* W, const float* bias, const float* y,
+                        const int32_t* x_sl, int B, int T, int Tp, int S, float sd_beta, float sd_eps, double* log_prob,
+                        float* ll_twise, void* stream);
+int blvm_gauss_head_bwd(const float* dec, int layout, const float* W, const float* bias, const float* y,
+                        const int32_t* x_sl, const float* g_b, int B, int T, int Tp, int S, float sd_beta, float sd_eps,
+                        float* d_dec, float* d_par, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * K8  fused analytic Gaussian KL + free-nats + mask + per-utterance sums.  Replaces
  *     `blvm/utils/variational.py:67-70,86-122` + `blvm/models/vrnn.py:271-276`.

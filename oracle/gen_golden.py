@@ -476,6 +476,29 @@ def gen_stcn():
     save("stcn.npz", **arrays)
 
 
+def gen_heads():
+    """VRNNAudio with the Gaussian-mixture likelihood head (reduced size, ragged lengths): loss / ELBO / log-likelihood /
+    latents and every parameter gradient.  (likelihood="Gaussian" raises in the reference for every model: its log_prob
+    comes back [B,T,1] and is multiplied with a [B,T] mask, vrnn.py:268 — there is no reference output to record.)"""
+    arrays = {}
+    x, x_sl = O.synth_batch(3, 76, seed=5, ragged=True)
+    arrays.update(x=x, x_sl=x_sl)
+    for tag, lik in (("gmm", "GMM"),):
+        torch.manual_seed(71)
+        m = RM.VRNNAudio(likelihood=lik, input_size=8, hidden_size=32, latent_size=16, residual_posterior=True, num_mix=10)
+        eps = replay_eps(17, 10, 3, 16)
+        torch.manual_seed(17)
+        loss, metrics, o = m(x, x_sl, beta=0.8, free_nats=1.0)
+        loss.backward()
+        arrays.update({f"{tag}_loss": loss, f"{tag}_elbo": o.elbo, f"{tag}_log_prob": o.log_prob, f"{tag}_kl": o.kl, f"{tag}_z": o.z,
+                       f"{tag}_eps": eps})
+        for k, v in m.state_dict().items():
+            arrays[f"{tag}_sd.{k}"] = v
+        for k, p in m.named_parameters():
+            arrays[f"{tag}_grad.{k}"] = p.grad
+    save("heads.npz", **arrays)
+
+
 def gen_lstm():
     """LSTMAudio: reduced size with full tensors, and BASELINE config C1 ([8,4000], h=256, s=64) pinned by checksums."""
     arrays = {}
@@ -520,6 +543,6 @@ def gen_lstm():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn", "wavenet", "rssm", "cwvae", "stcn"]
+    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn", "wavenet", "rssm", "cwvae", "stcn", "heads"]
     for w in which:
         globals()[f"gen_{w}"]()
