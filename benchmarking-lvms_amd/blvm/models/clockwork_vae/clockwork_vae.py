@@ -7,6 +7,7 @@ Everything between the input and the loss lives time-major channel-last [L,B,C] 
 the reference (levels x steps x per-example state gather) become 3 sequence launches + conv stacks per forward.
 """
 import math
+from types import SimpleNamespace
 from typing import List, Optional, Tuple, Union
 
 import numpy as np
@@ -193,8 +194,34 @@ class CWVAE(nn.Module):
             LatestMeanMetric(free_nats, name="free_nats"),
         ]
 
-    def generate(self, *args, **kwargs):
-        raise NotImplementedError("libblvm_hip: ancestral sampling for CWVAE is not built yet (SURVEY §8 'next' row 2)")
+    @torch.no_grad()
+    def generate(self, n_samples: int = 1, max_timesteps: int = 100, use_mode_observations: bool = False, state0=None,
+                 eps: Optional[List[torch.Tensor]] = None):  # fmt: skip
+        """Ancestral sampling (clockwork_vae.py:340-393): every level draws z_t from its prior given the decoded context of the
+        level above, top-down; the bottom context is decoded to the likelihood parameters.  One K5 launch chain per level
+        (posterior branch unused), the K11 context decoders, one head evaluation.  `eps[l]` [T_l,B,z_l] optionally supplies
+        the noise.  The reference passes (length, receptive_field, stride) positionally into
+        get_same_padding(length, stride, kernel_size) here (:357) — kept, so output lengths match."""
+        dev = self.cells[0].prior[0].weight.device
+        NL, os_ = self.num_levels, [int(s) for s in self.overall_strides]
+        same_paddings = []
+        for l in range(NL):
+            input_length = math.ceil(max_timesteps / self.strides[l - 1]) if l > 0 else max_timesteps
+            same_paddings.append(get_same_padding(input_length, self.receptive_fields[l], self.strides[l]))
+        states0 = [None] * NL if state0 is None else state0
+        context = None
+        for l in range(NL - 1, -1, -1):
+            T_l = max_timesteps // os_[l] if l == NL - 1 else context.shape[0]
+            if T_l < 1:
+                raise IndexError(f"generate: level {l} has no steps for {max_timesteps=}")
+            Z = self.z_size[l]
+            eps_l = eps[l].to(device=dev, dtype=torch.float32).contiguous() if eps is not None else torch.randn(T_l, n_samples, Z, device=dev)
+            zs, hs = self.cells[l].generate_sequence(context, states0[l], eps_l, T_l, n_samples)
+            _, context = self.decoder.forward_level_tm(torch.cat([zs[1:], hs[1:]], dim=-1), l, pad_right=same_paddings[l])
+        parameters = self.likelihood(context.transpose(0, 1).contiguous())
+        x = self.likelihood.mode(parameters) if use_mode_observations else self.likelihood.sample(parameters)
+        x_sl = torch.ones(n_samples, dtype=torch.int) * max_timesteps
+        return (x, x_sl), SimpleNamespace()
 
 
 class CWVAEAudio(BaseModel):

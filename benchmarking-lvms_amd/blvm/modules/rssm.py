@@ -58,6 +58,29 @@ class RSSMCell(nn.Module):
         return ops.rssm_sequence(enc, ctx, z0, h0, eps, x_sl_dev, self.kernel_params(), self.h_dim, self.z_dim, self.mode, stride,
                                  free_nats, self.prior[6].epsilon)  # fmt: skip
 
+    @torch.no_grad()
+    def generate_sequence(self, ctx, state0, eps, T: int, batch_size: int):
+        """Ancestral sampling over T steps (`generate`, rssm.py:106-123, stepped by `CWVAE.generate`): z_t ~ prior(h_t).
+        ctx [T,B,C] or None, eps [T,B,Z] (zeros = prior mode).  Returns (zs [T+1,B,Z], hs [T+1,B,H])."""
+        dev = eps.device
+        enc = torch.zeros(T, batch_size, self.e_dim, device=dev)  # the posterior branch is not used by mode 3
+        x_sl = torch.full((batch_size,), 2**30, dtype=torch.int32, device=dev)
+        z0, h0 = state0 if state0 is not None else (None, None)
+        zs, hs, *_ = ops.rssm_sequence(enc, ctx, z0, h0, eps, x_sl, self.kernel_params(), self.h_dim, self.z_dim, ops.RSSM_GENERATE,
+                                       1, 0.0, self.prior[6].epsilon)  # fmt: skip
+        return zs, hs
+
+    def generate(self, state, context, use_mode: bool = False, eps: Optional[torch.Tensor] = None):
+        """Single step of ancestral sampling (rssm.py:106-123)."""
+        z, h = state
+        B = z.size(0)
+        if eps is None:
+            eps = torch.zeros(B, self.z_dim, device=z.device) if use_mode else torch.randn(B, self.z_dim, device=z.device)
+        ctx = context.unsqueeze(0).contiguous() if context is not None and context.size(-1) > 0 else None
+        zs, hs = self.generate_sequence(ctx, (z.contiguous(), h.contiguous()), eps.unsqueeze(0).contiguous(), 1, B)
+        e = torch.empty(0, device=z.device)
+        return (zs[1], hs[1]), RSSMOutputs(z=zs[1], enc_mu=e, enc_sd=e, prior_mu=None, prior_sd=None)
+
     def forward(self, enc_inputs: torch.Tensor, state: Tuple[torch.Tensor, torch.Tensor], context: torch.Tensor,
                 use_mode: bool = False, eps: Optional[torch.Tensor] = None):  # fmt: skip
         """Single step (rssm.py:79-104) as a length-1 sequence."""

@@ -815,7 +815,7 @@ _RSSM_PARAM_ORDER = (
     + ["prior_w0", "prior_b0", "prior_w1", "prior_b1", "prior_w2", "prior_b2", "prior_hw", "prior_hb"]
     + ["post_w0", "post_b0", "post_w1", "post_b1", "post_w2", "post_b2", "post_hw", "post_hb"]
 )
-RSSM_PLAIN, RSSM_RESIDUAL, RSSM_PRECISION = 0, 1, 2
+RSSM_PLAIN, RSSM_RESIDUAL, RSSM_PRECISION, RSSM_GENERATE = 0, 1, 2, 3  # 3: z drawn from the prior (generation)
 
 
 def _pack_rssm(ts):

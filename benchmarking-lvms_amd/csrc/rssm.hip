@@ -154,7 +154,7 @@ extern "C" int blvm_rssm_seq_fwd(const BlvmRssmWeights* w, const float* enc, con
   if (rc) return rc;
   BLVM_REQUIRE(w && enc && eps && zs && hs && mu_q && sd_q && mu_p && sd_p && reserve, "rssm_fwd: null pointer");
   BLVM_REQUIRE(C == 0 || ctx != nullptr, "rssm_fwd: context missing");
-  BLVM_REQUIRE(mode >= 0 && mode <= 2, "rssm_fwd: mode must be 0 (plain), 1 (residual) or 2 (precision-weighted)");
+  BLVM_REQUIRE(mode >= 0 && mode <= 3, "rssm_fwd: mode must be 0 (plain), 1 (residual), 2 (precision-weighted) or 3 (generate: z from the prior)");
   BLVM_REQUIRE(aligned16(zs) && aligned16(hs) && aligned16(reserve), "rssm_fwd: buffers must be 16-byte aligned");
   RssmReserve rs;
   carve_rssm(reserve, T, B, H, Z, &rs);

@@ -79,7 +79,8 @@ struct HeadArgs {
   const float* eps;                   // [B,Z]
   float *mu_p, *sd_p, *mu_q, *sd_q, *z, *raw_p, *raw_q;  // [B,Z]
   float* muq_raw;  // [B,Z] posterior mean BEFORE the combination with the prior (needed by backward in mode 2), or null
-  int B, H, Z, residual;  // residual: 0 plain, 1 mu_q += mu_p, 2 precision-weighted product of q and p (variational.py:125-138)
+  int B, H, Z, residual;  // residual: 0 plain, 1 mu_q += mu_p, 2 precision-weighted product of q and p (variational.py:125-138),
+                          // 3 GENERATION: z is drawn from the prior (q := p), `VRNNCell.generate` vrnn.py:144-163, `RSSMCell.generate`
   float beta, inv_beta, sd_eps;
 };
 
@@ -118,6 +119,9 @@ __global__ __launch_bounds__(NW * 64) void head_stage_kernel(HeadArgs a) {
     const float var = 1.f / (pq + pp);
     mq = var * (mq * pq + mp * pp);
     sqc = sqrtf(var);
+  } else if (a.residual == 3) {
+    mq = mp;
+    sqc = sp;
   }
   a.mu_p[o] = mp; a.sd_p[o] = sp; a.mu_q[o] = mq; a.sd_q[o] = sqc;
   a.raw_p[o] = rp; a.raw_q[o] = rq;

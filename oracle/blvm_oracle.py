@@ -751,3 +751,42 @@ def stcn_forward(sd, x, x_sl, eps, n_layers, latent_size, n_stack_frames=1, base
     loss = -(log_prob - beta * kld_fn).sum() / x_sl.sum()
     return dict(loss=loss, elbo=elbo, log_prob=log_prob, kld=kld, klds=[k.sum((1, 2)) for k in kl], z=z, mu_q=mu_q, mu_p=mu_p,
                 bpd=float((-elbo.detach() / LN2).sum() / x_sl.sum()))
+
+
+def rssm_generate_step(sd, state, ctx_t, eps_t, prefix=""):
+    """RSSMCell.generate (rssm.py:106-123): GRU update from cat[z, context], z ~ prior(h)."""
+    z, h = state
+    p = prefix
+    g = F.relu(F.linear(torch.cat([z, ctx_t], -1), sd[f"{p}gru_in.0.weight"], sd[f"{p}gru_in.0.bias"]))
+    h_new = gru_cell(g, h, sd[f"{p}gru_cell.weight_ih"], sd[f"{p}gru_cell.weight_hh"], sd[f"{p}gru_cell.bias_ih"], sd[f"{p}gru_cell.bias_hh"])
+    pr = _mlp(h_new, sd, f"{p}prior", (0, 2, 4), F.relu)
+    mu_p, sd_p = gaussian_head(pr, sd[f"{p}prior.6.params.weight"], sd[f"{p}prior.6.params.bias"])
+    return (eps_t * sd_p + mu_p, h_new)
+
+
+def cwvae_audio_generate(sd, eps, n_samples, max_timesteps, strides, num_level_layers, stride_per_layer, num_mix=10, prefix="cwvae"):
+    """CWVAE.generate (clockwork_vae.py:340-393) up to the likelihood parameters; eps[l] [T_l,B,z_l] (zeros = prior means).
+    The same-padding call passes (length, receptive_field, stride) positionally into (length, stride, kernel_size) (:357)."""
+    NL = len(strides)
+    os_ = [int(v) for v in torch.tensor(strides).cumprod(0)]
+    bs = coder_block_strides(strides, num_level_layers, stride_per_layer)
+    rfs = coder_receptive_fields(bs)
+    same = []
+    for l in range(NL):
+        length = math.ceil(max_timesteps / strides[l - 1]) if l > 0 else max_timesteps
+        same.append(get_same_padding(length, rfs[l], strides[l]))  # (sic) stride=rf, kernel_size=stride
+    ctx, zs_l = None, [None] * NL
+    for l in range(NL - 1, -1, -1):
+        cell_sd = {k[len(f"{prefix}.cells.{l}."):]: v for k, v in sd.items() if k.startswith(f"{prefix}.cells.{l}.")}
+        Z, H = cell_sd["prior.6.params.weight"].size(0) // 2, cell_sd["gru_cell.weight_hh"].size(1)
+        T_l = max_timesteps // os_[l] if ctx is None else ctx.size(2)
+        c = torch.zeros(T_l, n_samples, 0) if ctx is None else ctx.permute(2, 0, 1)
+        state, zs, hs = (torch.zeros(n_samples, Z), torch.zeros(n_samples, H)), [], []
+        for t in range(T_l):
+            state = rssm_generate_step(cell_sd, state, c[t], eps[l][t])
+            zs.append(state[0]); hs.append(state[1])  # noqa: E702
+        zs_l[l] = torch.stack(zs, 0)
+        _, ctx = coder_level(sd, f"{prefix}.decoder", torch.cat([zs_l[l], torch.stack(hs, 0)], -1).permute(1, 2, 0), l, bs, True, same[l])
+    dec = ctx.permute(0, 2, 1)
+    logits, locs, log_scales = dmol_head(dec, sd["likelihood.params.weight"], sd["likelihood.params.bias"], num_mix)
+    return dict(logits=logits, locs=locs, log_scales=log_scales, mode=dmol_mode(logits, locs), z=zs_l)

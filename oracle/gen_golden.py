@@ -499,6 +499,38 @@ def gen_heads():
     save("heads.npz", **arrays)
 
 
+def gen_generate():
+    """Ancestral sampling: CWVAEAudio.generate with the mode of the observation model (the latents are still sampled; the
+    draw order — top level first, one randn(B, z) per step — is replayed into eps)."""
+    arrays = {}
+    cfg = dict(z_size=[32, 16, 16], h_size=16, strides=[4, 2, 2], num_level_layers=2, stride_per_layer=2, likelihood="DMoL",
+               num_mix=10, num_bins=2**16, precision_posterior=True)
+    torch.manual_seed(51)
+    m = RM.CWVAEAudio(**cfg)
+    B, T = 2, 64
+    torch.manual_seed(3)
+    (x, x_sl), _ = m.generate(n_samples=B, max_timesteps=T, use_mode_observations=True)
+    # Replay of the draws: level lengths are T // 16 at the top and, below, the length of the context the reference's own
+    # decoder returns (its same-padding arithmetic in generate is the positional-argument variant, clockwork_vae.py:357).
+    from blvm.utils.padding import get_same_padding
+
+    eps, ctx_len, os_ = [None] * 3, None, [4, 8, 16]
+    torch.manual_seed(3)
+    with torch.no_grad():
+        for l in (2, 1, 0):
+            T_l = T // os_[l] if l == 2 else ctx_len
+            eps[l] = torch.stack([torch.randn(B, cfg["z_size"][l]) for _ in range(T_l)], 0)
+            length = math.ceil(T / cfg["strides"][l - 1]) if l > 0 else T
+            pad = get_same_padding(length, m.cwvae.receptive_fields[l], cfg["strides"][l])
+            ctx_len = m.cwvae.decoder[l](torch.zeros(B, cfg["z_size"][l] + cfg["h_size"], T_l), pad_right=pad)[1].shape[-1]
+    arrays.update(cw_x_mode=x, cw_x_sl=x_sl, cw_T=np.array([T]))
+    for l in range(3):
+        arrays[f"cw_eps{l}"] = eps[l]
+    for k, v in m.state_dict().items():
+        arrays[f"cw_sd.{k}"] = v
+    save("generate.npz", **arrays)
+
+
 def gen_lstm():
     """LSTMAudio: reduced size with full tensors, and BASELINE config C1 ([8,4000], h=256, s=64) pinned by checksums."""
     arrays = {}
@@ -543,6 +575,6 @@ def gen_lstm():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn", "wavenet", "rssm", "cwvae", "stcn", "heads"]
+    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn", "wavenet", "rssm", "cwvae", "stcn", "heads", "generate"]
     for w in which:
         globals()[f"gen_{w}"]()

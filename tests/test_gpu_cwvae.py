@@ -219,3 +219,19 @@ def test_cwvae_c4_full_size_rows_are_independent():
         _, _, o2 = m(x[rows].contiguous(), x_sl[rows], beta=1.0, free_nats=4.0, eps=[e[:, rows].contiguous() for e in eps])
     close(o2.elbo, o.elbo[rows].cpu(), 1e-5)
     close(o2.kld, o.kld[rows].cpu(), 1e-4, 1e-4)
+
+
+def test_cwvae_generate_matches_reference():
+    """CWVAEAudio.generate (ancestral sampling, mode of the observation model) against the reference's own output for the
+    same prior draws (tests/golden/generate.npz); output length 205 for max_timesteps=64 is the reference's."""
+    g = np.load(os.path.join(GOLDEN, "generate.npz"))
+    m = CWVAEAudio(**CW_SMALL, precision_posterior=True)
+    m.load_state_dict({k[6:]: T(g[k]) for k in g.files if k.startswith("cw_sd.")})
+    m = m.to(DEV)
+    eps = [T(g[f"cw_eps{l}"]).to(DEV) for l in range(3)]
+    (x, x_sl), _ = m.generate(n_samples=2, max_timesteps=int(g["cw_T"][0]), use_mode_observations=True, eps=eps)
+    assert tuple(x.shape) == tuple(g["cw_x_mode"].shape)
+    close(x, g["cw_x_mode"], 1e-4, 1e-5)
+    assert torch.equal(x_sl, T(g["cw_x_sl"]).to(x_sl.dtype))
+    (xs, _), _ = m.generate(n_samples=3, max_timesteps=64)  # stochastic observations, device RNG
+    assert tuple(xs.shape) == (3, 205, 1) and torch.isfinite(xs).all() and float(xs.abs().max()) <= 1.0

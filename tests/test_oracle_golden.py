@@ -273,3 +273,11 @@ def test_stcn_small_forward_backward(tag, S, beta, fn_):
             continue
         ref = T(g[f"{tag}_grad.{k}"]).double()
         assert (ref - p.grad).norm() / (p.grad.norm() + 1e-12) < 1e-2, k
+
+
+def test_cwvae_generate_matches_reference():
+    g = np.load(os.path.join(GOLDEN, "generate.npz"))
+    sd = {k[6:]: T(g[k]) for k in g.files if k.startswith("cw_sd.")}
+    eps = [T(g[f"cw_eps{l}"]) for l in range(3)]
+    out = O.cwvae_audio_generate(sd, eps, 2, int(g["cw_T"][0]), [4, 2, 2], 2, 2)
+    close(out["mode"], g["cw_x_mode"], 1e-5, 1e-6)
