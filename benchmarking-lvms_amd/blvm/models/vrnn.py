@@ -84,14 +84,30 @@ class VRNNCell(nn.Module):
         out += [g.weight_ih, g.weight_hh, g.bias_ih, g.bias_hh]
         return out
 
-    def sequence(self, enc, h0, eps, x_sl_dev, stride: int, free_nats: float = 0.0):
+    def sequence(self, enc, h0, eps, x_sl_dev, stride: int, free_nats: float = 0.0, generate: bool = False):
+        """`generate=True`: z is drawn from the prior instead of the posterior (`VRNNCell.generate`, vrnn.py:143-164)."""
         if not self.condition_h_on_x:
             raise NotImplementedError("libblvm_hip: VRNN cell kernels implement condition_h_on_x=True (the VRNNAudio form)")
         head = self.prior[6]
         if head.initial_sd != 1 or self.posterior[6].epsilon != head.epsilon:
             raise NotImplementedError("libblvm_hip: Gaussian heads with initial_sd != 1 are not supported")
+        mode = 3 if generate else int(self.residual_posterior)
         return ops.vrnn_sequence(enc, h0, eps, x_sl_dev, self.kernel_params(), self.x_dim, self.h_dim, self.z_dim,
-                                 self.r_dim, self.residual_posterior, stride, free_nats, head.epsilon)  # fmt: skip
+                                 self.r_dim, mode, stride, free_nats, head.epsilon)  # fmt: skip
+
+    @torch.no_grad()
+    def generate(self, x: torch.Tensor, h: torch.Tensor, use_mode: bool = False, eps: Optional[torch.Tensor] = None):
+        """One step of ancestral sampling (vrnn.py:143-164) as a length-1 sequence in prior-sampling mode."""
+        B = x.size(0)
+        if eps is None:
+            eps = torch.zeros(B, self.z_dim, device=x.device) if use_mode else torch.randn(B, self.z_dim, device=x.device)
+        x_sl = torch.ones(B, dtype=torch.int32, device=x.device)
+        decin, _, _, _, _, mu_p, sd_p, z = self.sequence(x.unsqueeze(0).contiguous(), h, eps.view(1, B, self.z_dim).contiguous(),
+                                                         x_sl, 1, 0.0, generate=True)  # fmt: skip
+        h_new = decin[1, :, self.h_dim :]
+        out = SimpleNamespace(h=h_new, z=z[0], enc_mu=mu_p[0], enc_sd=sd_p[0], prior_mu=mu_p[0], prior_sd=sd_p[0],
+                              phi_z=decin[0, :, : self.h_dim])  # fmt: skip
+        return h_new, out
 
     def forward(self, x: torch.Tensor, h: torch.Tensor, eps: Optional[torch.Tensor] = None):
         """Single step (vrnn.py:109-141): a length-1 sequence through the same kernels."""
@@ -227,6 +243,43 @@ class VRNN(nn.Module):
         return loss, metrics, outputs
 
 
+    @torch.no_grad()
+    def generate(self, x: torch.Tensor, h0: Optional[torch.Tensor] = None, n_samples: int = 1, max_timesteps: int = 100,
+                 stop_value: float = None, use_mode: bool = False, eps: Optional[torch.Tensor] = None):  # fmt: skip
+        """Autoregressive sampling (vrnn.py:371-434): the previous frame stack is encoded, the cell draws z from its prior and
+        updates h, the decoder (on cat[phi_z, h_new] — the UPDATED state here, unlike `forward`) parameterises the next frame
+        stack, which is sampled (or its mode taken) and fed back.  x [B,S,1] initial frame stack; returns ((x [B,1+T,S], x_sl), ns).
+        `eps` [T,B,z] optionally supplies the prior noise.  Every step runs the K6 / K1 / K7-head kernels at T' = 1."""
+        S, enc_lin, dec_lin, lik = self._plan()
+        if x.size(0) > 1:
+            assert x.size(0) == n_samples
+        else:
+            x = x.repeat(n_samples, *[1] * (x.ndim - 1))
+        dev = x.device
+        H = self.h_dim
+        all_x = [x]
+        x_sl = torch.ones(n_samples, dtype=torch.int)
+        h = self.vrnn_cell.get_initial_state(n_samples, dev) if h0 is None else h0
+        seq_active = torch.ones(n_samples, dtype=torch.int)
+        t, all_ended = 0, False
+        while not all_ended and t < max_timesteps:
+            enc = ops.mlp(x.reshape(n_samples, S).to(torch.float32).contiguous(), enc_lin, ops.ACT_LEAKY, ops.LEAKY_SLOPE)
+            # the reference does not forward use_mode to the cell (vrnn.py:405): z is always SAMPLED from the prior
+            h, out = self.vrnn_cell.generate(enc, h.contiguous(), use_mode=False, eps=None if eps is None else eps[t])
+            dec = ops.mlp(torch.cat([out.phi_z, h], -1).contiguous(), dec_lin, ops.ACT_LEAKY, ops.LEAKY_SLOPE)  # [B, S*F]
+            parameters = lik(dec.view(n_samples, S, lik.out_features))
+            x = lik.mode(parameters) if use_mode else lik.sample(parameters)  # [B,S,1]
+            all_x.append(x)
+            x_sl += seq_active
+            if stop_value is not None:
+                ending = (x == stop_value).flatten(1).all(1).to(torch.int).cpu()
+                seq_active *= 1 - ending
+            t += 1
+            all_ended = bool(torch.all(1 - seq_active))
+        x = torch.cat(all_x, dim=-1).permute(0, 2, 1)
+        return (x, x_sl), SimpleNamespace()
+
+
 class VRNNAudio(BaseModel):
     def __init__(self, likelihood: Union[str, nn.Module], input_size: int = 200, hidden_size: int = 256,
                  latent_size: int = 64, residual_posterior: bool = False, condition_h_on_x: bool = True,
@@ -279,3 +332,9 @@ class VRNNAudio(BaseModel):
 
     def forward(self, x, x_sl, beta: float = 1, free_nats: float = 0, h0=None, eps=None):
         return self.vrnn(x, x_sl, beta, free_nats, h0, eps)
+
+    def generate(self, n_samples: int = 1, max_timesteps: int = 100, use_mode: bool = False, x=None, h0=None, eps=None):
+        """Same arguments as the reference (vrnn.py:529-546)."""
+        x = torch.zeros(n_samples, self.input_size, 1, device=self.device) if x is None else x
+        return self.vrnn.generate(n_samples=n_samples, max_timesteps=max_timesteps, stop_value=None, use_mode=use_mode, x=x, h0=h0,
+                                  eps=eps)  # fmt: skip

@@ -461,7 +461,7 @@ def vrnn_sequence(enc, h0, eps, x_sl_dev, params: Sequence[torch.Tensor], X, H, 
     (decin [T'+1,B,H+R], kld [B] f64, kld_fn [B] f64, mu_q, sd_q, mu_p, sd_p, z)."""
     Tp, B, _ = enc.shape
     fn_floor = float(free_nats) / Z if free_nats else 0.0
-    cfg = (Tp, B, X, H, Z, R, bool(residual_posterior), float(sd_eps), int(stride), fn_floor)
+    cfg = (Tp, B, X, H, Z, R, int(residual_posterior), float(sd_eps), int(stride), fn_floor)  # 0 plain, 1 residual, 3 generate
     return _VRNNSeqFunction.apply(enc, h0, eps, x_sl_dev, cfg, *params)
 
 
@@ -660,7 +660,7 @@ def srnn_latent_chain(d, a, z0, eps, x_sl_dev, params, H, Z, R, residual_posteri
     """d, a [T',B,R] -> (zs [T'+1,B,Z] with zs[0]=z0, kld [B] f64, kld_fn [B] f64, mu_q, sd_q, mu_p, sd_p)."""
     Tp, B, _ = d.shape
     fn_floor = float(free_nats) / Z if free_nats else 0.0
-    cfg = (Tp, B, H, Z, R, bool(residual_posterior), float(sd_eps), float(slope), int(stride), fn_floor)
+    cfg = (Tp, B, H, Z, R, int(residual_posterior), float(sd_eps), float(slope), int(stride), fn_floor)  # 3: generate
     return _SRNNLatentFunction.apply(d, a, z0, eps, x_sl_dev, cfg, *params)
 
 

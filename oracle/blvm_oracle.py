@@ -790,3 +790,28 @@ def cwvae_audio_generate(sd, eps, n_samples, max_timesteps, strides, num_level_l
     dec = ctx.permute(0, 2, 1)
     logits, locs, log_scales = dmol_head(dec, sd["likelihood.params.weight"], sd["likelihood.params.bias"], num_mix)
     return dict(logits=logits, locs=locs, log_scales=log_scales, mode=dmol_mode(logits, locs), z=zs_l)
+
+
+def vrnn_audio_generate(sd, n_samples, max_timesteps, stack, eps, num_mix=10, prefix="vrnn"):
+    """VRNNAudio.generate with use_mode semantics for the observations (vrnn.py:371-434, 529-546): frame stack x_t -> encoder ->
+    `VRNNCell.generate` (z = mu_p + sd_p * eps_t; :143-164) -> decoder(cat[phi_z, h_NEW]) -> DMoL head -> mode, fed back.
+    eps [T,B,z] (zeros = the reference's use_mode=True).  Returns x [B, 1+T, stack] (first frame = the zero start frame)."""
+    cell = f"{prefix}.vrnn_cell"
+    H = sd[f"{cell}.prior.0.weight"].size(0)
+    R = sd[f"{cell}.gru_cell.weight_hh"].size(1)
+    x = torch.zeros(n_samples, stack)
+    h = torch.zeros(n_samples, R)
+    frames = [x]
+    for t in range(max_timesteps):
+        enc = _mlp(x, sd, f"{prefix}.encoder", (2, 4, 6), F.leaky_relu)
+        p = _mlp(h, sd, f"{cell}.prior", (0, 2, 4), F.relu)
+        mu_p, sd_p = gaussian_head(p, sd[f"{cell}.prior.6.params.weight"], sd[f"{cell}.prior.6.params.bias"])
+        z = eps[t] * sd_p + mu_p
+        phi = _mlp(z, sd, f"{cell}.phi_z", (0, 2, 4, 6), F.relu)
+        h = gru_cell(torch.cat([enc, phi], -1), h, sd[f"{cell}.gru_cell.weight_ih"], sd[f"{cell}.gru_cell.weight_hh"],
+                     sd[f"{cell}.gru_cell.bias_ih"], sd[f"{cell}.gru_cell.bias_hh"])
+        dec = _mlp(torch.cat([phi, h], -1), sd, f"{prefix}.decoder", (0, 2, 4), F.leaky_relu).view(n_samples, stack, 3 * num_mix)
+        logits, locs, _ = dmol_head(dec, sd[f"{prefix}.likelihood.params.weight"], sd[f"{prefix}.likelihood.params.bias"], num_mix)
+        x = dmol_mode(logits, locs).squeeze(-1)
+        frames.append(x)
+    return torch.stack(frames, 1)

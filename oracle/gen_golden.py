@@ -528,6 +528,17 @@ def gen_generate():
         arrays[f"cw_eps{l}"] = eps[l]
     for k, v in m.state_dict().items():
         arrays[f"cw_sd.{k}"] = v
+
+    # VRNNAudio.generate, use_mode=True: observation modes are fed back, but `VRNN.generate` does not forward use_mode to the
+    # cell (vrnn.py:405), so z is still SAMPLED from the prior: one randn(B, z) per step, replayed into eps
+    torch.manual_seed(11)
+    v = RM.VRNNAudio(likelihood="DMoL", input_size=8, hidden_size=32, latent_size=16, residual_posterior=True, num_mix=10, num_bins=2**16)
+    arrays["vr_eps"] = replay_eps(29, 6, 3, 16)
+    torch.manual_seed(29)
+    (xv, xv_sl), _ = v.generate(n_samples=3, max_timesteps=6, use_mode=True)
+    arrays.update(vr_x=xv, vr_x_sl=xv_sl)
+    for k, p in v.state_dict().items():
+        arrays[f"vr_sd.{k}"] = p
     save("generate.npz", **arrays)
 
 

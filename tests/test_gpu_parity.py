@@ -602,3 +602,17 @@ def test_rssm_sequence_vs_reference_golden(tag, kw, c_dim):
         assert rel_l2(ctx.grad, T(g[f"{tag}_d_ctx"])) < 1e-3
     for k, p in cell.named_parameters():
         assert rel_l2(p.grad, T(g[f"{tag}_grad.{k}"])) < 1e-3, k
+
+
+def test_vrnn_generate_matches_reference():
+    """VRNNAudio.generate(use_mode=True): autoregressive roll-out (encode the previous frame stack, draw z from the prior,
+    update h, decode, feed the mode back) against the reference's own output for the same prior draws."""
+    g = np.load(os.path.join(GOLDEN, "generate.npz"))
+    m = VRNNAudio(likelihood="DMoL", input_size=8, hidden_size=32, latent_size=16, residual_posterior=True, num_mix=10, num_bins=2**16)
+    m.load_state_dict({k[6:]: T(g[k]) for k in g.files if k.startswith("vr_sd.")})
+    m = m.to(DEV)
+    (x, x_sl), _ = m.generate(n_samples=3, max_timesteps=6, use_mode=True, eps=T(g["vr_eps"]).to(DEV))
+    assert tuple(x.shape) == tuple(g["vr_x"].shape) and x_sl.tolist() == g["vr_x_sl"].tolist()
+    torch.testing.assert_close(x.cpu(), T(g["vr_x"]), rtol=1e-4, atol=2e-5)
+    (xs, xs_sl), _ = m.generate(n_samples=2, max_timesteps=4)  # stochastic observations from the device RNG
+    assert tuple(xs.shape) == (2, 5, 8) and torch.isfinite(xs).all() and float(xs.abs().max()) <= 1.0

@@ -281,3 +281,10 @@ def test_cwvae_generate_matches_reference():
     eps = [T(g[f"cw_eps{l}"]) for l in range(3)]
     out = O.cwvae_audio_generate(sd, eps, 2, int(g["cw_T"][0]), [4, 2, 2], 2, 2)
     close(out["mode"], g["cw_x_mode"], 1e-5, 1e-6)
+
+
+def test_vrnn_generate_matches_reference():
+    g = np.load(os.path.join(GOLDEN, "generate.npz"))
+    sd = {k[6:]: T(g[k]) for k in g.files if k.startswith("vr_sd.")}
+    x = O.vrnn_audio_generate(sd, 3, 6, 8, T(g["vr_eps"]))
+    close(x, g["vr_x"], 1e-6, 1e-7)
