@@ -7,6 +7,7 @@ KL + free nats (K8, backward fused into K3).  Faithful quirk: `kl` in the output
 loss uses the free-nats-clamped one (srnn.py:154-160; the VRNN returns the clamped one).
 """
 import math
+from types import SimpleNamespace
 from typing import Optional, Union
 
 import torch
@@ -172,6 +173,50 @@ class SRNN(nn.Module):
         return loss, metrics, outputs
 
 
+    @torch.no_grad()
+    def generate(self, x, u=None, d_0=None, a_0=None, z_0=None, h_p_0=None, n_samples: int = 1, max_timesteps: int = 100,
+                 stop_value: float = None, use_mode: bool = False, eps=None, uniforms=None):  # fmt: skip
+        """Unconditional autoregressive sampling (srnn.py:304-403): encode the previous frame stack, one GRU step for d_t, draw
+        z_t from the prior given cat[d_t, z_{t-1}] (its mean if use_mode), decode cat[z_t, d_t], SAMPLE the next frame stack and
+        feed it back.  x [B,1,S] start frames.  Returns ((x [B,T,S,1], x_sl), ns(h_p)).  `eps` [T,B,z] and `uniforms`
+        (list of the head sampler's draws per step) optionally supply the randomness.  Every step runs K6 / K2 / K3 at T' = 1."""
+        if u is not None or x.size(1) > 1:
+            raise NotImplementedError("libblvm_hip: SRNN.generate is built for unconditional generation (x [B,1,S], u=None)")
+        S, enc_lin, dec_lin, lik = self._plan()
+        dev = x.device
+        H, Z, R = self.h_dim, self.z_dim, self.r_dim
+        n = n_samples
+        x_sl = torch.zeros(n)
+        d_t = torch.zeros(n, R, device=dev) if d_0 is None else d_0.reshape(n, R).contiguous()
+        z_t = torch.zeros(n, Z, device=dev) if z_0 is None else z_0.contiguous()
+        ones = torch.ones(n, dtype=torch.int32, device=dev)
+        gd, head = self.d_forward_recurrent, self.prior[6]
+        all_x = []
+        seq_active = torch.ones(n, dtype=torch.int)
+        t, all_ended = 0, False
+        h_p = None
+        while not all_ended and t < max_timesteps:
+            enc = ops.mlp(x.reshape(n, S).to(torch.float32).contiguous(), enc_lin, ops.ACT_LEAKY, ops.LEAKY_SLOPE).view(1, n, -1)
+            d_seq, _ = ops.gru_sequence(enc, d_t, gd.weight_ih_l0, gd.weight_hh_l0, gd.bias_ih_l0, gd.bias_hh_l0)
+            d_t = d_seq[0].contiguous()
+            h_p = torch.cat([d_t, z_t], -1)
+            e = torch.zeros(1, n, Z, device=dev) if use_mode else (torch.randn(1, n, Z, device=dev) if eps is None else eps[t].view(1, n, Z))
+            zs, *_ = ops.srnn_latent_chain(d_t.unsqueeze(0), torch.zeros(1, n, R, device=dev), z_t, e.to(dev).contiguous(), ones,
+                                           self._chain_params(), H, Z, R, 3, 1, 0.0, head.epsilon)  # mode 3: z ~ prior
+            z_t = zs[1].contiguous()
+            dec = ops.mlp(torch.cat([z_t, d_t], -1).contiguous(), dec_lin, ops.ACT_LEAKY, ops.LEAKY_SLOPE)
+            parameters = lik(dec.view(n, S, lik.out_features))
+            xs = lik.sample(parameters) if uniforms is None else lik.sample(parameters, uniforms=uniforms[t])  # [B,S,1]
+            all_x.append(xs)
+            x = xs.unsqueeze(1)
+            x_sl += seq_active
+            if stop_value is not None:
+                seq_active *= 1 - (xs == stop_value).flatten(1).all(1).to(torch.int).cpu()
+            t += 1
+            all_ended = bool(torch.all(1 - seq_active))
+        return (torch.stack(all_x, dim=1), x_sl), SimpleNamespace(h_p=h_p)
+
+
 class SRNNAudio(BaseModel):
     def __init__(self, likelihood: Union[str, nn.Module], input_size: int = 200, hidden_size: int = 256, latent_size: int = 64,
                  dropout: float = 0, residual_posterior: bool = False, smoothing: bool = True, num_mix: int = 10,
@@ -224,3 +269,10 @@ class SRNNAudio(BaseModel):
         loss, metrics, outputs = self.srnn(x=x, x_sl=x_sl, d_0=d_0, a_0=a_0, z_0=z_0, beta=beta, free_nats=free_nats, eps=eps)
         outputs._lazy["x_hat"] = lambda: self.srnn.likelihood.sample(outputs.parameters)
         return loss, metrics, outputs
+
+    def generate(self, n_samples: int = 1, max_timesteps: int = 100, use_mode: bool = False, x=None, u=None, d_0=None, a_0=None,
+                 z_0=None, eps=None, uniforms=None):  # fmt: skip
+        """Same arguments as the reference (srnn.py:515-535)."""
+        x = torch.zeros(n_samples, 1, self.input_size, device=self.device) if x is None else x
+        return self.srnn.generate(x=x, u=u, d_0=d_0, a_0=a_0, z_0=z_0, n_samples=n_samples, max_timesteps=max_timesteps,
+                                  use_mode=use_mode, eps=eps, uniforms=uniforms)  # fmt: skip

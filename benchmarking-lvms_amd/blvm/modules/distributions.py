@@ -85,14 +85,15 @@ class DiscretizedLogisticMixtureDense(ConditionalDistribution):
         return torch.gather(params[1], index=idx, dim=-1).squeeze(-1).contiguous()
 
     @torch.no_grad()
-    def sample(self, params, eps: float = 1e-5):
-        """Gumbel-max component pick + logistic sample clamped to [-1,1] (blvm/utils/variational.py:309-349)."""
+    def sample(self, params, eps: float = 1e-5, uniforms=None):
+        """Gumbel-max component pick + logistic sample clamped to [-1,1] (blvm/utils/variational.py:309-349).  `uniforms` =
+        (u [*,K] in (eps, 1-eps), u2 [*,1] in (1e-8, 1-1e-8)) optionally supplies the two draws the reference makes, in its order."""
         logits, locs, log_scales = params
-        u = torch.empty_like(logits).uniform_(eps, 1.0 - eps)
+        u = torch.empty_like(logits).uniform_(eps, 1.0 - eps) if uniforms is None else uniforms[0].to(logits)
         idx = (logits - torch.log(-torch.log(u))).argmax(-1, keepdim=True).unsqueeze(-2)
         loc = torch.gather(locs, -1, idx.expand(*locs.shape[:-1], 1)).squeeze(-1)
         ls = torch.gather(log_scales, -1, idx.expand(*log_scales.shape[:-1], 1)).squeeze(-1)
-        u2 = torch.empty_like(loc).uniform_(1e-8, 1.0 - 1e-8)  # rsample_logistic default bounds (variational.py:281)
+        u2 = torch.empty_like(loc).uniform_(1e-8, 1.0 - 1e-8) if uniforms is None else uniforms[1].to(loc)  # variational.py:291
         x = loc + torch.exp(ls) * (torch.log(u2) - torch.log(1.0 - u2))
         return x.clamp(-1.0, 1.0)
 

@@ -815,3 +815,36 @@ def vrnn_audio_generate(sd, n_samples, max_timesteps, stack, eps, num_mix=10, pr
         x = dmol_mode(logits, locs).squeeze(-1)
         frames.append(x)
     return torch.stack(frames, 1)
+
+
+def dmol_sample(logits, locs, log_scales, u, u2):
+    """rsample_discretized_logistic_mixture (variational.py:309-349) with its two uniform draws made explicit:
+    u [*,K] in (1e-5, 1-1e-5) -> Gumbel-max component pick; u2 [*,1] in (1e-8, 1-1e-8) -> logistic sample, clamped to [-1,1]."""
+    idx = (logits - torch.log(-torch.log(u))).argmax(-1, keepdim=True).unsqueeze(-1)
+    loc = torch.gather(locs, -1, idx).squeeze(-1)
+    ls = torch.gather(log_scales, -1, idx).squeeze(-1)
+    return (loc + torch.exp(ls) * (torch.log(u2) - torch.log(1 - u2))).clamp(-1, 1)
+
+
+def srnn_audio_generate(sd, n_samples, max_timesteps, stack, eps, uniforms, num_mix=10, prefix="srnn"):
+    """SRNNAudio.generate, unconditional (srnn.py:304-403, 515-535): d_t = GRU(encoder(x_{t-1}), d_{t-1}); z_t ~ prior(cat[d_t, z_{t-1}])
+    (Elman transfer); x_t ~ DMoL(decoder(cat[z_t, d_t])) — always SAMPLED — fed back.  eps [T,B,z]; uniforms[t] = (u, u2).
+    Returns x [B,T,stack,1]."""
+    R = sd[f"{prefix}.d_forward_recurrent.weight_hh_l0"].size(1)
+    Z = sd[f"{prefix}.prior.6.params.weight"].size(0) // 2
+    g = f"{prefix}.d_forward_recurrent"
+    x = torch.zeros(n_samples, stack)
+    d_t, z_t = torch.zeros(n_samples, R), torch.zeros(n_samples, Z)
+    out = []
+    for t in range(max_timesteps):
+        enc = _mlp(x, sd, f"{prefix}.encoder", (2, 4, 6), F.leaky_relu)
+        d_t = gru_cell(enc, d_t, sd[f"{g}.weight_ih_l0"], sd[f"{g}.weight_hh_l0"], sd[f"{g}.bias_ih_l0"], sd[f"{g}.bias_hh_l0"])
+        hp = _mlp(torch.cat([d_t, z_t], -1), sd, f"{prefix}.prior", (0, 2, 4), F.leaky_relu)
+        mu_p, sd_p = gaussian_head(hp, sd[f"{prefix}.prior.6.params.weight"], sd[f"{prefix}.prior.6.params.bias"])
+        z_t = eps[t] * sd_p + mu_p
+        dec = _mlp(torch.cat([z_t, d_t], -1), sd, f"{prefix}.decoder", (0, 2, 4), F.leaky_relu).view(n_samples, stack, 3 * num_mix)
+        logits, locs, log_scales = dmol_head(dec, sd[f"{prefix}.likelihood.params.weight"], sd[f"{prefix}.likelihood.params.bias"], num_mix)
+        xs = dmol_sample(logits, locs, log_scales, *uniforms[t])  # [B,stack,1]
+        out.append(xs)
+        x = xs.squeeze(-1)
+    return torch.stack(out, 1)

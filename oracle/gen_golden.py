@@ -539,6 +539,23 @@ def gen_generate():
     arrays.update(vr_x=xv, vr_x_sl=xv_sl)
     for k, p in v.state_dict().items():
         arrays[f"vr_sd.{k}"] = p
+
+    # SRNNAudio.generate: per step one randn(B, z) (prior sample), then the head sampler's uniform_(1e-5, 1-1e-5) over the
+    # logits' shape [B,S,K] and uniform_(1e-8, 1-1e-8) over [B,S,1] (variational.py:337,291) — replayed in that order
+    torch.manual_seed(13)
+    sr = RM.SRNNAudio(likelihood="DMoL", input_size=8, hidden_size=32, latent_size=16, residual_posterior=True, smoothing=True)
+    Bn, Tn = 3, 5
+    torch.manual_seed(41)
+    e_l, u_l, u2_l = [], [], []
+    for _ in range(Tn):
+        e_l.append(torch.randn(Bn, 16))
+        u_l.append(torch.empty(Bn, 8, 10).uniform_(1e-5, 1 - 1e-5))
+        u2_l.append(torch.empty(Bn, 8, 1).uniform_(1e-8, 1 - 1e-8))
+    torch.manual_seed(41)
+    (xs_, xs_sl), _ = sr.generate(n_samples=Bn, max_timesteps=Tn)
+    arrays.update(sr_x=xs_, sr_x_sl=xs_sl, sr_eps=torch.stack(e_l), sr_u=torch.stack(u_l), sr_u2=torch.stack(u2_l))
+    for k, p in sr.state_dict().items():
+        arrays[f"sr_sd.{k}"] = p
     save("generate.npz", **arrays)
 
 

@@ -616,3 +616,24 @@ def test_vrnn_generate_matches_reference():
     torch.testing.assert_close(x.cpu(), T(g["vr_x"]), rtol=1e-4, atol=2e-5)
     (xs, xs_sl), _ = m.generate(n_samples=2, max_timesteps=4)  # stochastic observations from the device RNG
     assert tuple(xs.shape) == (2, 5, 8) and torch.isfinite(xs).all() and float(xs.abs().max()) <= 1.0
+
+
+def test_srnn_generate_matches_reference():
+    """SRNNAudio.generate: GRU step, prior sample, decode, SAMPLE the next frame stack, feed back — against the reference's own
+    samples for the same Gaussian and uniform draws (tests/golden/generate.npz)."""
+    from blvm.models import SRNNAudio
+
+    g = np.load(os.path.join(GOLDEN, "generate.npz"))
+    m = SRNNAudio(likelihood="DMoL", input_size=8, hidden_size=32, latent_size=16, residual_posterior=True, smoothing=True)
+    m.load_state_dict({k[6:]: T(g[k]) for k in g.files if k.startswith("sr_sd.")})
+    m = m.to(DEV)
+    uni = [(u.to(DEV), u2.to(DEV)) for u, u2 in zip(T(g["sr_u"]), T(g["sr_u2"]))]
+    (x, x_sl), out = m.generate(n_samples=3, max_timesteps=5, eps=T(g["sr_eps"]).to(DEV), uniforms=uni)
+    assert tuple(x.shape) == tuple(g["sr_x"].shape) and x_sl.tolist() == g["sr_x_sl"].tolist()
+    # a Gumbel-max pick can flip between two components whose perturbed logits tie to ~1e-6: compare allowing no more than
+    # a handful of such flips, everything else to fp32 accuracy
+    diff = (x.cpu() - T(g["sr_x"])).abs()
+    assert float((diff > 1e-4).float().mean()) < 0.02, float((diff > 1e-4).float().mean())
+    assert tuple(out.h_p.shape) == (3, 64 + 16)
+    (xs, _), _ = m.generate(n_samples=2, max_timesteps=3)
+    assert tuple(xs.shape) == (2, 3, 8, 1) and torch.isfinite(xs).all()

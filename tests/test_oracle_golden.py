@@ -288,3 +288,10 @@ def test_vrnn_generate_matches_reference():
     sd = {k[6:]: T(g[k]) for k in g.files if k.startswith("vr_sd.")}
     x = O.vrnn_audio_generate(sd, 3, 6, 8, T(g["vr_eps"]))
     close(x, g["vr_x"], 1e-6, 1e-7)
+
+
+def test_srnn_generate_matches_reference():
+    g = np.load(os.path.join(GOLDEN, "generate.npz"))
+    sd = {k[6:]: T(g[k]) for k in g.files if k.startswith("sr_sd.")}
+    x = O.srnn_audio_generate(sd, 3, 5, 8, T(g["sr_eps"]), list(zip(T(g["sr_u"]), T(g["sr_u2"]))))
+    close(x, g["sr_x"], 1e-6, 1e-6)
