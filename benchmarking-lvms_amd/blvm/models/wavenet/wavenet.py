@@ -136,3 +136,26 @@ class WaveNet(BaseModel):
 
     def forward_split(self, x, x_sl, i_split: int, y=None):
         return self.forward(x, x_sl, y=y, pad_causal=True, pad_receptive_field=(i_split == 0))
+
+    @torch.no_grad()
+    def generate(self, n_samples: int, n_frames: int = 48000, x=None, uniforms=None):
+        """Sample-by-sample generation from a zero start (wavenet.py:254-293): every frame re-runs the causal conv and the
+        whole residual stack over a receptive-field window (no cached sampling, as in the reference), takes the single skip
+        output, DIVIDES it by variance_scale (the reference's generate divides where forward multiplies, :274 — kept), applies
+        the output transform and the head, samples, and shifts the window (FIFO).  Returns x_hat [B, n_frames, 1].
+        `uniforms[t]` optionally supplies the head sampler's two uniform draws of frame t."""
+        lik, C = self.likelihood, self.res_channels
+        if self.n_stack_frames != 1:
+            raise NotImplementedError("libblvm_hip: WaveNet.generate is built for n_stack_frames=1")
+        dev = self.causal.conv.weight.device
+        win = torch.zeros(self.receptive_field, n_samples, self.in_channels, device=dev) if x is None else x.transpose(0, 1).contiguous()
+        x_hat = []
+        for t in range(n_frames):
+            out = self.causal.forward_tm(win, pad_causal=False)
+            skip = self.res_stack.forward_tm(out, 1)  # [1,B,C]
+            logits = self.out_transform.forward_rows(skip.view(n_samples, C), 1.0 / self.variance_scale)
+            parameters = lik(logits.view(n_samples, 1, C))
+            pred = lik.sample(parameters) if uniforms is None else lik.sample(parameters, uniforms=uniforms[t])  # [B,1,1]
+            x_hat.append(pred)
+            win = torch.cat([win[1:], pred.transpose(0, 1).to(torch.float32)], 0)
+        return torch.hstack(x_hat)

@@ -848,3 +848,23 @@ def srnn_audio_generate(sd, n_samples, max_timesteps, stack, eps, uniforms, num_
         out.append(xs)
         x = xs.squeeze(-1)
     return torch.stack(out, 1)
+
+
+def wavenet_generate(sd, n_samples, n_frames, n_layers, n_stacks, uniforms, num_mix=10, base_dilation=2):
+    """WaveNet.generate (wavenet.py:254-293), float input, n_stack_frames=1: per frame the stack runs over a receptive-field
+    window, the single skip output is DIVIDED by sqrt(n_layers/n_stacks) (:274), ReLU-Linear-ReLU, DMoL head,
+    sample (uniforms[t] = (u, u2)), FIFO shift.  Returns [B, n_frames, 1]."""
+    dil = wavenet_dilations(n_layers, n_stacks, base_dilation)
+    rf = sum(dil) + 1 + (sd["causal.conv.weight"].size(2) - 1)
+    x = torch.zeros(n_samples, 1, rf)
+    scale = math.sqrt(n_layers / n_stacks)
+    out = []
+    for t in range(n_frames):
+        h = F.conv1d(x, sd["causal.conv.weight"], sd["causal.conv.bias"])
+        skips = sum(residual_stack_skips(sd, "res_stack", h, dil, 1)) / scale  # [B,C,1]
+        o = F.relu(F.linear(F.relu(skips.transpose(1, 2)), sd["out_transform.linear.weight"], sd["out_transform.linear.bias"]))
+        logits, locs, log_scales = dmol_head(o, sd["likelihood.params.weight"], sd["likelihood.params.bias"], num_mix)
+        pred = dmol_sample(logits, locs, log_scales, *uniforms[t])  # [B,1,1]
+        out.append(pred)
+        x = torch.cat([x[:, :, 1:], pred], dim=2)
+    return torch.hstack(out)

@@ -556,6 +556,20 @@ def gen_generate():
     arrays.update(sr_x=xs_, sr_x_sl=xs_sl, sr_eps=torch.stack(e_l), sr_u=torch.stack(u_l), sr_u2=torch.stack(u2_l))
     for k, p in sr.state_dict().items():
         arrays[f"sr_sd.{k}"] = p
+
+    # WaveNet.generate: per frame the head sampler draws uniform_(1e-5, 1-1e-5) over [B,1,K] and uniform_(1e-8, 1-1e-8) over [B,1,1]
+    torch.manual_seed(15)
+    wn = RM.WaveNet(likelihood=DiscretizedLogisticMixtureDense(16, 1, num_mix=10, num_bins=2**16), n_layers=3, n_stacks=2, res_channels=16)
+    torch.manual_seed(43)
+    wu, wu2 = [], []
+    for _ in range(7):
+        wu.append(torch.empty(2, 1, 10).uniform_(1e-5, 1 - 1e-5))
+        wu2.append(torch.empty(2, 1, 1).uniform_(1e-8, 1 - 1e-8))
+    torch.manual_seed(43)
+    xw = wn.generate(n_samples=2, n_frames=7)
+    arrays.update(wn_x=xw, wn_u=torch.stack(wu), wn_u2=torch.stack(wu2))
+    for k, p in wn.state_dict().items():
+        arrays[f"wn_sd.{k}"] = p
     save("generate.npz", **arrays)
 
 

@@ -295,3 +295,10 @@ def test_srnn_generate_matches_reference():
     sd = {k[6:]: T(g[k]) for k in g.files if k.startswith("sr_sd.")}
     x = O.srnn_audio_generate(sd, 3, 5, 8, T(g["sr_eps"]), list(zip(T(g["sr_u"]), T(g["sr_u2"]))))
     close(x, g["sr_x"], 1e-6, 1e-6)
+
+
+def test_wavenet_generate_matches_reference():
+    g = np.load(os.path.join(GOLDEN, "generate.npz"))
+    sd = {k[6:]: T(g[k]) for k in g.files if k.startswith("wn_sd.")}
+    x = O.wavenet_generate(sd, 2, 7, 3, 2, list(zip(T(g["wn_u"]), T(g["wn_u2"]))))
+    close(x, g["wn_x"], 1e-6, 1e-6)
