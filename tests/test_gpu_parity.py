@@ -656,3 +656,16 @@ def test_wavenet_generate_matches_reference():
     assert float((diff > 1e-4).float().mean()) < 0.1, diff  # a Gumbel-max tie may flip one component pick
     xs = m.generate(n_samples=3, n_frames=4)
     assert tuple(xs.shape) == (3, 4, 1) and torch.isfinite(xs).all()
+
+
+@pytest.mark.parametrize("M,N,ld", [(1000, 192, 192), (84468, 288, 288), (77, 30, 30), (33, 6, 6), (5, 4, 4), (70000, 1920, 1920)])
+def test_colsum_vectorised_and_fallback_paths(M, N, ld):
+    g = torch.Generator().manual_seed(M + N)
+    X = torch.randn(M, ld, generator=g)
+    Xd = X.to(DEV)
+    out = torch.full((N,), 3.0, device=DEV)
+    ops.colsum(Xd[:, :N] if ld != N else Xd, out, accumulate=True)
+    ref = X[:, :N].double().sum(0) + 3
+    assert rel_l2(out, ref) < 1e-5
+    ops.colsum(Xd[:, :N] if ld != N else Xd, out)
+    assert rel_l2(out, X[:, :N].double().sum(0)) < 1e-5
