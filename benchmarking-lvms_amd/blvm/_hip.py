@@ -108,6 +108,7 @@ _SIGNATURES = {
     "blvm_gmm_bwd": (c_int, [c_void_p, c_int] + [c_void_p] * 5 + [c_int] * 5 + [c_float] * 2 + [c_void_p] * 3),
     "blvm_gauss_head_fwd": (c_int, [c_void_p, c_int] + [c_void_p] * 4 + [c_int] * 4 + [c_float] * 2 + [c_void_p] * 3),
     "blvm_gauss_head_bwd": (c_int, [c_void_p, c_int] + [c_void_p] * 5 + [c_int] * 4 + [c_float] * 2 + [c_void_p] * 3),
+    "blvm_mix_sample": (c_int, [c_void_p] * 3 + [ctypes.c_longlong] + [c_int] * 2 + [c_float] * 3 + [c_void_p] * 2),
     "blvm_gauss_latent_fwd": (c_int, [c_void_p] * 5 + [c_size_t] + [c_float] * 3 + [c_int] + [c_void_p] * 5),
     "blvm_gauss_latent_bwd": (c_int, [c_void_p] * 9 + [c_size_t] + [c_float] * 3 + [c_int] + [c_void_p] * 5),
     "blvm_chan_norm_workspace_doubles": (c_size_t, [c_int]),

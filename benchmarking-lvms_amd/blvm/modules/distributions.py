@@ -80,22 +80,24 @@ class DiscretizedLogisticMixtureDense(ConditionalDistribution):
         W, b = (self.params.weight, self.params.bias) if fused_linear else (None, None)
         return ops.dmol_log_prob(dec, W, b, y, x_sl_dev, layout, B, T, Tp, S, self.num_mix, self.num_bins, self.log_epsilon)
 
+    @staticmethod
+    def _pack(params):
+        """(logits [*,K], a [*,1,K], b [*,1,K]) -> head-output layout [*, 3K] the kernels read."""
+        return torch.cat([params[0], params[1].squeeze(-2), params[2].squeeze(-2)], -1).contiguous()
+
+    @torch.no_grad()
     def mode(self, params):
-        idx = params[0].argmax(-1, keepdim=True).unsqueeze(-2)
-        return torch.gather(params[1], index=idx, dim=-1).squeeze(-1).contiguous()
+        return ops.mix_sample(self._pack(params), None, None, 0, self.log_epsilon).unsqueeze(-1)
 
     @torch.no_grad()
     def sample(self, params, eps: float = 1e-5, uniforms=None):
-        """Gumbel-max component pick + logistic sample clamped to [-1,1] (blvm/utils/variational.py:309-349).  `uniforms` =
-        (u [*,K] in (eps, 1-eps), u2 [*,1] in (1e-8, 1-1e-8)) optionally supplies the two draws the reference makes, in its order."""
-        logits, locs, log_scales = params
+        """Gumbel-max component pick + logistic sample clamped to [-1,1] (blvm/utils/variational.py:309-349) in one kernel.
+        `uniforms` = (u [*,K] in (eps, 1-eps), u2 [*,1] in (1e-8, 1-1e-8)) optionally supplies the two draws the reference
+        makes, in its order; otherwise they come from the device RNG."""
+        logits = params[0]
         u = torch.empty_like(logits).uniform_(eps, 1.0 - eps) if uniforms is None else uniforms[0].to(logits)
-        idx = (logits - torch.log(-torch.log(u))).argmax(-1, keepdim=True).unsqueeze(-2)
-        loc = torch.gather(locs, -1, idx.expand(*locs.shape[:-1], 1)).squeeze(-1)
-        ls = torch.gather(log_scales, -1, idx.expand(*log_scales.shape[:-1], 1)).squeeze(-1)
-        u2 = torch.empty_like(loc).uniform_(1e-8, 1.0 - 1e-8) if uniforms is None else uniforms[1].to(loc)  # variational.py:291
-        x = loc + torch.exp(ls) * (torch.log(u2) - torch.log(1.0 - u2))
-        return x.clamp(-1.0, 1.0)
+        u2 = torch.empty(*logits.shape[:-1], device=logits.device).uniform_(1e-8, 1.0 - 1e-8) if uniforms is None else uniforms[1].to(logits)
+        return ops.mix_sample(self._pack(params), u, u2, 0, self.log_epsilon).unsqueeze(-1)
 
 
 class DiagonalGaussianMixtureDense(ConditionalDistribution):
@@ -131,16 +133,15 @@ class DiagonalGaussianMixtureDense(ConditionalDistribution):
         return ops.gmm_log_prob(dec, W, b, y, x_sl_dev, layout, B, T, Tp, S, self.num_mix, self.softplus_beta,
                                 self.epsilon if self.epsilon > 0 else 0.0)  # fmt: skip
 
+    @torch.no_grad()
     def mode(self, params):
-        idx = params[0].argmax(-1, keepdim=True).unsqueeze(-2)
-        return torch.gather(params[1], index=idx, dim=-1).squeeze(-1).contiguous()
+        return ops.mix_sample(DiscretizedLogisticMixtureDense._pack(params), None, None, 1).unsqueeze(-1)
 
     @torch.no_grad()
-    def sample(self, params, eps: float = 1e-6):
-        """Gumbel-max component pick + Gaussian sample (blvm/utils/variational.py:156-197)."""
-        logits, mu, sd = params
-        u = torch.empty_like(logits).uniform_(eps, 1.0 - eps)
-        idx = (logits - torch.log(-torch.log(u))).argmax(-1, keepdim=True).unsqueeze(-2)
-        m = torch.gather(mu, -1, idx.expand(*mu.shape[:-1], 1)).squeeze(-1)
-        s = torch.gather(sd, -1, idx.expand(*sd.shape[:-1], 1)).squeeze(-1)
-        return m + s * torch.randn_like(m)
+    def sample(self, params, eps: float = 1e-6, noise=None):
+        """Gumbel-max component pick + Gaussian sample (blvm/utils/variational.py:156-195) in one kernel; `noise` = (u [*,K]
+        uniforms, n [*,1] standard normals) optionally supplies the reference's two draws."""
+        logits = params[0]
+        u = torch.empty_like(logits).uniform_(eps, 1.0 - eps) if noise is None else noise[0].to(logits)
+        nrm = torch.randn(*logits.shape[:-1], device=logits.device) if noise is None else noise[1].to(logits)
+        return ops.mix_sample(DiscretizedLogisticMixtureDense._pack(params), u, nrm, 1, sd_beta=0.0).unsqueeze(-1)

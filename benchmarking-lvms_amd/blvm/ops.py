@@ -279,6 +279,20 @@ def gauss_log_prob(dec, W, b, y, x_sl_dev, layout, B, T, Tp, S, sd_beta, sd_eps)
     return _GaussHeadFunction.apply(dec, W, b, y, x_sl_dev, 2, layout, B, T, Tp, S, 10, float(sd_beta), float(sd_eps))
 
 
+def mix_sample(par, u, v, kind: int, log_eps: float = -7.0, sd_beta: float = 1.0, sd_eps: float = 0.0):
+    """Sample / mode of a 10-component mixture head (no autograd): par [..., 30] head outputs, u [..., 10] uniforms or None (mode),
+    v [...] component noise or None (location).  kind 0 DMoL, 1 GMM.  Returns [...]."""
+    par = _f32c(par)
+    lead = par.shape[:-1]
+    n = par.numel() // par.shape[-1]
+    out = torch.empty(n, device=par.device, dtype=torch.float32)
+    u = _f32c(u.reshape(n, -1)) if u is not None else None
+    v = _f32c(v.reshape(n)) if v is not None else None
+    check(load().blvm_mix_sample(ptr(par), ptr(u), ptr(v), n, par.shape[-1] // 3, kind, log_eps, sd_beta, sd_eps, ptr(out), stream_ptr()),
+          "blvm_mix_sample")  # fmt: skip
+    return out.view(*lead)
+
+
 def dmol_ll_twise(dec, W, b, y, x_sl_dev, layout, B, T, Tp, S, num_mix=10, num_bins=256, log_eps=-7.0):
     """Masked frame-wise log-likelihood [B,T] (no autograd)."""
     dec, y = _f32c(dec), _f32c(y)

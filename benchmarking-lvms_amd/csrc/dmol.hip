@@ -629,6 +629,59 @@ int launch_gauss(const DmolArgs& a, hipStream_t s) {
 }  // namespace
 }  // namespace blvm
 
+namespace blvm {
+namespace {
+
+// ---- samplers / modes of the mixture heads ---------------------------------------------------------------------------
+// par [n, 30] = head outputs (logits | locations | raw scales).  u [n, 10] in (0,1): Gumbel-max component pick
+// (`rsample_discretized_logistic_mixture` blvm/utils/variational.py:333-345, `rsample_gaussian_mixture` :179-191); NULL: the
+// arg-max-logit component (`mode`, distributions.py:359-368).  v [n]: the component's own noise — kind 0: uniform in (0,1),
+// x = loc + exp(max(raw, log_eps)) * (log v - log(1-v)), clamped to [-1,1] (:283-305); kind 1: standard normal,
+// x = mu + (softplus_beta(raw) + eps) * v (sd_beta == 0: the scales are already standard deviations).  NULL: x = the location.
+__global__ __launch_bounds__(256) void mix_sample_kernel(const float* __restrict__ par, const float* __restrict__ u,
+                                                         const float* __restrict__ v, long long n, int kind, float log_eps,
+                                                         float sd_beta, float sd_eps, float* __restrict__ out) {
+  const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (f >= n) return;
+  const float* p = par + f * F_MAX;
+  int best = 0;
+  float bv = -INFINITY;
+#pragma unroll
+  for (int m = 0; m < NMIX; ++m) {
+    float s = p[m];
+    if (u != nullptr) s -= logf(-logf(u[f * NMIX + m]));
+    if (s > bv) { bv = s; best = m; }  // first maximum, as torch.argmax
+  }
+  const float loc = p[NMIX + best], raw = p[2 * NMIX + best];
+  float x = loc;
+  if (v != nullptr) {
+    const float vv = v[f];
+    if (kind == 0) {
+      x = loc + expf(fmaxf(raw, log_eps)) * (logf(vv) - logf(1.f - vv));
+      x = fminf(fmaxf(x, -1.f), 1.f);
+    } else {
+      x = loc + (sd_beta > 0.f ? softplus_beta(raw, sd_beta, 1.f / sd_beta) + sd_eps : raw) * vv;  // sd_beta == 0: raw IS the sd
+    }
+  }
+  out[f] = x;
+}
+
+}  // namespace
+}  // namespace blvm
+
+extern "C" int blvm_mix_sample(const float* par, const float* u, const float* v, long long n, int num_mix, int kind,
+                               float log_eps, float sd_beta, float sd_eps, float* out, void* stream) {
+  using namespace blvm;
+  BLVM_REQUIRE(par && out && n >= 0 && num_mix == NMIX && (kind == 0 || kind == 1), "mix_sample: bad arguments");
+  if (n == 0) return BLVM_OK;
+  const long long blocks = (n + 255) / 256;
+  BLVM_REQUIRE(blocks < (1ll << 31), "mix_sample: too many frames");
+  hipLaunchKernelGGL(mix_sample_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), par, u, v, n, kind,
+                     log_eps, sd_beta, sd_eps, out);
+  BLVM_CHECK_LAUNCH("mix_sample");
+  return BLVM_OK;
+}
+
 extern "C" int blvm_gauss_head_fwd(const float* dec, int layout, const float* W, const float* bias, const float* y,
                                    const int32_t* x_sl, int B, int T, int Tp, int S, float sd_beta, float sd_eps,
                                    double* log_prob, float* ll_twise, void* stream) {

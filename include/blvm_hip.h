@@ -97,6 +97,14 @@ int blvm_gauss_head_bwd(const float* dec, int layout, const float* W, const floa
                         const int32_t* x_sl, const float* g_b, int B, int T, int Tp, int S, float sd_beta, float sd_eps,
                         float* d_dec, float* d_par, void* stream);
 
+/* Samplers / modes of the mixture heads (`DiscretizedLogisticMixtureDense.sample/.mode`, `DiagonalGaussianMixtureDense.sample/.mode`,
+ * `blvm/modules/distributions.py:173-186,359-368`; `blvm/utils/variational.py:156-195,283-349`).  par [n, 3*num_mix] = head outputs
+ * (logits | locations | raw scales); u [n,num_mix] uniforms for the Gumbel-max component pick (NULL: arg-max logit = mode);
+ * v [n] the picked component's noise (kind 0 DMoL: uniform -> logistic, clamped to [-1,1]; kind 1 GMM: standard normal;
+ * NULL: the location).  out [n].  The caller draws u, v (RNG stays with the host framework, as for eps). */
+int blvm_mix_sample(const float* par, const float* u, const float* v, long long n, int num_mix, int kind, float log_eps,
+                    float sd_beta, float sd_eps, float* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * K8  fused analytic Gaussian KL + free-nats + mask + per-utterance sums.  Replaces
  *     `blvm/utils/variational.py:67-70,86-122` + `blvm/models/vrnn.py:271-276`.

@@ -290,3 +290,34 @@ def test_all_models_run_with_gaussian_heads(lik):
         loss.backward()
         assert torch.isfinite(loss), type(m).__name__
         assert all(p.grad is None or torch.isfinite(p.grad).all() for p in m.parameters()), type(m).__name__
+
+
+@pytest.mark.parametrize("kind", ["dmol", "gmm"])
+def test_mixture_head_samplers_vs_oracle(kind):
+    """K7 samplers: mode and sample of the mixture heads against the oracle's explicit-draw restatements."""
+    from blvm.modules.distributions import DiagonalGaussianMixtureDense, DiscretizedLogisticMixtureDense
+
+    gen = torch.Generator().manual_seed(5)
+    B, Tn, K = 3, 50, 10
+    logits = torch.randn(B, Tn, K, generator=gen)
+    locs = torch.randn(B, Tn, 1, K, generator=gen) * 0.5
+    third = torch.randn(B, Tn, 1, K, generator=gen) - 2
+    u = torch.empty(B, Tn, K).uniform_(1e-5, 1 - 1e-5, generator=gen)
+    if kind == "dmol":
+        head = DiscretizedLogisticMixtureDense(30, 1, num_mix=10, num_bins=2**16)
+        params = (logits, locs, third.clamp(min=-7.0))
+        v = torch.empty(B, Tn, 1).uniform_(1e-8, 1 - 1e-8, generator=gen)
+        ref = O.dmol_sample(*params, u, v)
+        got = head.sample(tuple(p.to(DEV) for p in params), uniforms=(u.to(DEV), v.squeeze(-1).to(DEV)))
+    else:
+        head = DiagonalGaussianMixtureDense(30, 1, num_mix=10, epsilon=1e-4)
+        sd = torch.nn.functional.softplus(third) + 1e-4
+        params = (logits, locs, sd)
+        v = torch.randn(B, Tn, 1, generator=gen)
+        idx = (logits - torch.log(-torch.log(u))).argmax(-1, keepdim=True).unsqueeze(-1)
+        ref = torch.gather(locs, -1, idx).squeeze(-1) + torch.gather(sd, -1, idx).squeeze(-1) * v
+        got = head.sample(tuple(p.to(DEV) for p in params), noise=(u.to(DEV), v.squeeze(-1).to(DEV)))
+    assert tuple(got.shape) == (B, Tn, 1)
+    torch.testing.assert_close(got.cpu(), ref, rtol=1e-5, atol=1e-6)
+    mode = head.mode(tuple(p.to(DEV) for p in params))
+    torch.testing.assert_close(mode.cpu(), O.dmol_mode(logits, locs), rtol=0, atol=0)
