@@ -377,18 +377,23 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip_kernel(DwWArgs a) {
   for (int j = 0; j <= K; ++j) acc[j] = zero4();
   if (n < a.N && u0 < u1) {
     const float4 sc = a.sc ? ld4g(a.sc + n) : zero4(), sh = a.sc ? ld4g(a.sh + n) : zero4();
+    // loads are unconditional (row index clamped, value selected afterwards): no branch sits between a load and the next
+    // one, so the whole window refill of the following iteration is in flight under this iteration's FMAs
     auto ld_b = [&](int r) -> float4 {
-      if (r >= a.LB) return zero4();
-      float4 v = ld4g(a.Bm + (size_t)r * a.N + n);
-      if (a.mask && a.mask_on_b) v = relu_mask4(v, ld4g(a.mask + (size_t)r * a.N + n));
+      const bool ok = r < a.LB;
+      const size_t off = (size_t)(ok ? r : a.LB - 1) * a.N + n;
+      float4 v = ld4g(a.Bm + off);
+      if (a.mask && a.mask_on_b) v = relu_mask4(v, ld4g(a.mask + off));
       if (a.sc && !a.norm_on_a) v = fma4(v, sc, sh);
-      return v;
+      return ok ? v : zero4();
     };
     auto ld_a = [&](int u) -> float4 {
-      float4 v = ld4g(a.A + (size_t)u * a.N + n);
-      if (a.mask && !a.mask_on_b) v = relu_mask4(v, ld4g(a.mask + (size_t)u * a.N + n));
+      const bool ok = u < u1;
+      const size_t off = (size_t)(ok ? u : u1 - 1) * a.N + n;
+      float4 v = ld4g(a.A + off);
+      if (a.mask && !a.mask_on_b) v = relu_mask4(v, ld4g(a.mask + off));
       if (a.sc && a.norm_on_a) v = fma4(v, sc, sh);
-      return v;
+      return ok ? v : zero4();
     };
     float4 win[K];
 #pragma unroll
@@ -398,8 +403,8 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip_kernel(DwWArgs a) {
       constexpr int NS = S < K ? S : K;
       float4 nxt[NS];
 #pragma unroll
-      for (int j = 0; j < NS; ++j) nxt[j] = (u + 1 < u1) ? ld_b((u + 1) * S + (K - NS) + j) : zero4();
-      const float4 av_next = (u + 1 < u1) ? ld_a(u + 1) : zero4();
+      for (int j = 0; j < NS; ++j) nxt[j] = ld_b((u + 1) * S + (K - NS) + j);
+      const float4 av_next = ld_a(u + 1);
 #pragma unroll
       for (int j = 0; j < K; ++j) acc[j] = fma4(av, win[j], acc[j]);
       acc[K].x += av.x; acc[K].y += av.y; acc[K].z += av.z; acc[K].w += av.w;
