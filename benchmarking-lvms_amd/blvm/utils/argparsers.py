@@ -42,7 +42,11 @@ def build_parser() -> argparse.ArgumentParser:
     g.add_argument("--save_checkpoints", type=str2bool, default=False)
     g.add_argument("--test_every", type=int, default=10)
     g = parser.add_argument_group("data")
-    g.add_argument("--dataset", type=str, default="synthetic", choices=["synthetic"])
+    g.add_argument("--dataset", type=str, default="synthetic",
+                   help="'synthetic', or the path of a TRAIN source CSV (`filename,length.<ext>.samples`, WAV files next to it)")
+    g.add_argument("--test_source", type=str, default=None, help="source CSV of the test split (defaults to the train source)")
+    g.add_argument("--audio_ext", type=str, default="wav")
+    g.add_argument("--input_length", type=int, default=None, help="random training segment in samples (RandomSegment)")
     g.add_argument("--synthetic_utterances", type=int, default=256, help="utterances per synthetic epoch")
     g.add_argument("--synthetic_length", type=int, default=49152, help="maximum utterance length in samples (TIMIT-like 3 s)")
     g.add_argument("--checkpoint_dir", type=str, default=None)

@@ -50,6 +50,48 @@ class SyntheticUtterances:
             yield (x * (torch.arange(T).unsqueeze(0) < x_sl.unsqueeze(1))), x_sl
 
 
+def real_data_loaders(args, num_bits, rank, world, mu_law=True):
+    """Source-CSV datasets behind the reference's pipeline: AudioLoader -> (RandomSegment) -> MuLawEncode -> padded, longest-first
+    batches from the length-bucketed samplers; every rank builds the same batches and takes its strided share."""
+    import random
+
+    from blvm.data.base_dataset import BaseDataset
+    from blvm.data.batchers import DynamicTensorBatcher
+    from blvm.data.loaders import AudioLoader
+    from blvm.data.samplers import LengthEvalSampler, LengthTrainSampler
+    from blvm.data.transforms import Compose, RandomSegment
+
+    random.seed(args.seed)  # identical batches on every rank
+    enc = [MuLawEncode(num_bits)] if mu_law else []
+    seg = getattr(args, "random_segment_size", None) or args.input_length
+    tr_t = Compose(*([RandomSegment(seg)] if seg else []), *enc)
+    bl = args.batch_len or 64 * 16000
+    train_ds = BaseDataset(args.dataset, [(AudioLoader(args.audio_ext), tr_t, DynamicTensorBatcher())])
+    test_ds = BaseDataset(args.test_source or args.dataset, [(AudioLoader(args.audio_ext), Compose(*enc), DynamicTensorBatcher())])
+    lens = None
+    if seg:  # the sampler must bucket by the CROPPED lengths
+        from blvm.data.samplers.length_samplers import load_field
+        lens = [min(n, seg) for n in load_field(args.dataset, "length")]
+    tr_s = LengthTrainSampler(lens if lens is not None else args.dataset, batch_len=bl, min_pool_size=min(512, max(len(train_ds) // 4, 1)),
+                              rank=rank, world_size=world)  # fmt: skip
+    te_s = LengthEvalSampler(args.test_source or args.dataset, batch_len=bl, rank=rank, world_size=world)
+    mk = lambda ds, sm: torch.utils.data.DataLoader(ds, batch_sampler=sm, collate_fn=ds.collate, num_workers=args.num_workers)  # noqa: E731
+
+    class _XY:  # (x, x_sl) pairs like SyntheticUtterances
+        def __init__(self, loader):
+            self.loader = loader
+
+        def __len__(self):
+            return len(self.loader)
+
+        def __iter__(self):
+            for (x, x_sl), _ in self.loader:
+                if x.numel():
+                    yield x, x_sl
+
+    return _XY(mk(train_ds, tr_s)), _XY(mk(test_ds, te_s))
+
+
 def setup(args):
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -77,8 +119,11 @@ def run(args, model, forward_train, forward_eval, best_metric, num_bits, split_e
     scheduler = getattr(torch.optim.lr_scheduler, args.lr_scheduler)(optimizer, **args.lr_scheduler_kwargs)
     reducer = FlatGradAllReduce(params) if world > 1 else None
     bs, bl = args.batch_size, (args.batch_len or (0 if args.batch_size else 64 * 16000))
-    train = SyntheticUtterances(args.synthetic_utterances, args.synthetic_length, bs, bl, num_bits, args.seed, rank, world)
-    test = SyntheticUtterances(max(args.synthetic_utterances // 8, 1), args.synthetic_length, bs, bl, num_bits, args.seed + 1, rank, world)
+    if args.dataset == "synthetic":
+        train = SyntheticUtterances(args.synthetic_utterances, args.synthetic_length, bs, bl, num_bits, args.seed, rank, world)
+        test = SyntheticUtterances(max(args.synthetic_utterances // 8, 1), args.synthetic_length, bs, bl, num_bits, args.seed + 1, rank, world)
+    else:
+        train, test = real_data_loaders(args, num_bits, rank, world, mu_law=getattr(args, "input_coding", "mu_law") == "mu_law")
     tracker = Tracker()
     best = None
     for epoch in tracker.epochs(args.epochs):

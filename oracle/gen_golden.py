@@ -573,6 +573,44 @@ def gen_generate():
     save("generate.npz", **arrays)
 
 
+def gen_data():
+    """Host-side data front-end: batches of the reference's length samplers for a seeded `random`, pools, padded collation."""
+    import random
+
+    from blvm.data.batchers import DynamicTensorBatcher
+    from blvm.data.samplers import LengthEvalSampler, LengthTrainSampler
+
+    arrays = {}
+    g = torch.Generator().manual_seed(3)
+    lengths = (torch.randint(800, 64000, (700,), generator=g) // 16 * 16).tolist()  # ties on purpose
+    arrays["lengths"] = np.array(lengths)
+    random.seed(7)
+    s = LengthTrainSampler(lengths, batch_len=16000 * 20, min_pool_size=64, max_pool_difference=4000.0)
+    arrays["train_pools_flat"] = np.array([i for p in s.pools for i in p])
+    arrays["train_pool_sizes"] = np.array([len(p) for p in s.pools])
+    for ep in range(2):
+        bs = list(iter(s))
+        arrays[f"train_ep{ep}_flat"] = np.array([i for b in bs for i in b])
+        arrays[f"train_ep{ep}_sizes"] = np.array([len(b) for b in bs])
+    random.seed(9)
+    s = LengthTrainSampler(lengths, batch_len="2max", min_pool_size=128, num_batches=11, drop_last=False, longest_first=False)
+    bs = list(iter(s))
+    arrays["train_nb_flat"] = np.array([i for b in bs for i in b])
+    arrays["train_nb_sizes"] = np.array([len(b) for b in bs])
+    for tag, kw in (("len", dict(batch_len=16000 * 30)), ("size", dict(batch_size=32))):
+        e = LengthEvalSampler(lengths, **kw)
+        bs = list(iter(e))
+        arrays[f"eval_{tag}_flat"] = np.array([int(i) for b in bs for i in b])
+        arrays[f"eval_{tag}_sizes"] = np.array([len(b) for b in bs])
+    xs = [torch.randn(n, generator=g) for n in (50, 17, 33, 50, 1)]
+    out, sl = DynamicTensorBatcher().collate(xs)
+    arrays.update(collate_in=np.concatenate([x.numpy() for x in xs]), collate_lens=np.array([len(x) for x in xs]), collate_out=out, collate_sl=sl)
+    xs2 = [torch.randn(3, n, generator=g) for n in (7, 4, 9)]  # [channels, T], dynamic last dimension
+    out2, sl2 = DynamicTensorBatcher(dim=-1, pad_value=-1.0).collate(xs2)
+    arrays.update(collate2_in=np.concatenate([x.reshape(-1).numpy() for x in xs2]), collate2_out=out2, collate2_sl=sl2)
+    save("data.npz", **arrays)
+
+
 def gen_lstm():
     """LSTMAudio: reduced size with full tensors, and BASELINE config C1 ([8,4000], h=256, s=64) pinned by checksums."""
     arrays = {}
@@ -617,6 +655,6 @@ def gen_lstm():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn", "wavenet", "rssm", "cwvae", "stcn", "heads", "generate"]
+    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn", "wavenet", "rssm", "cwvae", "stcn", "heads", "generate", "data"]
     for w in which:
         globals()[f"gen_{w}"]()
