@@ -247,9 +247,9 @@ def test_gaussian_likelihood_heads_vs_oracle(kind, S, layout, with_linear):
     out = ops.gmm_log_prob(*args, 10, beta, eps_sd) if kind == "gmm" else ops.gauss_log_prob(*args, beta, eps_sd)
     (out * gb.to(DEV)).sum().backward()
     assert rel(out, ref) < 2e-6
-    assert rel(dd.grad, dec.grad) < 1e-5
+    assert rel(dd.grad, dec.grad) < 3e-5
     if with_linear:
-        assert rel(Wd.grad, W.grad) < 1e-5 and rel(bd.grad, b.grad) < 1e-5
+        assert rel(Wd.grad, W.grad) < 3e-5 and rel(bd.grad, b.grad) < 3e-5
 
 
 def test_vrnn_gmm_head_matches_reference():
