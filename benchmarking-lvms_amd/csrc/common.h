@@ -56,6 +56,17 @@ __device__ __forceinline__ float softplus_beta(float x, float beta, float inv_be
   return bx > 20.0f ? x : inv_beta * log1pf(expf(bx));
 }
 
+// Split-K factor of a weight-gradient GEMM [M,N] += A^T B over K rows: count the tiles the way gemm_f32 will cut them
+// (128-wide when both dimensions reach 128, else 64) and ask for ~3 workgroups per CU, at least 256 k per slice.
+inline int gemm_pick_split(int M, int N, int K) {
+  const int bm = (M >= 128 && N >= 128) ? 128 : 64;
+  const long tiles = (long)((M + bm - 1) / bm) * ((N + bm - 1) / bm);
+  int s = (int)((768 + tiles - 1) / tiles);
+  const int kmax = (K + 255) / 256;
+  if (s > kmax) s = kmax;
+  return s < 1 ? 1 : s;
+}
+
 // ---- 16x16 output tile, K split over the NW waves of a workgroup ------------------------------------------------
 // acc += A[r0+i][k] * W[c0+j][k] for the k-chunks owned by `wave` (chunk = 16 k, waves interleave chunks).
 // A rows >= nrows read as zero.  A, W must be 16-byte aligned with lda, ldw multiples of 4 and K a multiple of 16.

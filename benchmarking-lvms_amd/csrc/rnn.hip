@@ -27,13 +27,7 @@ inline int pick_nw(int K, int groups) {
   return 4;
 }
 
-inline int pick_split(int M, int N, int K) {
-  const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
-  int s = (int)((768 + tiles - 1) / tiles);
-  const int kmax = (K + 255) / 256;
-  if (s > kmax) s = kmax;
-  return s < 1 ? 1 : s;
-}
+inline int pick_split(int M, int N, int K) { return gemm_pick_split(M, N, K); }
 
 // time index processed by row `b` at recurrence step j: forward j; reversed: len-1-j inside the row's length, j in
 // the right padding (reverse_sequences leaves padding where it is).

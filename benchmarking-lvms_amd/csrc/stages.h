@@ -275,13 +275,7 @@ inline void launch_lin(const LinLaunch& l, hipStream_t s) {
   else launch_lin_n<3>(l, s);
 }
 
-inline int pick_split(int M, int N, int K) {
-  const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
-  int s = (int)((768 + tiles - 1) / tiles);
-  const int kmax = (K + 255) / 256;  // at least 256 k per slice
-  if (s > kmax) s = kmax;
-  return s < 1 ? 1 : s;
-}
+inline int pick_split(int M, int N, int K) { return gemm_pick_split(M, N, K); }
 
 // dW (+)= D^T Act over all rows
 inline int wgrad(const float* D, int ldd, int n_out, const float* Act, int lda, int k_in, float* dW, int ldw, size_t rows,

@@ -14,13 +14,7 @@
 namespace blvm {
 namespace {
 
-inline int pick_split(int M, int N, int K) {
-  const long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
-  int s = (int)((768 + tiles - 1) / tiles);
-  const int kmax = (K + 255) / 256;
-  if (s > kmax) s = kmax;
-  return s < 1 ? 1 : s;
-}
+inline int pick_split(int M, int N, int K) { return gemm_pick_split(M, N, K); }
 
 inline dim3 ew_grid(size_t n_items) {
   size_t blocks = (n_items + 255) / 256;
