@@ -125,6 +125,60 @@ __device__ __forceinline__ f32x4 wave_gemm16(const float* __restrict__ A, int ld
   return acc;
 }
 
+// ---- 32x32 output tile (large batches), K split over the NW waves of a workgroup ---------------------------------------
+// acc += A[r0+i][k] * W[c0+j][k] with v_mfma_f32_32x32x2_f32: lane (li = lane & 31, lh = lane >> 5) loads 4 consecutive k at
+// offset 4*lh of every 8-k chunk as one 16-byte load and feeds them to 4 MFMAs (MFMA c sums k = chunk + c and chunk + 4 + c;
+// A and B use the same permutation).  Compared with the 16x16 tile every operand byte fetched from L2 feeds twice the FLOPs:
+// at B >= 128 the links are bound by those bytes, not by launch latency.  K must be a multiple of 8.
+template <int NW>
+__device__ __forceinline__ f32x16 wave_gemm32(const float* __restrict__ A, int lda, int r0, int nrows,
+                                               const float* __restrict__ W, int ldw, int c0, int K, int wave, f32x16 acc) {
+  constexpr int STEP = NW * 8;
+  const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  const bool aok = (r0 + li) < nrows;
+  const float* ap = A + (size_t)(aok ? r0 + li : 0) * lda + 4 * lh;
+  const float* wp = W + (size_t)(c0 + li) * ldw + 4 * lh;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  int kc = wave * 8;
+  for (; kc + 3 * STEP < K; kc += 4 * STEP) {
+    float4 a0 = *reinterpret_cast<const float4*>(ap + kc);
+    float4 a1 = *reinterpret_cast<const float4*>(ap + kc + STEP);
+    float4 a2 = *reinterpret_cast<const float4*>(ap + kc + 2 * STEP);
+    float4 a3 = *reinterpret_cast<const float4*>(ap + kc + 3 * STEP);
+    const float4 w0 = *reinterpret_cast<const float4*>(wp + kc);
+    const float4 w1 = *reinterpret_cast<const float4*>(wp + kc + STEP);
+    const float4 w2 = *reinterpret_cast<const float4*>(wp + kc + 2 * STEP);
+    const float4 w3 = *reinterpret_cast<const float4*>(wp + kc + 3 * STEP);
+    if (!aok) { a0 = a1 = a2 = a3 = zero; }
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, w0.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, w0.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, w0.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, w0.w, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, w1.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, w1.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, w1.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, w1.w, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, w2.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, w2.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.z, w2.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.w, w2.w, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3.x, w3.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3.y, w3.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3.z, w3.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3.w, w3.w, acc, 0, 0, 0);
+  }
+  for (; kc < K; kc += STEP) {
+    float4 a0 = *reinterpret_cast<const float4*>(ap + kc);
+    const float4 w0 = *reinterpret_cast<const float4*>(wp + kc);
+    if (!aok) a0 = zero;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, w0.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, w0.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, w0.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, w0.w, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
 // Combine the NW waves' partial 16x16 tiles of G groups through LDS.  `red` must hold G*NW*256 floats.
 // After the call threads 0..255 own element (i = tid>>4, j = tid&15) of every group: out[g]; other threads get 0.
 template <int G, int NW>

@@ -70,6 +70,63 @@ __global__ __launch_bounds__(NW * 64) void lin_stage_kernel(LinArgs<NSEG> a) {
   out[(size_t)row * ldo + col] = x;
 }
 
+// The same stage on 32x32 tiles for large batches (B >= 128): `tiles` counts 32-column tiles.  The NW partial tiles are
+// combined through LDS (row stride 33: conflict-free); threads 0..255 then own 4 output elements each.
+template <int NW, int NSEG>
+__global__ __launch_bounds__(NW * 64) void lin_stage32_kernel(LinArgs<NSEG> a) {
+  __shared__ float red[NW * 32 * 33];
+  int ct = blockIdx.x, s = 0;
+  if (NSEG > 1) {
+    const int t0 = a.tiles[0], t1 = a.tiles[NSEG > 1 ? 1 : 0];
+    s = (ct >= t0 ? 1 : 0) + ((NSEG > 2 && ct >= t0 + t1) ? 1 : 0);
+    ct -= (s >= 1 ? t0 : 0) + (s >= 2 ? t1 : 0);
+  }
+  const float* A = PICK(A);
+  const float* W = PICK(W);
+  const float* bias = PICK(bias);
+  const float* add = PICK(add);
+  const float* gate = PICK(gate);
+  float* out = PICK(out);
+  const int lda = PICK(lda), ldw = PICK(ldw), ldadd = PICK(ldadd), ldgate = PICK(ldgate), ldo = PICK(ldo);
+  const int flags = PICK(flags);
+  const int K = PICK(K);
+  const int r0 = blockIdx.y * 32, c0 = ct * 32;
+  const int t = threadIdx.x & 255, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // epilogue operands of this thread's 4 elements (e = t + 256 q: row r0 + e/32, column c0 + e%32), before the K loop
+  float e_bias[4], e_add[4], e_gate[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = t + 256 * q, row = r0 + (e >> 5), col = c0 + (e & 31);
+    const int rowc = row < a.B ? row : r0;
+    e_bias[q] = bias[(flags & LF_BIAS) ? col : 0];
+    e_add[q] = add[(flags & LF_ADD) ? (size_t)rowc * ldadd + col : 0];
+    e_gate[q] = gate[(flags & LF_GATE) ? (size_t)rowc * ldgate + col : 0];
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  acc = wave_gemm32<NW>(A, lda, r0, a.B, W, ldw, c0, K, wave, acc);
+  {
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave * (32 * 33) + ((r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + li] = acc[r];
+  }
+  __syncthreads();
+  if (threadIdx.x >= 256) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = t + 256 * q, rr = e >> 5, cc = e & 31, row = r0 + rr;
+    if (row >= a.B) continue;
+    float x = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) x += red[w * (32 * 33) + rr * 33 + cc];
+    x += ((flags & LF_BIAS) ? e_bias[q] : 0.f) + ((flags & LF_ADD) ? e_add[q] : 0.f);
+    if (flags & LF_RELU) x = x > 0.f ? x : x * a.slope;
+    if (flags & LF_GATE) x = e_gate[q] > 0.f ? x : x * a.slope;
+    out[(size_t)row * ldo + c0 + cc] = x;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // F4: both Gaussian heads + residual mean + reparameterised sample
 // ---------------------------------------------------------------------------------------------------------------
@@ -243,10 +300,22 @@ struct LinLaunch {
   float slope = 0.f;
 };
 
+// large batches: 32x32 tiles when every segment's width allows it (env BLVM_LIN32_MIN_B overrides the threshold, 0 = never)
+inline int lin32_min_batch() {
+  static int v = [] {
+    const char* e = getenv("BLVM_LIN32_MIN_B");
+    return e ? atoi(e) : 128;
+  }();
+  return v;
+}
+
 template <int NSEG>
 inline void launch_lin_n(const LinLaunch& l, hipStream_t s) {
   LinArgs<NSEG> a{};
   int tiles = 0, kmax = 0;
+  bool wide = lin32_min_batch() > 0 && l.B >= lin32_min_batch();
+  for (int i = 0; i < NSEG; ++i) wide = wide && (l.seg[i].ncols % 32 == 0) && (l.seg[i].K % 8 == 0);
+  const int tw = wide ? 32 : 16;
   for (int i = 0; i < NSEG; ++i) {
     const LinSegH& g = l.seg[i];
     a.A[i] = g.A; a.W[i] = g.W; a.out[i] = g.out;
@@ -254,14 +323,23 @@ inline void launch_lin_n(const LinLaunch& l, hipStream_t s) {
     a.add[i] = g.add ? g.add : g.W;
     a.gate[i] = g.gate ? g.gate : g.W;
     a.lda[i] = g.lda; a.ldw[i] = g.ldw; a.ldadd[i] = g.ldadd; a.ldgate[i] = g.ldgate; a.ldo[i] = g.ldo;
-    a.tiles[i] = g.ncols / 16;
+    a.tiles[i] = g.ncols / tw;
     a.flags[i] = (g.bias ? LF_BIAS : 0) | (g.add ? LF_ADD : 0) | (g.gate ? LF_GATE : 0) | (g.relu ? LF_RELU : 0);
     a.K[i] = g.K;
     kmax = g.K > kmax ? g.K : kmax;
-    tiles += g.ncols / 16;
+    tiles += g.ncols / tw;
   }
   a.B = l.B;
   a.slope = l.slope;
+  if (wide) {  // chunks of 8 k: <= 8 chunks per wave where possible (a wave's dependent chain is 4 MFMAs of 64 cycles per chunk)
+    const int chunks = kmax / 8;
+    const int nw32 = chunks > 64 ? 16 : (chunks > 32 ? 8 : 4);
+    const dim3 grid32(tiles, (l.B + 31) / 32);
+    if (nw32 == 16) hipLaunchKernelGGL((lin_stage32_kernel<16, NSEG>), grid32, dim3(1024), 0, s, a);
+    else if (nw32 == 8) hipLaunchKernelGGL((lin_stage32_kernel<8, NSEG>), grid32, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((lin_stage32_kernel<4, NSEG>), grid32, dim3(256), 0, s, a);
+    return;
+  }
   const int nw = pick_nw(kmax, 1);
   const dim3 grid(tiles, (l.B + 15) / 16);
   if (nw == 16) hipLaunchKernelGGL((lin_stage_kernel<16, NSEG>), grid, dim3(1024), 0, s, a);

@@ -669,3 +669,30 @@ def test_colsum_vectorised_and_fallback_paths(M, N, ld):
     assert rel_l2(out, ref) < 1e-5
     ops.colsum(Xd[:, :N] if ld != N else Xd, out)
     assert rel_l2(out, X[:, :N].double().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("model", ["vrnn", "srnn"])
+def test_large_batch_links_on_32x32_tiles_vs_oracle(model):
+    """B >= 128 switches the linear links of the chains to the 32x32-tile kernel (more FLOPs per fetched operand byte): same
+    numbers as the oracle, ragged batch that is not a multiple of 32, non-trivial free nats."""
+    from blvm.models import SRNNAudio
+
+    torch.manual_seed(6)
+    B, S, Tp = 150, 16, 5
+    T_ = S * Tp - 3
+    cls = VRNNAudio if model == "vrnn" else SRNNAudio
+    kw = dict(likelihood="DMoL", input_size=S, hidden_size=64, latent_size=32, residual_posterior=True)
+    m = cls(**kw)
+    sd = {k: v.clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    x, x_sl = O.synth_batch(B, T_, seed=12, ragged=True)
+    eps = torch.randn(Tp, B, 32, generator=torch.Generator().manual_seed(3))
+    fwd = O.vrnn_audio_forward if model == "vrnn" else O.srnn_audio_forward
+    ref = fwd(sd, x, x_sl, eps, beta=0.9, free_nats=1.0, stack=S)
+    ref["loss"].backward()
+    m.to(DEV)
+    loss, _, out = m(x.to(DEV), x_sl, beta=0.9, free_nats=1.0, eps=eps.to(DEV))
+    loss.backward()
+    assert float(loss) == pytest.approx(float(ref["loss"]), rel=1e-5)
+    torch.testing.assert_close(out.elbo.cpu(), ref["elbo"].detach(), rtol=1e-5, atol=1e-3)
+    for k, p in m.named_parameters():
+        assert rel_l2(p.grad, sd[k].grad) < 1e-3, k
