@@ -696,3 +696,29 @@ def test_large_batch_links_on_32x32_tiles_vs_oracle(model):
     torch.testing.assert_close(out.elbo.cpu(), ref["elbo"].detach(), rtol=1e-5, atol=1e-3)
     for k, p in m.named_parameters():
         assert rel_l2(p.grad, sd[k].grad) < 1e-3, k
+
+
+def test_sharded_gradients_equal_full_batch_gradient():
+    """The data-parallel contract on the HIP path itself (one GPU, shards run one after the other): gradients of ragged shards,
+    weighted by their frame counts as `FlatGradAllReduce` does, equal the gradient of the whole batch."""
+    torch.manual_seed(2)
+    m = VRNNAudio(likelihood="DMoL", input_size=16, hidden_size=32, latent_size=16, residual_posterior=True).to(DEV)
+    B, T_ = 12, 16 * 7
+    x, x_sl = O.synth_batch(B, T_, seed=21, ragged=True)
+    eps = torch.randn(7, B, 16, generator=torch.Generator().manual_seed(4)).to(DEV)
+    x = x.to(DEV)
+
+    def grads(rows):
+        m.zero_grad()
+        Tm = int(x_sl[rows].max())
+        Tp = (Tm + 15) // 16
+        loss, _, _ = m(x[rows, :Tm].contiguous(), x_sl[rows], beta=0.9, free_nats=1.0, eps=eps[:Tp, rows].contiguous())
+        loss.backward()
+        return [p.grad.clone() for p in m.parameters()], float(x_sl[rows].sum())
+
+    full, n_full = grads(list(range(B)))
+    shards = [grads(list(range(0, 5))), grads(list(range(5, 9))), grads(list(range(9, 12)))]
+    assert sum(n for _, n in shards) == n_full
+    for i, gf in enumerate(full):
+        combined = sum(g[i] * n for g, n in shards) / n_full
+        assert rel_l2(combined, gf) < 1e-5, i
