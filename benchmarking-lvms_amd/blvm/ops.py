@@ -68,7 +68,7 @@ def _pick_split(M, N, K):
     if K >= 65536 and M >= 128 and N >= 128:  # conv-coder wgrads: K = L*B ~ 4e5 rows, 128x128 tiles, ~4 workgroups per CU
         tiles = ((M + 127) // 128) * ((N + 127) // 128)
         return max(1, min((1024 + tiles - 1) // tiles, K // 2048))
-    bm = 128 if (M >= 128 and N >= 128) else 64  # as gemm_f32 cuts the tiles (csrc/common.h: gemm_pick_split)
+    bm = 64  # gemm_f32 cuts weight-gradient GEMMs into 64x64 tiles (csrc/common.h: gemm_pick_split)
     tiles = ((M + bm - 1) // bm) * ((N + bm - 1) // bm)
     s = (768 + tiles - 1) // tiles
     return max(1, min(s, (K + 255) // 256))

@@ -56,10 +56,10 @@ __device__ __forceinline__ float softplus_beta(float x, float beta, float inv_be
   return bx > 20.0f ? x : inv_beta * log1pf(expf(bx));
 }
 
-// Split-K factor of a weight-gradient GEMM [M,N] += A^T B over K rows: count the tiles the way gemm_f32 will cut them
-// (128-wide when both dimensions reach 128, else 64) and ask for ~3 workgroups per CU, at least 256 k per slice.
+// Split-K factor of a weight-gradient GEMM [M,N] += A^T B over K rows: gemm_f32 cuts that form into 64x64 tiles; ask for
+// ~3 workgroups per CU, at least 256 k per slice.
 inline int gemm_pick_split(int M, int N, int K) {
-  const int bm = (M >= 128 && N >= 128) ? 128 : 64;
+  const int bm = 64;
   const long tiles = (long)((M + bm - 1) / bm) * ((N + bm - 1) / bm);
   int s = (int)((768 + tiles - 1) / tiles);
   const int kmax = (K + 255) / 256;

@@ -276,10 +276,17 @@ int gemm_f32(int op_a, int op_b, int M, int N, int K, const float* A, int lda, c
   g.a_vec = aligned16(A) && (lda % 4 == 0);
   g.b_vec = aligned16(B) && (ldb % 4 == 0);
   if (split_k < 1) split_k = 1;
-  const bool big = (M >= 128 && N >= 128 && (size_t)((M + 127) / 128) * ((N + 127) / 128) * split_k >= 192);
+  bool big = (M >= 128 && N >= 128 && (size_t)((M + 127) / 128) * ((N + 127) / 128) * split_k >= 192);
   // 192-wide tiles for the conv coders' channel counts (192 = 1.5 x 128 would waste a quarter of a 128-tile pair and
   // re-read the other operand): N % 192 == 0 -> 128x192, else M % 192 == 0 -> 192x128
-  const bool n192 = big && N % 192 == 0 && N % 128 != 0;
+  // Measured on MI355X (tools/gemm_bench.py, tools/gemm_cw.py with BLVM_GEMM_TILE forcing each variant): the 64x64 tile wins
+  // for every weight-gradient form (both operands read "transposed": 76 -> 91 TF/s at 768x192x4e5, 71 -> 91 at 1536x512x16000)
+  // and for short reductions on narrow outputs (K <= 256 and N <= 256: 43 -> 65 TF/s at K = 96, 53 -> 61 at 256x256); the
+  // 128-wide tiles win once N >= 512 or K >= 512 (84 vs 74 TF/s at N = 768, K = 192; 114 vs 95 at 4096^3).
+  static const int force_tile = [] { const char* e = getenv("BLVM_GEMM_TILE"); return e ? atoi(e) : 0; }();  // experiments only
+  if ((op_a == 1 && op_b == 1) || (K <= 256 && N <= 256)) big = false;
+  if (force_tile == 1) big = false;
+  const bool n192 = big && N % 192 == 0 && N % 128 != 0 && force_tile != 2;
   const bool m192 = big && !n192 && M % 192 == 0 && M % 128 != 0;
   const int bm = big ? (m192 ? 192 : 128) : 64;
   const int bn = big ? (n192 ? 192 : 128) : 64;
