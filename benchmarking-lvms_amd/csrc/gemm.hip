@@ -15,7 +15,11 @@ namespace blvm {
 
 namespace {
 
-constexpr int BK = 16;
+#ifndef BLVM_GEMM_BK
+#define BLVM_GEMM_BK 16
+#endif
+constexpr int BK = BLVM_GEMM_BK;
+constexpr int KV = BK / 4;  // 16-byte vectors per tile row along k
 constexpr int PAD = 4;
 
 struct GemmArgs {
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     for (int v = 0; v < A_V; ++v) {
       const int id = tid + v * 256;
       if (OPA == 0) {  // A[m][k], k contiguous: 4 float4 per row of the tile
-        const int m = id >> 2, k4 = (id & 3) * 4;
+        const int m = id / KV, k4 = (id % KV) * 4;
         const int gm = m0 + m, gk = k0 + k4;
         const int nv = (gm < g.M) ? max(0, min(4, kend - gk)) : 0;
         ra[v] = ld4(g.A + (size_t)(gm < g.M ? gm : 0) * g.lda + gk, nv, g.a_vec);
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     for (int v = 0; v < B_V; ++v) {
       const int id = tid + v * 256;
       if (OPB == 0) {  // B[n][k], k contiguous
-        const int n = id >> 2, k4 = (id & 3) * 4;
+        const int n = id / KV, k4 = (id % KV) * 4;
         const int gn = n0 + n, gk = k0 + k4;
         const int nv = (gn < g.N) ? max(0, min(4, kend - gk)) : 0;
         rb[v] = ld4(g.B + (size_t)(gn < g.N ? gn : 0) * g.ldb + gk, nv, g.b_vec);
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     for (int v = 0; v < A_V; ++v) {
       const int id = tid + v * 256;
       if (OPA == 0) {
-        const int m = id >> 2, k4 = (id & 3) * 4;
+        const int m = id / KV, k4 = (id % KV) * 4;
         As[(k4 + 0) * LDA_S + m] = ra[v].x;
         As[(k4 + 1) * LDA_S + m] = ra[v].y;
         As[(k4 + 2) * LDA_S + m] = ra[v].z;
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     for (int v = 0; v < B_V; ++v) {
       const int id = tid + v * 256;
       if (OPB == 0) {
-        const int n = id >> 2, k4 = (id & 3) * 4;
+        const int n = id / KV, k4 = (id % KV) * 4;
         Bs[(k4 + 0) * LDB_S + n] = rb[v].x;
         Bs[(k4 + 1) * LDB_S + n] = rb[v].y;
         Bs[(k4 + 2) * LDB_S + n] = rb[v].z;
