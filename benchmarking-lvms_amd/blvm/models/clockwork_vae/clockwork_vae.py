@@ -164,8 +164,8 @@ class CWVAE(nn.Module):
 
         lazy = dict(
             reconstructions_parameters=parameters,
-            reconstructions=lambda: lik.sample(outputs.reconstructions_parameters),
-            reconstructions_mode=lambda: lik.mode(outputs.reconstructions_parameters),
+            reconstructions=lambda ns: lik.sample(ns.reconstructions_parameters),
+            reconstructions_mode=lambda ns: lik.mode(ns.reconstructions_parameters),
             seq_mask=lambda: torch.arange(int(x_sl.max()), device=dev).unsqueeze(0) < x_sl_dev.unsqueeze(1),
         )
         outputs = LazyNamespace(lazy, elbo=elbo, log_prob=log_prob, kld=kld, y=y.unsqueeze(-1), z=latents, z_sl=level_sl,

@@ -88,8 +88,8 @@ class LSTMAudio(BaseModel):
 
         lazy = dict(
             _parameters=parameters,
-            reconstruction_sample=lambda: lik.sample(outputs._parameters),
-            reconstruction_mode=lambda: lik.mode(outputs._parameters),
+            reconstruction_sample=lambda ns: lik.sample(ns._parameters),
+            reconstruction_mode=lambda ns: lik.mode(ns._parameters),
         )
         outputs = LazyNamespace(lazy, loss=loss, ll=log_prob, z=out.transpose(0, 1), z_sl=x_sl_stack,
                                 s_n=(hn.unsqueeze(0), cn.unsqueeze(0)))  # fmt: skip

@@ -161,9 +161,9 @@ class SRNN(nn.Module):
 
         lazy = dict(
             parameters=parameters,
-            reconstructions_parameters=lambda: outputs.parameters,
-            reconstructions=lambda: lik.sample(outputs.parameters),
-            reconstructions_mode=lambda: lik.mode(outputs.parameters),
+            reconstructions_parameters=lambda ns: ns.parameters,
+            reconstructions=lambda ns: lik.sample(ns.parameters),
+            reconstructions_mode=lambda ns: lik.mode(ns.parameters),
             seq_mask=lambda: (torch.arange(max_len, device=dev).unsqueeze(0) < x_sl_dev.unsqueeze(1)).to(torch.float64),
         )
         outputs = LazyNamespace(
@@ -267,7 +267,7 @@ class SRNNAudio(BaseModel):
 
     def forward(self, x, x_sl, beta: float = 1, free_nats: float = 0, d_0=None, a_0=None, z_0=None, eps=None):
         loss, metrics, outputs = self.srnn(x=x, x_sl=x_sl, d_0=d_0, a_0=a_0, z_0=z_0, beta=beta, free_nats=free_nats, eps=eps)
-        outputs._lazy["x_hat"] = lambda: self.srnn.likelihood.sample(outputs.parameters)
+        outputs._lazy["x_hat"] = lambda ns: self.srnn.likelihood.sample(ns.parameters)
         return loss, metrics, outputs
 
     def generate(self, n_samples: int = 1, max_timesteps: int = 100, use_mode: bool = False, x=None, u=None, d_0=None, a_0=None,

@@ -205,7 +205,7 @@ class STCN(BaseModel):
             return lik(d.contiguous())
 
         bt = lambda ts: [t.transpose(0, 1) for t in ts]  # noqa: E731  (reference layout [B,T,Z])
-        lazy = dict(params=params, reconstructions=lambda: lik.sample(output.params), reconstructions_mode=lambda: lik.mode(output.params))
+        lazy = dict(params=params, reconstructions=lambda ns: lik.sample(ns.params), reconstructions_mode=lambda ns: lik.mode(ns.params))
         output = LazyNamespace(lazy, loss=loss, elbo=elbo, klds=klds, log_prob=log_prob, z=bt(z),
                                z_sl=[torch.ceil(x_sl_host / S).long()] * self.n_stacks, enc_mus=bt(mu_q), prior_mus=bt(mu_p),
                                y=y.unsqueeze(-1))  # fmt: skip

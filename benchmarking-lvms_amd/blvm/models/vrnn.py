@@ -27,7 +27,9 @@ LIKELIHOOD_HEADS = (DiscretizedLogisticMixtureDense, DiagonalGaussianMixtureDens
 
 class LazyNamespace(SimpleNamespace):
     """SimpleNamespace whose expensive fields are computed on first access (the reference computes samples / modes /
-    masks on every forward although the loss never uses them, vrnn.py:332-333)."""
+    masks on every forward although the loss never uses them, vrnn.py:332-333).  A lazy callable that needs other fields
+    takes the namespace as its argument (`lambda ns: ...`) instead of closing over it: a closure would make a reference cycle
+    namespace -> dict -> lambda -> namespace that keeps the step's activations alive until the cyclic garbage collector runs."""
 
     def __init__(self, _lazy=None, **kwargs):
         super().__init__(**kwargs)
@@ -36,7 +38,8 @@ class LazyNamespace(SimpleNamespace):
     def __getattr__(self, name):
         lazy = object.__getattribute__(self, "_lazy")
         if name in lazy:
-            value = lazy.pop(name)()
+            fn = lazy.pop(name)
+            value = fn(self) if fn.__code__.co_argcount else fn()
             setattr(self, name, value)
             return value
         raise AttributeError(name)
@@ -226,8 +229,8 @@ class VRNN(nn.Module):
 
         lazy = dict(
             reconstructions_parameters=parameters,
-            reconstructions=lambda: lik.sample(outputs.reconstructions_parameters),
-            reconstructions_mode=lambda: lik.mode(outputs.reconstructions_parameters),
+            reconstructions=lambda ns: lik.sample(ns.reconstructions_parameters),
+            reconstructions_mode=lambda ns: lik.mode(ns.reconstructions_parameters),
             seq_mask=lambda: (torch.arange(max_len, device=dev).unsqueeze(0) < x_sl_dev.unsqueeze(1)).to(torch.float64),
         )
         outputs = LazyNamespace(

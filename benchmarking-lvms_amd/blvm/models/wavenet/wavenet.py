@@ -117,8 +117,8 @@ class WaveNet(BaseModel):
         lazy = dict(
             parameters=parameters,
             log_prob_twise=ll_twise,
-            predictions=lambda: lik.sample(output.parameters),
-            predictions_mode=lambda: lik.mode(output.parameters),
+            predictions=lambda ns: lik.sample(ns.parameters),
+            predictions_mode=lambda ns: lik.mode(ns.parameters),
         )
         output = LazyNamespace(lazy, loss=loss, log_prob=log_prob, z=[skip_sum.detach().transpose(0, 1)], z_sl=x_sl_strided,
                                y=y.unsqueeze(-1))  # fmt: skip
