@@ -1,0 +1,1 @@
+from blvm.data.base_dataset import BaseDataset  # noqa: F401

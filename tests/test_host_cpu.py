@@ -204,3 +204,36 @@ def test_wavenet_init_matches_reference_and_oracle_c5_dims():
     out["loss"].backward()
     for name, ref in zip(g["f_grad_names"].tolist(), g["f_grad_norms"].tolist()):
         assert sd[name].grad.double().norm().item() == pytest.approx(ref, rel=5e-4), name
+
+
+def test_host_helper_modules_the_entry_points_import(tmp_path):
+    """The small host-side modules the reference's experiment scripts import resolve here too (argparsing, rand, device,
+    optimization, restore, data registry), and a run checkpoint round-trips."""
+    import torch
+
+    from blvm.data import BaseDataset  # noqa: F401
+    from blvm.data.datasets import DATASETS
+    from blvm.models import LSTMAudio
+    from blvm.training.restore import load_run, save_run
+    from blvm.utils.argparsing import str2bool
+    from blvm.utils.device import get_device  # noqa: F401
+    from blvm.utils.optimization import get_learning_rates_dict
+    from blvm.utils.rand import get_random_seed, set_seed
+
+    assert str2bool("true") is True and "timit" in DATASETS and DATASETS["timit"].audio_ext == "flac"
+    set_seed(5)
+    a = torch.rand(3)
+    set_seed(5)
+    assert torch.equal(a, torch.rand(3)) and 0 <= get_random_seed() < 2**32
+    m = LSTMAudio(stack_size=8, hidden_size=16, num_layers=1, num_mix=10, num_bins=256)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[1], gamma=0.1)
+    assert get_learning_rates_dict(opt) == {"lr": 1e-3}
+    sched.step()
+    save_run(str(tmp_path), model=m, optimizer=opt, lr_scheduler=sched)
+    m2 = LSTMAudio(stack_size=8, hidden_size=16, num_layers=1, num_mix=10, num_bins=256)
+    opt2 = torch.optim.Adam(m2.parameters(), lr=1e-3)
+    sched2 = torch.optim.lr_scheduler.MultiStepLR(opt2, milestones=[1], gamma=0.1)
+    _, ck = load_run(str(tmp_path), model=m2, optimizer=opt2, lr_scheduler=sched2)
+    assert all(torch.equal(p, q) for p, q in zip(m.state_dict().values(), m2.state_dict().values()))
+    assert get_learning_rates_dict(opt2)["lr"] == get_learning_rates_dict(opt)["lr"] and "optimizer_state_dict" in ck
