@@ -138,15 +138,24 @@ class WaveNet(BaseModel):
         return self.forward(x, x_sl, y=y, pad_causal=True, pad_receptive_field=(i_split == 0))
 
     @torch.no_grad()
-    def generate(self, n_samples: int, n_frames: int = 48000, x=None, uniforms=None):
+    def generate(self, n_samples: int, n_frames: int = 48000, x=None, uniforms=None, cached: bool = False):
         """Sample-by-sample generation from a zero start (wavenet.py:254-293): every frame re-runs the causal conv and the
         whole residual stack over a receptive-field window (no cached sampling, as in the reference), takes the single skip
         output, DIVIDES it by variance_scale (the reference's generate divides where forward multiplies, :274 — kept), applies
         the output transform and the head, samples, and shifts the window (FIFO).  Returns x_hat [B, n_frames, 1].
-        `uniforms[t]` optionally supplies the head sampler's two uniform draws of frame t."""
+        `uniforms[t]` optionally supplies the head sampler's two uniform draws of frame t.
+        `cached=True` (the reference's TODO, arXiv:1611.09482): the same samples from per-block queues of past activations —
+        one new frame per block per step instead of the whole window; with the DMoL head and widths the decode kernel takes
+        (K10c: every frame in one launch) through `ops.wavenet_decode`, otherwise block by block (`_generate_cached`)."""
         lik, C = self.likelihood, self.res_channels
         if self.n_stack_frames != 1:
             raise NotImplementedError("libblvm_hip: WaveNet.generate is built for n_stack_frames=1")
+        if cached:
+            if x is not None:
+                raise NotImplementedError("libblvm_hip: cached generation starts from the all-zero window")
+            if self._decode_kernel_applies():
+                return self._generate_decode_kernel(n_samples, n_frames, uniforms)
+            return self._generate_cached(n_samples, n_frames, uniforms)
         dev = self.causal.conv.weight.device
         win = torch.zeros(self.receptive_field, n_samples, self.in_channels, device=dev) if x is None else x.transpose(0, 1).contiguous()
         x_hat = []
@@ -158,4 +167,78 @@ class WaveNet(BaseModel):
             pred = lik.sample(parameters) if uniforms is None else lik.sample(parameters, uniforms=uniforms[t])  # [B,1,1]
             x_hat.append(pred)
             win = torch.cat([win[1:], pred.transpose(0, 1).to(torch.float32)], 0)
+        return torch.hstack(x_hat)
+
+    def _decode_kernel_applies(self):
+        C, blk, lik = self.res_channels, self.res_stack.res_blocks[0], self.likelihood
+        return (isinstance(lik, DiscretizedLogisticMixtureDense) and lik.y_dim == 1 and lik.out_features <= 32 and self.in_channels == 1
+                and C % 16 == 0 and blk.skip_channels % 16 == 0 and C <= 128 and blk.skip_channels <= 128 and len(self.res_stack.res_blocks) <= 64)  # fmt: skip
+
+    @torch.no_grad()
+    def _generate_decode_kernel(self, n_samples: int, n_frames: int, uniforms=None):
+        lik, rs, B = self.likelihood, self.res_stack, n_samples
+        dev = self.causal.conv.weight.device
+        if uniforms is None:
+            u = torch.empty(n_frames, B, lik.num_mix, device=dev).uniform_(1e-5, 1.0 - 1e-5)  # the reference's two draws (variational.py:309-349)
+            v = torch.empty(n_frames, B, device=dev).uniform_(1e-8, 1.0 - 1e-8)
+        else:
+            u = torch.stack([a.reshape(B, lik.num_mix) for a, _ in uniforms[:n_frames]]).to(dev)
+            v = torch.stack([b.reshape(B) for _, b in uniforms[:n_frames]]).to(dev)
+        t_in, blk = rs.in_transform, rs.res_blocks[0]
+        x = ops.wavenet_decode((self.causal.conv.weight, self.causal.conv.bias), (t_in.weight.view(t_in.out_channels, -1), t_in.bias),
+                               [b.kernel_params() for b in rs.res_blocks], rs.dilations,
+                               (self.out_transform.linear.weight, self.out_transform.linear.bias), (lik.params.weight, lik.params.bias),
+                               B, n_frames, blk.inv_std, 1.0 / self.variance_scale, lik.num_mix, lik.log_epsilon, u, v)  # fmt: skip
+        return x.unsqueeze(-1)
+
+    @torch.no_grad()
+    def _generate_cached(self, n_samples: int, n_frames: int, uniforms=None):
+        """Queue-based generation.  A window of zeros is an all-zero past, under which every layer sits at a constant
+        activation (its response to zero input, biases included); the queues start from those steady states — one chain of
+        single-frame block evaluations with both taps on the same vector — and each step then feeds the last two samples
+        through the causal conv and ONE frame through every block (tap 0 = the block's input `dilation` steps ago, from its
+        ring buffer; tap 1 = its input now), accumulating the skip branches."""
+        lik, C, B = self.likelihood, self.res_channels, n_samples
+        dev = self.causal.conv.weight.device
+        rs, blocks = self.res_stack, self.res_stack.res_blocks
+        S, inv_std = blocks[0].skip_channels, blocks[0].inv_std
+        t_in = rs.in_transform
+
+        def causal_pair(x_prev, x_now):  # [B,Cin] each -> causal conv output for the newest position, then the 1x1 in_transform
+            c = self.causal.forward_tm(torch.stack([x_prev, x_now], 0), pad_causal=False)  # [1,B,C]
+            return ops.linear(c.view(B, C), t_in.weight.view(t_in.out_channels, C), t_in.bias)
+
+        def through_blocks(h, taps0, skip):
+            """h [B,C]: input of block 0 now; taps0[i] [B,C]: block i's input `dilation_i` steps ago.  Returns every block's input."""
+            inputs = []
+            for i, blk in enumerate(blocks):
+                inputs.append(h)
+                last = i == len(blocks) - 1
+                o = ops.wavenet_block_step(torch.stack([taps0[i], h], 0), blk.kernel_params(), inv_std, S, skip, want_output=not last)
+                h = o.view(B, C) if o is not None else None
+            return inputs
+
+        zero_x = torch.zeros(B, self.in_channels, device=dev)
+        # steady state under an all-zero past: block i's delayed input equals its current input
+        h, steady = causal_pair(zero_x, zero_x), []
+        for i, blk in enumerate(blocks):
+            steady.append(h)
+            if i < len(blocks) - 1:
+                h = ops.wavenet_block_step(torch.stack([h, h], 0), blk.kernel_params(), inv_std, S, torch.zeros(1, B, S, device=dev)).view(B, C)
+        queues = [steady[i].unsqueeze(0).repeat(d, 1, 1) for i, d in enumerate(rs.dilations)]  # ring buffers [d_i,B,C]
+        heads = [0] * len(blocks)
+        x_prev, x_now = zero_x, zero_x
+        x_hat = []
+        for t in range(n_frames):
+            skip = torch.zeros(1, B, S, device=dev)
+            taps0 = [queues[i][heads[i]] for i in range(len(blocks))]
+            inputs = through_blocks(causal_pair(x_prev, x_now), taps0, skip)
+            for i, d in enumerate(rs.dilations):  # overwrite the oldest entry with the current input
+                queues[i][heads[i]] = inputs[i]
+                heads[i] = (heads[i] + 1) % d
+            logits = self.out_transform.forward_rows(skip.view(B, C), 1.0 / self.variance_scale)
+            parameters = lik(logits.view(B, 1, C))
+            pred = lik.sample(parameters) if uniforms is None else lik.sample(parameters, uniforms=uniforms[t])  # [B,1,1]
+            x_hat.append(pred)
+            x_prev, x_now = x_now, pred.view(B, 1).to(torch.float32)
         return torch.hstack(x_hat)

@@ -812,6 +812,56 @@ class _WaveNetStackFunction(torch.autograd.Function):
         return (d_o, None, None, None, None, None, *grads)
 
 
+@torch.no_grad()
+def wavenet_block_step(x2, params, inv_std: float, S: int, skip_acc, want_output: bool = True):
+    """One gated residual block on ONE new frame for cached generation: x2 [2,B,C] = (the block's input `dilation` frames ago,
+    its input now) -> the block's output now [1,B,C]; the skip branch is accumulated into skip_acc [1,B,S].  The same fused
+    block kernel as training (K10) at L_in = 2, dilation = 1."""
+    x2 = _f32c(x2)
+    _, B, C = x2.shape
+    cw, cb, rw, rb = (_f32c(p) for p in params)
+    lib = load()
+    f32 = dict(device=x2.device, dtype=torch.float32)
+    o = torch.empty(1, B, C, **f32) if want_output else None
+    res = torch.empty(lib.blvm_wavenet_block_reserve_floats(2, B, C, 1), **f32)
+    ws = torch.empty(lib.blvm_wavenet_block_workspace_floats(2, B, C, S, 1), **f32)
+    check(lib.blvm_wavenet_block_fwd(ptr(x2), ptr(cw), ptr(cb), ptr(rw), ptr(rb), 2, B, C, S, 1, 1, inv_std, ptr(o), ptr(skip_acc),
+                                     ptr(res), ptr(ws), stream_ptr()), "blvm_wavenet_block_fwd")  # fmt: skip
+    return o
+
+
+@torch.no_grad()
+def wavenet_decode(causal, in_transform, blocks_params, dilations, out_linear, head_linear, B: int, n_frames: int, inv_std: float,
+                   skip_scale: float, num_mix: int, log_eps: float, u=None, v=None):
+    """K10c: all frames of B utterances in one launch.  causal / in_transform / out_linear / head_linear = (weight, bias);
+    blocks_params as for wavenet_stack; u [n_frames,B,num_mix], v [n_frames,B] uniform draws (None: the mode).  -> x [B,n_frames]."""
+    import ctypes
+
+    lib = load()
+    C, S, O = in_transform[0].shape[0], blocks_params[0][2].shape[0] - in_transform[0].shape[0], out_linear[0].shape[0]
+    dev = causal[0].device
+    if causal[0].numel() != 2 * C:
+        raise NotImplementedError("libblvm_hip: wavenet_decode is built for in_channels = n_stack_frames = 1")
+    hw, hb = head_linear
+    if hw.shape[0] > 32 or hw.shape[0] != 3 * num_mix:
+        raise NotImplementedError("libblvm_hip: wavenet_decode head must have 3 * num_mix <= 32 outputs")
+    pad_w = torch.zeros(32 - hw.shape[0], hw.shape[1], device=dev)
+    parts = [*causal, *in_transform, *(p for blk in blocks_params for p in blk), *out_linear, hw, pad_w, hb, pad_w.new_zeros(32 - hb.numel())]
+    packed = torch.cat([_f32c(p).reshape(-1) for p in parts])
+    if packed.numel() != lib.blvm_wavenet_decode_pack_floats(C, S, O, len(blocks_params)):
+        raise ValueError("wavenet_decode: parameter shapes do not match the packed layout")
+    dil = (ctypes.c_int * len(dilations))(*dilations)
+    queues = torch.empty(lib.blvm_wavenet_decode_queue_floats(dil, len(dilations), B, C), device=dev, dtype=torch.float32)
+    x = torch.empty(B, n_frames, device=dev, dtype=torch.float32)
+    if u is not None:
+        u, v = _f32c(u), _f32c(v)
+        if tuple(u.shape) != (n_frames, B, num_mix) or tuple(v.shape) != (n_frames, B):
+            raise ValueError("wavenet_decode: u must be [n_frames,B,num_mix] and v [n_frames,B]")
+    check(lib.blvm_wavenet_decode(ptr(packed), dil, len(dilations), B, C, S, O, num_mix, n_frames, inv_std, skip_scale, log_eps,
+                                  ptr(u), ptr(v), ptr(queues), ptr(x), stream_ptr()), "blvm_wavenet_decode")  # fmt: skip
+    return x
+
+
 def wavenet_stack(x, blocks_params, dilations, T_skip: int, inv_std: float, S: int, groups=None):
     """x [L,B,C] -> skip output(s) [T_skip,B,S]: the sum over blocks of the last T_skip frames of each block's skip branch
     (groups=None: one sum over all blocks, returned as a tensor; otherwise a tuple, see _WaveNetStackFunction)."""

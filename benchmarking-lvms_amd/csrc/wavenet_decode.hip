@@ -1,0 +1,273 @@
+// wavenet_decode.hip — K10c: autoregressive WaveNet sampling, every frame of every utterance in ONE launch.
+//
+// Replaces the per-frame loop of WaveNet.generate (blvm/models/wavenet/wavenet.py:254-293).  The reference re-runs the
+// causal convolution and all residual blocks over a receptive-field window for each new sample; its TODO names the cached
+// formulation (arXiv:1611.09482), which this kernel is: block i keeps a ring buffer of its own input over the last
+// `dilation_i` frames, so one new frame costs one [2C]x[2C] and one [C+S]x[C] product per block.
+//
+// Decoding is a chain of ~2 * n_blocks dependent small products per frame — pure latency.  One workgroup owns 16
+// utterances (the M dimension of v_mfma_f32_16x16x4_f32) and walks the whole network for them with all activations in
+// LDS; the only global traffic is the weights (which stay L2 / Infinity-Cache resident across frames, the kernel is never
+// left), one ring-buffer row per block, the two uniform draws and the sample.  No launch, no host, no inter-workgroup
+// synchronisation inside the loop.
+//
+// A window of zeros is an all-zero past; under it every block input is constant in time (the network's response to zero
+// input, biases included).  The prologue evaluates that steady state once — each block with both taps on the same vector —
+// and fills the ring buffers with it, which makes frame 0 identical to the reference's first window evaluation.
+#include "common.h"
+
+namespace blvm {
+namespace {
+
+constexpr int DEC_ROWS = 16;        // utterances per workgroup
+constexpr int DEC_MAX_BLOCKS = 64;  // dilations travel by value in the kernel arguments
+constexpr int DEC_HEAD_ROWS = 32;   // head weight rows in the packed image (3 * num_mix <= 30, zero padded)
+
+// Offsets (floats) into the packed weight image; every region starts on a 16-byte boundary (C, S, O multiples of 16).
+struct DecodeLayout {
+  size_t causal_w, causal_b, in_w, in_b, blocks, block_stride, out_w, out_b, head_w, head_b, total;
+  size_t conv_b, rs_w, rs_b;  // relative to a block's start (conv_w is at 0)
+};
+
+__host__ __device__ inline DecodeLayout decode_layout(int C, int S, int O, int n_blocks) {
+  DecodeLayout L;
+  size_t o = 0;
+  L.causal_w = o; o += (size_t)C * 2;  // [C,1,2]
+  L.causal_b = o; o += C;
+  L.in_w = o; o += (size_t)C * C;
+  L.in_b = o; o += C;
+  L.conv_b = (size_t)2 * C * 2 * C;
+  L.rs_w = L.conv_b + 2 * C;
+  L.rs_b = L.rs_w + (size_t)(C + S) * C;
+  L.block_stride = L.rs_b + (C + S);
+  L.blocks = o; o += L.block_stride * n_blocks;
+  L.out_w = o; o += (size_t)O * S;
+  L.out_b = o; o += O;
+  L.head_w = o; o += (size_t)DEC_HEAD_ROWS * O;
+  L.head_b = o; o += DEC_HEAD_ROWS;
+  L.total = o;
+  return L;
+}
+
+struct DecodeArgs {
+  const float* w;
+  int dil[DEC_MAX_BLOCKS];
+  int n_blocks, B, C, S, O, n_frames, num_mix;
+  float inv_std, skip_scale, log_eps;
+  const float* u;  // [n_frames,B,num_mix] or NULL
+  const float* v;  // [n_frames,B] or NULL
+  float* queues;   // block i: [dil_i,B,C] at B*C*sum(dil[:i])
+  float* x_out;    // [B,n_frames]
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void wn_decode_kernel(DecodeArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  constexpr int NT = NW * 64;
+  const int C = a.C, S = a.S, O = a.O, B = a.B;
+  const int CA = C > O ? C : O;
+  const int ldV = 2 * C + 4, ldA = CA + 4, ldS = S + 4, ldP = 2 * C;
+  float* sV = smem;                    // [16][2C+4]  interleaved taps: k = 2c + tap
+  float* sPre = sV + DEC_ROWS * ldV;   // [16][2C]    gate pre-activations
+  float* sAct = sPre + DEC_ROWS * ldP; // [16][max(C,O)+4]
+  float* sH = sAct + DEC_ROWS * ldA;   // [16][C]     current block input
+  float* sSkip = sH + DEC_ROWS * C;    // [16][S+4]
+  float* sPar = sSkip + DEC_ROWS * ldS;  // [16][32]  head outputs
+  float* sX = sPar + DEC_ROWS * DEC_HEAD_ROWS;  // [16][2] previous / newest sample
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, cc = lane & 15;
+  const int b0 = blockIdx.x * DEC_ROWS;
+  const DecodeLayout L = decode_layout(C, S, O, a.n_blocks);
+  const float* w = a.w;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  for (int i = tid; i < DEC_ROWS * 2; i += NT) sX[i] = 0.f;
+  __syncthreads();
+
+  // causal conv on (previous, newest) sample -> 1x1 in_transform -> sH; clears the skip accumulators
+  auto front = [&]() {
+    const float* cw = w + L.causal_w;
+    const float* cb = w + L.causal_b;
+    for (int idx = tid; idx < DEC_ROWS * C; idx += NT) {
+      const int r = idx / C, o = idx - r * C;
+      sAct[r * ldA + o] = cw[2 * o] * sX[2 * r] + cw[2 * o + 1] * sX[2 * r + 1] + cb[o];
+    }
+    for (int idx = tid; idx < DEC_ROWS * S; idx += NT) {
+      const int r = idx / S;
+      sSkip[r * ldS + (idx - r * S)] = 0.f;
+    }
+    __syncthreads();
+    for (int tile = wave; tile < C / 16; tile += NW) {
+      const f32x4 acc = wave_gemm16<1>(sAct, ldA, 0, DEC_ROWS, w + L.in_w, C, tile * 16, C, 0, zero4);
+      const int o = tile * 16 + cc;
+      const float bias = w[L.in_b + o];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sH[(4 * q + r) * C + o] = acc[r] + bias;
+    }
+    __syncthreads();
+  };
+
+  // one gated residual block on the frame in sH.  steady: both taps = sH, ring buffer filled with sH, skip untouched.
+  auto block = [&](int i, float* qi, int slot, bool steady) {
+    const float* bw = w + L.blocks + (size_t)i * L.block_stride;
+    const int d = a.dil[i];
+    for (int idx = tid; idx < DEC_ROWS * C; idx += NT) {
+      const int r = idx / C, c = idx - r * C;
+      const float cur = sH[idx];
+      float old = cur;
+      if (b0 + r < B) {
+        if (steady) {
+          for (int s = 0; s < d; ++s) qi[((size_t)s * B + b0 + r) * C + c] = cur;
+        } else {
+          float* p = qi + ((size_t)slot * B + b0 + r) * C + c;
+          old = *p;
+          *p = cur;
+        }
+      }
+      sV[r * ldV + 2 * c] = old;
+      sV[r * ldV + 2 * c + 1] = cur;
+    }
+    __syncthreads();
+    for (int tile = wave; tile < 2 * C / 16; tile += NW) {
+      const f32x4 acc = wave_gemm16<1>(sV, ldV, 0, DEC_ROWS, bw, 2 * C, tile * 16, 2 * C, 0, zero4);
+      const int o = tile * 16 + cc;
+      const float bias = bw[L.conv_b + o];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sPre[(4 * q + r) * ldP + o] = acc[r] + bias;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < DEC_ROWS * C; idx += NT) {
+      const int r = idx / C, c = idx - r * C;
+      sAct[r * ldA + c] = tanhf(sPre[r * ldP + c]) * sigmoidf_(sPre[r * ldP + C + c]);
+    }
+    __syncthreads();
+    for (int tile = wave; tile < (C + S) / 16; tile += NW) {
+      const f32x4 acc = wave_gemm16<1>(sAct, ldA, 0, DEC_ROWS, bw + L.rs_w, C, tile * 16, C, 0, zero4);
+      const int o = tile * 16 + cc;
+      const float bias = bw[L.rs_b + o];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 4 * q + r;
+        const float val = acc[r] + bias;
+        if (o < C) sH[row * C + o] = (val + sH[row * C + o]) * a.inv_std;
+        else if (!steady) sSkip[row * ldS + (o - C)] += val;
+      }
+    }
+    __syncthreads();
+  };
+
+  // steady state under an all-zero past
+  front();
+  {
+    float* qi = a.queues;
+    for (int i = 0; i < a.n_blocks; ++i) {
+      block(i, qi, 0, true);
+      qi += (size_t)a.dil[i] * B * C;
+    }
+  }
+
+  for (int t = 0; t < a.n_frames; ++t) {
+    front();
+    float* qi = a.queues;
+    for (int i = 0; i < a.n_blocks; ++i) {
+      block(i, qi, t % a.dil[i], false);
+      qi += (size_t)a.dil[i] * B * C;
+    }
+    // relu(skip * scale) -> Linear -> relu -> head Linear -> sample
+    for (int idx = tid; idx < DEC_ROWS * S; idx += NT) {
+      const int r = idx / S, c = idx - r * S;
+      sSkip[r * ldS + c] = fmaxf(sSkip[r * ldS + c] * a.skip_scale, 0.f);
+    }
+    __syncthreads();
+    for (int tile = wave; tile < O / 16; tile += NW) {
+      const f32x4 acc = wave_gemm16<1>(sSkip, ldS, 0, DEC_ROWS, w + L.out_w, S, tile * 16, S, 0, zero4);
+      const int o = tile * 16 + cc;
+      const float bias = w[L.out_b + o];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sAct[(4 * q + r) * ldA + o] = fmaxf(acc[r] + bias, 0.f);
+    }
+    __syncthreads();
+    for (int tile = wave; tile < DEC_HEAD_ROWS / 16; tile += NW) {
+      const f32x4 acc = wave_gemm16<1>(sAct, ldA, 0, DEC_ROWS, w + L.head_w, O, tile * 16, O, 0, zero4);
+      const int o = tile * 16 + cc;
+      const float bias = w[L.head_b + o];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sPar[(4 * q + r) * DEC_HEAD_ROWS + o] = acc[r] + bias;
+    }
+    __syncthreads();
+    if (tid < DEC_ROWS && b0 + tid < B) {
+      // Gumbel-max component pick + clamped logistic draw, as mix_sample_kernel (dmol.hip; blvm/utils/variational.py:309-349)
+      const float* p = sPar + tid * DEC_HEAD_ROWS;
+      const int K = a.num_mix;
+      const size_t f = (size_t)t * B + b0 + tid;
+      int best = 0;
+      float bv = -INFINITY;
+      for (int m = 0; m < K; ++m) {
+        float s = p[m];
+        if (a.u != nullptr) s -= logf(-logf(a.u[f * K + m]));
+        if (s > bv) { bv = s; best = m; }
+      }
+      const float loc = p[K + best], raw = p[2 * K + best];
+      float x = loc;
+      if (a.v != nullptr) {
+        const float vv = a.v[f];
+        x = loc + expf(fmaxf(raw, a.log_eps)) * (logf(vv) - logf(1.f - vv));
+        x = fminf(fmaxf(x, -1.f), 1.f);
+      }
+      a.x_out[(size_t)(b0 + tid) * a.n_frames + t] = x;
+      sX[2 * tid] = sX[2 * tid + 1];
+      sX[2 * tid + 1] = x;
+    }
+    __syncthreads();
+  }
+}
+
+inline size_t decode_lds_bytes(int C, int S, int O) {
+  const int CA = C > O ? C : O;
+  return sizeof(float) * ((size_t)DEC_ROWS * ((2 * C + 4) + 2 * C + (CA + 4) + C + (S + 4) + DEC_HEAD_ROWS) + 2 * DEC_ROWS);
+}
+
+}  // namespace
+}  // namespace blvm
+
+extern "C" size_t blvm_wavenet_decode_pack_floats(int C, int S, int O, int n_blocks) {
+  if (C <= 0 || S <= 0 || O <= 0 || n_blocks <= 0) return 0;
+  return blvm::decode_layout(C, S, O, n_blocks).total;
+}
+
+extern "C" size_t blvm_wavenet_decode_queue_floats(const int* dilations, int n_blocks, int B, int C) {
+  if (!dilations || n_blocks <= 0 || B <= 0 || C <= 0) return 0;
+  size_t n = 0;
+  for (int i = 0; i < n_blocks; ++i) n += (size_t)(dilations[i] > 0 ? dilations[i] : 0);
+  return n * B * C;
+}
+
+extern "C" int blvm_wavenet_decode(const float* packed, const int* dilations, int n_blocks, int B, int C, int S, int O,
+                                   int num_mix, int n_frames, float inv_std, float skip_scale, float log_eps,
+                                   const float* u, const float* v, float* queues, float* x_out, void* stream) {
+  using namespace blvm;
+  BLVM_REQUIRE(packed && dilations && queues && x_out && aligned16(packed), "wavenet_decode: NULL or misaligned argument");
+  BLVM_REQUIRE(B > 0 && n_frames >= 0 && n_blocks > 0 && n_blocks <= DEC_MAX_BLOCKS, "wavenet_decode: need B > 0, 1 <= n_blocks <= %d", DEC_MAX_BLOCKS);
+  BLVM_REQUIRE(C > 0 && S > 0 && O > 0 && C % 16 == 0 && S % 16 == 0 && O % 16 == 0, "wavenet_decode: C, S, O must be multiples of 16");
+  BLVM_REQUIRE(num_mix > 0 && 3 * num_mix <= DEC_HEAD_ROWS, "wavenet_decode: num_mix must be in [1, %d]", DEC_HEAD_ROWS / 3);
+  BLVM_REQUIRE((u == nullptr) == (v == nullptr), "wavenet_decode: u and v are given together (both NULL: the mode)");
+  const size_t lds = decode_lds_bytes(C, S, O);
+  BLVM_REQUIRE(lds <= 160 * 1024, "wavenet_decode: C=%d, S=%d, O=%d need %zu bytes of LDS (> 160 KB)", C, S, O, lds);
+  if (n_frames == 0) return BLVM_OK;
+  DecodeArgs a;
+  a.w = packed;
+  for (int i = 0; i < n_blocks; ++i) {
+    BLVM_REQUIRE(dilations[i] >= 1, "wavenet_decode: dilation %d of block %d", dilations[i], i);
+    a.dil[i] = dilations[i];
+  }
+  for (int i = n_blocks; i < DEC_MAX_BLOCKS; ++i) a.dil[i] = 1;
+  a.n_blocks = n_blocks; a.B = B; a.C = C; a.S = S; a.O = O; a.n_frames = n_frames; a.num_mix = num_mix;
+  a.inv_std = inv_std; a.skip_scale = skip_scale; a.log_eps = log_eps;
+  a.u = u; a.v = v; a.queues = queues; a.x_out = x_out;
+  constexpr int NW = 8;
+  auto kern = wn_decode_kernel<NW>;
+  if (lds > 64 * 1024) BLVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)((B + DEC_ROWS - 1) / DEC_ROWS)), dim3(NW * 64), lds, static_cast<hipStream_t>(stream), a);
+  BLVM_CHECK_LAUNCH("wavenet_decode");
+  return BLVM_OK;
+}

@@ -284,6 +284,23 @@ int blvm_wavenet_block_bwd(const float* x, const float* conv_w, const float* rs_
                            int T_skip, float inv_std, float* d_x, float* dconv_w, float* dconv_b, float* drs_w,
                            float* drs_b, float* workspace, void* stream);
 
+/* K10c  Autoregressive WaveNet sampling: all frames of all utterances in ONE launch, from an all-zero start.  Replaces the
+ *   per-frame loop of `WaveNet.generate` (`blvm/models/wavenet/wavenet.py:254-293`) with the cached formulation its TODO
+ *   names: block i keeps a ring buffer of its input over the last dilation_i frames.  in_channels = n_stack_frames = 1.
+ *   packed: one weight image of blvm_wavenet_decode_pack_floats(C,S,O,n_blocks) floats, in this order (row-major,
+ *     PyTorch parameter layouts): causal conv w [C,1,2], b [C]; in_transform w [C,C], b [C]; per block conv w [2C,C,2],
+ *     b [2C], rs w [C+S,C], b [C+S]; out_transform Linear w [O,S], b [O]; head Linear w zero-padded to [32,O], b to [32].
+ *   dilations: HOST array [n_blocks], n_blocks <= 64.  C, S, O multiples of 16; 3*num_mix <= 32.
+ *   Per frame: skip sum * skip_scale -> ReLU -> Linear -> ReLU -> head Linear -> (logits, locs, log_scales) -> Gumbel-max
+ *   component pick with u [n_frames,B,num_mix], logistic draw with v [n_frames,B] clamped to [-1,1] (as blvm_mix_sample
+ *   kind 0; u = v = NULL: the mode) -> x_out [B,n_frames], fed back as the next input.
+ *   queues: scratch of blvm_wavenet_decode_queue_floats(...) floats (contents need no initialisation). */
+size_t blvm_wavenet_decode_pack_floats(int C, int S, int O, int n_blocks);
+size_t blvm_wavenet_decode_queue_floats(const int* dilations, int n_blocks, int B, int C);
+int blvm_wavenet_decode(const float* packed, const int* dilations, int n_blocks, int B, int C, int S, int O, int num_mix,
+                        int n_frames, float inv_std, float skip_scale, float log_eps, const float* u, const float* v,
+                        float* queues, float* x_out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * K5  RSSM cell of the Clockwork-VAE over a sequence (forward + BPTT).  Replaces the per-level time loop
  *     `blvm/models/clockwork_vae/clockwork_vae.py:272-281` over `RSSMCell.forward` (`blvm/modules/rssm.py:79-104`).

@@ -654,6 +654,8 @@ def test_wavenet_generate_matches_reference():
     assert tuple(x.shape) == tuple(g["wn_x"].shape)
     diff = (x.cpu() - T(g["wn_x"])).abs()
     assert float((diff > 1e-4).float().mean()) < 0.1, diff  # a Gumbel-max tie may flip one component pick
+    xc = m.generate(n_samples=2, n_frames=7, uniforms=uni, cached=True)  # the queue-based path against the same reference samples
+    assert float(((xc.cpu() - T(g["wn_x"])).abs() > 1e-4).float().mean()) < 0.1
     xs = m.generate(n_samples=3, n_frames=4)
     assert tuple(xs.shape) == (3, 4, 1) and torch.isfinite(xs).all()
 
@@ -722,3 +724,45 @@ def test_sharded_gradients_equal_full_batch_gradient():
     for i, gf in enumerate(full):
         combined = sum(g[i] * n for g, n in shards) / n_full
         assert rel_l2(combined, gf) < 1e-5, i
+
+
+def test_wavenet_cached_generation_equals_window_generation():
+    """Queue-based generation (one frame per block per step) draws exactly the samples of the reference's window
+    re-evaluation for the same uniform draws; n_frames beyond the longest dilation so every ring buffer wraps."""
+    from blvm.models import WaveNet
+    from blvm.modules.distributions import DiscretizedLogisticMixtureDense
+
+    torch.manual_seed(8)
+    m = WaveNet(likelihood=DiscretizedLogisticMixtureDense(16, 1, num_mix=10, num_bins=2**16), n_layers=4, n_stacks=2, res_channels=16).to(DEV)
+    gen = torch.Generator().manual_seed(1)
+    n = 24  # dilations 1,2,4,8 x 2
+    uni = [(torch.empty(3, 1, 10).uniform_(1e-5, 1 - 1e-5, generator=gen).to(DEV), torch.empty(3, 1).uniform_(1e-8, 1 - 1e-8, generator=gen).to(DEV))
+           for _ in range(n)]
+    a = m.generate(n_samples=3, n_frames=n, uniforms=uni)
+    b = m.generate(n_samples=3, n_frames=n, uniforms=uni, cached=True)  # K10c: one launch
+    c = m._generate_cached(3, n, uni)  # block by block
+    assert tuple(a.shape) == tuple(b.shape) == tuple(c.shape) == (3, n, 1)
+    assert float(((a - b).abs() > 1e-4).float().mean()) < 0.05, (a - b).abs().max()
+    assert float(((a - c).abs() > 1e-4).float().mean()) < 0.05, (a - c).abs().max()
+
+
+@pytest.mark.parametrize("B,C,layers,stacks", [(1, 64, 10, 5), (19, 32, 5, 2), (40, 128, 3, 1)])
+def test_wavenet_decode_kernel_matches_window_generation(B, C, layers, stacks):
+    """The one-launch decoder over partial 16-utterance groups, several widths and the default 50-block stack (ring buffers up
+    to 512 frames deep; frames 0.. read the steady-state fill) against the per-frame window path."""
+    from blvm.models import WaveNet
+    from blvm.modules.distributions import DiscretizedLogisticMixtureDense
+
+    torch.manual_seed(B + C)
+    m = WaveNet(likelihood=DiscretizedLogisticMixtureDense(C, 1, num_mix=10, num_bins=2**16), n_layers=layers, n_stacks=stacks, res_channels=C).to(DEV)
+    gen = torch.Generator().manual_seed(B)
+    n = 12
+    uni = [(torch.empty(B, 1, 10).uniform_(1e-5, 1 - 1e-5, generator=gen).to(DEV), torch.empty(B, 1).uniform_(1e-8, 1 - 1e-8, generator=gen).to(DEV))
+           for _ in range(n)]
+    assert m._decode_kernel_applies()
+    a = m.generate(n_samples=B, n_frames=n, uniforms=uni)
+    b = m.generate(n_samples=B, n_frames=n, uniforms=uni, cached=True)
+    assert tuple(b.shape) == (B, n, 1) and torch.isfinite(b).all()
+    assert float(((a - b).abs() > 1e-4).float().mean()) < 0.05, (a - b).abs().max()
+    free = m.generate(n_samples=B, n_frames=5, cached=True)  # device RNG
+    assert tuple(free.shape) == (B, 5, 1) and torch.isfinite(free).all() and float(free.abs().max()) <= 1.0
