@@ -9,7 +9,8 @@ import os
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libblvm_hip.so")
+# BLVM_HIP_LIB: an alternative build of the same library (kernel experiments); the default is the in-tree build
+_LIB_PATH = os.environ.get("BLVM_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libblvm_hip.so")
 _lib = None
 
 c_int, c_float, c_void_p, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t

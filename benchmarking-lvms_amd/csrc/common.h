@@ -73,7 +73,14 @@ inline int gemm_pick_split(int M, int N, int K) {
 // v_mfma_f32_16x16x4_f32: lane l supplies A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D: col=l&15, row=(l>>4)*4+reg.
 // Each lane fetches 4 consecutive k as one 16-byte load and feeds them to 4 MFMAs; A and B use the same
 // k-permutation, so the sum over k is complete.
-template <int NW>
+//
+// WT16: W is in the T16 OPERAND LAYOUT (t16_pack below) instead of row-major.  Row-major, one wave load of the operand
+// touches 16 rows x 64 bytes — 16 half-used cache lines — and a workgroup ingests ~38 GB/s from L2; in T16 every
+// (16 rows x 16 k) block is stored as the 64 lanes' 16-byte fragments back to back, so the same load is ONE contiguous
+// 1 KB read (~150 GB/s per workgroup, tools/cu_ingest.hip).  Block (row tile t, k chunk j) of a [R,K] matrix sits at
+// ((t * K/16 + j) * 256) floats, element (rr, 4q+e) of it at (rr + 16 q) * 4 + e: the fragment address of lane
+// (rr = lane & 15, q = lane >> 4) is W + c0 * ldw + 16 * k0 + 4 * lane with ldw = the packed matrix's K.
+template <int NW, bool WT16 = false>
 __device__ __forceinline__ f32x4 wave_gemm16(const float* __restrict__ A, int lda, int r0, int nrows,
                                               const float* __restrict__ W, int ldw, int c0, int K, int wave,
                                               f32x4 acc) {
@@ -82,7 +89,8 @@ __device__ __forceinline__ f32x4 wave_gemm16(const float* __restrict__ A, int ld
   const int rr = lane & 15, q = lane >> 4;
   const bool aok = (r0 + rr) < nrows;
   const float* ap = A + (size_t)(aok ? r0 + rr : 0) * lda + 4 * q;
-  const float* wp = W + (size_t)(c0 + rr) * ldw + 4 * q;
+  const float* wp = WT16 ? W + (size_t)c0 * ldw + 4 * lane : W + (size_t)(c0 + rr) * ldw + 4 * q;
+  constexpr int WS = WT16 ? 16 : 1;  // k stride of the W fragment address
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   int kc = wave * 16;
   // 4 chunks per trip keeps 8 x 16-byte loads in flight
@@ -91,10 +99,10 @@ __device__ __forceinline__ f32x4 wave_gemm16(const float* __restrict__ A, int ld
     float4 a1 = *reinterpret_cast<const float4*>(ap + kc + STEP);
     float4 a2 = *reinterpret_cast<const float4*>(ap + kc + 2 * STEP);
     float4 a3 = *reinterpret_cast<const float4*>(ap + kc + 3 * STEP);
-    const float4 w0 = *reinterpret_cast<const float4*>(wp + kc);
-    const float4 w1 = *reinterpret_cast<const float4*>(wp + kc + STEP);
-    const float4 w2 = *reinterpret_cast<const float4*>(wp + kc + 2 * STEP);
-    const float4 w3 = *reinterpret_cast<const float4*>(wp + kc + 3 * STEP);
+    const float4 w0 = *reinterpret_cast<const float4*>(wp + WS * (kc));
+    const float4 w1 = *reinterpret_cast<const float4*>(wp + WS * (kc + STEP));
+    const float4 w2 = *reinterpret_cast<const float4*>(wp + WS * (kc + 2 * STEP));
+    const float4 w3 = *reinterpret_cast<const float4*>(wp + WS * (kc + 3 * STEP));
     if (!aok) { a0 = a1 = a2 = a3 = zero; }
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, w0.x, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, w0.y, acc, 0, 0, 0);
@@ -115,7 +123,7 @@ __device__ __forceinline__ f32x4 wave_gemm16(const float* __restrict__ A, int ld
   }
   for (; kc < K; kc += STEP) {
     float4 a0 = *reinterpret_cast<const float4*>(ap + kc);
-    const float4 w0 = *reinterpret_cast<const float4*>(wp + kc);
+    const float4 w0 = *reinterpret_cast<const float4*>(wp + WS * (kc));
     if (!aok) a0 = zero;
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, w0.x, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, w0.y, acc, 0, 0, 0);
@@ -130,14 +138,16 @@ __device__ __forceinline__ f32x4 wave_gemm16(const float* __restrict__ A, int ld
 // offset 4*lh of every 8-k chunk as one 16-byte load and feeds them to 4 MFMAs (MFMA c sums k = chunk + c and chunk + 4 + c;
 // A and B use the same permutation).  Compared with the 16x16 tile every operand byte fetched from L2 feeds twice the FLOPs:
 // at B >= 128 the links are bound by those bytes, not by launch latency.  K must be a multiple of 8.
-template <int NW>
+template <int NW, bool WT16 = false>
 __device__ __forceinline__ f32x16 wave_gemm32(const float* __restrict__ A, int lda, int r0, int nrows,
                                                const float* __restrict__ W, int ldw, int c0, int K, int wave, f32x16 acc) {
   constexpr int STEP = NW * 8;
   const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
   const bool aok = (r0 + li) < nrows;
   const float* ap = A + (size_t)(aok ? r0 + li : 0) * lda + 4 * lh;
-  const float* wp = W + (size_t)(c0 + li) * ldw + 4 * lh;
+  // T16: rows c0 + li live in row tile c0/16 + (li >> 4); k = kc + 4 lh is quad 2 * ((kc >> 3) & 1) + lh of chunk kc >> 4
+  const float* wp = WT16 ? W + (size_t)(c0 / 16 + (li >> 4)) * ldw * 16 + ((li & 15) + 16 * lh) * 4 : W + (size_t)(c0 + li) * ldw + 4 * lh;
+  constexpr int WS = WT16 ? 16 : 1;
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   int kc = wave * 8;
   for (; kc + 3 * STEP < K; kc += 4 * STEP) {
@@ -145,10 +155,10 @@ __device__ __forceinline__ f32x16 wave_gemm32(const float* __restrict__ A, int l
     float4 a1 = *reinterpret_cast<const float4*>(ap + kc + STEP);
     float4 a2 = *reinterpret_cast<const float4*>(ap + kc + 2 * STEP);
     float4 a3 = *reinterpret_cast<const float4*>(ap + kc + 3 * STEP);
-    const float4 w0 = *reinterpret_cast<const float4*>(wp + kc);
-    const float4 w1 = *reinterpret_cast<const float4*>(wp + kc + STEP);
-    const float4 w2 = *reinterpret_cast<const float4*>(wp + kc + 2 * STEP);
-    const float4 w3 = *reinterpret_cast<const float4*>(wp + kc + 3 * STEP);
+    const float4 w0 = *reinterpret_cast<const float4*>(wp + WS * (kc));
+    const float4 w1 = *reinterpret_cast<const float4*>(wp + WS * (kc + STEP));
+    const float4 w2 = *reinterpret_cast<const float4*>(wp + WS * (kc + 2 * STEP));
+    const float4 w3 = *reinterpret_cast<const float4*>(wp + WS * (kc + 3 * STEP));
     if (!aok) { a0 = a1 = a2 = a3 = zero; }
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, w0.x, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, w0.y, acc, 0, 0, 0);
@@ -169,7 +179,7 @@ __device__ __forceinline__ f32x16 wave_gemm32(const float* __restrict__ A, int l
   }
   for (; kc < K; kc += STEP) {
     float4 a0 = *reinterpret_cast<const float4*>(ap + kc);
-    const float4 w0 = *reinterpret_cast<const float4*>(wp + kc);
+    const float4 w0 = *reinterpret_cast<const float4*>(wp + WS * (kc));
     if (!aok) a0 = zero;
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, w0.x, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, w0.y, acc, 0, 0, 0);
@@ -208,5 +218,10 @@ int gemm_f32(int op_a, int op_b, int M, int N, int K, const float* A, int lda, c
              int split_k, hipStream_t stream);
 int colsum_f32(int M, int N, const float* X, int ldx, float* out, int accumulate, hipStream_t stream);
 int transpose_f32(int M, int N, const float* X, int ldx, float* out, int ldo, hipStream_t stream);
+// dst = T16 operand layout (see wave_gemm16) of the [R,K] matrix M[r][k] = src[r * rs + k * cs]; R, K multiples of 16.
+int t16_pack(const float* src, long rs, long cs, int R, int K, float* dst, hipStream_t stream);
+inline int t16_pack_rows(const float* W, int ldw, int R, int K, float* dst, hipStream_t s) { return t16_pack(W, ldw, 1, R, K, dst, s); }
+// the transpose of X[:M,:N] (row stride ldx): a [N,M] matrix
+inline int t16_pack_transposed(const float* X, int ldx, int M, int N, float* dst, hipStream_t s) { return t16_pack(X, 1, ldx, N, M, dst, s); }
 
 }  // namespace blvm

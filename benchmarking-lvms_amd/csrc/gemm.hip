@@ -341,6 +341,27 @@ int colsum_f32(int M, int N, const float* X, int ldx, float* out, int accumulate
   return BLVM_OK;
 }
 
+__global__ __launch_bounds__(256) void t16_pack_kernel(const float* __restrict__ src, long rs, long cs, int KB, size_t n,
+                                                       float* __restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int e = (int)(i & 3), lane = (int)((i >> 2) & 63);
+  const size_t blk = i >> 8;
+  const int j = (int)(blk % KB);
+  const size_t t = blk / KB;
+  const size_t r = 16 * t + (lane & 15);
+  const int k = 16 * j + 4 * (lane >> 4) + e;
+  dst[i] = src[r * rs + (size_t)k * cs];
+}
+
+int t16_pack(const float* src, long rs, long cs, int R, int K, float* dst, hipStream_t stream) {
+  BLVM_REQUIRE(src && dst && R > 0 && K > 0 && R % 16 == 0 && K % 16 == 0 && aligned16(dst), "t16_pack: R=%d, K=%d must be multiples of 16", R, K);
+  const size_t n = (size_t)R * K;
+  hipLaunchKernelGGL(t16_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, rs, cs, K / 16, n, dst);
+  BLVM_CHECK_LAUNCH("t16_pack");
+  return BLVM_OK;
+}
+
 int transpose_f32(int M, int N, const float* X, int ldx, float* out, int ldo, hipStream_t stream) {
   if (M == 0 || N == 0) return BLVM_OK;
   dim3 grid((N + 31) / 32, (M + 31) / 32);

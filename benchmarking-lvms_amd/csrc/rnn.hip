@@ -42,7 +42,7 @@ __device__ __forceinline__ int time_index(int j, int reverse, const int32_t* len
 // ===================================================================================================================
 struct LstmFwdArgs {
   const float *hprev, *cprev;   // [B,H]
-  const float* Whh;             // [4H,H] rows [i|f|g|o]
+  const float* Whh;             // [4H,H] rows [i|f|g|o], in T16 (common.h)
   const float* bhh;             // [4H]
   const float* xg;              // [B,4H] input projection incl. b_ih
   const int32_t* lens;          // [B] valid steps per row (packed-sequence semantics) or null
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_kernel(LstmFwdArgs a) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[g] = wave_gemm16<NW>(a.hprev, H, r0, a.B, a.Whh, H, g * H + c0, H, wave, acc[g]);
+    acc[g] = wave_gemm16<NW, true>(a.hprev, H, r0, a.B, a.Whh, H, g * H + c0, H, wave, acc[g]);
   }
   float v[4];
   reduce_tiles<4, NW>(acc, red, v);
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_kernel(LstmFwdArgs a) {
 
 struct LstmBwdArgs {
   const float* DGn;     // [B,4H] gate pre-activation grads of step s+1 (unused when has_gemm == 0)
-  const float* WhhT;    // [H,4H]
+  const float* WhhT;    // [H,4H] in T16
   const float* dout;    // [B,H] grad wrt out_s
   const float* gates;   // [B,4H] step s
   const float *c_s, *c_s1;  // cell state entering / leaving step s
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
   float v[1] = {0.f};
   if (a.has_gemm) {
     f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-    acc[0] = wave_gemm16<NW>(a.DGn, 4 * H, r0, a.B, a.WhhT, 4 * H, c0, 4 * H, threadIdx.x >> 6, acc[0]);
+    acc[0] = wave_gemm16<NW, true>(a.DGn, 4 * H, r0, a.B, a.WhhT, 4 * H, c0, 4 * H, threadIdx.x >> 6, acc[0]);
     reduce_tiles<1, NW>(acc, red, v);
   }
   if (!own) return;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
   a.DC[o] = dct * fg;
 }
 
-struct LstmReserve { float *XG, *Hs, *Cs, *GATES; };
+struct LstmReserve { float *XG, *Hs, *Cs, *GATES, *WhhP; };  // WhhP: T16 copy of Whh
 size_t carve_lstm(float* base, int T, int B, int H, LstmReserve* r) {
   size_t off = 0;
   auto take = [&](size_t cnt) { float* p = base ? base + off : nullptr; off += (cnt + 3) & ~(size_t)3; return p; };
@@ -141,6 +141,7 @@ size_t carve_lstm(float* base, int T, int B, int H, LstmReserve* r) {
   t.Hs = take((size_t)(T + 1) * B * H);
   t.Cs = take((size_t)(T + 1) * B * H);
   t.GATES = take((size_t)T * B * 4 * H);
+  t.WhhP = take((size_t)4 * H * H);
   if (r) *r = t;
   return off;
 }
@@ -161,7 +162,7 @@ size_t carve_lstm_ws(float* base, int T, int B, int H, LstmWs* w) {
 // ===================================================================================================================
 struct GruFwdArgs {
   const float* hprev;    // [B,R] state entering recurrence step j
-  const float* Whh;      // [3R,R] rows [r|z|n]
+  const float* Whh;      // [3R,R] rows [r|z|n], in T16
   const float* bhh;      // [3R]
   const float* xg;       // [T,B,3R] input projection incl. b_ih, TIME indexed
   const int32_t* lens;   // [B] (reverse map) or null
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(NW * 64) void gru_fwd_kernel(GruFwdArgs a) {
 #pragma unroll
   for (int g = 0; g < 3; ++g) {
     acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[g] = wave_gemm16<NW>(a.hprev, R, r0, a.B, a.Whh, R, g * R + c0, R, wave, acc[g]);
+    acc[g] = wave_gemm16<NW, true>(a.hprev, R, r0, a.B, a.Whh, R, g * R + c0, R, wave, acc[g]);
   }
   float v[3];
   reduce_tiles<3, NW>(acc, red, v);
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(NW * 64) void gru_fwd_kernel(GruFwdArgs a) {
 
 struct GruBwdArgs {
   const float* DGHn;    // [B,3R] hidden-projection grads of recurrence step j+1 (unused when has_gemm == 0)
-  const float* WhhT;    // [R,3R]
+  const float* WhhT;    // [R,3R] in T16
   const float* dout;    // time-indexed grad wrt the outputs (same addressing as GruFwdArgs::out)
   const float *rg, *ug, *ng, *ghn, *hprev;  // saves of step j; hprev = state entering step j
   const int32_t* lens;
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(NW * 64) void gru_bwd_kernel(GruBwdArgs a) {
   float v[1] = {0.f};
   if (a.has_gemm) {
     f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-    acc[0] = wave_gemm16<NW>(a.DGHn, 3 * R, r0, a.B, a.WhhT, 3 * R, c0, 3 * R, threadIdx.x >> 6, acc[0]);
+    acc[0] = wave_gemm16<NW, true>(a.DGHn, 3 * R, r0, a.B, a.WhhT, 3 * R, c0, 3 * R, threadIdx.x >> 6, acc[0]);
     reduce_tiles<1, NW>(acc, red, v);
   }
   if (!own) return;
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(NW * 64) void gru_bwd_kernel(GruBwdArgs a) {
   a.G[o] = g * u;
 }
 
-struct GruReserve { float *XG, *Hs, *RG, *UG, *NG, *GHN; };
+struct GruReserve { float *XG, *Hs, *RG, *UG, *NG, *GHN, *WhhP; };  // WhhP: T16 copy of Whh
 size_t carve_gru(float* base, int T, int B, int R, GruReserve* r) {
   size_t off = 0;
   auto take = [&](size_t cnt) { float* p = base ? base + off : nullptr; off += (cnt + 3) & ~(size_t)3; return p; };
@@ -263,6 +264,7 @@ size_t carve_gru(float* base, int T, int B, int R, GruReserve* r) {
   t.XG = take(n * 3 * R);
   t.Hs = take((size_t)(T + 1) * B * R);
   t.RG = take(n * R); t.UG = take(n * R); t.NG = take(n * R); t.GHN = take(n * R);
+  t.WhhP = take((size_t)3 * R * R);
   if (r) *r = t;
   return off;
 }
@@ -313,11 +315,13 @@ extern "C" int blvm_lstm_seq_fwd(const float* Wih, const float* Whh, const float
   else BLVM_HIP(hipMemsetAsync(rs.Hs, 0, sizeof(float) * bh, s));
   if (c0) BLVM_HIP(hipMemcpyAsync(rs.Cs, c0, sizeof(float) * bh, hipMemcpyDeviceToDevice, s));
   else BLVM_HIP(hipMemsetAsync(rs.Cs, 0, sizeof(float) * bh, s));
+  rc = t16_pack_rows(Whh, H, 4 * H, H, rs.WhhP, s);  // operand layout of the chain (once per sequence)
+  if (rc) return rc;
   const int nw = pick_nw(H, 4);
   const dim3 grid(H / 16, (B + 15) / 16);
   for (int t = 0; t < T; ++t) {
     LstmFwdArgs a;
-    a.hprev = rs.Hs + t * bh; a.cprev = rs.Cs + t * bh; a.Whh = Whh; a.bhh = bhh;
+    a.hprev = rs.Hs + t * bh; a.cprev = rs.Cs + t * bh; a.Whh = rs.WhhP; a.bhh = bhh;
     a.xg = rs.XG + (size_t)t * B * 4 * H; a.lens = lens;
     a.hnext = rs.Hs + (t + 1) * bh; a.cnext = rs.Cs + (t + 1) * bh;
     a.out = out + t * bh; a.gates = rs.GATES + (size_t)t * B * 4 * H;
@@ -343,7 +347,7 @@ extern "C" int blvm_lstm_seq_bwd(const float* Wih, const float* Whh, const float
   LstmWs ws;
   carve_lstm_ws(workspace, T, B, H, &ws);
   const size_t n = (size_t)T * B, bh = (size_t)B * H;
-  rc = transpose_f32(4 * H, H, Whh, H, ws.WhhT, 4 * H, s);
+  rc = t16_pack_transposed(Whh, H, 4 * H, H, ws.WhhT, s);
   if (rc) return rc;
   BLVM_HIP(hipMemsetAsync(ws.DC, 0, sizeof(float) * bh, s));
   const int nw = pick_nw(4 * H, 1);
@@ -396,11 +400,13 @@ extern "C" int blvm_gru_seq_fwd(const float* Wih, const float* Whh, const float*
   if (rc) return rc;
   if (h0) BLVM_HIP(hipMemcpyAsync(rs.Hs, h0, sizeof(float) * br, hipMemcpyDeviceToDevice, s));
   else BLVM_HIP(hipMemsetAsync(rs.Hs, 0, sizeof(float) * br, s));
+  rc = t16_pack_rows(Whh, R, 3 * R, R, rs.WhhP, s);  // operand layout of the chain (once per sequence)
+  if (rc) return rc;
   const int nw = pick_nw(R, 3);
   const dim3 grid(R / 16, (B + 15) / 16);
   for (int j = 0; j < T; ++j) {
     GruFwdArgs a;
-    a.hprev = rs.Hs + j * br; a.Whh = Whh; a.bhh = bhh; a.xg = rs.XG; a.lens = lens;
+    a.hprev = rs.Hs + j * br; a.Whh = rs.WhhP; a.bhh = bhh; a.xg = rs.XG; a.lens = lens;
     a.hnext = rs.Hs + (j + 1) * br; a.out = out;
     a.rg = rs.RG + j * br; a.ug = rs.UG + j * br; a.ng = rs.NG + j * br; a.ghn = rs.GHN + j * br;
     a.out_ts = out_ts; a.out_ld = out_ld; a.B = B; a.R = R; a.j = j; a.reverse = reverse;
@@ -426,7 +432,7 @@ extern "C" int blvm_gru_seq_bwd(const float* Wih, const float* Whh, const float*
   GruWs ws;
   carve_gru_ws(workspace, T, B, R, &ws);
   const size_t n = (size_t)T * B, br = (size_t)B * R;
-  rc = transpose_f32(3 * R, R, Whh, R, ws.WhhT, 3 * R, s);
+  rc = t16_pack_transposed(Whh, R, 3 * R, R, ws.WhhT, s);
   if (rc) return rc;
   BLVM_HIP(hipMemsetAsync(ws.G, 0, sizeof(float) * br, s));
   const int nw = pick_nw(3 * R, 1);

@@ -18,7 +18,7 @@ namespace {
 // ---- GRU link: gi = A Wih^T + bih (3 gate tiles) ; gates with the precomputed hidden projection ; state update ------
 struct GruCellArgs {
   const float* A;      int lda;   // [B,K] GRU input
-  const float* Wih;    int ldw;   // [3H,K]
+  const float* Wih;    int ldw;   // [3H,K] in T16 (ldw = K)
   const float* bih;               // [3H]
   const float* gh;                // [B,3H] hidden projection incl. b_hh
   const float* hprev;  int ldh;   // [B,H]
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(NW * 64) void gru_cell_stage_kernel(GruCellArgs a) 
 #pragma unroll
   for (int g = 0; g < 3; ++g) {
     acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[g] = wave_gemm16<NW>(a.A, a.lda, r0, a.B, a.Wih, a.ldw, g * H + c0, a.K, wave, acc[g]);
+    acc[g] = wave_gemm16<NW, true>(a.A, a.lda, r0, a.B, a.Wih, a.ldw, g * H + c0, a.K, wave, acc[g]);
   }
   float v[3];
   reduce_tiles<3, NW>(acc, red, v);
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(NW * 64) void gru_cell_stage_kernel(GruCellArgs a) 
 // ---- backward GRU link: complete dL/dh_t, then the gate derivatives of step t -------------------------------------------
 struct RssmDhArgs {
   const float *DQ0, *DP0;   // [B,H] grads wrt the first posterior / prior layer pre-activations of step t
-  const float *WqT, *WpT;   // [H,H] h-part of post_w0 / prior_w0, transposed
+  const float *WqT, *WpT;   // [H,H] h-part of post_w0 / prior_w0, transposed, in T16
   const float* dh_add;      // [B,H] direct gradient wrt h_t (from the level below / the decoder) or null
   float* G;                 // [B,H] running gradient wrt h (in: from step t+1; out: towards step t-1 through the u gate)
   const float *rg, *ug, *ng, *gh;  // step t saves; gh [B,3H]
@@ -82,8 +82,8 @@ __global__ __launch_bounds__(NW * 64) void rssm_dh_stage_kernel(RssmDhArgs a) {
   f32x4 acc[2];
   acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
   acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  acc[0] = wave_gemm16<NW>(a.DQ0, H, r0, a.B, a.WqT, H, c0, H, wave, acc[0]);
-  acc[1] = wave_gemm16<NW>(a.DP0, H, r0, a.B, a.WpT, H, c0, H, wave, acc[1]);
+  acc[0] = wave_gemm16<NW, true>(a.DQ0, H, r0, a.B, a.WqT, H, c0, H, wave, acc[0]);
+  acc[1] = wave_gemm16<NW, true>(a.DP0, H, r0, a.B, a.WpT, H, c0, H, wave, acc[1]);
   float v[2];
   reduce_tiles<2, NW>(acc, red, v);
   if (!own) return;
@@ -96,7 +96,10 @@ __global__ __launch_bounds__(NW * 64) void rssm_dh_stage_kernel(RssmDhArgs a) {
   a.G[o] = g * u;
 }
 
-struct RssmReserve { float *GIN, *GHb, *RG, *UG, *NG, *Q[3], *P[3], *RAWQ, *RAWP, *MUQR, *XGIN, *XQ; };
+struct RssmReserve {
+  float *GIN, *GHb, *RG, *UG, *NG, *Q[3], *P[3], *RAWQ, *RAWP, *MUQR, *XGIN, *XQ;
+  float *Wgz, *Wih, *Whh, *Wq[3], *Wp[3], *Wqh, *Wph;  // T16 copies of the weights the forward chain multiplies by
+};
 size_t carve_rssm(float* base, int T, int B, int H, int Z, RssmReserve* r) {
   const size_t n = (size_t)T * B;
   size_t off = 0;
@@ -108,6 +111,9 @@ size_t carve_rssm(float* base, int T, int B, int H, int Z, RssmReserve* r) {
   for (int i = 0; i < 3; ++i) t.P[i] = take(n * H);
   t.RAWQ = take(n * Z); t.RAWP = take(n * Z); t.MUQR = take(n * Z);
   t.XGIN = take(n * H); t.XQ = take(n * H);
+  t.Wgz = take((size_t)H * Z); t.Wih = take((size_t)3 * H * H); t.Whh = take((size_t)3 * H * H);
+  for (int i = 0; i < 3; ++i) { t.Wq[i] = take((size_t)H * H); t.Wp[i] = take((size_t)H * H); }
+  t.Wqh = take((size_t)2 * Z * H); t.Wph = take((size_t)2 * Z * H);
   if (r) *r = t;
   return off;
 }
@@ -167,6 +173,18 @@ extern "C" int blvm_rssm_seq_fwd(const BlvmRssmWeights* w, const float* enc, con
   }
   rc = gemm_f32(0, 0, (int)n, H, E, enc, E, w->post_w[0] + H, ldq, rs.XQ, H, w->post_b[0], 0, 0.f, nullptr, 0, 0, 1, s);
   if (rc) return rc;
+  // T16 operand copies of the chain's weights (once per sequence): z columns of the GRU input layer, h columns of post_w0
+  rc = t16_pack_rows(w->gin_w, ldg, H, Z, rs.Wgz, s); if (rc) return rc;
+  rc = t16_pack_rows(w->gru_wih, H, 3 * H, H, rs.Wih, s); if (rc) return rc;
+  rc = t16_pack_rows(w->gru_whh, H, 3 * H, H, rs.Whh, s); if (rc) return rc;
+  rc = t16_pack_rows(w->post_w[0], ldq, H, H, rs.Wq[0], s); if (rc) return rc;
+  rc = t16_pack_rows(w->prior_w[0], H, H, H, rs.Wp[0], s); if (rc) return rc;
+  for (int k = 1; k < 3; ++k) {
+    rc = t16_pack_rows(w->post_w[k], H, H, H, rs.Wq[k], s); if (rc) return rc;
+    rc = t16_pack_rows(w->prior_w[k], H, H, H, rs.Wp[k], s); if (rc) return rc;
+  }
+  rc = t16_pack_rows(w->post_hw, H, 2 * Z, H, rs.Wqh, s); if (rc) return rc;
+  rc = t16_pack_rows(w->prior_hw, H, 2 * Z, H, rs.Wph, s); if (rc) return rc;
   if (z0) BLVM_HIP(hipMemcpyAsync(zs, z0, sizeof(float) * (size_t)B * Z, hipMemcpyDeviceToDevice, s));
   else BLVM_HIP(hipMemsetAsync(zs, 0, sizeof(float) * (size_t)B * Z, s));
   if (h0) BLVM_HIP(hipMemcpyAsync(hs, h0, sizeof(float) * (size_t)B * H, hipMemcpyDeviceToDevice, s));
@@ -180,28 +198,28 @@ extern "C" int blvm_rssm_seq_fwd(const BlvmRssmWeights* w, const float* enc, con
     LinLaunch l;
     l.B = B; l.nseg = 2;
     // L1: GRU input layer (z half; context half hoisted) | hidden projection of the GRU
-    l.seg[0] = seg(zprev, Z, w->gin_w, ldg, C > 0 ? nullptr : w->gin_b, C > 0 ? rs.XGIN + oH : nullptr, H, nullptr, 0, rs.GIN + oH, H, H, Z, 1);
-    l.seg[1] = seg(hprev, H, w->gru_whh, H, w->gru_bhh, nullptr, 0, nullptr, 0, rs.GHb + o3, 3 * H, 3 * H, H, 0);
+    l.seg[0] = seg(zprev, Z, rs.Wgz, Z, C > 0 ? nullptr : w->gin_b, C > 0 ? rs.XGIN + oH : nullptr, H, nullptr, 0, rs.GIN + oH, H, H, Z, 1);
+    l.seg[1] = seg(hprev, H, rs.Whh, H, w->gru_bhh, nullptr, 0, nullptr, 0, rs.GHb + o3, 3 * H, 3 * H, H, 0);
     launch_lin(l, s);
     // L2: GRU
     GruCellArgs g;
-    g.A = rs.GIN + oH; g.lda = H; g.Wih = w->gru_wih; g.ldw = H; g.bih = w->gru_bih; g.gh = rs.GHb + o3;
+    g.A = rs.GIN + oH; g.lda = H; g.Wih = rs.Wih; g.ldw = H; g.bih = w->gru_bih; g.gh = rs.GHb + o3;
     g.hprev = hprev; g.ldh = H; g.hnext = hnew; g.ldn = H;
     g.rg = rs.RG + oH; g.ug = rs.UG + oH; g.ng = rs.NG + oH; g.B = B; g.H = H; g.K = H;
     LAUNCH_NW(gru_cell_stage_kernel, pick_nw(H, 3), dim3(H / 16, rt), s, g);
     // L3..L5: posterior | prior MLPs on h_t
-    l.seg[0] = seg(hnew, H, w->post_w[0], ldq, nullptr, rs.XQ + oH, H, nullptr, 0, rs.Q[0] + oH, H, H, H, 1);
-    l.seg[1] = seg(hnew, H, w->prior_w[0], H, w->prior_b[0], nullptr, 0, nullptr, 0, rs.P[0] + oH, H, H, H, 1);
+    l.seg[0] = seg(hnew, H, rs.Wq[0], H, nullptr, rs.XQ + oH, H, nullptr, 0, rs.Q[0] + oH, H, H, H, 1);
+    l.seg[1] = seg(hnew, H, rs.Wp[0], H, w->prior_b[0], nullptr, 0, nullptr, 0, rs.P[0] + oH, H, H, H, 1);
     launch_lin(l, s);
     for (int k = 1; k < 3; ++k) {
-      l.seg[0] = seg(rs.Q[k - 1] + oH, H, w->post_w[k], H, w->post_b[k], nullptr, 0, nullptr, 0, rs.Q[k] + oH, H, H, H, 1);
-      l.seg[1] = seg(rs.P[k - 1] + oH, H, w->prior_w[k], H, w->prior_b[k], nullptr, 0, nullptr, 0, rs.P[k] + oH, H, H, H, 1);
+      l.seg[0] = seg(rs.Q[k - 1] + oH, H, rs.Wq[k], H, w->post_b[k], nullptr, 0, nullptr, 0, rs.Q[k] + oH, H, H, H, 1);
+      l.seg[1] = seg(rs.P[k - 1] + oH, H, rs.Wp[k], H, w->prior_b[k], nullptr, 0, nullptr, 0, rs.P[k] + oH, H, H, H, 1);
       launch_lin(l, s);
     }
     // L6: heads, combination, sample
     HeadArgs h;
     h.P = rs.P[2] + oH; h.Q = rs.Q[2] + oH;
-    h.Wp = w->prior_hw; h.bp = w->prior_hb; h.Wq = w->post_hw; h.bq = w->post_hb;
+    h.Wp = rs.Wph; h.bp = w->prior_hb; h.Wq = rs.Wqh; h.bq = w->post_hb;
     h.eps = eps + oZ;
     h.mu_p = mu_p + oZ; h.sd_p = sd_p + oZ; h.mu_q = mu_q + oZ; h.sd_q = sd_q + oZ;
     h.z = zs + oZ + (size_t)B * Z;
@@ -236,17 +254,17 @@ extern "C" int blvm_rssm_seq_bwd(const BlvmRssmWeights* w, const float* enc, con
   const int ldg = Z + C, ldq = H + E;
   const float beta = (float)(0.6931471805599453 / (1.0 - (double)sd_eps));
 #define TRY(x) do { rc = (x); if (rc) return rc; } while (0)
-  TRY(transpose_f32(H, Z, w->gin_w, ldg, ws.gzT, H, s));
-  TRY(transpose_f32(3 * H, H, w->gru_wih, H, ws.wihT, 3 * H, s));
-  TRY(transpose_f32(3 * H, H, w->gru_whh, H, ws.whhT, 3 * H, s));
-  TRY(transpose_f32(H, H, w->post_w[0], ldq, ws.qT[0], H, s));
-  TRY(transpose_f32(H, H, w->prior_w[0], H, ws.pT[0], H, s));
+  TRY(t16_pack_transposed(w->gin_w, ldg, H, Z, ws.gzT, s));
+  TRY(t16_pack_transposed(w->gru_wih, H, 3 * H, H, ws.wihT, s));
+  TRY(t16_pack_transposed(w->gru_whh, H, 3 * H, H, ws.whhT, s));
+  TRY(t16_pack_transposed(w->post_w[0], ldq, H, H, ws.qT[0], s));
+  TRY(t16_pack_transposed(w->prior_w[0], H, H, H, ws.pT[0], s));
   for (int k = 1; k < 3; ++k) {
-    TRY(transpose_f32(H, H, w->post_w[k], H, ws.qT[k], H, s));
-    TRY(transpose_f32(H, H, w->prior_w[k], H, ws.pT[k], H, s));
+    TRY(t16_pack_transposed(w->post_w[k], H, H, H, ws.qT[k], s));
+    TRY(t16_pack_transposed(w->prior_w[k], H, H, H, ws.pT[k], s));
   }
-  TRY(transpose_f32(2 * Z, H, w->post_hw, H, ws.qhT, 2 * Z, s));
-  TRY(transpose_f32(2 * Z, H, w->prior_hw, H, ws.phT, 2 * Z, s));
+  TRY(t16_pack_transposed(w->post_hw, H, 2 * Z, H, ws.qhT, s));
+  TRY(t16_pack_transposed(w->prior_hw, H, 2 * Z, H, ws.phT, s));
   BLVM_HIP(hipMemsetAsync(ws.G, 0, sizeof(float) * bh, s));
   const int rt = (B + 15) / 16;
   for (int t = T - 1; t >= 0; --t) {

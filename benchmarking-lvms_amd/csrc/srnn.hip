@@ -14,7 +14,7 @@ namespace {
 
 #include "stages.h"
 
-struct SrnnReserve { float *P[3], *Q[3], *XP, *XQ, *RAWP, *RAWQ; };
+struct SrnnReserve { float *P[3], *Q[3], *XP, *XQ, *RAWP, *RAWQ, *Wp[3], *Wq[3], *Wph, *Wqh; };  // W*: T16 weight copies
 size_t carve_srnn(float* base, int Tp, int B, int H, int Z, SrnnReserve* r) {
   const size_t n = (size_t)Tp * B;
   size_t off = 0;
@@ -24,6 +24,9 @@ size_t carve_srnn(float* base, int Tp, int B, int H, int Z, SrnnReserve* r) {
   for (int i = 0; i < 3; ++i) t.Q[i] = take(n * H);
   t.XP = take(n * H); t.XQ = take(n * H);
   t.RAWP = take(n * Z); t.RAWQ = take(n * Z);
+  t.Wp[0] = take((size_t)H * Z); t.Wq[0] = take((size_t)H * Z);
+  for (int i = 1; i < 3; ++i) { t.Wp[i] = take((size_t)H * H); t.Wq[i] = take((size_t)H * H); }
+  t.Wph = take((size_t)2 * Z * H); t.Wqh = take((size_t)2 * Z * H);
   if (r) *r = t;
   return off;
 }
@@ -85,6 +88,15 @@ extern "C" int blvm_srnn_latent_fwd(const BlvmSrnnWeights* w, const float* d, co
   if (rc) return rc;
   rc = gemm_f32(0, 0, (int)n, H, R, a, R, w->post_w[0], ldw0, rs.XQ, H, w->post_b[0], 0, 0.f, nullptr, 0, 0, 1, s);
   if (rc) return rc;
+  // T16 operand copies of the chain's weights (once per sequence); layer 0: the z columns
+  rc = t16_pack_rows(w->prior_w[0] + R, ldw0, H, Z, rs.Wp[0], s); if (rc) return rc;
+  rc = t16_pack_rows(w->post_w[0] + R, ldw0, H, Z, rs.Wq[0], s); if (rc) return rc;
+  for (int k = 1; k < 3; ++k) {
+    rc = t16_pack_rows(w->prior_w[k], H, H, H, rs.Wp[k], s); if (rc) return rc;
+    rc = t16_pack_rows(w->post_w[k], H, H, H, rs.Wq[k], s); if (rc) return rc;
+  }
+  rc = t16_pack_rows(w->prior_hw, H, 2 * Z, H, rs.Wph, s); if (rc) return rc;
+  rc = t16_pack_rows(w->post_hw, H, 2 * Z, H, rs.Wqh, s); if (rc) return rc;
   if (z0) BLVM_HIP(hipMemcpyAsync(zs, z0, sizeof(float) * (size_t)B * Z, hipMemcpyDeviceToDevice, s));
   else BLVM_HIP(hipMemsetAsync(zs, 0, sizeof(float) * (size_t)B * Z, s));
   const int rt = (B + 15) / 16;
@@ -93,17 +105,17 @@ extern "C" int blvm_srnn_latent_fwd(const BlvmSrnnWeights* w, const float* d, co
     const float* zprev = zs + oZ;
     LinLaunch l;
     l.B = B; l.slope = slope; l.nseg = 2;
-    l.seg[0] = seg(zprev, Z, w->prior_w[0] + R, ldw0, nullptr, rs.XP + oH, H, nullptr, 0, rs.P[0] + oH, H, H, Z, 1);
-    l.seg[1] = seg(zprev, Z, w->post_w[0] + R, ldw0, nullptr, rs.XQ + oH, H, nullptr, 0, rs.Q[0] + oH, H, H, Z, 1);
+    l.seg[0] = seg(zprev, Z, rs.Wp[0], Z, nullptr, rs.XP + oH, H, nullptr, 0, rs.P[0] + oH, H, H, Z, 1);
+    l.seg[1] = seg(zprev, Z, rs.Wq[0], Z, nullptr, rs.XQ + oH, H, nullptr, 0, rs.Q[0] + oH, H, H, Z, 1);
     launch_lin(l, s);
     for (int k = 1; k < 3; ++k) {
-      l.seg[0] = seg(rs.P[k - 1] + oH, H, w->prior_w[k], H, w->prior_b[k], nullptr, 0, nullptr, 0, rs.P[k] + oH, H, H, H, 1);
-      l.seg[1] = seg(rs.Q[k - 1] + oH, H, w->post_w[k], H, w->post_b[k], nullptr, 0, nullptr, 0, rs.Q[k] + oH, H, H, H, 1);
+      l.seg[0] = seg(rs.P[k - 1] + oH, H, rs.Wp[k], H, w->prior_b[k], nullptr, 0, nullptr, 0, rs.P[k] + oH, H, H, H, 1);
+      l.seg[1] = seg(rs.Q[k - 1] + oH, H, rs.Wq[k], H, w->post_b[k], nullptr, 0, nullptr, 0, rs.Q[k] + oH, H, H, H, 1);
       launch_lin(l, s);
     }
     HeadArgs h;
     h.P = rs.P[2] + oH; h.Q = rs.Q[2] + oH;
-    h.Wp = w->prior_hw; h.bp = w->prior_hb; h.Wq = w->post_hw; h.bq = w->post_hb;
+    h.Wp = rs.Wph; h.bp = w->prior_hb; h.Wq = rs.Wqh; h.bq = w->post_hb;
     h.eps = eps + oZ;
     h.mu_p = mu_p + oZ; h.sd_p = sd_p + oZ; h.mu_q = mu_q + oZ; h.sd_q = sd_q + oZ;
     h.z = zs + (size_t)(t + 1) * B * Z;
@@ -136,14 +148,14 @@ extern "C" int blvm_srnn_latent_bwd(const BlvmSrnnWeights* w, const float* d, co
   const int ldw0 = R + Z;
   const float beta = (float)(0.6931471805599453 / (1.0 - (double)sd_eps));
 #define TRY(x) do { rc = (x); if (rc) return rc; } while (0)
-  TRY(transpose_f32(H, Z, w->prior_w[0] + R, ldw0, ws.pzT, H, s));
-  TRY(transpose_f32(H, Z, w->post_w[0] + R, ldw0, ws.qzT, H, s));
+  TRY(t16_pack_transposed(w->prior_w[0] + R, ldw0, H, Z, ws.pzT, s));
+  TRY(t16_pack_transposed(w->post_w[0] + R, ldw0, H, Z, ws.qzT, s));
   for (int k = 1; k < 3; ++k) {
-    TRY(transpose_f32(H, H, w->prior_w[k], H, ws.pT[k], H, s));
-    TRY(transpose_f32(H, H, w->post_w[k], H, ws.qT[k], H, s));
+    TRY(t16_pack_transposed(w->prior_w[k], H, H, H, ws.pT[k], s));
+    TRY(t16_pack_transposed(w->post_w[k], H, H, H, ws.qT[k], s));
   }
-  TRY(transpose_f32(2 * Z, H, w->prior_hw, H, ws.phT, 2 * Z, s));
-  TRY(transpose_f32(2 * Z, H, w->post_hw, H, ws.qhT, 2 * Z, s));
+  TRY(t16_pack_transposed(w->prior_hw, H, 2 * Z, H, ws.phT, s));
+  TRY(t16_pack_transposed(w->post_hw, H, 2 * Z, H, ws.qhT, s));
   const int rt = (B + 15) / 16;
   for (int t = Tp - 1; t >= 0; --t) {
     const size_t oH = (size_t)t * B * H, oZ = (size_t)t * B * Z, o2Z = (size_t)t * B * 2 * Z;

@@ -12,6 +12,9 @@
 // wave's dependent MFMA chain is <= 24 instructions.
 // ---------------------------------------------------------------------------------------------------------------
 
+// EVERY weight operand of the stage kernels (W, Wp, Wq, WT ...) is in the T16 operand layout (common.h: t16_pack /
+// wave_gemm16<NW, true>), packed once per sequence by the host code of the chain; `ldw` is the packed matrix's K.
+//
 // generic multi-segment linear stage:  out = gate( act( A W^T + bias + add ) )
 // Struct-of-arrays + scalar selects: every field is a plain kernarg scalar (s_load -> SGPR -> s_cselect); absent
 // operands are replaced on the host by a valid dummy pointer (W) plus a flag bit, so all prefetches are unconditional.
@@ -20,7 +23,7 @@ enum { LF_BIAS = 1, LF_ADD = 2, LF_GATE = 4, LF_RELU = 8 };
 template <int NSEG>
 struct LinArgs {
   const float* A[NSEG];     // [B,K]
-  const float* W[NSEG];     // [ncols,K], k contiguous
+  const float* W[NSEG];     // [ncols,K] in T16
   const float* bias[NSEG];  // [ncols]
   const float* add[NSEG];   // [B,ncols] (may alias out)
   const float* gate[NSEG];  // [B,ncols]: result *= (gate > 0)
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(NW * 64) void lin_stage_kernel(LinArgs<NSEG> a) {
   const float e_add = add[(flags & LF_ADD) ? (size_t)rowc * ldadd + col : 0];
   const float e_gate = gate[(flags & LF_GATE) ? (size_t)rowc * ldgate + col : 0];
   f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-  acc[0] = wave_gemm16<NW>(A, lda, r0, a.B, W, ldw, c0, K, threadIdx.x >> 6, acc[0]);
+  acc[0] = wave_gemm16<NW, true>(A, lda, r0, a.B, W, ldw, c0, K, threadIdx.x >> 6, acc[0]);
   float v[1];
   reduce_tiles<1, NW>(acc, red, v);
   if (!own) return;
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(NW * 64) void lin_stage32_kernel(LinArgs<NSEG> a) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  acc = wave_gemm32<NW>(A, lda, r0, a.B, W, ldw, c0, K, wave, acc);
+  acc = wave_gemm32<NW, true>(A, lda, r0, a.B, W, ldw, c0, K, wave, acc);
   {
     const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(NW * 64) void lin_stage32_kernel(LinArgs<NSEG> a) {
 // ---------------------------------------------------------------------------------------------------------------
 struct HeadArgs {
   const float *P, *Q;                 // [B,H] last hidden of prior / posterior MLP
-  const float *Wp, *bp, *Wq, *bq;     // [2Z,H], [2Z]
+  const float *Wp, *bp, *Wq, *bq;     // [2Z,H] in T16, [2Z]
   const float* eps;                   // [B,Z]
   float *mu_p, *sd_p, *mu_q, *sd_q, *z, *raw_p, *raw_q;  // [B,Z]
   float* muq_raw;  // [B,Z] posterior mean BEFORE the combination with the prior (needed by backward in mode 2), or null
@@ -154,10 +157,10 @@ __global__ __launch_bounds__(NW * 64) void head_stage_kernel(HeadArgs a) {
   f32x4 acc[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  acc[0] = wave_gemm16<NW>(a.P, a.H, r0, a.B, a.Wp, a.H, c0, a.H, wave, acc[0]);
-  acc[1] = wave_gemm16<NW>(a.P, a.H, r0, a.B, a.Wp, a.H, a.Z + c0, a.H, wave, acc[1]);
-  acc[2] = wave_gemm16<NW>(a.Q, a.H, r0, a.B, a.Wq, a.H, c0, a.H, wave, acc[2]);
-  acc[3] = wave_gemm16<NW>(a.Q, a.H, r0, a.B, a.Wq, a.H, a.Z + c0, a.H, wave, acc[3]);
+  acc[0] = wave_gemm16<NW, true>(a.P, a.H, r0, a.B, a.Wp, a.H, c0, a.H, wave, acc[0]);
+  acc[1] = wave_gemm16<NW, true>(a.P, a.H, r0, a.B, a.Wp, a.H, a.Z + c0, a.H, wave, acc[1]);
+  acc[2] = wave_gemm16<NW, true>(a.Q, a.H, r0, a.B, a.Wq, a.H, c0, a.H, wave, acc[2]);
+  acc[3] = wave_gemm16<NW, true>(a.Q, a.H, r0, a.B, a.Wq, a.H, a.Z + c0, a.H, wave, acc[3]);
   float v[4];
   reduce_tiles<4, NW>(acc, red, v);
   if (!own) return;
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(NW * 64) void head_stage_kernel(HeadArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 struct DzArgs {
   const float* D;    // [B,H] grad wrt the pre-activation of the layer that consumes z (VRNN: phi layer 0)
-  const float* WT;   // [Z,H] that layer's weight, transposed
+  const float* WT;   // [Z,H] that layer's weight, transposed, in T16
   const float* D2;   // optional second consumer of z (SRNN: posterior layer 0 of the NEXT step), or null
   const float* WT2;  // [Z,H]
   const float* dz_add;  // optional [B,Z] (row stride ld_add) direct gradient wrt z (SRNN: from the decoder), or null
@@ -228,8 +231,8 @@ __global__ __launch_bounds__(NW * 64) void dz_stage_kernel(DzArgs a) {
     f32x4 acc[2];
     acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[0] = wave_gemm16<NW>(a.D, a.H, r0, a.B, a.WT, a.H, c0, a.H, threadIdx.x >> 6, acc[0]);
-    if (a.D2 != nullptr) acc[1] = wave_gemm16<NW>(a.D2, a.H, r0, a.B, a.WT2, a.H, c0, a.H, threadIdx.x >> 6, acc[1]);
+    acc[0] = wave_gemm16<NW, true>(a.D, a.H, r0, a.B, a.WT, a.H, c0, a.H, threadIdx.x >> 6, acc[0]);
+    if (a.D2 != nullptr) acc[1] = wave_gemm16<NW, true>(a.D2, a.H, r0, a.B, a.WT2, a.H, c0, a.H, threadIdx.x >> 6, acc[1]);
     reduce_tiles<2, NW>(acc, red, v);
   }
   if (!own) return;

@@ -29,7 +29,7 @@ namespace {
 struct GruArgs {
   const float* decin_t;   // row block t of decin: [B, H+R] = [phi | h_prev]
   float* decin_next;      // row block t+1 (h-part written)
-  const float* Wih;       // [3R, X+H]
+  const float* Wih;       // [3R,H]: the phi columns of the GRU input weight, in T16
   const float* xg;        // [B,3R] x-part of the input projection incl. b_ih
   const float* gh;        // [B,3R] hidden projection incl. b_hh
   float *rg, *ug, *ng;    // [B,R] saved gates
@@ -40,7 +40,7 @@ template <int NW>
 __global__ __launch_bounds__(NW * 64) void gru_stage_kernel(GruArgs a) {
   __shared__ float red[3 * NW * 256];
   const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, wave = threadIdx.x >> 6;
-  const int ldd = a.H + a.R, ldw = a.X + a.H;
+  const int ldd = a.H + a.R;
   const int t = threadIdx.x & 255;
   const int row = r0 + (t >> 4), col = c0 + (t & 15);
   const bool own = threadIdx.x < 256 && row < a.B;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(NW * 64) void gru_stage_kernel(GruArgs a) {
 #pragma unroll
   for (int g = 0; g < 3; ++g) {
     acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[g] = wave_gemm16<NW>(a.decin_t, ldd, r0, a.B, a.Wih + a.X, ldw, g * a.R + c0, a.H, wave, acc[g]);
+    acc[g] = wave_gemm16<NW, true>(a.decin_t, ldd, r0, a.B, a.Wih, a.H, g * a.R + c0, a.H, wave, acc[g]);
   }
   float v[3];
   reduce_tiles<3, NW>(acc, red, v);
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(NW * 64) void gru_stage_kernel(GruArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 struct DhArgs {
   const float *DP0, *DQ0;   // [B,H]   (null when has_gemm == 0)
-  const float *WpT, *WqT;   // [R,H]
+  const float *WpT, *WqT;   // [R,H] in T16
   float* G;                 // [B,R] running gradient wrt the recurrent state (in/out)
   // step s (the step whose OUTPUT state G refers to); has_gates == 0 for the very first state
   const float *rg, *ug, *ng, *gh;   // [B,R] x3, [B,3R]
@@ -103,8 +103,8 @@ __global__ __launch_bounds__(NW * 64) void dh_stage_kernel(DhArgs a) {
     f32x4 acc[2];
     acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[0] = wave_gemm16<NW>(a.DP0, a.H, r0, a.B, a.WpT, a.H, c0, a.H, wave, acc[0]);
-    acc[1] = wave_gemm16<NW>(a.DQ0, a.H, r0, a.B, a.WqT, a.H, c0, a.H, wave, acc[1]);
+    acc[0] = wave_gemm16<NW, true>(a.DP0, a.H, r0, a.B, a.WpT, a.H, c0, a.H, wave, acc[0]);
+    acc[1] = wave_gemm16<NW, true>(a.DQ0, a.H, r0, a.B, a.WqT, a.H, c0, a.H, wave, acc[1]);
     reduce_tiles<2, NW>(acc, red, v);
   }
   if (!own) return;
@@ -123,6 +123,7 @@ __global__ __launch_bounds__(NW * 64) void dh_stage_kernel(DhArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 struct Reserve {
   float *P[3], *Q[3], *FZ[3], *GHb, *RG, *UG, *NG, *XQ, *XG, *RAWQ, *RAWP;
+  float *Wp[3], *Wq[3], *Wph, *Wqh, *Wf[4], *Wih, *Whh;  // T16 copies of the weights the forward chain multiplies by
 };
 
 size_t carve_reserve(float* base, int Tp, int B, int H, int Z, int R, Reserve* r) {
@@ -138,12 +139,18 @@ size_t carve_reserve(float* base, int Tp, int B, int H, int Z, int R, Reserve* r
   tmp.XQ = take(n * H);
   tmp.XG = take(n * 3 * R);
   tmp.RAWQ = take(n * Z); tmp.RAWP = take(n * Z);
+  tmp.Wp[0] = take((size_t)H * R); tmp.Wq[0] = take((size_t)H * R);
+  for (int i = 1; i < 3; ++i) { tmp.Wp[i] = take((size_t)H * H); tmp.Wq[i] = take((size_t)H * H); }
+  tmp.Wph = take((size_t)2 * Z * H); tmp.Wqh = take((size_t)2 * Z * H);
+  tmp.Wf[0] = take((size_t)H * Z);
+  for (int i = 1; i < 4; ++i) tmp.Wf[i] = take((size_t)H * H);
+  tmp.Wih = take((size_t)3 * R * H); tmp.Whh = take((size_t)3 * R * R);
   if (r) *r = tmp;
   return off;
 }
 
 struct BwdWs {
-  float *pT[3], *phT, *qT[3], *qhT, *fT[4], *wihT, *whhT;   // transposed weights
+  float *pT[3], *phT, *qT[3], *qhT, *fT[4], *wihT, *whhT;   // transposed weights, T16
   float *DGI, *DGH, *DPHI[4], *DQH, *DPH, *DP[3], *DQ[3], *G;
 };
 
@@ -246,6 +253,20 @@ extern "C" int blvm_vrnn_seq_fwd(const BlvmVrnnWeights* w, const float* enc, con
   rc = gemm_f32(0, 0, (int)n, 3 * R, X, enc, X, w->gru_wih, X + H, rs.XG, 3 * R, w->gru_bih, 0, 0.f, nullptr, 0, 0, 1, s);
   if (rc) return rc;
 
+  // T16 operand copies of the chain's weights (once per sequence)
+  rc = t16_pack_rows(w->prior_w[0], R, H, R, rs.Wp[0], s); if (rc) return rc;
+  rc = t16_pack_rows(w->post_w[0], R + X, H, R, rs.Wq[0], s); if (rc) return rc;  // the h columns
+  for (int l = 1; l < 3; ++l) {
+    rc = t16_pack_rows(w->prior_w[l], H, H, H, rs.Wp[l], s); if (rc) return rc;
+    rc = t16_pack_rows(w->post_w[l], H, H, H, rs.Wq[l], s); if (rc) return rc;
+  }
+  rc = t16_pack_rows(w->prior_hw, H, 2 * Z, H, rs.Wph, s); if (rc) return rc;
+  rc = t16_pack_rows(w->post_hw, H, 2 * Z, H, rs.Wqh, s); if (rc) return rc;
+  rc = t16_pack_rows(w->phi_w[0], Z, H, Z, rs.Wf[0], s); if (rc) return rc;
+  for (int l = 1; l < 4; ++l) { rc = t16_pack_rows(w->phi_w[l], H, H, H, rs.Wf[l], s); if (rc) return rc; }
+  rc = t16_pack_rows(w->gru_wih + X, X + H, 3 * R, H, rs.Wih, s); if (rc) return rc;  // the phi columns
+  rc = t16_pack_rows(w->gru_whh, R, 3 * R, R, rs.Whh, s); if (rc) return rc;
+
   // initial state -> h-part of decin row 0
   if (h0) BLVM_HIP(hipMemcpy2DAsync(decin + H, sizeof(float) * ldd, h0, sizeof(float) * R, sizeof(float) * R, B, hipMemcpyDeviceToDevice, s));
   else BLVM_HIP(hipMemset2DAsync(decin + H, sizeof(float) * ldd, 0, sizeof(float) * R, B, s));
@@ -260,21 +281,21 @@ extern "C" int blvm_vrnn_seq_fwd(const BlvmVrnnWeights* w, const float* enc, con
     a.B = B;
     // F1: first prior layer | h-half of first posterior layer | GRU hidden projection
     a.nseg = 3;
-    a.seg[0] = seg(hprev, ldd, w->prior_w[0], R, w->prior_b[0], nullptr, 0, nullptr, 0, rs.P[0] + oH, H, H, R, 1);
-    a.seg[1] = seg(hprev, ldd, w->post_w[0], R + X, nullptr, rs.XQ + oH, H, nullptr, 0, rs.Q[0] + oH, H, H, R, 1);
-    a.seg[2] = seg(hprev, ldd, w->gru_whh, R, w->gru_bhh, nullptr, 0, nullptr, 0, rs.GHb + o3R, 3 * R, 3 * R, R, 0);
+    a.seg[0] = seg(hprev, ldd, rs.Wp[0], R, w->prior_b[0], nullptr, 0, nullptr, 0, rs.P[0] + oH, H, H, R, 1);
+    a.seg[1] = seg(hprev, ldd, rs.Wq[0], R, nullptr, rs.XQ + oH, H, nullptr, 0, rs.Q[0] + oH, H, H, R, 1);
+    a.seg[2] = seg(hprev, ldd, rs.Whh, R, w->gru_bhh, nullptr, 0, nullptr, 0, rs.GHb + o3R, 3 * R, 3 * R, R, 0);
     launch_lin(a, s);
     // F2, F3
     a.nseg = 2;
     for (int l = 1; l < 3; ++l) {
-      a.seg[0] = seg(rs.P[l - 1] + oH, H, w->prior_w[l], H, w->prior_b[l], nullptr, 0, nullptr, 0, rs.P[l] + oH, H, H, H, 1);
-      a.seg[1] = seg(rs.Q[l - 1] + oH, H, w->post_w[l], H, w->post_b[l], nullptr, 0, nullptr, 0, rs.Q[l] + oH, H, H, H, 1);
+      a.seg[0] = seg(rs.P[l - 1] + oH, H, rs.Wp[l], H, w->prior_b[l], nullptr, 0, nullptr, 0, rs.P[l] + oH, H, H, H, 1);
+      a.seg[1] = seg(rs.Q[l - 1] + oH, H, rs.Wq[l], H, w->post_b[l], nullptr, 0, nullptr, 0, rs.Q[l] + oH, H, H, H, 1);
       launch_lin(a, s);
     }
     // F4: heads + sample
     HeadArgs h;
     h.P = rs.P[2] + oH; h.Q = rs.Q[2] + oH;
-    h.Wp = w->prior_hw; h.bp = w->prior_hb; h.Wq = w->post_hw; h.bq = w->post_hb;
+    h.Wp = rs.Wph; h.bp = w->prior_hb; h.Wq = rs.Wqh; h.bq = w->post_hb;
     h.eps = eps + oZ;
     h.mu_p = mu_p + oZ; h.sd_p = sd_p + oZ; h.mu_q = mu_q + oZ; h.sd_q = sd_q + oZ; h.z = z + oZ;
     h.raw_p = rs.RAWP + oZ; h.raw_q = rs.RAWQ + oZ;
@@ -283,17 +304,17 @@ extern "C" int blvm_vrnn_seq_fwd(const BlvmVrnnWeights* w, const float* enc, con
     LAUNCH_NW(head_stage_kernel, pick_nw(H, 4), dim3(Z / 16, rt), s, h);
     // F5..F8: phi_z MLP (last layer writes phi into decin row t)
     a.nseg = 1;
-    a.seg[0] = seg(z + oZ, Z, w->phi_w[0], Z, w->phi_b[0], nullptr, 0, nullptr, 0, rs.FZ[0] + oH, H, H, Z, 1);
+    a.seg[0] = seg(z + oZ, Z, rs.Wf[0], Z, w->phi_b[0], nullptr, 0, nullptr, 0, rs.FZ[0] + oH, H, H, Z, 1);
     launch_lin(a, s);
-    a.seg[0] = seg(rs.FZ[0] + oH, H, w->phi_w[1], H, w->phi_b[1], nullptr, 0, nullptr, 0, rs.FZ[1] + oH, H, H, H, 1);
+    a.seg[0] = seg(rs.FZ[0] + oH, H, rs.Wf[1], H, w->phi_b[1], nullptr, 0, nullptr, 0, rs.FZ[1] + oH, H, H, H, 1);
     launch_lin(a, s);
-    a.seg[0] = seg(rs.FZ[1] + oH, H, w->phi_w[2], H, w->phi_b[2], nullptr, 0, nullptr, 0, rs.FZ[2] + oH, H, H, H, 1);
+    a.seg[0] = seg(rs.FZ[1] + oH, H, rs.Wf[2], H, w->phi_b[2], nullptr, 0, nullptr, 0, rs.FZ[2] + oH, H, H, H, 1);
     launch_lin(a, s);
-    a.seg[0] = seg(rs.FZ[2] + oH, H, w->phi_w[3], H, w->phi_b[3], nullptr, 0, nullptr, 0, decin + (size_t)t * B * ldd, ldd, H, H, 1);
+    a.seg[0] = seg(rs.FZ[2] + oH, H, rs.Wf[3], H, w->phi_b[3], nullptr, 0, nullptr, 0, decin + (size_t)t * B * ldd, ldd, H, H, 1);
     launch_lin(a, s);
     // F9: GRU
     GruArgs g;
-    g.decin_t = dec_t; g.decin_next = dec_n; g.Wih = w->gru_wih;
+    g.decin_t = dec_t; g.decin_next = dec_n; g.Wih = rs.Wih;
     g.xg = rs.XG + o3R; g.gh = rs.GHb + o3R;
     g.rg = rs.RG + oR; g.ug = rs.UG + oR; g.ng = rs.NG + oR;
     g.B = B; g.X = X; g.H = H; g.R = R;
@@ -324,19 +345,19 @@ extern "C" int blvm_vrnn_seq_bwd(const BlvmVrnnWeights* w, const float* enc, con
   const int ldd = H + R;
   const float beta = (float)(0.6931471805599453 / (1.0 - (double)sd_eps));
 
-  // k-contiguous (transposed) copies of every weight the chain multiplies from the right
-  rc = transpose_f32(H, R, w->prior_w[0], R, ws.pT[0], H, s); if (rc) return rc;
-  rc = transpose_f32(H, H, w->prior_w[1], H, ws.pT[1], H, s); if (rc) return rc;
-  rc = transpose_f32(H, H, w->prior_w[2], H, ws.pT[2], H, s); if (rc) return rc;
-  rc = transpose_f32(2 * Z, H, w->prior_hw, H, ws.phT, 2 * Z, s); if (rc) return rc;
-  rc = transpose_f32(H, R, w->post_w[0], R + X, ws.qT[0], H, s); if (rc) return rc;
-  rc = transpose_f32(H, H, w->post_w[1], H, ws.qT[1], H, s); if (rc) return rc;
-  rc = transpose_f32(H, H, w->post_w[2], H, ws.qT[2], H, s); if (rc) return rc;
-  rc = transpose_f32(2 * Z, H, w->post_hw, H, ws.qhT, 2 * Z, s); if (rc) return rc;
-  rc = transpose_f32(H, Z, w->phi_w[0], Z, ws.fT[0], H, s); if (rc) return rc;
-  for (int i = 1; i < 4; ++i) { rc = transpose_f32(H, H, w->phi_w[i], H, ws.fT[i], H, s); if (rc) return rc; }
-  rc = transpose_f32(3 * R, H, w->gru_wih + X, X + H, ws.wihT, 3 * R, s); if (rc) return rc;
-  rc = transpose_f32(3 * R, R, w->gru_whh, R, ws.whhT, 3 * R, s); if (rc) return rc;
+  // transposed T16 operand copies of every weight the chain multiplies from the right
+  rc = t16_pack_transposed(w->prior_w[0], R, H, R, ws.pT[0], s); if (rc) return rc;
+  rc = t16_pack_transposed(w->prior_w[1], H, H, H, ws.pT[1], s); if (rc) return rc;
+  rc = t16_pack_transposed(w->prior_w[2], H, H, H, ws.pT[2], s); if (rc) return rc;
+  rc = t16_pack_transposed(w->prior_hw, H, 2 * Z, H, ws.phT, s); if (rc) return rc;
+  rc = t16_pack_transposed(w->post_w[0], R + X, H, R, ws.qT[0], s); if (rc) return rc;
+  rc = t16_pack_transposed(w->post_w[1], H, H, H, ws.qT[1], s); if (rc) return rc;
+  rc = t16_pack_transposed(w->post_w[2], H, H, H, ws.qT[2], s); if (rc) return rc;
+  rc = t16_pack_transposed(w->post_hw, H, 2 * Z, H, ws.qhT, s); if (rc) return rc;
+  rc = t16_pack_transposed(w->phi_w[0], Z, H, Z, ws.fT[0], s); if (rc) return rc;
+  for (int i = 1; i < 4; ++i) { rc = t16_pack_transposed(w->phi_w[i], H, H, H, ws.fT[i], s); if (rc) return rc; }
+  rc = t16_pack_transposed(w->gru_wih + X, X + H, 3 * R, H, ws.wihT, s); if (rc) return rc;
+  rc = t16_pack_transposed(w->gru_whh, R, 3 * R, R, ws.whhT, s); if (rc) return rc;
 
   BLVM_HIP(hipMemsetAsync(ws.G, 0, sizeof(float) * (size_t)B * R, s));
   const int rt = (B + 15) / 16;

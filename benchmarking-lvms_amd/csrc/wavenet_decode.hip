@@ -60,11 +60,36 @@ struct DecodeArgs {
   float* x_out;    // [B,n_frames]
 };
 
-template <int NW>
+// LDS-only barrier: waits for this wave's LDS traffic, not for its global loads.  No thread of the decoder ever reads
+// global memory another thread wrote (ring-buffer elements are read and rewritten by the same thread, weights and draws are
+// read-only), so weight / ring-buffer loads issued for the NEXT block stay in flight across it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// 16x16 output tile from an LDS operand and weights already in registers: wreg[j] holds W[col][16 j + 4 q .. +3]
+template <int KCH>
+__device__ __forceinline__ f32x4 tile_from_regs(const float* __restrict__ A, int lda, const float4 (&wreg)[KCH]) {
+  const int lane = threadIdx.x & 63;
+  const float* ap = A + (lane & 15) * lda + 4 * (lane >> 4);
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < KCH; ++j) {
+    const float4 x = *reinterpret_cast<const float4*>(ap + 16 * j);
+    f32x4& acc = (j & 1) ? acc1 : acc0;
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, wreg[j].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, wreg[j].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.z, wreg[j].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x.w, wreg[j].w, acc, 0, 0, 0);
+  }
+  return acc0 + acc1;
+}
+
+// CC, SS > 0: widths known at compile time — the main loop keeps each wave's weight tiles, biases and ring-buffer taps of
+// the NEXT block in registers, loaded while the current block computes.  CC == 0: any width, loads where they are used.
+template <int NW, int CC, int SS>
 __global__ __launch_bounds__(NW * 64) void wn_decode_kernel(DecodeArgs a) {
   extern __shared__ __align__(16) float smem[];
   constexpr int NT = NW * 64;
-  const int C = a.C, S = a.S, O = a.O, B = a.B;
+  const int C = CC > 0 ? CC : a.C, S = SS > 0 ? SS : a.S, O = a.O, B = a.B;
   const int CA = C > O ? C : O;
   const int ldV = 2 * C + 4, ldA = CA + 4, ldS = S + 4, ldP = 2 * C;
   float* sV = smem;                    // [16][2C+4]  interleaved taps: k = 2c + tap
@@ -166,12 +191,140 @@ __global__ __launch_bounds__(NW * 64) void wn_decode_kernel(DecodeArgs a) {
     }
   }
 
+  // ---- register-resident prefetch state of the compile-time-width path
+  constexpr int C_ = CC > 0 ? CC : 16, S_ = SS > 0 ? SS : 16;
+  constexpr int NT1 = 2 * C_ / 16, T1 = (NT1 + NW - 1) / NW, K1 = 2 * C_ / 16;  // conv: tiles, tiles per wave, k chunks
+  constexpr int NT2 = (C_ + S_) / 16, T2 = (NT2 + NW - 1) / NW, K2 = C_ / 16;   // rs
+  constexpr int NQ = (DEC_ROWS * C_ + NT - 1) / NT;                             // ring-buffer elements per thread
+  struct BlockRegs {
+    float4 wc[T1][K1], wr[T2][K2];
+    float bc[T1], br[T2], oldv[NQ];
+  };
+  BlockRegs R0, R1;  // ping-pong: one block computes from one set while the next block's operands land in the other
+  auto load_block = [&](BlockRegs& R, int i, const float* qi, int slot) {
+    const float* bw = w + L.blocks + (size_t)i * L.block_stride;
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+      const int idx = tid + n * NT;
+      const int r = idx / C_, c = idx - r * C_;
+      R.oldv[n] = (idx < DEC_ROWS * C_ && b0 + r < B) ? qi[((size_t)slot * B + b0 + r) * C_ + c] : 0.f;
+    }
+#pragma unroll
+    for (int tt = 0; tt < T1; ++tt) {
+      const int tile = wave + tt * NW;
+      if (tile < NT1) {
+        const float* wp = bw + (size_t)(tile * 16 + cc) * (2 * C_) + 4 * q;
+#pragma unroll
+        for (int j = 0; j < K1; ++j) R.wc[tt][j] = *reinterpret_cast<const float4*>(wp + 16 * j);
+        R.bc[tt] = bw[L.conv_b + tile * 16 + cc];
+      }
+    }
+#pragma unroll
+    for (int tt = 0; tt < T2; ++tt) {
+      const int tile = wave + tt * NW;
+      if (tile < NT2) {
+        const float* wp = bw + L.rs_w + (size_t)(tile * 16 + cc) * C_ + 4 * q;
+#pragma unroll
+        for (int j = 0; j < K2; ++j) R.wr[tt][j] = *reinterpret_cast<const float4*>(wp + 16 * j);
+        R.br[tt] = bw[L.rs_b + tile * 16 + cc];
+      }
+    }
+  };
+#ifdef DEC_PROF
+  long long prof[6] = {0, 0, 0, 0, 0, 0};
+#define DEC_TICK(k) { const long long now__ = __builtin_readcyclecounter(); prof[k] += now__ - tick__; tick__ = now__; }
+#else
+#define DEC_TICK(k)
+#endif
+  // the block of the main loop: operands in `cur` (loaded one block ago); issues every load of the next block
+  // (ni, nqi, nslot) into `nxt` right after staging — a whole block ahead of their first use
+  auto block_fast = [&](BlockRegs& cur, BlockRegs& nxt, float* qi, int slot, int ni, const float* nqi, int nslot) {
+#ifdef DEC_PROF
+    long long tick__ = __builtin_readcyclecounter();
+#endif
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+      const int idx = tid + n * NT;
+      if (idx < DEC_ROWS * C_) {
+        const int r = idx / C_, c = idx - r * C_;
+        *reinterpret_cast<float2*>(sV + r * ldV + 2 * c) = make_float2(cur.oldv[n], sH[idx]);
+      }
+    }
+    // vmcnt counts loads and stores in order: the ring-buffer store goes out AFTER the last use of a loaded tap, or the
+    // wait for the tap would also wait for the store's acknowledgement
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+      const int idx = tid + n * NT;
+      const int r = idx / C_, c = idx - r * C_;
+      if (idx < DEC_ROWS * C_ && b0 + r < B) qi[((size_t)slot * B + b0 + r) * C_ + c] = sH[idx];
+    }
+    load_block(nxt, ni, nqi, nslot);
+    DEC_TICK(0)
+    lds_barrier();
+    DEC_TICK(1)
+#pragma unroll
+    for (int tt = 0; tt < T1; ++tt) {
+      const int tile = wave + tt * NW;
+      if (tile < NT1) {
+        const f32x4 acc = tile_from_regs<K1>(sV, ldV, cur.wc[tt]);
+        const int o = tile * 16 + cc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sPre[(4 * q + r) * ldP + o] = acc[r] + cur.bc[tt];
+      }
+    }
+    DEC_TICK(2)
+    lds_barrier();
+    DEC_TICK(1)
+    for (int idx = tid; idx < DEC_ROWS * C_; idx += NT) {
+      const int r = idx / C_, c = idx - r * C_;
+      sAct[r * ldA + c] = tanhf(sPre[r * ldP + c]) * sigmoidf_(sPre[r * ldP + C_ + c]);
+    }
+    DEC_TICK(3)
+    lds_barrier();
+    DEC_TICK(1)
+#pragma unroll
+    for (int tt = 0; tt < T2; ++tt) {
+      const int tile = wave + tt * NW;
+      if (tile < NT2) {
+        const f32x4 acc = tile_from_regs<K2>(sAct, ldA, cur.wr[tt]);
+        const int o = tile * 16 + cc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * q + r;
+          const float val = acc[r] + cur.br[tt];
+          if (o < C_) sH[row * C_ + o] = (val + sH[row * C_ + o]) * a.inv_std;
+          else sSkip[row * ldS + (o - C_)] += val;
+        }
+      }
+    }
+    DEC_TICK(4)
+    lds_barrier();
+    DEC_TICK(1)
+  };
+  if constexpr (CC > 0) load_block(R0, 0, a.queues, 0);
+
   for (int t = 0; t < a.n_frames; ++t) {
     front();
     float* qi = a.queues;
-    for (int i = 0; i < a.n_blocks; ++i) {
-      block(i, qi, t % a.dil[i], false);
-      qi += (size_t)a.dil[i] * B * C;
+    if constexpr (CC > 0) {
+      // two blocks per trip (n_blocks is even on this path): the register sets swap roles by position in the code, not by
+      // a run-time choice the compiler would turn into register copies behind a full vmcnt wait
+      for (int i = 0; i < a.n_blocks; i += 2) {
+        const int d0 = a.dil[i], d1 = a.dil[i + 1];
+        float* q1 = qi + (size_t)d0 * B * C;
+        float* q2 = q1 + (size_t)d1 * B * C;
+        const bool last = i + 2 == a.n_blocks;
+        const int ni = last ? 0 : i + 2;
+        block_fast(R0, R1, qi, t % d0, i + 1, q1, t % d1);
+        block_fast(R1, R0, q1, t % d1, ni, last ? a.queues : q2, (last ? t + 1 : t) % a.dil[ni]);
+        qi = q2;
+      }
+    } else {
+      for (int i = 0; i < a.n_blocks; ++i) {
+        block(i, qi, t % a.dil[i], false);
+        qi += (size_t)a.dil[i] * B * C;
+      }
     }
     // relu(skip * scale) -> Linear -> relu -> head Linear -> sample
     for (int idx = tid; idx < DEC_ROWS * S; idx += NT) {
@@ -220,6 +373,10 @@ __global__ __launch_bounds__(NW * 64) void wn_decode_kernel(DecodeArgs a) {
     }
     __syncthreads();
   }
+#ifdef DEC_PROF
+  if (blockIdx.x == 0 && (tid == 0 || tid == NT - 1))
+    for (int k = 0; k < 6; ++k) a.x_out[(size_t)B * a.n_frames + (tid ? 6 : 0) + k] = (float)(prof[k] / 1000);
+#endif
 }
 
 inline size_t decode_lds_bytes(int C, int S, int O) {
@@ -265,7 +422,9 @@ extern "C" int blvm_wavenet_decode(const float* packed, const int* dilations, in
   a.inv_std = inv_std; a.skip_scale = skip_scale; a.log_eps = log_eps;
   a.u = u; a.v = v; a.queues = queues; a.x_out = x_out;
   constexpr int NW = 8;
-  auto kern = wn_decode_kernel<NW>;
+  auto kern = wn_decode_kernel<NW, 0, 0>;
+  if (n_blocks % 2 == 0 && C == 64 && S == 64) kern = wn_decode_kernel<NW, 64, 64>;
+  else if (n_blocks % 2 == 0 && C == 32 && S == 32) kern = wn_decode_kernel<NW, 32, 32>;
   if (lds > 64 * 1024) BLVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)((B + DEC_ROWS - 1) / DEC_ROWS)), dim3(NW * 64), lds, static_cast<hipStream_t>(stream), a);
   BLVM_CHECK_LAUNCH("wavenet_decode");
