@@ -101,7 +101,7 @@ _SIGNATURES = {
     "blvm_wavenet_block_fwd": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_float] + [c_void_p] * 5),
     "blvm_wavenet_block_bwd": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_float] + [c_void_p] * 7),
     "blvm_wavenet_decode_pack_floats": (c_size_t, [c_int] * 4),
-    "blvm_wavenet_decode_queue_floats": (c_size_t, [c_void_p] + [c_int] * 3),
+    "blvm_wavenet_decode_scratch_floats": (c_size_t, [c_void_p] + [c_int] * 4),
     "blvm_wavenet_decode": (c_int, [c_void_p] * 2 + [c_int] * 7 + [c_float] * 3 + [c_void_p] * 5),
     "blvm_rssm_reserve_floats": (c_size_t, [c_int] * 4),
     "blvm_rssm_bwd_workspace_floats": (c_size_t, [c_int] * 4),

@@ -851,7 +851,7 @@ def wavenet_decode(causal, in_transform, blocks_params, dilations, out_linear, h
     if packed.numel() != lib.blvm_wavenet_decode_pack_floats(C, S, O, len(blocks_params)):
         raise ValueError("wavenet_decode: parameter shapes do not match the packed layout")
     dil = (ctypes.c_int * len(dilations))(*dilations)
-    queues = torch.empty(lib.blvm_wavenet_decode_queue_floats(dil, len(dilations), B, C), device=dev, dtype=torch.float32)
+    queues = torch.empty(lib.blvm_wavenet_decode_scratch_floats(dil, len(dilations), B, C, S), device=dev, dtype=torch.float32)
     x = torch.empty(B, n_frames, device=dev, dtype=torch.float32)
     if u is not None:
         u, v = _f32c(u), _f32c(v)

@@ -51,6 +51,7 @@ __host__ __device__ inline DecodeLayout decode_layout(int C, int S, int O, int n
 
 struct DecodeArgs {
   const float* w;
+  const float* wt;  // T16 operand copies (common.h) of the blocks' matrices: block i at i * ((2C)^2 + (C+S) C): conv [2C,2C], rs [C+S,C]
   int dil[DEC_MAX_BLOCKS];
   int n_blocks, B, C, S, O, n_frames, num_mix;
   float inv_std, skip_scale, log_eps;
@@ -133,8 +134,10 @@ __global__ __launch_bounds__(NW * 64) void wn_decode_kernel(DecodeArgs a) {
   };
 
   // one gated residual block on the frame in sH.  steady: both taps = sH, ring buffer filled with sH, skip untouched.
+  const size_t wt_stride = (size_t)2 * C * 2 * C + (size_t)(C + S) * C;
   auto block = [&](int i, float* qi, int slot, bool steady) {
     const float* bw = w + L.blocks + (size_t)i * L.block_stride;
+    const float* bt = a.wt + (size_t)i * wt_stride;
     const int d = a.dil[i];
     for (int idx = tid; idx < DEC_ROWS * C; idx += NT) {
       const int r = idx / C, c = idx - r * C;
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(NW * 64) void wn_decode_kernel(DecodeArgs a) {
     }
     __syncthreads();
     for (int tile = wave; tile < 2 * C / 16; tile += NW) {
-      const f32x4 acc = wave_gemm16<1>(sV, ldV, 0, DEC_ROWS, bw, 2 * C, tile * 16, 2 * C, 0, zero4);
+      const f32x4 acc = wave_gemm16<1, true>(sV, ldV, 0, DEC_ROWS, bt, 2 * C, tile * 16, 2 * C, 0, zero4);
       const int o = tile * 16 + cc;
       const float bias = bw[L.conv_b + o];
 #pragma unroll
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(NW * 64) void wn_decode_kernel(DecodeArgs a) {
     }
     __syncthreads();
     for (int tile = wave; tile < (C + S) / 16; tile += NW) {
-      const f32x4 acc = wave_gemm16<1>(sAct, ldA, 0, DEC_ROWS, bw + L.rs_w, C, tile * 16, C, 0, zero4);
+      const f32x4 acc = wave_gemm16<1, true>(sAct, ldA, 0, DEC_ROWS, bt + (size_t)2 * C * 2 * C, C, tile * 16, C, 0, zero4);
       const int o = tile * 16 + cc;
       const float bias = bw[L.rs_b + o];
 #pragma unroll
@@ -203,6 +206,7 @@ __global__ __launch_bounds__(NW * 64) void wn_decode_kernel(DecodeArgs a) {
   BlockRegs R0, R1;  // ping-pong: one block computes from one set while the next block's operands land in the other
   auto load_block = [&](BlockRegs& R, int i, const float* qi, int slot) {
     const float* bw = w + L.blocks + (size_t)i * L.block_stride;
+    const float* bt = a.wt + (size_t)i * wt_stride;
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
       const int idx = tid + n * NT;
@@ -213,9 +217,9 @@ __global__ __launch_bounds__(NW * 64) void wn_decode_kernel(DecodeArgs a) {
     for (int tt = 0; tt < T1; ++tt) {
       const int tile = wave + tt * NW;
       if (tile < NT1) {
-        const float* wp = bw + (size_t)(tile * 16 + cc) * (2 * C_) + 4 * q;
+        const float* wp = bt + (size_t)(tile * 16) * (2 * C_) + 4 * lane;  // T16: chunk j of the tile is one contiguous 1 KB
 #pragma unroll
-        for (int j = 0; j < K1; ++j) R.wc[tt][j] = *reinterpret_cast<const float4*>(wp + 16 * j);
+        for (int j = 0; j < K1; ++j) R.wc[tt][j] = *reinterpret_cast<const float4*>(wp + 256 * j);
         R.bc[tt] = bw[L.conv_b + tile * 16 + cc];
       }
     }
@@ -223,9 +227,9 @@ __global__ __launch_bounds__(NW * 64) void wn_decode_kernel(DecodeArgs a) {
     for (int tt = 0; tt < T2; ++tt) {
       const int tile = wave + tt * NW;
       if (tile < NT2) {
-        const float* wp = bw + L.rs_w + (size_t)(tile * 16 + cc) * C_ + 4 * q;
+        const float* wp = bt + (size_t)2 * C_ * 2 * C_ + (size_t)(tile * 16) * C_ + 4 * lane;
 #pragma unroll
-        for (int j = 0; j < K2; ++j) R.wr[tt][j] = *reinterpret_cast<const float4*>(wp + 16 * j);
+        for (int j = 0; j < K2; ++j) R.wr[tt][j] = *reinterpret_cast<const float4*>(wp + 256 * j);
         R.br[tt] = bw[L.rs_b + tile * 16 + cc];
       }
     }
@@ -392,18 +396,22 @@ extern "C" size_t blvm_wavenet_decode_pack_floats(int C, int S, int O, int n_blo
   return blvm::decode_layout(C, S, O, n_blocks).total;
 }
 
-extern "C" size_t blvm_wavenet_decode_queue_floats(const int* dilations, int n_blocks, int B, int C) {
-  if (!dilations || n_blocks <= 0 || B <= 0 || C <= 0) return 0;
+static size_t decode_ring_floats(const int* dilations, int n_blocks, int B, int C) {
   size_t n = 0;
   for (int i = 0; i < n_blocks; ++i) n += (size_t)(dilations[i] > 0 ? dilations[i] : 0);
   return n * B * C;
 }
 
+extern "C" size_t blvm_wavenet_decode_scratch_floats(const int* dilations, int n_blocks, int B, int C, int S) {
+  if (!dilations || n_blocks <= 0 || B <= 0 || C <= 0 || S <= 0) return 0;
+  return decode_ring_floats(dilations, n_blocks, B, C) + (size_t)n_blocks * ((size_t)2 * C * 2 * C + (size_t)(C + S) * C);
+}
+
 extern "C" int blvm_wavenet_decode(const float* packed, const int* dilations, int n_blocks, int B, int C, int S, int O,
                                    int num_mix, int n_frames, float inv_std, float skip_scale, float log_eps,
-                                   const float* u, const float* v, float* queues, float* x_out, void* stream) {
+                                   const float* u, const float* v, float* scratch, float* x_out, void* stream) {
   using namespace blvm;
-  BLVM_REQUIRE(packed && dilations && queues && x_out && aligned16(packed), "wavenet_decode: NULL or misaligned argument");
+  BLVM_REQUIRE(packed && dilations && scratch && x_out && aligned16(packed) && aligned16(scratch), "wavenet_decode: NULL or misaligned argument");
   BLVM_REQUIRE(B > 0 && n_frames >= 0 && n_blocks > 0 && n_blocks <= DEC_MAX_BLOCKS, "wavenet_decode: need B > 0, 1 <= n_blocks <= %d", DEC_MAX_BLOCKS);
   BLVM_REQUIRE(C > 0 && S > 0 && O > 0 && C % 16 == 0 && S % 16 == 0 && O % 16 == 0, "wavenet_decode: C, S, O must be multiples of 16");
   BLVM_REQUIRE(num_mix > 0 && 3 * num_mix <= DEC_HEAD_ROWS, "wavenet_decode: num_mix must be in [1, %d]", DEC_HEAD_ROWS / 3);
@@ -420,7 +428,20 @@ extern "C" int blvm_wavenet_decode(const float* packed, const int* dilations, in
   for (int i = n_blocks; i < DEC_MAX_BLOCKS; ++i) a.dil[i] = 1;
   a.n_blocks = n_blocks; a.B = B; a.C = C; a.S = S; a.O = O; a.n_frames = n_frames; a.num_mix = num_mix;
   a.inv_std = inv_std; a.skip_scale = skip_scale; a.log_eps = log_eps;
-  a.u = u; a.v = v; a.queues = queues; a.x_out = x_out;
+  a.u = u; a.v = v; a.x_out = x_out;
+  // scratch = [T16 operand copies of the blocks' matrices | ring buffers]
+  const DecodeLayout L = decode_layout(C, S, O, n_blocks);
+  const size_t wt_stride = (size_t)2 * C * 2 * C + (size_t)(C + S) * C;
+  for (int i = 0; i < n_blocks; ++i) {
+    const float* bw = packed + L.blocks + (size_t)i * L.block_stride;
+    float* bt = scratch + (size_t)i * wt_stride;
+    int rc = t16_pack_rows(bw, 2 * C, 2 * C, 2 * C, bt, static_cast<hipStream_t>(stream));
+    if (rc) return rc;
+    rc = t16_pack_rows(bw + L.rs_w, C, C + S, C, bt + (size_t)2 * C * 2 * C, static_cast<hipStream_t>(stream));
+    if (rc) return rc;
+  }
+  a.wt = scratch;
+  a.queues = scratch + (size_t)n_blocks * wt_stride;
   constexpr int NW = 8;
   auto kern = wn_decode_kernel<NW, 0, 0>;
   if (n_blocks % 2 == 0 && C == 64 && S == 64) kern = wn_decode_kernel<NW, 64, 64>;

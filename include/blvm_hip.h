@@ -294,12 +294,13 @@ int blvm_wavenet_block_bwd(const float* x, const float* conv_w, const float* rs_
  *   Per frame: skip sum * skip_scale -> ReLU -> Linear -> ReLU -> head Linear -> (logits, locs, log_scales) -> Gumbel-max
  *   component pick with u [n_frames,B,num_mix], logistic draw with v [n_frames,B] clamped to [-1,1] (as blvm_mix_sample
  *   kind 0; u = v = NULL: the mode) -> x_out [B,n_frames], fed back as the next input.
- *   queues: scratch of blvm_wavenet_decode_queue_floats(...) floats (contents need no initialisation). */
+ *   scratch: blvm_wavenet_decode_scratch_floats(...) floats (ring buffers + operand-layout copies of the block weights;
+ *   contents need no initialisation). */
 size_t blvm_wavenet_decode_pack_floats(int C, int S, int O, int n_blocks);
-size_t blvm_wavenet_decode_queue_floats(const int* dilations, int n_blocks, int B, int C);
+size_t blvm_wavenet_decode_scratch_floats(const int* dilations, int n_blocks, int B, int C, int S);
 int blvm_wavenet_decode(const float* packed, const int* dilations, int n_blocks, int B, int C, int S, int O, int num_mix,
                         int n_frames, float inv_std, float skip_scale, float log_eps, const float* u, const float* v,
-                        float* queues, float* x_out, void* stream);
+                        float* scratch, float* x_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * K5  RSSM cell of the Clockwork-VAE over a sequence (forward + BPTT).  Replaces the per-level time loop
