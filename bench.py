@@ -286,10 +286,13 @@ def main():
             "data": "synthetic",
             "bits_per_dim": bpd,
             "config": {
-                "workload": (f"experiment_clockwork_audio.py: CWVAEAudio DMoL h=192 z=[128,64,32] strides [64,16,16] 8 blocks/level precision posterior, "
-                             f"synthetic mu-law [{B},1,{T}] per GPU, full train step fwd+bwd+clip+Adam, random init") if args.model == "cwvae" else
-                            f"experiment_{args.model}_audio.py: {type(model).__name__} DMoL s=64 h=256 z=256, synthetic mu-law [{B},1,{T}] per GPU "
-                            f"(T'={Tp} recurrent steps), full train step fwd+bwd+clip+Adam, random init",
+                "workload": {
+                    "cwvae": "experiment_clockwork_audio.py: CWVAEAudio DMoL h=192 z=[128,64,32] strides [64,16,16] 8 blocks/level precision posterior",
+                    "wavenet": "experiment_wavenet_audio.py: WaveNet DMoL 5 stacks x 10 layers, 96 channels, sample-level (50 gated residual blocks)",
+                    "stcn": "experiment_stcn_audio.py: STCN DMoL 5 latent levels [256,128,64,32,16], 256 channels, 64-sample frames",
+                    "lstm": f"experiment_lstm_audio.py: LSTMAudio DMoL s=64 h=256 (T'={Tp} recurrent steps)",
+                }.get(args.model, f"experiment_{args.model}_audio.py: {type(model).__name__} DMoL s=64 h=256 z=256 (T'={Tp} recurrent steps)")
+                + f", synthetic mu-law [{B},1,{T}] per GPU, full train step fwd+bwd+clip+Adam, random init",
                 "batch_per_gpu": B, "global_batch": world * B, "samples_per_utterance": T, "parallelism": f"dp{world}",
             },
             "roofline": {
