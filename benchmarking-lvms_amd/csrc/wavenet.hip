@@ -129,6 +129,254 @@ __global__ __launch_bounds__(256) void scale_act_kernel(const float* __restrict_
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused forward of one gated residual block (C in {32, 64, 96}, 16 <= S <= C).  The unfused sequence (two tap GEMMs, gate
+// pass, 1x1 GEMM, residual/skip pass) moves ~20 floats per row and channel through HBM; everything between the block's
+// input and its outputs fits a wave's LDS slice, so here a wave owns 16 rows end to end:
+//   x[r], x[r + d B] -> LDS;  pre = X0 W0^T + X1 W1^T + b (tanh tile and sigmoid tile of the same channels side by side on
+//   the matrix pipe);  act = tanh * sigma in registers -> LDS;  rs = act Wrs^T + b;  o = (rs[:C] + X1) * inv_std;
+//   skip += rs[C:];  pre / act are written once for backward (16 rows of a [rows, 2C] buffer are one contiguous run).
+// Weights arrive in the T16 operand layout (one contiguous 1 KB read per fragment, common.h); the four waves of a workgroup
+// walk the column tiles in step (one barrier per tile) so three of every four fragment reads hit the CU's L1.
+// ---------------------------------------------------------------------------------------------------------------
+struct FusedFwdArgs {
+  const float* x;                      // [L_in*B, C]
+  const float *W0, *W1, *Wrs;          // T16: [2C,C], [2C,C], [C+S,C]
+  const float *conv_b, *rs_b;          // [2C], [C+S]
+  float *pre, *act, *o, *skip;         // [rows,2C], [rows,C], [rows,C] or null, [T_skip*B,S]
+  size_t rows, shift, off;             // off: first row that contributes to the skip sum
+  float inv_std;
+};
+
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <int C, int S>
+__global__ __launch_bounds__(256, 2) void wn_block_fused_fwd_kernel(FusedFwdArgs a) {
+  constexpr int LDX = C + 4, KC = C / 16, NT = C / 16, NR = (C + S) / 16;
+  constexpr int WAVE_FLOATS = 16 * 3 * LDX;
+  constexpr int NX = (16 * C / 4 + 63) / 64;  // 16-byte pieces of a 16-row slab per lane
+  extern __shared__ __align__(16) float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, rr = lane & 15, q = lane >> 4, cc = lane & 15;
+  float* sX0 = smem + wave * WAVE_FLOATS;
+  float* sX1 = sX0 + 16 * LDX;
+  float* sAct = sX1 + 16 * LDX;
+  const size_t r0 = ((size_t)blockIdx.x * 4 + wave) * 16;
+#ifdef BLVM_WN_PROF
+  long long tk = __builtin_readcyclecounter(), ph[6] = {0, 0, 0, 0, 0, 0};
+#define WN_TICK(k) { const long long n__ = __builtin_readcyclecounter(); ph[k] += n__ - tk; tk = n__; }
+#else
+#define WN_TICK(k)
+#endif
+
+  // a "stage" of the convolution = JH k-chunks of one (tanh, sigmoid) tile pair: its 4 JH weight fragments are what one
+  // register set holds (C = 96: half a pair, so that two sets + the 1x1 sets stay under 256 VGPRs at two waves per SIMD)
+  constexpr int JH = KC > 4 ? KC / 2 : KC, SPC = KC / JH, NST = NT * SPC;
+  struct ConvFrag { float4 t0[JH], s0[JH], t1[JH], s1[JH]; float bT, bS; };
+  struct RsFrag { float4 f0[KC], f1[KC]; float b0, b1; };
+  auto load_conv = [&](ConvFrag& F, int st) {
+    const int ct = st / SPC, j0 = (st - ct * SPC) * JH;
+    const float* wT0 = a.W0 + (size_t)(ct * 16) * C + 4 * lane + 256 * j0;
+    const float* wS0 = a.W0 + (size_t)((NT + ct) * 16) * C + 4 * lane + 256 * j0;
+    const float* wT1 = a.W1 + (size_t)(ct * 16) * C + 4 * lane + 256 * j0;
+    const float* wS1 = a.W1 + (size_t)((NT + ct) * 16) * C + 4 * lane + 256 * j0;
+#pragma unroll
+    for (int j = 0; j < JH; ++j) {
+      F.t0[j] = *reinterpret_cast<const float4*>(wT0 + 256 * j);
+      F.s0[j] = *reinterpret_cast<const float4*>(wS0 + 256 * j);
+      F.t1[j] = *reinterpret_cast<const float4*>(wT1 + 256 * j);
+      F.s1[j] = *reinterpret_cast<const float4*>(wS1 + 256 * j);
+    }
+    F.bT = a.conv_b[ct * 16 + cc];
+    F.bS = a.conv_b[C + ct * 16 + cc];
+  };
+  auto load_rs = [&](RsFrag& G, int ct) {  // column tiles ct, ct + 1 (NR is even)
+    const float* w0 = a.Wrs + (size_t)(ct * 16) * C + 4 * lane;
+    const float* w1 = a.Wrs + (size_t)((ct + 1) * 16) * C + 4 * lane;
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+      G.f0[j] = *reinterpret_cast<const float4*>(w0 + 256 * j);
+      G.f1[j] = *reinterpret_cast<const float4*>(w1 + 256 * j);
+    }
+    G.b0 = a.rs_b[ct * 16 + cc];
+    G.b1 = a.rs_b[(ct + 1) * 16 + cc];
+  };
+  ConvFrag F0, F1;
+  RsFrag G0, G1;
+  static_assert(NST % 2 == 0 && NR % 4 == 0 && KC % JH == 0, "fused WaveNet block: tile counts");
+
+  // 1. the two taps' input rows (16 consecutive rows = one contiguous run of 16 C floats each): every load is issued before
+  // the first LDS write, and the first pair's weight fragments travel with them
+  {
+    float4 v0[NX], v1[NX];
+#pragma unroll
+    for (int n = 0; n < NX; ++n) {
+      const int i = lane + 64 * n;
+      const int row = (i * 4) / C, col = (i * 4) - row * C;
+      const size_t gr = r0 + row;
+      v0[n] = v1[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < 16 * C / 4 && gr < a.rows) {
+        v0[n] = *reinterpret_cast<const float4*>(a.x + gr * C + col);
+        v1[n] = *reinterpret_cast<const float4*>(a.x + (gr + a.shift) * C + col);
+      }
+    }
+    load_conv(F0, 0);
+#pragma unroll
+    for (int n = 0; n < NX; ++n) {
+      const int i = lane + 64 * n;
+      const int row = (i * 4) / C, col = (i * 4) - row * C;
+      if (i < 16 * C / 4) {
+        *reinterpret_cast<float4*>(sX0 + row * LDX + col) = v0[n];
+        *reinterpret_cast<float4*>(sX1 + row * LDX + col) = v1[n];
+      }
+    }
+  }
+  wave_lds_fence();
+  WN_TICK(0)
+
+  // 2. dilated convolution + gate, one (tanh, sigmoid) pair of column tiles at a time.  The weight fragments of the NEXT pair
+  // are loaded into a second register set while this pair runs on the matrix pipe (the two sets swap roles by position in a
+  // 2-pair loop body); the barrier only keeps the four waves on the same fragments (L1).  Two workgroups share a CU, so one
+  // wave's epilogue (tanh, sigma, stores) runs under the other's MFMAs.  pre leaves straight from the accumulators (D layout:
+  // column lane & 15, rows 4 (lane >> 4) + r — 64-byte runs that pair up into full lines in L2).
+  const float* ap0 = sX0 + rr * LDX + 4 * q;
+  const float* ap1 = sX1 + rr * LDX + 4 * q;
+  f32x4 aT = {0.f, 0.f, 0.f, 0.f}, aS = {0.f, 0.f, 0.f, 0.f};
+  auto conv_stage = [&](const ConvFrag& F, int st) {
+    const int ct = st / SPC, j0 = (st - ct * SPC) * JH;
+    if (j0 == 0) { aT = (f32x4){0.f, 0.f, 0.f, 0.f}; aS = aT; }
+#pragma unroll
+    for (int j = 0; j < JH; ++j) {
+      const float4 x0 = *reinterpret_cast<const float4*>(ap0 + 16 * (j0 + j));
+      const float4 x1 = *reinterpret_cast<const float4*>(ap1 + 16 * (j0 + j));
+      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.x, F.t0[j].x, aT, 0, 0, 0);
+      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.x, F.s0[j].x, aS, 0, 0, 0);
+      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.y, F.t0[j].y, aT, 0, 0, 0);
+      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.y, F.s0[j].y, aS, 0, 0, 0);
+      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.z, F.t0[j].z, aT, 0, 0, 0);
+      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.z, F.s0[j].z, aS, 0, 0, 0);
+      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.w, F.t0[j].w, aT, 0, 0, 0);
+      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.w, F.s0[j].w, aS, 0, 0, 0);
+      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.x, F.t1[j].x, aT, 0, 0, 0);
+      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.x, F.s1[j].x, aS, 0, 0, 0);
+      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.y, F.t1[j].y, aT, 0, 0, 0);
+      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.y, F.s1[j].y, aS, 0, 0, 0);
+      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.z, F.t1[j].z, aT, 0, 0, 0);
+      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.z, F.s1[j].z, aS, 0, 0, 0);
+      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.w, F.t1[j].w, aT, 0, 0, 0);
+      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.w, F.s1[j].w, aS, 0, 0, 0);
+    }
+    if (j0 + JH < KC) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * q + r, col = ct * 16 + cc;
+      const float pT = aT[r] + F.bT, pS = aS[r] + F.bS;
+      sAct[row * LDX + col] = tanhf(pT) * sigmoidf_(pS);
+      if (r0 + row < a.rows) {
+        a.pre[(r0 + row) * 2 * C + col] = pT;
+        a.pre[(r0 + row) * 2 * C + C + col] = pS;
+      }
+    }
+  };
+  for (int st = 0; st < NST; st += 2) {
+    asm volatile("s_barrier" ::: "memory");
+    load_conv(F1, st + 1);
+    conv_stage(F0, st);
+    if (st + 2 < NST) load_conv(F0, st + 2);
+    else load_rs(G0, 0);
+    conv_stage(F1, st + 1);
+  }
+  wave_lds_fence();
+  WN_TICK(1)
+
+  // 3. the gate output for backward (a contiguous run)
+  for (int i = lane; i < 16 * C / 4; i += 64) {
+    const int row = (i * 4) / C, col = (i * 4) - row * C;
+    if (r0 + row < a.rows) *reinterpret_cast<float4*>(a.act + (r0 + row) * C + col) = *reinterpret_cast<const float4*>(sAct + row * LDX + col);
+  }
+  WN_TICK(2)
+
+  // 4. 1x1 convolution (residual | skip columns), two column tiles at a time; the residual columns take x[r + d B]; the
+  // skip rows are accumulated in place (the stack's blocks run one after the other, each the only writer of its launch),
+  // their old values requested before the MFMAs
+  const float* ap = sAct + rr * LDX + 4 * q;
+  auto rs_pair = [&](const RsFrag& G, int ct) {
+    float old[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int col = (ct + h) * 16 + cc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t gr = r0 + 4 * q + r;
+        old[h][r] = (col >= C && gr < a.rows && gr >= a.off) ? a.skip[(gr - a.off) * S + (col - C)] : 0.f;
+      }
+    }
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(ap + 16 * j);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, G.f0[j].x, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, G.f1[j].x, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, G.f0[j].y, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, G.f1[j].y, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, G.f0[j].z, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, G.f1[j].z, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, G.f0[j].w, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, G.f1[j].w, c1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int col = (ct + h) * 16 + cc;
+      const float bias = h ? G.b1 : G.b0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 4 * q + r;
+        const size_t gr = r0 + row;
+        const float v = (h ? c1[r] : c0[r]) + bias;
+        if (gr >= a.rows) continue;
+        if (col < C) {
+          if (a.o != nullptr) a.o[gr * C + col] = (v + sX1[row * LDX + col]) * a.inv_std;
+        } else if (gr >= a.off) {
+          a.skip[(gr - a.off) * S + (col - C)] = old[h][r] + v;
+        }
+      }
+    }
+  };
+  for (int ct = 0; ct < NR; ct += 4) {
+    asm volatile("s_barrier" ::: "memory");
+    load_rs(G1, ct + 2);
+    rs_pair(G0, ct);
+    asm volatile("s_barrier" ::: "memory");
+    if (ct + 4 < NR) load_rs(G0, ct + 4);
+    rs_pair(G1, ct + 2);
+  }
+  WN_TICK(3)
+#ifdef BLVM_WN_PROF
+  if (blockIdx.x == 1000 && lane == 0) for (int k = 0; k < 4; ++k) a.act[k + 8 * wave] = (float)ph[k];
+#endif
+}
+
+template <int C, int S>
+int launch_fused_fwd(const FusedFwdArgs& a, hipStream_t s) {
+  constexpr size_t lds = sizeof(float) * 4 * 16 * 3 * (C + 4);
+  static_assert(2 * lds <= 160 * 1024, "fused WaveNet block: two workgroups per CU");
+  auto kern = wn_block_fused_fwd_kernel<C, S>;
+  if (lds > 64 * 1024) BLVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const size_t tiles = (a.rows + 63) / 64;
+  BLVM_REQUIRE(tiles < (1ull << 31), "wavenet_block_fwd: too many rows");
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, s, a);
+  return BLVM_OK;
+}
+
+// env BLVM_WN_FUSED=0 keeps the unfused sequence (experiments)
+inline bool fused_fwd_enabled() {
+  static int v = [] {
+    const char* e = getenv("BLVM_WN_FUSED");
+    return e ? atoi(e) : 1;
+  }();
+  return v != 0;
+}
+
 struct ConvWs { float *W0, *W1, *dW0, *dW1; };
 
 }  // namespace
@@ -222,6 +470,21 @@ extern "C" int blvm_wavenet_block_fwd(const float* x, const float* conv_w, const
   const size_t rows = (size_t)L_out * B, shift = (size_t)dilation * B, nk = (size_t)2 * C * C;
   float *pre = reserve, *act = reserve + rows * 2 * C;
   float *W0 = workspace, *W1 = W0 + nk, *rs = W1 + 3 * nk + 64;
+  if (fused_fwd_enabled() && S == C && (C == 32 || C == 64 || C == 96) && aligned16(skip) && (o == nullptr || aligned16(o))) {
+    // operand-layout copies: the two taps straight out of the interleaved Conv1d weight, the 1x1 weight behind them
+    float* Wrs = W1 + nk;
+    int rc = t16_pack(conv_w, 2 * C, 2, 2 * C, C, W0, s); if (rc) return rc;
+    rc = t16_pack(conv_w + 1, 2 * C, 2, 2 * C, C, W1, s); if (rc) return rc;
+    rc = t16_pack_rows(rs_w, C, C + S, C, Wrs, s); if (rc) return rc;
+    FusedFwdArgs a;
+    a.x = x; a.W0 = W0; a.W1 = W1; a.Wrs = Wrs; a.conv_b = conv_b; a.rs_b = rs_b;
+    a.pre = pre; a.act = act; a.o = o; a.skip = skip;
+    a.rows = rows; a.shift = shift; a.off = rows - (size_t)T_skip * B; a.inv_std = inv_std;
+    rc = C == 32 ? launch_fused_fwd<32, 32>(a, s) : C == 64 ? launch_fused_fwd<64, 64>(a, s) : launch_fused_fwd<96, 96>(a, s);
+    if (rc) return rc;
+    BLVM_CHECK_LAUNCH("wavenet_block_fwd (fused)");
+    return BLVM_OK;
+  }
   hipLaunchKernelGGL(split_taps_kernel, ew_grid(nk), dim3(256), 0, s, conv_w, W0, W1, nk);
   int rc = conv_k2_apply(x, C, W0, W1, conv_b, rows, shift, 2 * C, pre, s);
   if (rc) return rc;
