@@ -377,6 +377,217 @@ inline bool fused_fwd_enabled() {
   return v != 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused backward of the block's data path, two kernels with the forward kernel's structure (a wave owns 16 rows, weights in
+// T16, the next tile's fragments loaded under the current tile's MFMAs):
+//   A: d_rs = [d_o * inv_std | d_skip] (written for the weight-gradient GEMM / column sum), d_act = d_rs Wrs, through the gate
+//      derivative to d_pre (written once; pre is read in the accumulators' layout).
+//   B: d_x[r] = d_pre[r] W0 + d_pre[r - d B] W1 + d_o[r - d B] * inv_std in ONE pass over d_x (the unfused sequence zero-fills
+//      d_x and accumulates the two taps into it with two read-modify-write GEMMs).
+// ---------------------------------------------------------------------------------------------------------------
+struct FusedBwdAArgs {
+  const float *d_o, *d_skip, *pre, *WrsT;  // WrsT: T16 [C, C+S]
+  float *d_rs, *d_pre;                     // [rows, C+S], [rows, 2C]
+  size_t rows, off;
+  float inv_std;
+};
+
+template <int C, int S>
+__global__ __launch_bounds__(256, 2) void wn_block_fused_bwd_a_kernel(FusedBwdAArgs a) {
+  constexpr int W = C + S, LDR = W + 4, KR = W / 16, NT = C / 16, KH = KR / 2;
+  constexpr int NP = (16 * W / 4 + 63) / 64;
+  static_assert(NT % 2 == 0 && KR % 2 == 0, "fused WaveNet block: tile counts");
+  extern __shared__ __align__(16) float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, rr = lane & 15, q = lane >> 4, cc = lane & 15;
+  float* sD = smem + wave * 16 * LDR;
+  const size_t r0 = ((size_t)blockIdx.x * 4 + wave) * 16;
+  struct Frag { float4 f[KR]; float pT[4], pS[4]; };
+  auto load_tile = [&](Frag& F, int ct) {
+    const float* w = a.WrsT + (size_t)(ct * 16) * W + 4 * lane;
+#pragma unroll
+    for (int j = 0; j < KR; ++j) F.f[j] = *reinterpret_cast<const float4*>(w + 256 * j);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t gr = r0 + 4 * q + r;
+      const size_t o = (gr < a.rows ? gr : 0) * 2 * C + ct * 16 + cc;
+      F.pT[r] = a.pre[o];
+      F.pS[r] = a.pre[o + C];
+    }
+  };
+  Frag F0, F1;
+  // 1. d_rs rows: [d_o * inv_std | d_skip of the rows that fed the skip sum]
+  {
+    float4 v[NP];
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+      const int i = lane + 64 * n;
+      const int row = (i * 4) / W, col = (i * 4) - row * W;
+      const size_t gr = r0 + row;
+      v[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < 16 * W / 4 && gr < a.rows) {
+        if (col < C) {
+          if (a.d_o != nullptr) {
+            v[n] = *reinterpret_cast<const float4*>(a.d_o + gr * C + col);
+            v[n].x *= a.inv_std; v[n].y *= a.inv_std; v[n].z *= a.inv_std; v[n].w *= a.inv_std;
+          }
+        } else if (gr >= a.off) {
+          v[n] = *reinterpret_cast<const float4*>(a.d_skip + (gr - a.off) * S + (col - C));
+        }
+      }
+    }
+    load_tile(F0, 0);
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+      const int i = lane + 64 * n;
+      const int row = (i * 4) / W, col = (i * 4) - row * W;
+      if (i < 16 * W / 4) {
+        *reinterpret_cast<float4*>(sD + row * LDR + col) = v[n];
+        if (r0 + row < a.rows) *reinterpret_cast<float4*>(a.d_rs + (r0 + row) * W + col) = v[n];
+      }
+    }
+  }
+  wave_lds_fence();
+  // 2. d_act = d_rs Wrs per column tile (two half-K chains), gate derivative in the accumulators' layout
+  const float* ap = sD + rr * LDR + 4 * q;
+  auto tile = [&](const Frag& F, int ct) {
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < KH; ++j) {
+      const float4 u = *reinterpret_cast<const float4*>(ap + 16 * j);
+      const float4 v = *reinterpret_cast<const float4*>(ap + 16 * (KH + j));
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(u.x, F.f[j].x, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, F.f[KH + j].x, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(u.y, F.f[j].y, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, F.f[KH + j].y, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(u.z, F.f[j].z, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, F.f[KH + j].z, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(u.w, F.f[j].w, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, F.f[KH + j].w, c1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t gr = r0 + 4 * q + r;
+      if (gr >= a.rows) continue;
+      const float g = c0[r] + c1[r];
+      const float ta = tanhf(F.pT[r]), sb = sigmoidf_(F.pS[r]);
+      const size_t o = gr * 2 * C + ct * 16 + cc;
+      a.d_pre[o] = g * sb * (1.f - ta * ta);
+      a.d_pre[o + C] = g * ta * sb * (1.f - sb);
+    }
+  };
+  for (int ct = 0; ct < NT; ct += 2) {
+    asm volatile("s_barrier" ::: "memory");
+    load_tile(F1, ct + 1);
+    tile(F0, ct);
+    if (ct + 2 < NT) load_tile(F0, ct + 2);
+    tile(F1, ct + 1);
+  }
+}
+
+struct FusedBwdBArgs {
+  const float *d_pre, *d_o, *W0T, *W1T;  // W0T / W1T: T16 [C, 2C] (the taps' weights transposed)
+  float* d_x;                            // [rows + shift, C]
+  size_t rows, shift;
+  float inv_std;
+};
+
+template <int C>
+__global__ __launch_bounds__(256, 2) void wn_block_fused_bwd_b_kernel(FusedBwdBArgs a) {
+  constexpr int K2 = 2 * C, LDA = K2 + 4, KR = K2 / 16, NT = C / 16, KH = KR / 2;
+  constexpr int NP = (16 * K2 / 4 + 63) / 64;
+  static_assert(NT % 2 == 0 && KR % 2 == 0, "fused WaveNet block: tile counts");
+  extern __shared__ __align__(16) float smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, rr = lane & 15, q = lane >> 4, cc = lane & 15;
+  float* sA = smem + wave * 16 * LDA;
+  const size_t r0 = ((size_t)blockIdx.x * 4 + wave) * 16;  // rows of d_x
+  const size_t rows_in = a.rows + a.shift;
+  struct Frag { float4 f[KR]; };
+  auto load_tile = [&](Frag& F, const float* WT, int ct) {
+    const float* w = WT + (size_t)(ct * 16) * K2 + 4 * lane;
+#pragma unroll
+    for (int j = 0; j < KR; ++j) F.f[j] = *reinterpret_cast<const float4*>(w + 256 * j);
+  };
+  // d_pre rows [first, first + 16) -> LDS (rows outside [0, rows) are zero); `first` may be "negative" (tap 1 near the start)
+  auto stage = [&](long long first) {
+    float4 v[NP];
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+      const int i = lane + 64 * n;
+      const int row = (i * 4) / K2, col = (i * 4) - row * K2;
+      const long long gr = first + row;
+      v[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < 16 * K2 / 4 && gr >= 0 && gr < (long long)a.rows) v[n] = *reinterpret_cast<const float4*>(a.d_pre + (size_t)gr * K2 + col);
+    }
+#pragma unroll
+    for (int n = 0; n < NP; ++n) {
+      const int i = lane + 64 * n;
+      const int row = (i * 4) / K2, col = (i * 4) - row * K2;
+      if (i < 16 * K2 / 4) *reinterpret_cast<float4*>(sA + row * LDA + col) = v[n];
+    }
+  };
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* ap = sA + rr * LDA + 4 * q;
+  auto tile = [&](const Frag& F, f32x4& c) {
+    f32x4 c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < KH; ++j) {
+      const float4 u = *reinterpret_cast<const float4*>(ap + 16 * j);
+      const float4 v = *reinterpret_cast<const float4*>(ap + 16 * (KH + j));
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(u.x, F.f[j].x, c, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, F.f[KH + j].x, c1, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(u.y, F.f[j].y, c, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, F.f[KH + j].y, c1, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(u.z, F.f[j].z, c, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, F.f[KH + j].z, c1, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(u.w, F.f[j].w, c, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, F.f[KH + j].w, c1, 0, 0, 0);
+    }
+    c += c1;
+  };
+  Frag F0, F1;
+#pragma unroll
+  for (int tap = 0; tap < 2; ++tap) {
+    const float* WT = tap ? a.W1T : a.W0T;
+    load_tile(F0, WT, 0);
+    stage(tap ? (long long)r0 - (long long)a.shift : (long long)r0);
+    wave_lds_fence();
+#pragma unroll
+    for (int ct = 0; ct < NT; ct += 2) {
+      asm volatile("s_barrier" ::: "memory");
+      load_tile(F1, WT, ct + 1);
+      tile(F0, acc[ct]);
+      if (ct + 2 < NT) load_tile(F0, WT, ct + 2);
+      tile(F1, acc[ct + 1]);
+    }
+    wave_lds_fence();  // every fragment read of this tap's rows is done before the buffer is refilled
+  }
+#pragma unroll
+  for (int ct = 0; ct < NT; ++ct) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t gr = r0 + 4 * q + r;
+      if (gr >= rows_in) continue;
+      const int col = ct * 16 + cc;
+      float v = acc[ct][r];
+      if (a.d_o != nullptr && gr >= a.shift) v += a.d_o[(gr - a.shift) * C + col] * a.inv_std;
+      a.d_x[gr * C + col] = v;
+    }
+  }
+}
+
+template <int C, int S>
+int launch_fused_bwd(const FusedBwdAArgs& aa, const FusedBwdBArgs& ab, hipStream_t s) {
+  constexpr size_t lds_a = sizeof(float) * 4 * 16 * (C + S + 4), lds_b = sizeof(float) * 4 * 16 * (2 * C + 4);
+  static_assert(2 * lds_a <= 160 * 1024 && 2 * lds_b <= 160 * 1024, "fused WaveNet block backward: two workgroups per CU");
+  const size_t ta = (aa.rows + 63) / 64, tb = (ab.rows + ab.shift + 63) / 64;
+  BLVM_REQUIRE(tb < (1ull << 31), "wavenet_block_bwd: too many rows");
+  hipLaunchKernelGGL((wn_block_fused_bwd_a_kernel<C, S>), dim3((unsigned)ta), dim3(256), lds_a, s, aa);
+  hipLaunchKernelGGL((wn_block_fused_bwd_b_kernel<C>), dim3((unsigned)tb), dim3(256), lds_b, s, ab);
+  return BLVM_OK;
+}
+
 struct ConvWs { float *W0, *W1, *dW0, *dW1; };
 
 }  // namespace
@@ -514,18 +725,37 @@ extern "C" int blvm_wavenet_block_bwd(const float* x, const float* conv_w, const
   float* d_act = d_rs + rows * (C + S);
   float* d_pre = d_act + rows * C;
   int rc;
-  hipLaunchKernelGGL(split_taps_kernel, ew_grid(nk), dim3(256), 0, s, conv_w, W0, W1, nk);
-  // d_x: rows [0, d*B) start at zero, rows [d*B, L*B) start with the residual path d_o * inv_std
-  BLVM_HIP(hipMemsetAsync(d_x, 0, sizeof(float) * shift * C, s));
-  hipLaunchKernelGGL(resskip_bwd_kernel, ew_grid(rows * (C + S)), dim3(256), 0, s, d_o, d_skip, d_rs, d_x + shift * C, rows,
-                     rows - (size_t)T_skip * B, C, S, inv_std);
-  // 1x1 convolution
-  rc = gemm_f32(0, 1, (int)rows, C, C + S, d_rs, C + S, rs_w, C, d_act, C, nullptr, 0, 0.f, nullptr, 0, 0, 1, s);
-  if (rc) return rc;
+  const bool fused = fused_fwd_enabled() && S == C && (C == 32 || C == 64 || C == 96) && (d_o == nullptr || aligned16(d_o)) && aligned16(d_skip);
+  if (fused) {
+    // operand-layout copies, 2 C^2 floats each: Wrs^T [C, C+S] in the W0 slot, the taps' transposes [C, 2C] in the W1 and
+    // dW0 slots (dW0 is zero-filled for the weight-gradient GEMMs further down the stream, after kernel B has read it)
+    float* WrsT = W0;
+    float* W0T = W1;
+    float* W1T = dW0;
+    rc = t16_pack_transposed(rs_w, C, C + S, C, WrsT, s); if (rc) return rc;
+    rc = t16_pack(conv_w, 2, 2 * C, C, 2 * C, W0T, s); if (rc) return rc;
+    rc = t16_pack(conv_w + 1, 2, 2 * C, C, 2 * C, W1T, s); if (rc) return rc;
+    FusedBwdAArgs aa;
+    aa.d_o = d_o; aa.d_skip = d_skip; aa.pre = pre; aa.WrsT = WrsT; aa.d_rs = d_rs; aa.d_pre = d_pre;
+    aa.rows = rows; aa.off = rows - (size_t)T_skip * B; aa.inv_std = inv_std;
+    FusedBwdBArgs ab;
+    ab.d_pre = d_pre; ab.d_o = d_o; ab.W0T = W0T; ab.W1T = W1T; ab.d_x = d_x; ab.rows = rows; ab.shift = shift; ab.inv_std = inv_std;
+    rc = C == 32 ? launch_fused_bwd<32, 32>(aa, ab, s) : C == 64 ? launch_fused_bwd<64, 64>(aa, ab, s) : launch_fused_bwd<96, 96>(aa, ab, s);
+    if (rc) return rc;
+  } else {
+    hipLaunchKernelGGL(split_taps_kernel, ew_grid(nk), dim3(256), 0, s, conv_w, W0, W1, nk);
+    // d_x: rows [0, d*B) start at zero, rows [d*B, L*B) start with the residual path d_o * inv_std
+    BLVM_HIP(hipMemsetAsync(d_x, 0, sizeof(float) * shift * C, s));
+    hipLaunchKernelGGL(resskip_bwd_kernel, ew_grid(rows * (C + S)), dim3(256), 0, s, d_o, d_skip, d_rs, d_x + shift * C, rows,
+                       rows - (size_t)T_skip * B, C, S, inv_std);
+    // 1x1 convolution
+    rc = gemm_f32(0, 1, (int)rows, C, C + S, d_rs, C + S, rs_w, C, d_act, C, nullptr, 0, 0.f, nullptr, 0, 0, 1, s);
+    if (rc) return rc;
+  }
   if (drs_w) { rc = gemm_f32(1, 1, C + S, C, (int)rows, d_rs, C + S, act, C, drs_w, C, nullptr, 0, 0.f, nullptr, 0, 1, pick_split(C + S, C, (int)rows), s); if (rc) return rc; }
   if (drs_b) { rc = colsum_f32((int)rows, C + S, d_rs, C + S, drs_b, 1, s); if (rc) return rc; }
   // gate
-  hipLaunchKernelGGL(gate_bwd_kernel, ew_grid(rows * (C / 4)), dim3(256), 0, s, pre, d_act, d_pre, rows, C);
+  if (!fused) hipLaunchKernelGGL(gate_bwd_kernel, ew_grid(rows * (C / 4)), dim3(256), 0, s, pre, d_act, d_pre, rows, C);
   // dilated convolution: weight gradients of both taps, then the two shifted input gradients
   if (dconv_w) {
     BLVM_HIP(hipMemsetAsync(dW0, 0, sizeof(float) * 2 * nk, s));
@@ -537,10 +767,12 @@ extern "C" int blvm_wavenet_block_bwd(const float* x, const float* conv_w, const
     hipLaunchKernelGGL(merge_taps_kernel, ew_grid(nk), dim3(256), 0, s, dW0, dW1, dconv_w, nk);
   }
   if (dconv_b) { rc = colsum_f32((int)rows, 2 * C, d_pre, 2 * C, dconv_b, 1, s); if (rc) return rc; }
-  rc = gemm_f32(0, 1, (int)rows, C, 2 * C, d_pre, 2 * C, W0, C, d_x, C, nullptr, 0, 0.f, nullptr, 0, 1, 1, s);
-  if (rc) return rc;
-  rc = gemm_f32(0, 1, (int)rows, C, 2 * C, d_pre, 2 * C, W1, C, d_x + shift * C, C, nullptr, 0, 0.f, nullptr, 0, 1, 1, s);
-  if (rc) return rc;
+  if (!fused) {
+    rc = gemm_f32(0, 1, (int)rows, C, 2 * C, d_pre, 2 * C, W0, C, d_x, C, nullptr, 0, 0.f, nullptr, 0, 1, 1, s);
+    if (rc) return rc;
+    rc = gemm_f32(0, 1, (int)rows, C, 2 * C, d_pre, 2 * C, W1, C, d_x + shift * C, C, nullptr, 0, 0.f, nullptr, 0, 1, 1, s);
+    if (rc) return rc;
+  }
   BLVM_CHECK_LAUNCH("wavenet_block_bwd");
   return BLVM_OK;
 }

@@ -6,6 +6,7 @@ plus size-independent properties at BASELINE's full sizes.
 Tolerances (fp32 kernels vs fp32/fp64 CPU): ELBO / log-likelihood / loss 1e-4 relative (north_star), usually far
 tighter; gradients: relative L2 per tensor <= 1e-3 (SURVEY §8d parity bar).
 """
+import math
 import os
 
 import numpy as np
@@ -766,3 +767,48 @@ def test_wavenet_decode_kernel_matches_window_generation(B, C, layers, stacks):
     assert float(((a - b).abs() > 1e-4).float().mean()) < 0.05, (a - b).abs().max()
     free = m.generate(n_samples=B, n_frames=5, cached=True)  # device RNG
     assert tuple(free.shape) == (B, 5, 1) and torch.isfinite(free).all() and float(free.abs().max()) <= 1.0
+
+
+@pytest.mark.parametrize("C,B,L,dil,T_skip", [(32, 3, 77, (1, 2, 4), 50), (64, 5, 203, (1, 8), 120), (96, 2, 131, (4, 1, 2), 100)])
+def test_wavenet_fused_block_kernels_match_torch(C, B, L, dil, T_skip):
+    """The fused block kernels (C in {32, 64, 96}: forward; backward A / B) against a float64 torch restatement of the residual
+    stack (`wavenet_modules.py:53-117,178-215`): row counts that are not multiples of the 64-row tile, a skip window that starts
+    inside a tile, a last block without residual output."""
+    from blvm import ops
+
+    g = torch.Generator().manual_seed(C + L)
+    x = torch.randn(L, B, C, generator=g)
+    params = []
+    for _ in dil:
+        params += [torch.randn(2 * C, C, 2, generator=g) * 0.08, torch.randn(2 * C, generator=g) * 0.1,
+                   torch.randn(2 * C, C, generator=g) * 0.08, torch.randn(2 * C, generator=g) * 0.1]
+    gs = torch.randn(T_skip, B, C, generator=g)
+
+    def ref(x, params):
+        h, skip = x.permute(1, 2, 0), 0.0  # [B,C,L]
+        for i, d in enumerate(dil):
+            cw, cb, rw, rb = params[4 * i : 4 * i + 4]
+            pre = torch.nn.functional.conv1d(h, cw, cb, dilation=d)
+            act = torch.tanh(pre[:, :C]) * torch.sigmoid(pre[:, C:])
+            rs = torch.nn.functional.conv1d(act, rw.unsqueeze(-1), rb)
+            skip = skip + rs[:, C:, -T_skip:]
+            h = (rs[:, :C] + h[:, :, d:]) * math.sqrt(0.5)
+        return skip.permute(2, 0, 1)
+
+    xr = x.double().requires_grad_(True)
+    pr = [p.double().requires_grad_(True) for p in params]
+    (ref(xr, pr) * gs.double()).sum().backward()
+
+    xd = x.to(DEV).requires_grad_(True)
+    pd = [p.to(DEV).requires_grad_(True) for p in params]
+    blocks = [tuple(pd[4 * i : 4 * i + 4]) for i in range(len(dil))]
+    out = ops.wavenet_stack(xd, blocks, list(dil), T_skip, math.sqrt(0.5), C)
+    (out * gs.to(DEV)).sum().backward()
+    assert rel_l2(out.detach(), ref(x.double(), [p.double() for p in params])) < 2e-6
+    assert rel_l2(xd.grad, xr.grad) < 5e-6
+    last = len(dil) - 1
+    for i, (a, b) in enumerate(zip(pd, pr)):
+        if i // 4 == last and i % 4 >= 2:  # the last block's residual rows of the 1x1 conv never reach an output
+            assert rel_l2(a.grad[C:], b.grad[C:]) < 2e-5, i
+        else:
+            assert rel_l2(a.grad, b.grad) < 2e-5, i
