@@ -588,6 +588,144 @@ int launch_fused_bwd(const FusedBwdAArgs& aa, const FusedBwdBArgs& ab, hipStream
   return BLVM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight / bias gradients of the block: out[m][n] += sum_r A[r][m] B[r][n] with M = 2C, N = C small and ~10^6 rows.  A 64x64-tile
+// split-K GEMM re-reads A once per column tile and B once per row tile (2.75 GB for the 1.18 GB of operands at C = 96); here
+// a workgroup owns a slice of rows and the WHOLE [2C, C] output (every wave (2C/16)/4 row tiles x all column tiles, in
+// accumulators), so the operands stream through LDS exactly once.  DUAL: both taps of the dilated convolution share the
+// A = d_pre stream (B0 = x[r], B1 = x[r + d B]) and land interleaved in the Conv1d weight layout [2C, C, 2]; the column sums of
+// A (the bias gradient) come from the same LDS tiles.
+// ---------------------------------------------------------------------------------------------------------------
+struct TsArgs {
+  const float* A;    // [rows, 2C]
+  const float* B0;   // [rows, C]
+  const float* B1;   // [rows, C] (DUAL) or null
+  size_t rows, chunks_per_wg;
+  float* out;        // element (m, n) of tap t at out[(m * C + n) * ostride + t]
+  int ostride;
+  float* colsum;     // [2C] += column sums of A, or null
+};
+
+template <int C, bool DUAL>
+__global__ __launch_bounds__(256) void wn_ts_wgrad_kernel(TsArgs a) {
+  constexpr int M = 2 * C, N = C, MT = M / 16, NT = N / 16, MW = MT / 4, NB = DUAL ? 2 : 1, KB = 16;
+  constexpr int LDA = M + 16, LDB = N + 16;  // row stride = 16 mod 32 banks: the 4 k-rows of a fragment read spread over all banks
+  constexpr int NA4 = KB * M / 4, NB4 = KB * N / 4;           // 16-byte pieces per chunk
+  constexpr int PA = (NA4 + 255) / 256, PB = (NB4 + 255) / 256;
+  __shared__ __align__(16) float sA[2][KB * LDA];
+  __shared__ __align__(16) float sB[2][NB][KB * LDB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+  const size_t c_begin = (size_t)blockIdx.x * a.chunks_per_wg;
+  const size_t n_chunks = (a.rows + KB - 1) / KB;
+  size_t c_end = c_begin + a.chunks_per_wg;
+  if (c_end > n_chunks) c_end = n_chunks;
+  if (c_begin >= c_end) return;
+
+  f32x4 acc[NB][MW][NT];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[b][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float csum = 0.f;
+
+  float4 ra[PA], rb[NB][PB];
+  auto fetch = [&](size_t chunk) {
+    const size_t row0 = chunk * KB;
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      const int i = tid + 256 * p;
+      const int row = (i * 4) / M, col = (i * 4) - row * M;
+      ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < NA4 && row0 + row < a.rows) ra[p] = *reinterpret_cast<const float4*>(a.A + (row0 + row) * M + col);
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      const int i = tid + 256 * p;
+      const int row = (i * 4) / N, col = (i * 4) - row * N;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        rb[b][p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < NB4 && row0 + row < a.rows) rb[b][p] = *reinterpret_cast<const float4*>((b ? a.B1 : a.B0) + (row0 + row) * N + col);
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      const int i = tid + 256 * p;
+      const int row = (i * 4) / M, col = (i * 4) - row * M;
+      if (i < NA4) *reinterpret_cast<float4*>(&sA[buf][row * LDA + col]) = ra[p];
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      const int i = tid + 256 * p;
+      const int row = (i * 4) / N, col = (i * 4) - row * N;
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        if (i < NB4) *reinterpret_cast<float4*>(&sB[buf][b][row * LDB + col]) = rb[b][p];
+    }
+  };
+  fetch(c_begin);
+  stash(0);
+  __syncthreads();
+  int buf = 0;
+  for (size_t c = c_begin; c < c_end; ++c) {
+    const bool more = c + 1 < c_end;
+    if (more) fetch(c + 1);  // in flight under this chunk's MFMAs
+    const float* A_ = sA[buf];
+#pragma unroll
+    for (int step = 0; step < KB / 4; ++step) {
+      const int row = 4 * step + kq;
+      float fa[MW], fb[NB][NT];
+#pragma unroll
+      for (int i = 0; i < MW; ++i) fa[i] = A_[row * LDA + (wave * MW + i) * 16 + li];
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[b][j] = sB[buf][b][row * LDB + j * 16 + li];
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int i = 0; i < MW; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[b][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[b][j], acc[b][i][j], 0, 0, 0);
+    }
+    if (a.colsum != nullptr && tid < M) {
+#pragma unroll
+      for (int r = 0; r < KB; ++r) csum += A_[r * LDA + tid];
+    }
+    if (more) stash(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // D layout: column (n) lane & 15, rows (m) 4 (lane >> 4) + r
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int i = 0; i < MW; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = (wave * MW + i) * 16 + 4 * kq + r, n = j * 16 + li;
+          atomicAdd(a.out + ((size_t)m * N + n) * a.ostride + b, acc[b][i][j][r]);
+        }
+  if (a.colsum != nullptr && tid < M) atomicAdd(a.colsum + tid, csum);
+}
+
+template <int C, bool DUAL>
+int launch_ts_wgrad(TsArgs a, hipStream_t s) {
+  const size_t n_chunks = (a.rows + 15) / 16;
+  size_t grid = 512;  // two workgroups per CU
+  if (grid > n_chunks) grid = n_chunks;
+  a.chunks_per_wg = (n_chunks + grid - 1) / grid;
+  grid = (n_chunks + a.chunks_per_wg - 1) / a.chunks_per_wg;
+  hipLaunchKernelGGL((wn_ts_wgrad_kernel<C, DUAL>), dim3((unsigned)grid), dim3(256), 0, s, a);
+  return BLVM_OK;
+}
+
 struct ConvWs { float *W0, *W1, *dW0, *dW1; };
 
 }  // namespace
@@ -751,6 +889,25 @@ extern "C" int blvm_wavenet_block_bwd(const float* x, const float* conv_w, const
     // 1x1 convolution
     rc = gemm_f32(0, 1, (int)rows, C, C + S, d_rs, C + S, rs_w, C, d_act, C, nullptr, 0, 0.f, nullptr, 0, 0, 1, s);
     if (rc) return rc;
+  }
+  if (fused) {
+    // weight and bias gradients: the operands stream once (wn_ts_wgrad_kernel); the taps land interleaved in dconv_w
+    if (drs_w || drs_b) {
+      TsArgs t{};
+      t.A = d_rs; t.B0 = act; t.B1 = nullptr; t.rows = rows; t.out = drs_w; t.ostride = 1; t.colsum = drs_b;
+      BLVM_REQUIRE(drs_w != nullptr, "wavenet_block_bwd: drs_b without drs_w");
+      rc = C == 32 ? launch_ts_wgrad<32, false>(t, s) : C == 64 ? launch_ts_wgrad<64, false>(t, s) : launch_ts_wgrad<96, false>(t, s);
+      if (rc) return rc;
+    }
+    if (dconv_w || dconv_b) {
+      TsArgs t{};
+      t.A = d_pre; t.B0 = x; t.B1 = x + shift * C; t.rows = rows; t.out = dconv_w; t.ostride = 2; t.colsum = dconv_b;
+      BLVM_REQUIRE(dconv_w != nullptr, "wavenet_block_bwd: dconv_b without dconv_w");
+      rc = C == 32 ? launch_ts_wgrad<32, true>(t, s) : C == 64 ? launch_ts_wgrad<64, true>(t, s) : launch_ts_wgrad<96, true>(t, s);
+      if (rc) return rc;
+    }
+    BLVM_CHECK_LAUNCH("wavenet_block_bwd (fused)");
+    return BLVM_OK;
   }
   if (drs_w) { rc = gemm_f32(1, 1, C + S, C, (int)rows, d_rs, C + S, act, C, drs_w, C, nullptr, 0, 0.f, nullptr, 0, 1, pick_split(C + S, C, (int)rows), s); if (rc) return rc; }
   if (drs_b) { rc = colsum_f32((int)rows, C + S, d_rs, C + S, drs_b, 1, s); if (rc) return rc; }
