@@ -212,6 +212,35 @@ __device__ __forceinline__ void reduce_tiles(const f32x4 (&acc)[G], float* __res
   }
 }
 
+}  // namespace blvm
+#include <functional>
+#include <string>
+namespace blvm {
+// ---- chain graphs (core.hip): an experiment switch, OFF by default (BLVM_GRAPHS=1 enables) ----------------------------------
+// A recurrent sequence is thousands of tiny dependent launches, and at B = 64 the HOST is what bounds it: enqueueing the VRNN
+// forward chain (2 260 launches) takes 8.9 ms of CPU time for 9.2 ms of wall time, forward + backward 20.4 of 21.4 ms
+// (scratch/graph_probe.py) — ~3.9 us per launch (argument block + AQL packet + doorbell), against ~3 us of GPU time per link.
+// In a microbenchmark a captured hipGraph runs such a chain at 1.75 us per link instead of 3.25 (tools/graph_chain.hip), so
+// run_chain() can capture a call into a graph and replay it: a call is identified by the bytes of ALL its arguments (every
+// pointer, size and flag, the weight / gradient pointer tables included); the first time a key is seen the body runs as plain
+// launches, the second time it is captured (on the library's own stream: the caller's may be the legacy null stream, which
+// cannot capture), afterwards the graph is replayed between two events on the caller's stream.  A training loop with a caching
+// allocator hands out the same buffers step after step, so the steady state replays.  Measured on the real chain (ROCm 7.2):
+// hipGraphLaunch of the 2 260-node graph costs 10.9 ms of host time — 4.8 us per node, MORE than launching them — and the step
+// goes from 21.5 to 26.4 ms.  So it stays off; what does remove the host from the chain is fewer launches (several links per
+// launch behind an in-kernel barrier), the next step for this kernel.
+// The body must only enqueue work on the stream it is given and decide nothing from device data.
+struct ChainKey {
+  std::string bytes;
+  explicit ChainKey(const char* tag) : bytes(tag) {}
+  template <class T>
+  ChainKey& add(const T& v) {
+    bytes.append(reinterpret_cast<const char*>(&v), sizeof(T));
+    return *this;
+  }
+};
+int run_chain(const ChainKey& key, hipStream_t user, const std::function<int(hipStream_t)>& body);
+
 // internal launchers shared between translation units (defined in gemm.hip)
 int gemm_f32(int op_a, int op_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
              int ldc, const float* bias, int act, float slope, const float* gate, int ldg, int accumulate,

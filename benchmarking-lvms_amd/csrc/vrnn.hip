@@ -231,11 +231,10 @@ extern "C" size_t blvm_vrnn_bwd_workspace_floats(int Tp, int B, int X, int H, in
   return carve_ws(nullptr, Tp, B, X, H, Z, R, nullptr);
 }
 
-extern "C" int blvm_vrnn_seq_fwd(const BlvmVrnnWeights* w, const float* enc, const float* h0, const float* eps,
-                                 int Tp, int B, int X, int H, int Z, int R, int residual_posterior, float sd_eps,
-                                 float* decin, float* mu_q, float* sd_q, float* mu_p, float* sd_p, float* z,
-                                 float* reserve, void* stream_) {
-  hipStream_t s = static_cast<hipStream_t>(stream_);
+static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const float* h0, const float* eps,
+                             int Tp, int B, int X, int H, int Z, int R, int residual_posterior, float sd_eps,
+                             float* decin, float* mu_q, float* sd_q, float* mu_p, float* sd_p, float* z,
+                             float* reserve, hipStream_t s) {
   int rc = check_dims(Tp, B, X, H, Z, R);
   if (rc) return rc;
   BLVM_REQUIRE(w && enc && eps && decin && mu_q && sd_q && mu_p && sd_p && z && reserve, "vrnn_fwd: null pointer");
@@ -324,13 +323,25 @@ extern "C" int blvm_vrnn_seq_fwd(const BlvmVrnnWeights* w, const float* enc, con
   return BLVM_OK;
 }
 
-extern "C" int blvm_vrnn_seq_bwd(const BlvmVrnnWeights* w, const float* enc, const float* eps, const float* decin,
-                                 const float* mu_q, const float* sd_q, const float* mu_p, const float* sd_p,
-                                 const float* z, const float* reserve, const float* d_decin, const int32_t* x_sl,
-                                 const float* c_raw, const float* c_fn, int stride, float fn_floor, int Tp, int B, int X, int H, int Z,
-                                 int R, int residual_posterior, float sd_eps, float* d_enc, float* d_h0,
-                                 const BlvmVrnnGrads* gr, float* workspace, void* stream_) {
-  hipStream_t s = static_cast<hipStream_t>(stream_);
+extern "C" int blvm_vrnn_seq_fwd(const BlvmVrnnWeights* w, const float* enc, const float* h0, const float* eps,
+                                 int Tp, int B, int X, int H, int Z, int R, int residual_posterior, float sd_eps,
+                                 float* decin, float* mu_q, float* sd_q, float* mu_p, float* sd_p, float* z,
+                                 float* reserve, void* stream_) {
+  BLVM_REQUIRE(w != nullptr, "vrnn_fwd: null pointer");
+  ChainKey key("vrnn_fwd");
+  key.add(*w).add(enc).add(h0).add(eps).add(Tp).add(B).add(X).add(H).add(Z).add(R).add(residual_posterior).add(sd_eps);
+  key.add(decin).add(mu_q).add(sd_q).add(mu_p).add(sd_p).add(z).add(reserve);
+  return run_chain(key, static_cast<hipStream_t>(stream_), [&](hipStream_t s) {
+    return vrnn_seq_fwd_impl(w, enc, h0, eps, Tp, B, X, H, Z, R, residual_posterior, sd_eps, decin, mu_q, sd_q, mu_p, sd_p, z, reserve, s);
+  });
+}
+
+static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const float* eps, const float* decin,
+                             const float* mu_q, const float* sd_q, const float* mu_p, const float* sd_p,
+                             const float* z, const float* reserve, const float* d_decin, const int32_t* x_sl,
+                             const float* c_raw, const float* c_fn, int stride, float fn_floor, int Tp, int B, int X, int H, int Z,
+                             int R, int residual_posterior, float sd_eps, float* d_enc, float* d_h0,
+                             const BlvmVrnnGrads* gr, float* workspace, hipStream_t s) {
   int rc = check_dims(Tp, B, X, H, Z, R);
   if (rc) return rc;
   BLVM_REQUIRE(w && enc && eps && decin && mu_q && sd_q && mu_p && sd_p && z && reserve && d_decin && workspace && gr,
@@ -491,4 +502,23 @@ extern "C" int blvm_vrnn_seq_bwd(const BlvmVrnnWeights* w, const float* enc, con
     if (rc) return rc;
   }
   return BLVM_OK;
+}
+
+extern "C" int blvm_vrnn_seq_bwd(const BlvmVrnnWeights* w, const float* enc, const float* eps, const float* decin,
+                                 const float* mu_q, const float* sd_q, const float* mu_p, const float* sd_p,
+                                 const float* z, const float* reserve, const float* d_decin, const int32_t* x_sl,
+                                 const float* c_raw, const float* c_fn, int stride, float fn_floor, int Tp, int B, int X, int H, int Z,
+                                 int R, int residual_posterior, float sd_eps, float* d_enc, float* d_h0,
+                                 const BlvmVrnnGrads* gr, float* workspace, void* stream_) {
+  BLVM_REQUIRE(w != nullptr && gr != nullptr, "vrnn_bwd: null pointer");
+  auto body = [&](hipStream_t s) {
+    return vrnn_seq_bwd_impl(w, enc, eps, decin, mu_q, sd_q, mu_p, sd_p, z, reserve, d_decin, x_sl, c_raw, c_fn, stride, fn_floor, Tp, B, X,
+                             H, Z, R, residual_posterior, sd_eps, d_enc, d_h0, gr, workspace, s);
+  };
+  if (overlap_chunk_steps() > 0) return body(static_cast<hipStream_t>(stream_));  // the side-stream experiment is not capturable
+  ChainKey key("vrnn_bwd");
+  key.add(*w).add(enc).add(eps).add(decin).add(mu_q).add(sd_q).add(mu_p).add(sd_p).add(z).add(reserve).add(d_decin).add(x_sl);
+  key.add(c_raw).add(c_fn).add(stride).add(fn_floor).add(Tp).add(B).add(X).add(H).add(Z).add(R).add(residual_posterior).add(sd_eps);
+  key.add(d_enc).add(d_h0).add(*gr).add(workspace);
+  return run_chain(key, static_cast<hipStream_t>(stream_), body);
 }
