@@ -217,18 +217,20 @@ __device__ __forceinline__ void reduce_tiles(const f32x4 (&acc)[G], float* __res
 #include <string>
 namespace blvm {
 // ---- chain graphs (core.hip): an experiment switch, OFF by default (BLVM_GRAPHS=1 enables) ----------------------------------
-// A recurrent sequence is thousands of tiny dependent launches, and at B = 64 the HOST is what bounds it: enqueueing the VRNN
-// forward chain (2 260 launches) takes 8.9 ms of CPU time for 9.2 ms of wall time, forward + backward 20.4 of 21.4 ms
-// (scratch/graph_probe.py) — ~3.9 us per launch (argument block + AQL packet + doorbell), against ~3 us of GPU time per link.
-// In a microbenchmark a captured hipGraph runs such a chain at 1.75 us per link instead of 3.25 (tools/graph_chain.hip), so
-// run_chain() can capture a call into a graph and replay it: a call is identified by the bytes of ALL its arguments (every
-// pointer, size and flag, the weight / gradient pointer tables included); the first time a key is seen the body runs as plain
-// launches, the second time it is captured (on the library's own stream: the caller's may be the legacy null stream, which
-// cannot capture), afterwards the graph is replayed between two events on the caller's stream.  A training loop with a caching
-// allocator hands out the same buffers step after step, so the steady state replays.  Measured on the real chain (ROCm 7.2):
-// hipGraphLaunch of the 2 260-node graph costs 10.9 ms of host time — 4.8 us per node, MORE than launching them — and the step
-// goes from 21.5 to 26.4 ms.  So it stays off; what does remove the host from the chain is fewer launches (several links per
-// launch behind an in-kernel barrier), the next step for this kernel.
+// A recurrent sequence is thousands of tiny dependent launches.  What a launch costs (tools/launch_host.hip, graph_chain.hip):
+// the GPU's dependent-dispatch floor is 1.53 us; the HOST pays 0.74 us for a launch without arguments but 2.6-3.1 us for one
+// with arguments (the runtime writes the argument block into device memory per launch; with HIP_FORCE_DEV_KERNARG=0 the host
+// pays 0.9 us and the GPU 3.65 us per kernel fetching arguments from host memory); a captured hipGraph replays a chain of
+// trivial kernels at 1.75 us each.  On the VRNN step the host spends ~4.6 us per launch (20.4-21.1 of 21.4-21.9 ms) against
+// ~3.3 us of GPU time per link, so run_chain() can capture a call into a graph and replay it: a call is identified by the bytes
+// of ALL its arguments (every pointer, size and flag, the weight / gradient pointer tables included); the first time a key is
+// seen the body runs as plain launches, the second time it is captured (on the library's own stream: the caller's may be the
+// legacy null stream, which cannot capture), afterwards the graph is replayed between two events on the caller's stream.
+// Measured on the real chain (ROCm 7.2): hipGraphLaunch of the 2 260-node forward graph takes 10.9 ms — 4.8 us per node, more
+// than launching them — and the step goes from 21.5 to 26.4 ms.  So it stays off.  (Also tried and removed: argument-less twin
+// kernels that rebuild their arguments from a device table and a step counter — host enqueue falls to 0.6 us per launch, but
+// the table fetch after every kernel boundary and the 10x larger code object put a link at ~5 us on the GPU, 27.3 ms/step.)
+// What is left is fewer launches: several links per launch behind an in-kernel barrier.
 // The body must only enqueue work on the stream it is given and decide nothing from device data.
 struct ChainKey {
   std::string bytes;
