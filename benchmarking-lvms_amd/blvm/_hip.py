@@ -52,6 +52,7 @@ class RssmWeights(ctypes.Structure):
 
 
 _SIGNATURES = {
+    "blvm_upload_i32": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "blvm_version": (c_int, []),
     "blvm_last_error": (ctypes.c_char_p, []),
     "blvm_device_ok": (c_int, []),

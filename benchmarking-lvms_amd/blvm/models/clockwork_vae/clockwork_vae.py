@@ -104,7 +104,7 @@ class CWVAE(nn.Module):
             y = y[:, :-consumed]
         y = y.contiguous()
         B, T = y.shape
-        x_sl_dev = x_sl.to(device=dev, dtype=torch.int32)
+        x_sl_dev = ops.upload_i32(x_sl, dev)
         level_sl = [torch.div(x_sl + s - 1, s, rounding_mode="floor") for s in os_]
 
         same_paddings = []
@@ -138,7 +138,7 @@ class CWVAE(nn.Module):
             latents[l], enc_mus[l], prior_mus[l] = zs[1:].transpose(0, 1), mu_q.transpose(0, 1), mu_p.transpose(0, 1)
 
             # state to carry into the next split: the one at each example's last valid step (clockwork_vae.py:283-290)
-            stop = (level_sl[l] - 1).clamp(0, T_l - 1).to(dev) + 1
+            stop = ops.upload_i32((level_sl[l] - 1).clamp(0, T_l - 1) + 1, dev).long()
             rows = torch.arange(B, device=dev)
             state_n[l] = (zs[stop, rows], hs[stop, rows])
 

@@ -59,7 +59,7 @@ class LSTMAudio(BaseModel):
         inp = xs[:, :-1].transpose(0, 1).contiguous().view(L * B, S)  # time-major inputs
         emb = ops.mlp(inp, [m for m in self.embedding if isinstance(m, nn.Linear)], ops.ACT_RELU, 0.0).view(L, B, H)
 
-        lens = (x_sl_stack - 1).clamp(min=0).to(device=dev, dtype=torch.int32)
+        lens = ops.upload_i32((x_sl_stack - 1).clamp(min=0), dev)
         h0 = c0 = None
         if s_0 is not None:
             h0, c0 = s_0[0].reshape(B, H), s_0[1].reshape(B, H)
@@ -68,7 +68,7 @@ class LSTMAudio(BaseModel):
         dec = ops.mlp(out.view(L * B, H), [m for m in self.decoder if isinstance(m, nn.Linear)], ops.ACT_RELU, 0.0)
 
         # mask = arange(L*S) < x_sl  (lstm.py:111): lengths are compared with the SHIFTED target axis
-        mask_len = x_sl_host.clamp(max=L * S).to(device=dev, dtype=torch.int32)
+        mask_len = ops.upload_i32(x_sl_host.clamp(max=L * S), dev)
         log_prob = ops.dmol_log_prob(dec, lik.params.weight, lik.params.bias, y, mask_len, ops.LAYOUT_TIME_MAJOR, B, L * S, L,
                                      S, lik.num_mix, lik.num_bins, lik.log_epsilon).to(torch.float32)  # fmt: skip
         n_frames = float(x_sl_host.sum())

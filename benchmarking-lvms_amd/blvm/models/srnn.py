@@ -95,12 +95,12 @@ class SRNN(nn.Module):
         dev = x.device
         B, T = x.shape
         x_sl_host = x_sl.detach().cpu().to(torch.int64)
-        x_sl_dev = x_sl_host.to(device=dev, dtype=torch.int32)
+        x_sl_dev = ops.upload_i32(x_sl_host, dev)
         y = x.detach().to(torch.float32).contiguous()
         Tp = (T + S - 1) // S
         stride = math.ceil(T / Tp)
         x_sl_strided = (x_sl_host / stride).ceil().int()
-        lens_dev = x_sl_strided.to(device=dev, dtype=torch.int32)
+        lens_dev = ops.upload_i32(x_sl_strided, dev)
         H, Z, R = self.h_dim, self.z_dim, self.r_dim
 
         xs = torch.nn.functional.pad(y, (0, Tp * S - T)) if Tp * S != T else y

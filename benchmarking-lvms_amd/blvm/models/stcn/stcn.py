@@ -164,7 +164,7 @@ class STCN(BaseModel):
             if Tp <= rf:
                 raise ValueError(f"Input must be at least as long as the receptive field if {pad_receptive_field=}")
         T_y = y.size(1)
-        mask_len = x_sl_host.clamp(min=0, max=T_y).to(device=dev, dtype=torch.int32)
+        mask_len = ops.upload_i32(x_sl_host.clamp(min=0, max=T_y), dev)
 
         out = self.causal.forward_tm(xt, pad_causal=False)  # [T + rf - 1, B, C]
         n = self.n_latents

@@ -183,7 +183,7 @@ class VRNN(nn.Module):
         dev = x.device
         B, T = x.shape
         x_sl_host = x_sl.detach().cpu().to(torch.int64)
-        x_sl_dev = x_sl_host.to(device=dev, dtype=torch.int32)
+        x_sl_dev = ops.upload_i32(x_sl_host, dev)
         y = x.detach().to(torch.float32).contiguous()
         Tp = (T + S - 1) // S
         stride = math.ceil(T / Tp)

@@ -88,7 +88,7 @@ class WaveNet(BaseModel):
         par = ops.linear(logits.view(skip_size * B * nsf, C), lik.params.weight, lik.params.bias)  # [skip*B*nsf, 3K]
 
         T_y = y.size(1)
-        mask_len = x_sl_host.clamp(min=0, max=T_y).to(device=dev, dtype=torch.int32)
+        mask_len = ops.upload_i32(x_sl_host.clamp(min=0, max=T_y), dev)
         log_prob = ops.dmol_log_prob(par.view(skip_size * B, nsf * lik.out_features), None, None, y, mask_len,
                                      ops.LAYOUT_TIME_MAJOR, B, T_y, skip_size, nsf, lik.num_mix, lik.num_bins,
                                      lik.log_epsilon).to(torch.float32)  # fmt: skip

@@ -51,6 +51,15 @@ def colsum(X2d: torch.Tensor, out: torch.Tensor, accumulate=False):
     check(load().blvm_colsum_f32(M, N, ptr(X2d), X2d.stride(0), ptr(out), int(accumulate), stream_ptr()), "blvm_colsum_f32")
 
 
+def upload_i32(host, device):
+    """Small host integer tensor -> int32 device tensor without blocking the host (the values travel in kernel arguments)."""
+    h = host.detach().to(device="cpu", dtype=torch.int32).contiguous()
+    out = torch.empty(h.shape, device=device, dtype=torch.int32)
+    if h.numel():
+        check(load().blvm_upload_i32(h.data_ptr(), h.numel(), ptr(out), stream_ptr()), "blvm_upload_i32")
+    return out
+
+
 def _zeros_like_many(tensors):
     """Zero-initialised gradient buffers for `tensors` carved out of ONE allocation (one fill launch instead of one per
     tensor; offsets kept 16-byte aligned)."""

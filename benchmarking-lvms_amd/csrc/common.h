@@ -221,8 +221,8 @@ namespace blvm {
 // the GPU's dependent-dispatch floor is 1.53 us; the HOST pays 0.74 us for a launch without arguments but 2.6-3.1 us for one
 // with arguments (the runtime writes the argument block into device memory per launch; with HIP_FORCE_DEV_KERNARG=0 the host
 // pays 0.9 us and the GPU 3.65 us per kernel fetching arguments from host memory); a captured hipGraph replays a chain of
-// trivial kernels at 1.75 us each.  On the VRNN step the host spends ~4.6 us per launch (20.4-21.1 of 21.4-21.9 ms) against
-// ~3.3 us of GPU time per link, so run_chain() can capture a call into a graph and replay it: a call is identified by the bytes
+// trivial kernels at 1.75 us each.  On the VRNN step a chain launch costs the host ~3 us and the GPU ~4 us per link (DESIGN.md,
+// "Host or GPU?"), so replaying pre-built graphs looked worth having: run_chain() captures a call and replays it, identified by the bytes
 // of ALL its arguments (every pointer, size and flag, the weight / gradient pointer tables included); the first time a key is
 // seen the body runs as plain launches, the second time it is captured (on the library's own stream: the caller's may be the
 // legacy null stream, which cannot capture), afterwards the graph is replayed between two events on the caller's stream.

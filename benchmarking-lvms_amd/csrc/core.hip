@@ -138,6 +138,31 @@ void set_error(const char* fmt, ...) {
 
 }  // namespace blvm
 
+namespace blvm {
+namespace {
+struct I32Chunk { int32_t v[256]; };
+__global__ __launch_bounds__(256) void upload_i32_kernel(I32Chunk c, int32_t* dst, int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = c.v[threadIdx.x];
+}
+}  // namespace
+}  // namespace blvm
+
+// Host integers -> device, carried in kernel arguments (256 per launch): nothing is staged, nothing waits.  A pageable
+// host-to-device copy of the batch's lengths blocks the host until the stream has drained, i.e. once per training step it stops
+// the host from running ahead of the GPU.
+extern "C" int blvm_upload_i32(const int32_t* host, int n, int32_t* dst, void* stream) {
+  using namespace blvm;
+  BLVM_REQUIRE(n >= 0 && (n == 0 || (host != nullptr && dst != nullptr)), "upload_i32: null pointer");
+  for (int off = 0; off < n; off += 256) {
+    I32Chunk c;
+    const int m = n - off < 256 ? n - off : 256;
+    memcpy(c.v, host + off, sizeof(int32_t) * m);
+    hipLaunchKernelGGL(upload_i32_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), c, dst + off, m);
+  }
+  BLVM_CHECK_LAUNCH("upload_i32");
+  return BLVM_OK;
+}
+
 extern "C" int blvm_version(void) { return 100; /* 0.1.0 */ }
 
 extern "C" const char* blvm_last_error(void) { return blvm::g_err; }

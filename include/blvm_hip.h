@@ -32,6 +32,9 @@ int blvm_version(void);
 const char* blvm_last_error(void);
 /* 1 if a gfx950 device is visible to the HIP runtime, else 0 (never throws). */
 int blvm_device_ok(void);
+/* n host integers -> device memory through kernel arguments (asynchronous on `stream`; a pageable hipMemcpy would block the host
+ * until the stream has drained).  Carries the batch's lengths `x_sl` (`blvm/data/batchers.py:145-151` hands them over on the host). */
+int blvm_upload_i32(const int32_t* host, int n, int32_t* dst, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * K6  fp32 MFMA GEMM with fused epilogue — replaces nn.Linear(+LeakyReLU/ReLU) chains
