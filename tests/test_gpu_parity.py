@@ -812,3 +812,13 @@ def test_wavenet_fused_block_kernels_match_torch(C, B, L, dil, T_skip):
             assert rel_l2(a.grad[C:], b.grad[C:]) < 2e-5, i
         else:
             assert rel_l2(a.grad, b.grad) < 2e-5, i
+
+
+@pytest.mark.parametrize("n", [1, 64, 256, 257, 1000])
+def test_upload_i32_carries_host_integers_in_kernel_arguments(n):
+    from blvm import ops
+
+    h = torch.randint(-(2**31), 2**31 - 1, (n,), dtype=torch.int64)
+    d = ops.upload_i32(h.to(torch.int32), DEV)
+    assert d.dtype == torch.int32 and d.device.type == "cuda"
+    assert torch.equal(d.cpu(), h.to(torch.int32))
