@@ -172,8 +172,8 @@ __global__ __launch_bounds__(256, 2) void wn_block_fused_fwd_kernel(FusedFwdArgs
   // a "stage" of the convolution = JH k-chunks of one (tanh, sigmoid) tile pair: its 4 JH weight fragments are what one
   // register set holds (C = 96: half a pair, so that two sets + the 1x1 sets stay under 256 VGPRs at two waves per SIMD)
   constexpr int JH = KC > 4 ? KC / 2 : KC, SPC = KC / JH, NST = NT * SPC;
-  struct ConvFrag { float4 t0[JH], s0[JH], t1[JH], s1[JH]; float bT, bS; };
-  struct RsFrag { float4 f0[KC], f1[KC]; float b0, b1; };
+  struct ConvFrag { float4 t0[JH], s0[JH], t1[JH], s1[JH], bT, bS; };
+  struct RsFrag { float4 f0[KC], f1[KC], b0, b1; };
   auto load_conv = [&](ConvFrag& F, int st) {
     const int ct = st / SPC, j0 = (st - ct * SPC) * JH;
     const float* wT0 = a.W0 + (size_t)(ct * 16) * C + 4 * lane + 256 * j0;
@@ -187,8 +187,8 @@ __global__ __launch_bounds__(256, 2) void wn_block_fused_fwd_kernel(FusedFwdArgs
       F.t1[j] = *reinterpret_cast<const float4*>(wT1 + 256 * j);
       F.s1[j] = *reinterpret_cast<const float4*>(wS1 + 256 * j);
     }
-    F.bT = a.conv_b[ct * 16 + cc];
-    F.bS = a.conv_b[C + ct * 16 + cc];
+    F.bT = *reinterpret_cast<const float4*>(a.conv_b + ct * 16 + 4 * q);
+    F.bS = *reinterpret_cast<const float4*>(a.conv_b + C + ct * 16 + 4 * q);
   };
   auto load_rs = [&](RsFrag& G, int ct) {  // column tiles ct, ct + 1 (NR is even)
     const float* w0 = a.Wrs + (size_t)(ct * 16) * C + 4 * lane;
@@ -198,8 +198,8 @@ __global__ __launch_bounds__(256, 2) void wn_block_fused_fwd_kernel(FusedFwdArgs
       G.f0[j] = *reinterpret_cast<const float4*>(w0 + 256 * j);
       G.f1[j] = *reinterpret_cast<const float4*>(w1 + 256 * j);
     }
-    G.b0 = a.rs_b[ct * 16 + cc];
-    G.b1 = a.rs_b[(ct + 1) * 16 + cc];
+    G.b0 = *reinterpret_cast<const float4*>(a.rs_b + ct * 16 + 4 * q);
+    G.b1 = *reinterpret_cast<const float4*>(a.rs_b + (ct + 1) * 16 + 4 * q);
   };
   ConvFrag F0, F1;
   RsFrag G0, G1;
@@ -249,33 +249,33 @@ __global__ __launch_bounds__(256, 2) void wn_block_fused_fwd_kernel(FusedFwdArgs
     for (int j = 0; j < JH; ++j) {
       const float4 x0 = *reinterpret_cast<const float4*>(ap0 + 16 * (j0 + j));
       const float4 x1 = *reinterpret_cast<const float4*>(ap1 + 16 * (j0 + j));
-      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.x, F.t0[j].x, aT, 0, 0, 0);
-      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.x, F.s0[j].x, aS, 0, 0, 0);
-      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.y, F.t0[j].y, aT, 0, 0, 0);
-      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.y, F.s0[j].y, aS, 0, 0, 0);
-      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.z, F.t0[j].z, aT, 0, 0, 0);
-      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.z, F.s0[j].z, aS, 0, 0, 0);
-      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.w, F.t0[j].w, aT, 0, 0, 0);
-      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.w, F.s0[j].w, aS, 0, 0, 0);
-      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.x, F.t1[j].x, aT, 0, 0, 0);
-      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.x, F.s1[j].x, aS, 0, 0, 0);
-      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.y, F.t1[j].y, aT, 0, 0, 0);
-      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.y, F.s1[j].y, aS, 0, 0, 0);
-      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.z, F.t1[j].z, aT, 0, 0, 0);
-      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.z, F.s1[j].z, aS, 0, 0, 0);
-      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.w, F.t1[j].w, aT, 0, 0, 0);
-      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.w, F.s1[j].w, aS, 0, 0, 0);
+      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(F.t0[j].x, x0.x, aT, 0, 0, 0);
+      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(F.s0[j].x, x0.x, aS, 0, 0, 0);
+      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(F.t0[j].y, x0.y, aT, 0, 0, 0);
+      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(F.s0[j].y, x0.y, aS, 0, 0, 0);
+      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(F.t0[j].z, x0.z, aT, 0, 0, 0);
+      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(F.s0[j].z, x0.z, aS, 0, 0, 0);
+      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(F.t0[j].w, x0.w, aT, 0, 0, 0);
+      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(F.s0[j].w, x0.w, aS, 0, 0, 0);
+      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(F.t1[j].x, x1.x, aT, 0, 0, 0);
+      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(F.s1[j].x, x1.x, aS, 0, 0, 0);
+      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(F.t1[j].y, x1.y, aT, 0, 0, 0);
+      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(F.s1[j].y, x1.y, aS, 0, 0, 0);
+      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(F.t1[j].z, x1.z, aT, 0, 0, 0);
+      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(F.s1[j].z, x1.z, aS, 0, 0, 0);
+      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(F.t1[j].w, x1.w, aT, 0, 0, 0);
+      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(F.s1[j].w, x1.w, aS, 0, 0, 0);
     }
     if (j0 + JH < KC) return;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 4 * q + r, col = ct * 16 + cc;
-      const float pT = aT[r] + F.bT, pS = aS[r] + F.bS;
-      sAct[row * LDX + col] = tanhf(pT) * sigmoidf_(pS);
-      if (r0 + row < a.rows) {
-        a.pre[(r0 + row) * 2 * C + col] = pT;
-        a.pre[(r0 + row) * 2 * C + C + col] = pS;
-      }
+    // weights as the A operand: the accumulator holds data row lane & 15, channels 4 (lane >> 4) + r — 16-byte pieces of a row
+    const int col = ct * 16 + 4 * q;
+    const float4 pT = make_float4(aT[0] + F.bT.x, aT[1] + F.bT.y, aT[2] + F.bT.z, aT[3] + F.bT.w);
+    const float4 pS = make_float4(aS[0] + F.bS.x, aS[1] + F.bS.y, aS[2] + F.bS.z, aS[3] + F.bS.w);
+    *reinterpret_cast<float4*>(sAct + rr * LDX + col) = make_float4(tanhf(pT.x) * sigmoidf_(pS.x), tanhf(pT.y) * sigmoidf_(pS.y),
+                                                                    tanhf(pT.z) * sigmoidf_(pS.z), tanhf(pT.w) * sigmoidf_(pS.w));
+    if (r0 + rr < a.rows) {
+      *reinterpret_cast<float4*>(a.pre + (r0 + rr) * 2 * C + col) = pT;
+      *reinterpret_cast<float4*>(a.pre + (r0 + rr) * 2 * C + C + col) = pS;
     }
   };
   for (int st = 0; st < NST; st += 2) {
@@ -301,44 +301,43 @@ __global__ __launch_bounds__(256, 2) void wn_block_fused_fwd_kernel(FusedFwdArgs
   // their old values requested before the MFMAs
   const float* ap = sAct + rr * LDX + 4 * q;
   auto rs_pair = [&](const RsFrag& G, int ct) {
-    float old[2][4];
+    const size_t gr = r0 + rr;
+    const bool live = gr < a.rows;
+    float4 old[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int col = (ct + h) * 16 + cc;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const size_t gr = r0 + 4 * q + r;
-        old[h][r] = (col >= C && gr < a.rows && gr >= a.off) ? a.skip[(gr - a.off) * S + (col - C)] : 0.f;
-      }
+      const int col = (ct + h) * 16 + 4 * q;
+      old[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (col >= C && live && gr >= a.off) old[h] = *reinterpret_cast<const float4*>(a.skip + (gr - a.off) * S + (col - C));
     }
     f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < KC; ++j) {
       const float4 v = *reinterpret_cast<const float4*>(ap + 16 * j);
-      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, G.f0[j].x, c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, G.f1[j].x, c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, G.f0[j].y, c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, G.f1[j].y, c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, G.f0[j].z, c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, G.f1[j].z, c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, G.f0[j].w, c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, G.f1[j].w, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(G.f0[j].x, v.x, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(G.f1[j].x, v.x, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(G.f0[j].y, v.y, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(G.f1[j].y, v.y, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(G.f0[j].z, v.z, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(G.f1[j].z, v.z, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(G.f0[j].w, v.w, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(G.f1[j].w, v.w, c1, 0, 0, 0);
     }
+    if (!live) return;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int col = (ct + h) * 16 + cc;
-      const float bias = h ? G.b1 : G.b0;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 4 * q + r;
-        const size_t gr = r0 + row;
-        const float v = (h ? c1[r] : c0[r]) + bias;
-        if (gr >= a.rows) continue;
-        if (col < C) {
-          if (a.o != nullptr) a.o[gr * C + col] = (v + sX1[row * LDX + col]) * a.inv_std;
-        } else if (gr >= a.off) {
-          a.skip[(gr - a.off) * S + (col - C)] = old[h][r] + v;
+      const int col = (ct + h) * 16 + 4 * q;
+      const float4 b = h ? G.b1 : G.b0;
+      const f32x4 c = h ? c1 : c0;
+      float4 v = make_float4(c[0] + b.x, c[1] + b.y, c[2] + b.z, c[3] + b.w);
+      if (col < C) {
+        if (a.o != nullptr) {
+          const float4 x1 = *reinterpret_cast<const float4*>(sX1 + rr * LDX + col);
+          *reinterpret_cast<float4*>(a.o + gr * C + col) =
+              make_float4((v.x + x1.x) * a.inv_std, (v.y + x1.y) * a.inv_std, (v.z + x1.z) * a.inv_std, (v.w + x1.w) * a.inv_std);
         }
+      } else if (gr >= a.off) {
+        *reinterpret_cast<float4*>(a.skip + (gr - a.off) * S + (col - C)) = make_float4(old[h].x + v.x, old[h].y + v.y, old[h].z + v.z, old[h].w + v.w);
       }
     }
   };
@@ -401,18 +400,14 @@ __global__ __launch_bounds__(256, 2) void wn_block_fused_bwd_a_kernel(FusedBwdAA
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, rr = lane & 15, q = lane >> 4, cc = lane & 15;
   float* sD = smem + wave * 16 * LDR;
   const size_t r0 = ((size_t)blockIdx.x * 4 + wave) * 16;
-  struct Frag { float4 f[KR]; float pT[4], pS[4]; };
+  struct Frag { float4 f[KR], pT, pS; };
   auto load_tile = [&](Frag& F, int ct) {
     const float* w = a.WrsT + (size_t)(ct * 16) * W + 4 * lane;
 #pragma unroll
     for (int j = 0; j < KR; ++j) F.f[j] = *reinterpret_cast<const float4*>(w + 256 * j);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const size_t gr = r0 + 4 * q + r;
-      const size_t o = (gr < a.rows ? gr : 0) * 2 * C + ct * 16 + cc;
-      F.pT[r] = a.pre[o];
-      F.pS[r] = a.pre[o + C];
-    }
+    const size_t o = (r0 + rr < a.rows ? r0 + rr : 0) * 2 * C + ct * 16 + 4 * q;
+    F.pT = *reinterpret_cast<const float4*>(a.pre + o);
+    F.pS = *reinterpret_cast<const float4*>(a.pre + o + C);
   };
   Frag F0, F1;
   // 1. d_rs rows: [d_o * inv_std | d_skip of the rows that fed the skip sum]
@@ -455,25 +450,30 @@ __global__ __launch_bounds__(256, 2) void wn_block_fused_bwd_a_kernel(FusedBwdAA
     for (int j = 0; j < KH; ++j) {
       const float4 u = *reinterpret_cast<const float4*>(ap + 16 * j);
       const float4 v = *reinterpret_cast<const float4*>(ap + 16 * (KH + j));
-      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(u.x, F.f[j].x, c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, F.f[KH + j].x, c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(u.y, F.f[j].y, c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, F.f[KH + j].y, c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(u.z, F.f[j].z, c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, F.f[KH + j].z, c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(u.w, F.f[j].w, c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, F.f[KH + j].w, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[j].x, u.x, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[KH + j].x, v.x, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[j].y, u.y, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[KH + j].y, v.y, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[j].z, u.z, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[KH + j].z, v.z, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[j].w, u.w, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[KH + j].w, v.w, c1, 0, 0, 0);
     }
+    // accumulators: data row lane & 15, channels 4 (lane >> 4) + r
+    const size_t gr = r0 + rr;
+    if (gr >= a.rows) return;
+    const float pt[4] = {F.pT.x, F.pT.y, F.pT.z, F.pT.w}, ps[4] = {F.pS.x, F.pS.y, F.pS.z, F.pS.w};
+    float dt[4], ds[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const size_t gr = r0 + 4 * q + r;
-      if (gr >= a.rows) continue;
       const float g = c0[r] + c1[r];
-      const float ta = tanhf(F.pT[r]), sb = sigmoidf_(F.pS[r]);
-      const size_t o = gr * 2 * C + ct * 16 + cc;
-      a.d_pre[o] = g * sb * (1.f - ta * ta);
-      a.d_pre[o + C] = g * ta * sb * (1.f - sb);
+      const float ta = tanhf(pt[r]), sb = sigmoidf_(ps[r]);
+      dt[r] = g * sb * (1.f - ta * ta);
+      ds[r] = g * ta * sb * (1.f - sb);
     }
+    const size_t o = gr * 2 * C + ct * 16 + 4 * q;
+    *reinterpret_cast<float4*>(a.d_pre + o) = make_float4(dt[0], dt[1], dt[2], dt[3]);
+    *reinterpret_cast<float4*>(a.d_pre + o + C) = make_float4(ds[0], ds[1], ds[2], ds[3]);
   };
   for (int ct = 0; ct < NT; ct += 2) {
     asm volatile("s_barrier" ::: "memory");
@@ -535,14 +535,14 @@ __global__ __launch_bounds__(256, 2) void wn_block_fused_bwd_b_kernel(FusedBwdBA
     for (int j = 0; j < KH; ++j) {
       const float4 u = *reinterpret_cast<const float4*>(ap + 16 * j);
       const float4 v = *reinterpret_cast<const float4*>(ap + 16 * (KH + j));
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(u.x, F.f[j].x, c, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, F.f[KH + j].x, c1, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(u.y, F.f[j].y, c, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, F.f[KH + j].y, c1, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(u.z, F.f[j].z, c, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, F.f[KH + j].z, c1, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(u.w, F.f[j].w, c, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, F.f[KH + j].w, c1, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[j].x, u.x, c, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[KH + j].x, v.x, c1, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[j].y, u.y, c, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[KH + j].y, v.y, c1, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[j].z, u.z, c, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[KH + j].z, v.z, c1, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[j].w, u.w, c, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[KH + j].w, v.w, c1, 0, 0, 0);
     }
     c += c1;
   };
@@ -563,16 +563,17 @@ __global__ __launch_bounds__(256, 2) void wn_block_fused_bwd_b_kernel(FusedBwdBA
     }
     wave_lds_fence();  // every fragment read of this tap's rows is done before the buffer is refilled
   }
+  const size_t gr = r0 + rr;  // accumulators: data row lane & 15, channels 4 (lane >> 4) + r
+  if (gr < rows_in) {
 #pragma unroll
-  for (int ct = 0; ct < NT; ++ct) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const size_t gr = r0 + 4 * q + r;
-      if (gr >= rows_in) continue;
-      const int col = ct * 16 + cc;
-      float v = acc[ct][r];
-      if (a.d_o != nullptr && gr >= a.shift) v += a.d_o[(gr - a.shift) * C + col] * a.inv_std;
-      a.d_x[gr * C + col] = v;
+    for (int ct = 0; ct < NT; ++ct) {
+      const int col = ct * 16 + 4 * q;
+      float4 v = make_float4(acc[ct][0], acc[ct][1], acc[ct][2], acc[ct][3]);
+      if (a.d_o != nullptr && gr >= a.shift) {
+        const float4 g = *reinterpret_cast<const float4*>(a.d_o + (gr - a.shift) * C + col);
+        v.x += g.x * a.inv_std; v.y += g.y * a.inv_std; v.z += g.z * a.inv_std; v.w += g.w * a.inv_std;
+      }
+      *reinterpret_cast<float4*>(a.d_x + gr * C + col) = v;
     }
   }
 }
