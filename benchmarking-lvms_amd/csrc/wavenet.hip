@@ -610,7 +610,7 @@ struct TsArgs {
 template <int C, bool DUAL>
 __global__ __launch_bounds__(256) void wn_ts_wgrad_kernel(TsArgs a) {
   constexpr int M = 2 * C, N = C, MT = M / 16, NT = N / 16, MW = MT / 4, NB = DUAL ? 2 : 1, KB = 16;
-  constexpr int LDA = M + 16, LDB = N + 16;  // row stride = 16 mod 32 banks: the 4 k-rows of a fragment read spread over all banks
+  constexpr int LDA = M + 4, LDB = N + 4;  // a lane's fragment = rows 4 kq .. 4 kq + 3 of one column: stride = 4 mod 8 spreads the 4 kq groups over all banks
   constexpr int NA4 = KB * M / 4, NB4 = KB * N / 4;           // 16-byte pieces per chunk
   constexpr int PA = (NA4 + 255) / 256, PB = (NB4 + 255) / 256;
   __shared__ __align__(16) float sA[2][KB * LDA];
@@ -676,22 +676,31 @@ __global__ __launch_bounds__(256) void wn_ts_wgrad_kernel(TsArgs a) {
     const bool more = c + 1 < c_end;
     if (more) fetch(c + 1);  // in flight under this chunk's MFMAs
     const float* A_ = sA[buf];
+    {
+      // fragments: k = rows 4 kq + e of the chunk, e = 0..3 (the same assignment for both operands), one MFMA per e
+      float fa[MW][4], fb[NB][NT][4];
 #pragma unroll
-    for (int step = 0; step < KB / 4; ++step) {
-      const int row = 4 * step + kq;
-      float fa[MW], fb[NB][NT];
+      for (int i = 0; i < MW; ++i) {
+        const float* p = A_ + (4 * kq) * LDA + (wave * MW + i) * 16 + li;
 #pragma unroll
-      for (int i = 0; i < MW; ++i) fa[i] = A_[row * LDA + (wave * MW + i) * 16 + li];
+        for (int e = 0; e < 4; ++e) fa[i][e] = p[e * LDA];
+      }
 #pragma unroll
       for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) fb[b][j] = sB[buf][b][row * LDB + j * 16 + li];
+        for (int j = 0; j < NT; ++j) {
+          const float* p = sB[buf][b] + (4 * kq) * LDB + j * 16 + li;
 #pragma unroll
-      for (int b = 0; b < NB; ++b)
+          for (int e = 0; e < 4; ++e) fb[b][j][e] = p[e * LDB];
+        }
 #pragma unroll
-        for (int i = 0; i < MW; ++i)
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[b][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[b][j], acc[b][i][j], 0, 0, 0);
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int i = 0; i < MW; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[b][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[b][j][e], acc[b][i][j], 0, 0, 0);
     }
     if (a.colsum != nullptr && tid < M) {
 #pragma unroll
