@@ -210,8 +210,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(int M, int N, const float* 
 }
 
 // 16-byte loads: a lane owns 4 adjacent columns, a wave 256 columns of one row (1 KiB contiguous); 4 row-lanes (waves)
+// nmod: the sums of columns c, c + nmod, c + 2 nmod ... land in out[c % nmod] (a dense [M, n] matrix with n % 4 != 0 read as
+// [M / g, n g]: g consecutive rows per "row")
 __global__ __launch_bounds__(256) void colsum4_kernel(int M, int N, const float* __restrict__ X, int ldx,
-                                                      float* __restrict__ out, int rows_per_block) {
+                                                      float* __restrict__ out, int rows_per_block, int nmod) {
   __shared__ float part[4][4][64];
   const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = (blockIdx.x * 64 + lane) * 4;
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256) void colsum4_kernel(int M, int N, const float*
   __syncthreads();
   if (rl == 0 && c < N) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) atomicAdd(out + c + q, part[0][q][lane] + part[1][q][lane] + part[2][q][lane] + part[3][q][lane]);
+    for (int q = 0; q < 4; ++q) atomicAdd(out + (c + q) % nmod, part[0][q][lane] + part[1][q][lane] + part[2][q][lane] + part[3][q][lane]);
   }
 }
 
@@ -318,6 +320,17 @@ int colsum_f32(int M, int N, const float* X, int ldx, float* out, int accumulate
   BLVM_REQUIRE(X && out, "colsum: null operand");
   if (!accumulate) BLVM_HIP(hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, stream));
   if (M == 0) return BLVM_OK;
+  int nmod = N;
+  if (N % 4 != 0 && ldx == N && aligned16(X)) {  // dense and narrow (the 30-wide DMoL parameter rows): fold g rows into one
+    const int g = N % 2 == 0 ? 2 : 4;
+    const int tail = M % g;
+    if (tail) {  // the last M % g rows through the scalar kernel
+      hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, 1), dim3(256), 0, stream, tail, N, X + (size_t)(M - tail) * ldx, ldx, out, 64);
+      M -= tail;
+    }
+    if (M == 0) return BLVM_OK;
+    M /= g; N *= g; ldx *= g;
+  }
   if (N % 4 == 0 && ldx % 4 == 0 && aligned16(X)) {
     const int col_blocks = (N / 4 + 63) / 64;
     // every row block ends in one float atomic per column: many row blocks on few columns serialise on the same addresses
@@ -329,7 +342,7 @@ int colsum_f32(int M, int N, const float* X, int ldx, float* out, int accumulate
     if (rows_per_block < 64) rows_per_block = 64;
     rows_per_block = (rows_per_block + 3) / 4 * 4;
     dim3 grid(col_blocks, (M + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL(colsum4_kernel, grid, dim3(256), 0, stream, M, N, X, ldx, out, rows_per_block);
+    hipLaunchKernelGGL(colsum4_kernel, grid, dim3(256), 0, stream, M, N, X, ldx, out, rows_per_block, nmod);
     BLVM_CHECK_LAUNCH("colsum_f32");
     return BLVM_OK;
   }

@@ -661,7 +661,8 @@ def test_wavenet_generate_matches_reference():
     assert tuple(xs.shape) == (3, 4, 1) and torch.isfinite(xs).all()
 
 
-@pytest.mark.parametrize("M,N,ld", [(1000, 192, 192), (84468, 288, 288), (77, 30, 30), (33, 6, 6), (5, 4, 4), (70000, 1920, 1920)])
+@pytest.mark.parametrize("M,N,ld", [(1000, 192, 192), (84468, 288, 288), (77, 30, 30), (33, 6, 6), (5, 4, 4), (70000, 1920, 1920),
+                                    (100001, 30, 30), (64000, 30, 30), (1001, 7, 7), (3, 30, 30)])
 def test_colsum_vectorised_and_fallback_paths(M, N, ld):
     g = torch.Generator().manual_seed(M + N)
     X = torch.randn(M, ld, generator=g)
