@@ -210,7 +210,7 @@ class _DMoLFunction(torch.autograd.Function):
         dW = db = None
         if ctx.has_linear and ctx.needs_input_grad[1]:
             dW = torch.zeros_like(W)
-            gemm(1, 1, F, F, n_frames, d_par, F, dec, F, dW, F, accumulate=True, split_k=256)
+            gemm(1, 1, F, F, n_frames, d_par, F, dec, F, dW, F, accumulate=True, split_k=max(256, min(1024, n_frames // 1024)))
         if ctx.has_linear and ctx.needs_input_grad[2]:
             db = torch.empty_like(b)
             colsum(d_par.view(n_frames, F), db)
@@ -272,7 +272,7 @@ class _GaussHeadFunction(torch.autograd.Function):
         dW = db = None
         if ctx.has_linear and ctx.needs_input_grad[1]:
             dW = torch.zeros_like(W)
-            gemm(1, 1, F, F, n_frames, d_par, F, dec, F, dW, F, accumulate=True, split_k=256)
+            gemm(1, 1, F, F, n_frames, d_par, F, dec, F, dW, F, accumulate=True, split_k=max(256, min(1024, n_frames // 1024)))
         if ctx.has_linear and ctx.needs_input_grad[2]:
             db = torch.empty_like(b)
             colsum(d_par.view(n_frames, F), db)
