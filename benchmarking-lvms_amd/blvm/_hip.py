@@ -31,6 +31,15 @@ class VrnnWeights(ctypes.Structure):
     ]  # fmt: skip
 
 
+class VrnnDecodeWeights(ctypes.Structure):
+    """struct BlvmVrnnDecodeWeights."""
+
+    _fields_ = [
+        ("enc_w", c_void_p * 3), ("enc_b", c_void_p * 3), ("cell", ctypes.POINTER(VrnnWeights)),
+        ("dec_w", c_void_p * 3), ("dec_b", c_void_p * 3), ("lik_w", c_void_p), ("lik_b", c_void_p),
+    ]  # fmt: skip
+
+
 class SrnnWeights(ctypes.Structure):
     """struct BlvmSrnnWeights / BlvmSrnnGrads."""
 
@@ -68,6 +77,8 @@ _SIGNATURES = {
                             c_float, c_void_p, c_void_p, c_void_p]),
     "blvm_kl_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
                             c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "blvm_vrnn_decode_scratch_floats": (c_size_t, [c_int] * 4),
+    "blvm_vrnn_decode": (c_int, [ctypes.POINTER(VrnnDecodeWeights)] + [c_void_p] * 5 + [c_int] * 7 + [c_float] * 3 + [c_void_p] * 4),
     "blvm_vrnn_reserve_floats": (c_size_t, [c_int] * 6),
     "blvm_vrnn_bwd_workspace_floats": (c_size_t, [c_int] * 6),
     "blvm_vrnn_seq_fwd": (c_int, [ctypes.POINTER(VrnnWeights), c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

@@ -248,12 +248,16 @@ class VRNN(nn.Module):
 
     @torch.no_grad()
     def generate(self, x: torch.Tensor, h0: Optional[torch.Tensor] = None, n_samples: int = 1, max_timesteps: int = 100,
-                 stop_value: float = None, use_mode: bool = False, eps: Optional[torch.Tensor] = None):  # fmt: skip
+                 stop_value: float = None, use_mode: bool = False, eps: Optional[torch.Tensor] = None, uniforms=None,
+                 fused: bool = False):  # fmt: skip
         """Autoregressive sampling (vrnn.py:371-434): the previous frame stack is encoded, the cell draws z from its prior and
         updates h, the decoder (on cat[phi_z, h_new] — the UPDATED state here, unlike `forward`) parameterises the next frame
         stack, which is sampled (or its mode taken) and fed back.  x [B,S,1] initial frame stack; returns ((x [B,1+T,S], x_sl), ns).
-        `eps` [T,B,z] optionally supplies the prior noise.  Every step runs the K6 / K1 / K7-head kernels at T' = 1."""
+        `eps` [T,B,z] optionally supplies the prior noise, `uniforms` = (u [T,B,S,K], v [T,B,S]) the sampler's draws.  Every step
+        runs the K6 / K1 / K7-head kernels at T' = 1; `fused=True` (DMoL head, no stop value) runs ALL steps in one launch (K1c)."""
         S, enc_lin, dec_lin, lik = self._plan()
+        if fused:
+            return self._generate_fused(x, h0, n_samples, max_timesteps, stop_value, use_mode, eps, uniforms)
         if x.size(0) > 1:
             assert x.size(0) == n_samples
         else:
@@ -271,7 +275,10 @@ class VRNN(nn.Module):
             h, out = self.vrnn_cell.generate(enc, h.contiguous(), use_mode=False, eps=None if eps is None else eps[t])
             dec = ops.mlp(torch.cat([out.phi_z, h], -1).contiguous(), dec_lin, ops.ACT_LEAKY, ops.LEAKY_SLOPE)  # [B, S*F]
             parameters = lik(dec.view(n_samples, S, lik.out_features))
-            x = lik.mode(parameters) if use_mode else lik.sample(parameters)  # [B,S,1]
+            if use_mode:
+                x = lik.mode(parameters)
+            else:
+                x = lik.sample(parameters) if uniforms is None else lik.sample(parameters, uniforms=(uniforms[0][t], uniforms[1][t]))  # [B,S,1]
             all_x.append(x)
             x_sl += seq_active
             if stop_value is not None:
@@ -281,6 +288,32 @@ class VRNN(nn.Module):
             all_ended = bool(torch.all(1 - seq_active))
         x = torch.cat(all_x, dim=-1).permute(0, 2, 1)
         return (x, x_sl), SimpleNamespace()
+
+
+    @torch.no_grad()
+    def _generate_fused(self, x, h0, n_samples, max_timesteps, stop_value, use_mode, eps, uniforms):
+        S, enc_lin, dec_lin, lik = self._plan()
+        cell = self.vrnn_cell
+        if stop_value is not None or not isinstance(lik, DiscretizedLogisticMixtureDense) or len(enc_lin) != 3 or len(dec_lin) != 3:
+            raise NotImplementedError("libblvm_hip: the one-launch decoder is built for the VRNNAudio(DMoL) structure without a stop value")
+        if x.size(0) == 1:
+            x = x.repeat(n_samples, *[1] * (x.ndim - 1))
+        assert x.size(0) == n_samples
+        dev, T, B = x.device, max_timesteps, n_samples
+        if eps is None:
+            eps = torch.randn(T, B, cell.z_dim, device=dev)
+        if use_mode:
+            u = v = None
+        elif uniforms is None:
+            u = torch.empty(T, B, S, lik.num_mix, device=dev).uniform_(1e-5, 1.0 - 1e-5)
+            v = torch.empty(T, B, S, device=dev).uniform_(1e-8, 1.0 - 1e-8)
+        else:
+            u, v = uniforms[0].reshape(T, B, S, lik.num_mix).to(dev), uniforms[1].reshape(T, B, S).to(dev)
+        slope = next(m.negative_slope for m in self.encoder if isinstance(m, nn.LeakyReLU))
+        xs, _ = ops.vrnn_decode(enc_lin, cell.kernel_params(), dec_lin, lik.params, x.reshape(B, S), h0, eps[:T], u, v, S, cell.h_dim,
+                                cell.z_dim, cell.r_dim, lik.num_mix, cell.prior[6].epsilon, slope, lik.log_epsilon)  # fmt: skip
+        out = torch.cat([x.reshape(B, 1, S), xs], 1)  # [B,1+T,S] like the step-by-step path
+        return (out, torch.full((B,), T + 1, dtype=torch.int)), SimpleNamespace()
 
 
 class VRNNAudio(BaseModel):
@@ -336,8 +369,9 @@ class VRNNAudio(BaseModel):
     def forward(self, x, x_sl, beta: float = 1, free_nats: float = 0, h0=None, eps=None):
         return self.vrnn(x, x_sl, beta, free_nats, h0, eps)
 
-    def generate(self, n_samples: int = 1, max_timesteps: int = 100, use_mode: bool = False, x=None, h0=None, eps=None):
-        """Same arguments as the reference (vrnn.py:529-546)."""
+    def generate(self, n_samples: int = 1, max_timesteps: int = 100, use_mode: bool = False, x=None, h0=None, eps=None, uniforms=None,
+                 fused: bool = False):  # fmt: skip
+        """Same arguments as the reference (vrnn.py:529-546); `fused=True`: every step in one launch (K1c)."""
         x = torch.zeros(n_samples, self.input_size, 1, device=self.device) if x is None else x
         return self.vrnn.generate(n_samples=n_samples, max_timesteps=max_timesteps, stop_value=None, use_mode=use_mode, x=x, h0=h0,
-                                  eps=eps)  # fmt: skip
+                                  eps=eps, uniforms=uniforms, fused=fused)  # fmt: skip

@@ -416,6 +416,39 @@ def _pack_weights(ts: Sequence[Optional[torch.Tensor]]) -> VrnnWeights:
     return w
 
 
+@torch.no_grad()
+def vrnn_decode(enc_lin, cell_params, dec_lin, lik_lin, x0, h0, eps, u, v, S, H, Z, R, num_mix, sd_eps, slope, log_eps):
+    """K1c: T = eps.shape[0] steps of ancestral sampling for all B utterances in one launch.  enc_lin / dec_lin: 3 nn.Linear each;
+    cell_params in `_VRNN_PARAM_ORDER`; lik_lin the DMoL head's Linear.  x0 [B,S], h0 [B,R] or None, eps [T,B,Z],
+    u [T,B,S,num_mix] / v [T,B,S] uniforms (None: the mode).  -> (x [B,T,S], h_n [B,R])."""
+    from ._hip import VrnnDecodeWeights
+
+    lib = load()
+    T, B = eps.shape[0], x0.shape[0]
+    dev = x0.device
+    keep = [_f32c(t) for lin in (*enc_lin, *dec_lin, lik_lin) for t in (lin.weight, lin.bias)]
+    cp = [_f32c(p) for p in cell_params]
+    cw = _pack_weights(cp)
+    w = VrnnDecodeWeights()
+    for i in range(3):
+        w.enc_w[i], w.enc_b[i] = ptr(keep[2 * i]), ptr(keep[2 * i + 1])
+        w.dec_w[i], w.dec_b[i] = ptr(keep[6 + 2 * i]), ptr(keep[6 + 2 * i + 1])
+    w.lik_w, w.lik_b = ptr(keep[12]), ptr(keep[13])
+    import ctypes
+
+    w.cell = ctypes.pointer(cw)
+    x0, eps = _f32c(x0), _f32c(eps)
+    h0 = _f32c(h0) if h0 is not None else None
+    u = _f32c(u) if u is not None else None
+    v = _f32c(v) if v is not None else None
+    scratch = torch.empty(lib.blvm_vrnn_decode_scratch_floats(S, H, Z, R), device=dev, dtype=torch.float32)
+    x = torch.empty(B, T, S, device=dev, dtype=torch.float32)
+    hn = torch.empty(B, R, device=dev, dtype=torch.float32)
+    check(lib.blvm_vrnn_decode(ctypes.byref(w), ptr(x0), ptr(h0), ptr(eps), ptr(u), ptr(v), T, B, S, H, Z, R, num_mix, sd_eps, slope,
+                               log_eps, ptr(x), ptr(hn), ptr(scratch), stream_ptr()), "blvm_vrnn_decode")  # fmt: skip
+    return x, hn
+
+
 class _VRNNSeqFunction(torch.autograd.Function):
     """(enc, h0, eps, 28 params) -> decin [T'+1,B,H+R], kld [B], kld_fn [B]  (+ non-differentiable mu/sd/z)."""
 

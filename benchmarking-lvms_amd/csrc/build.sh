@@ -6,5 +6,5 @@ OUT="$HERE/../blvm/lib"
 mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I"$HERE/../../include" \
-  -o "$OUT/libblvm_hip.so" "$HERE"/core.hip "$HERE"/gemm.hip "$HERE"/dmol.hip "$HERE"/kl.hip "$HERE"/vrnn.hip "$HERE"/rnn.hip "$HERE"/srnn.hip "$HERE"/wavenet.hip "$HERE"/wavenet_decode.hip "$HERE"/rssm.hip "$HERE"/convcoder.hip
+  -o "$OUT/libblvm_hip.so" "$HERE"/core.hip "$HERE"/gemm.hip "$HERE"/dmol.hip "$HERE"/kl.hip "$HERE"/vrnn.hip "$HERE"/vrnn_decode.hip "$HERE"/rnn.hip "$HERE"/srnn.hip "$HERE"/wavenet.hip "$HERE"/wavenet_decode.hip "$HERE"/rssm.hip "$HERE"/convcoder.hip
 echo "built $OUT/libblvm_hip.so"

@@ -1,0 +1,433 @@
+// vrnn_decode.hip — K1c: ancestral sampling from VRNNAudio, every step of every utterance in ONE launch.
+//
+// Replaces the Python loop of VRNN.generate (blvm/models/vrnn.py:371-434): per step  enc = encoder(x_t)  ->  cell in
+// prior-sampling mode (VRNNCell.generate, vrnn.py:143-164: prior MLP -> (mu, softplus sd) -> z = mu + sd eps -> phi_z MLP ->
+// GRU([enc, phi_z], h))  ->  decoder(cat[phi_z, h_new])  ->  DMoL head per sample  ->  sample  ->  x_{t+1}.
+// That is 17 dependent matrix-vector products per step with M = the batch; launched one by one a step costs ~0.45 ms of host
+// and dispatch time for 12.5 MB of weights.  Here a workgroup owns 16 utterances (the M of v_mfma_f32_16x16x4_f32), keeps
+// every activation in LDS and walks the layers itself: the only traffic is the weight stream (T16 operand layout: one
+// contiguous 1 KB read per fragment), the noise and the samples — the decode step is bound by how fast one CU ingests weights.
+#include "common.h"
+
+namespace blvm {
+namespace {
+
+constexpr int VD_ROWS = 16, VD_NW = 8, VD_CHUNK = 8;  // utterances per workgroup, waves, samples per decoder chunk
+constexpr int VD_F = 30, VD_K = 10;                   // DMoL head: 3 * num_mix parameters per sample
+
+struct VDArgs {
+  // T16 operand copies (common.h) and the biases
+  const float *enc_w[3], *enc_b[3];
+  const float *prior_w[3], *prior_b[3], *prior_hw, *prior_hb;
+  const float *phi_w[4], *phi_b[4];
+  const float *wih, *whh, *bih, *bhh;
+  const float *dec_w[3], *dec_b[3];
+  const float *lik_w, *lik_b;  // [30,30] row-major, [30]
+  const float *x0, *h0, *eps, *u, *v;
+  float *x_out, *h_out;
+  int T, B, S, H, Z, R;
+  float sd_eps, beta, slope, log_eps;
+};
+
+__device__ __forceinline__ float leaky(float x, float slope) { return x > 0.f ? x : x * slope; }
+
+__global__ __launch_bounds__(VD_NW * 64) void vrnn_decode_kernel(VDArgs a) {
+  extern __shared__ __align__(16) float smem[];
+  const int S = a.S, H = a.H, Z = a.Z, R = a.R, B = a.B;
+  const int ldS = S + 4, ldH = H + 4, ldZ = Z + 4, ldR = R + 4, ldD = VD_CHUNK * VD_F + 4;
+  float* sX = smem;                      // [16][S]   current frame stack
+  float* sEnc = sX + VD_ROWS * ldS;      // [16][H]   encoder output (GRU input)
+  float* sH = sEnc + VD_ROWS * ldH;      // [16][R]   recurrent state
+  float* sT0 = sH + VD_ROWS * ldR;       // [16][H]   ping
+  float* sT1 = sT0 + VD_ROWS * ldH;      // [16][H]   pong
+  float* sZ = sT1 + VD_ROWS * ldH;       // [16][Z]
+  float* sPhi = sZ + VD_ROWS * ldZ;      // [16][H]
+  float* sDec = sPhi + VD_ROWS * ldH;    // [16][8*30] one chunk of the decoder's last layer
+  float* sLik = sDec + VD_ROWS * ldD;    // head Linear [30,30] zero-padded to [32,32] in the T16 operand layout (1024) + bias (32)
+  float* sPar = sLik + 1024 + 32;        // [16*8][32] head outputs of a chunk
+
+  const int tid = threadIdx.x, lane = tid & 63, q = lane >> 4, cc = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform for the compiler too: the item bookkeeping stays scalar
+  const int b0 = blockIdx.x * VD_ROWS;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  for (int i = tid; i < VD_ROWS * S; i += VD_NW * 64) {
+    const int r = i / S, c = i - r * S;
+    sX[r * ldS + c] = b0 + r < B ? a.x0[(size_t)(b0 + r) * S + c] : 0.f;
+  }
+  for (int i = tid; i < VD_ROWS * R; i += VD_NW * 64) {
+    const int r = i / R, c = i - r * R;
+    sH[r * ldR + c] = (a.h0 != nullptr && b0 + r < B) ? a.h0[(size_t)(b0 + r) * R + c] : 0.f;
+  }
+  for (int i = tid; i < 1024 + 32; i += VD_NW * 64) {
+    float val = 0.f;
+    if (i < 1024) {  // block (o / 16, k / 16), fragment of lane (o % 16) + 16 ((k % 16) / 4), element k % 4
+      const int e = i & 3, ln = (i >> 2) & 63, blk = i >> 8;
+      const int o = (blk >> 1) * 16 + (ln & 15), k = (blk & 1) * 16 + 4 * (ln >> 4) + e;
+      if (o < VD_F && k < VD_F) val = a.lik_w[o * VD_F + k];
+    } else if (i - 1024 < VD_F) {
+      val = a.lik_b[i - 1024];
+    }
+    sLik[i] = val;
+  }
+  for (int i = tid; i < VD_ROWS * 4; i += VD_NW * 64) sDec[(i >> 2) * ldD + VD_CHUNK * VD_F + (i & 3)] = 0.f;  // the k = 30, 31 padding reads
+  __syncthreads();
+
+  // ---- the weight stream.  A layer is, per wave, a flat list of ITEMS = (column tile, input segment, batch of <= 16 k-chunks):
+  // the 16 KB of weight fragments of the NEXT item are requested while the current item runs on the matrix pipe (two register
+  // sets that swap roles by position in the loop body), across tile and segment boundaries alike — with one wave per SIMD
+  // nothing else hides the latency of a read that misses L2.
+  constexpr int NB = 8;  // k-chunks per item
+  struct Item { const float* W; const float* A; int n, acc; bool last; int tile; };
+  auto fetch = [&](float4 (&w)[NB], const Item& I) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) w[j] = j < I.n ? *reinterpret_cast<const float4*>(I.W + 256 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto mac = [&](const float4 (&w)[NB], const Item& I, f32x4& acc) {
+    // unconditional: chunks beyond I.n carry zero weights (fetch) and re-read the item's last valid chunk, so the LDS reads
+    // of the whole item can be issued ahead of its MFMAs; two accumulator chains
+    float4 x[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) x[j] = *reinterpret_cast<const float4*>(I.A + 16 * (j < I.n ? j : I.n - 1));
+    f32x4 c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NB; j += 2) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j].x, w[j].x, acc, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j + 1].x, w[j + 1].x, c1, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j].y, w[j].y, acc, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j + 1].y, w[j + 1].y, c1, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j].z, w[j].z, acc, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j + 1].z, w[j + 1].z, c1, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j].w, w[j].w, acc, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j + 1].w, w[j + 1].w, c1, 0, 0, 0);
+    }
+    acc += c1;
+  };
+  f32x4 acc[6];
+  auto mac_sel = [&](const float4 (&w)[NB], const Item& I) {
+    switch (I.acc) {  // wave-uniform: keeps the accumulators in registers
+      case 0: mac(w, I, acc[0]); break;
+      case 1: mac(w, I, acc[1]); break;
+      case 2: mac(w, I, acc[2]); break;
+      case 3: mac(w, I, acc[3]); break;
+      case 4: mac(w, I, acc[4]); break;
+      default: mac(w, I, acc[5]); break;
+    }
+  };
+  auto run = [&](int nit, auto item, auto epi) {
+    float4 w0[NB], w1[NB];
+#pragma unroll
+    for (int g = 0; g < 6; ++g) acc[g] = zero4;
+    if (nit > 0) {
+      Item I0 = item(0), I1 = I0;
+      fetch(w0, I0);
+      for (int it = 0; it < nit; it += 2) {
+        const bool two = it + 1 < nit;
+        if (two) { I1 = item(it + 1); fetch(w1, I1); }
+        mac_sel(w0, I0);
+        if (I0.last) epi(I0.tile);
+        if (it + 2 < nit) { I0 = item(it + 2); fetch(w0, I0); }
+        if (two) {
+          mac_sel(w1, I1);
+          if (I1.last) epi(I1.tile);
+        }
+      }
+    }
+    __syncthreads();
+  };
+  const int a_off = (lane & 15), a_q = 4 * q;  // A fragment: row lane & 15, k = 4 (lane >> 4) .. + 3 of a chunk
+  // items of a plain layer: tiles of this wave x segments (in0 | in1) x batches of 256 k
+  auto dense = [&](int N, const float* W, const float* bias, const float* in0, int ld0, int K0, const float* in1, int ld1, int K1,
+                   float* out, int ldo, float slope) {
+    const int Kt = K0 + K1, nb0 = (K0 + 16 * NB - 1) / (16 * NB), nb1 = (K1 + 16 * NB - 1) / (16 * NB), ipt = nb0 + nb1;
+    const int my_tiles = (N / 16 - wave + VD_NW - 1) / VD_NW;
+    auto item = [&](int it) {
+      Item I;
+      const int ti = it / ipt, r = it - ti * ipt;
+      I.tile = wave + ti * VD_NW;
+      const bool second = r >= nb0;
+      const int kb = second ? r - nb0 : r, Ks = second ? K1 : K0;
+      const int k0 = kb * 16 * NB;
+      I.n = (Ks - k0 < 16 * NB ? Ks - k0 : 16 * NB) / 16;
+      I.W = W + (size_t)I.tile * 16 * Kt + (size_t)((second ? K0 : 0) + k0) * 16 + 4 * lane;
+      I.A = (second ? in1 + a_off * ld1 : in0 + a_off * ld0) + a_q + k0;
+      I.acc = 0;
+      I.last = r == ipt - 1;
+      return I;
+    };
+    run(my_tiles > 0 ? my_tiles * ipt : 0, item, [&](int tile) {
+      const float bv = bias[tile * 16 + cc];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(4 * q + r) * ldo + tile * 16 + cc] = leaky(acc[0][r] + bv, slope);
+      acc[0] = zero4;
+    });
+  };
+
+#ifdef VD_PROF
+  long long tk = __builtin_readcyclecounter(), ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define VD_TICK(k) { const long long n__ = __builtin_readcyclecounter(); ph[k] += n__ - tk; tk = n__; }
+#else
+#define VD_TICK(k)
+#endif
+  for (int t = 0; t < a.T; ++t) {
+    // encoder: 3 x (Linear + LeakyReLU)
+    dense(H, a.enc_w[0], a.enc_b[0], sX, ldS, S, nullptr, 0, 0, sT0, ldH, a.slope);
+    dense(H, a.enc_w[1], a.enc_b[1], sT0, ldH, H, nullptr, 0, 0, sT1, ldH, a.slope);
+    dense(H, a.enc_w[2], a.enc_b[2], sT1, ldH, H, nullptr, 0, 0, sEnc, ldH, a.slope);
+    VD_TICK(0)
+    // prior: 3 x (Linear + ReLU), Gaussian head, z = mu + sd * eps
+    dense(H, a.prior_w[0], a.prior_b[0], sH, ldR, R, nullptr, 0, 0, sT0, ldH, 0.f);
+    dense(H, a.prior_w[1], a.prior_b[1], sT0, ldH, H, nullptr, 0, 0, sT1, ldH, 0.f);
+    dense(H, a.prior_w[2], a.prior_b[2], sT1, ldH, H, nullptr, 0, 0, sT0, ldH, 0.f);
+    {  // head: mean tile (acc 0) and raw-scale tile (acc 1) of the same columns
+      const int nbh = (H + 16 * NB - 1) / (16 * NB), ipt = 2 * nbh;
+      const int my_tiles = (Z / 16 - wave + VD_NW - 1) / VD_NW;
+      auto item = [&](int it) {
+        Item I;
+        const int ti = it / ipt, r = it - ti * ipt;
+        I.tile = wave + ti * VD_NW;
+        const int half = r / nbh, kb = r - half * nbh, k0 = kb * 16 * NB;
+        I.n = (H - k0 < 16 * NB ? H - k0 : 16 * NB) / 16;
+        I.W = a.prior_hw + (size_t)(half * Z + I.tile * 16) * H + (size_t)k0 * 16 + 4 * lane;
+        I.A = sT0 + a_off * ldH + a_q + k0;
+        I.acc = half;
+        I.last = r == ipt - 1;
+        return I;
+      };
+      run(my_tiles > 0 ? my_tiles * ipt : 0, item, [&](int tile) {
+        const int col = tile * 16 + cc;
+        const float bm = a.prior_hb[col], br = a.prior_hb[Z + col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = b0 + 4 * q + r < B ? a.eps[((size_t)t * B + b0 + 4 * q + r) * Z + col] : 0.f;
+          const float sd = softplus_beta(acc[1][r] + br, a.beta, 1.f / a.beta) + a.sd_eps;
+          sZ[(4 * q + r) * ldZ + col] = e * sd + (acc[0][r] + bm);
+        }
+        acc[0] = zero4; acc[1] = zero4;
+      });
+    }
+    VD_TICK(1)
+    // phi_z: 4 x (Linear + ReLU)
+    dense(H, a.phi_w[0], a.phi_b[0], sZ, ldZ, Z, nullptr, 0, 0, sT1, ldH, 0.f);
+    dense(H, a.phi_w[1], a.phi_b[1], sT1, ldH, H, nullptr, 0, 0, sT0, ldH, 0.f);
+    dense(H, a.phi_w[2], a.phi_b[2], sT0, ldH, H, nullptr, 0, 0, sT1, ldH, 0.f);
+    dense(H, a.phi_w[3], a.phi_b[3], sT1, ldH, H, nullptr, 0, 0, sPhi, ldH, 0.f);
+    VD_TICK(2)
+    // GRU on cat[enc, phi_z] and h: per column tile 3 gates x (input projection over [enc | phi], hidden projection over h);
+    // the new state stays in registers until every wave has read the old one
+    {
+      const int KI = 2 * H;  // X = H in VRNNAudio
+      const int nbi = (H + 16 * NB - 1) / (16 * NB), nbh = (R + 16 * NB - 1) / (16 * NB), ipg = 2 * nbi + nbh, ipt = 3 * ipg;
+      const int my_tiles = (R / 16 - wave + VD_NW - 1) / VD_NW;
+      float hn[4][4];
+      auto item = [&](int it) {
+        Item I;
+        const int ti = it / ipt, r = it - ti * ipt, g = r / ipg, p = r - g * ipg;
+        I.tile = wave + ti * VD_NW;
+        const size_t wrow = (size_t)(g * R + I.tile * 16);
+        if (p < 2 * nbi) {  // input projection: enc then phi
+          const int seg = p / nbi, kb = p - seg * nbi, k0 = kb * 16 * NB;
+          I.n = (H - k0 < 16 * NB ? H - k0 : 16 * NB) / 16;
+          I.W = a.wih + wrow * KI + (size_t)(seg * H + k0) * 16 + 4 * lane;
+          I.A = (seg ? sPhi : sEnc) + a_off * ldH + a_q + k0;
+          I.acc = g;
+        } else {
+          const int kb = p - 2 * nbi, k0 = kb * 16 * NB;
+          I.n = (R - k0 < 16 * NB ? R - k0 : 16 * NB) / 16;
+          I.W = a.whh + wrow * R + (size_t)k0 * 16 + 4 * lane;
+          I.A = sH + a_off * ldR + a_q + k0;
+          I.acc = 3 + g;
+        }
+        I.last = r == ipt - 1;
+        return I;
+      };
+      int nt = 0;
+      // no barrier inside run() may separate the last read of sH from its update: run() ends with one
+      run(my_tiles > 0 ? my_tiles * ipt : 0, item, [&](int tile) {
+        const int col = tile * 16 + cc;
+        const float bir = a.bih[col], biu = a.bih[R + col], bin = a.bih[2 * R + col];
+        const float bhr = a.bhh[col], bhu = a.bhh[R + col], bhn = a.bhh[2 * R + col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float rg = sigmoidf_(acc[0][r] + bir + acc[3][r] + bhr);
+          const float ug = sigmoidf_(acc[1][r] + biu + acc[4][r] + bhu);
+          const float ng = tanhf(acc[2][r] + bin + rg * (acc[5][r] + bhn));
+          const float hv = (1.f - ug) * ng + ug * sH[(4 * q + r) * ldR + col];
+          switch (nt) {  // static register indices
+            case 0: hn[0][r] = hv; break;
+            case 1: hn[1][r] = hv; break;
+            case 2: hn[2][r] = hv; break;
+            default: hn[3][r] = hv; break;
+          }
+        }
+        ++nt;
+#pragma unroll
+        for (int g = 0; g < 6; ++g) acc[g] = zero4;
+      });
+      nt = 0;
+      for (int tile = wave; tile < R / 16; tile += VD_NW, ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float hv;
+          switch (nt) { case 0: hv = hn[0][r]; break; case 1: hv = hn[1][r]; break; case 2: hv = hn[2][r]; break; default: hv = hn[3][r]; break; }
+          sH[(4 * q + r) * ldR + tile * 16 + cc] = hv;
+        }
+      __syncthreads();
+    }
+    VD_TICK(3)
+    // decoder on cat[phi_z, h_new]: 2 hidden layers, then the last layer in chunks of 8 samples with the head and the draw
+    dense(H, a.dec_w[0], a.dec_b[0], sPhi, ldH, H, sH, ldR, R, sT0, ldH, a.slope);
+    dense(H, a.dec_w[1], a.dec_b[1], sT0, ldH, H, nullptr, 0, 0, sT1, ldH, a.slope);
+    VD_TICK(4)
+    for (int ch = 0; ch < S / VD_CHUNK; ++ch) {
+      const int c0 = ch * VD_CHUNK * VD_F;  // first output column of the chunk (240 per chunk: a multiple of 16)
+      dense(VD_CHUNK * VD_F, a.dec_w[2] + (size_t)c0 * H, a.dec_b[2] + c0, sT1, ldH, H, nullptr, 0, 0, sDec, ldD, a.slope);
+      VD_TICK(5)
+      // the sampler's draws of this chunk travel while the head runs
+      float uu[VD_K], vv = 0.5f;
+      if (tid < VD_ROWS * VD_CHUNK) {
+        const int r = tid / VD_CHUNK, sm = tid - r * VD_CHUNK;
+        const size_t f = ((size_t)t * B + (b0 + r < B ? b0 + r : 0)) * S + ch * VD_CHUNK + sm;
+        if (a.u != nullptr) {
+#pragma unroll
+          for (int m = 0; m < VD_K; ++m) uu[m] = a.u[f * VD_K + m];
+          vv = a.v[f];
+        }
+      }
+      // head Linear [30,30] per (utterance, sample) on the matrix pipe: K and N padded to 32 with zero weights; (sample, column
+      // tile) pairs over the waves.  A fragments start at 30 sm + 16 j + 4 q floats: 8-byte aligned
+      for (int w2 = wave; w2 < VD_CHUNK * 2; w2 += VD_NW) {
+        const int sm = w2 >> 1, ct = w2 & 1;
+        f32x4 c = zero4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float* ap = sDec + (lane & 15) * ldD + sm * VD_F + 16 * j + 4 * q;
+          const float2 x01 = *reinterpret_cast<const float2*>(ap), x23 = *reinterpret_cast<const float2*>(ap + 2);
+          const float4 wf = *reinterpret_cast<const float4*>(sLik + ((ct * 2 + j) * 64 + lane) * 4);
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(x01.x, wf.x, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(x01.y, wf.y, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(x23.x, wf.z, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(x23.y, wf.w, c, 0, 0, 0);
+        }
+        const float bv = sLik[1024 + ct * 16 + cc];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sPar[((4 * q + r) * VD_CHUNK + sm) * 32 + ct * 16 + cc] = c[r] + bv;
+      }
+      __syncthreads();
+      if (tid < VD_ROWS * VD_CHUNK) {  // Gumbel-max component pick + clamped logistic draw (as mix_sample_kernel, dmol.hip)
+        const int r = tid / VD_CHUNK, sm = tid - r * VD_CHUNK, s_idx = ch * VD_CHUNK + sm;
+        if (b0 + r < B) {
+          const float* p = sPar + tid * 32;
+          const size_t f = ((size_t)t * B + b0 + r) * S + s_idx;
+          int best = 0;
+          float bvv = -INFINITY;
+          for (int m = 0; m < VD_K; ++m) {
+            float sc = p[m];
+            if (a.u != nullptr) sc -= logf(-logf(uu[m]));
+            if (sc > bvv) { bvv = sc; best = m; }
+          }
+          float x = p[VD_K + best];
+          if (a.v != nullptr) {
+            x += expf(fmaxf(p[2 * VD_K + best], a.log_eps)) * (logf(vv) - logf(1.f - vv));
+            x = fminf(fmaxf(x, -1.f), 1.f);
+          }
+          a.x_out[((size_t)(b0 + r) * a.T + t) * S + s_idx] = x;
+          sX[r * ldS + s_idx] = x;
+        }
+      }
+      __syncthreads();
+      VD_TICK(6)
+    }
+  }
+
+  if (a.h_out != nullptr)
+    for (int i = tid; i < VD_ROWS * R; i += VD_NW * 64) {
+      const int r = i / R, c = i - r * R;
+      if (b0 + r < B) a.h_out[(size_t)(b0 + r) * R + c] = sH[r * ldR + c];
+    }
+#ifdef VD_PROF
+  __syncthreads();
+  if (blockIdx.x == 0 && tid == 0 && a.h_out != nullptr)
+    for (int k = 0; k < 7; ++k) a.h_out[k] = (float)(ph[k] / 1000);
+#endif
+}
+
+size_t vd_lds_bytes(int S, int H, int Z, int R) {
+  return sizeof(float) * ((size_t)VD_ROWS * ((S + 4) + 4 * (H + 4) + (R + 4) + (Z + 4) + (VD_CHUNK * VD_F + 4)) + 1024 + 32 + VD_ROWS * VD_CHUNK * 32);
+}
+
+struct VdPack { size_t enc[3], prior[3], prior_h, phi[4], wih, whh, dec[3], total; };
+VdPack vd_pack_layout(int S, int H, int Z, int R) {
+  VdPack p;
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t at = o; o += (n + 3) & ~(size_t)3; return at; };
+  p.enc[0] = take((size_t)H * S); p.enc[1] = take((size_t)H * H); p.enc[2] = take((size_t)H * H);
+  p.prior[0] = take((size_t)H * R); p.prior[1] = take((size_t)H * H); p.prior[2] = take((size_t)H * H);
+  p.prior_h = take((size_t)2 * Z * H);
+  p.phi[0] = take((size_t)H * Z);
+  for (int i = 1; i < 4; ++i) p.phi[i] = take((size_t)H * H);
+  p.wih = take((size_t)3 * R * 2 * H); p.whh = take((size_t)3 * R * R);
+  p.dec[0] = take((size_t)H * (H + R)); p.dec[1] = take((size_t)H * H); p.dec[2] = take((size_t)S * VD_F * H);
+  p.total = o;
+  return p;
+}
+
+}  // namespace
+}  // namespace blvm
+
+using namespace blvm;
+
+extern "C" size_t blvm_vrnn_decode_scratch_floats(int S, int H, int Z, int R) {
+  if (S <= 0 || H <= 0 || Z <= 0 || R <= 0) return 0;
+  return vd_pack_layout(S, H, Z, R).total;
+}
+
+extern "C" int blvm_vrnn_decode(const BlvmVrnnDecodeWeights* w, const float* x0, const float* h0, const float* eps, const float* u,
+                                const float* v, int T, int B, int S, int H, int Z, int R, int num_mix, float sd_eps, float slope,
+                                float log_eps, float* x_out, float* h_out, float* scratch, void* stream_) {
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  BLVM_REQUIRE(w && w->cell && x0 && eps && x_out && scratch, "vrnn_decode: null pointer");
+  BLVM_REQUIRE(T >= 0 && B > 0, "vrnn_decode: bad T=%d B=%d", T, B);
+  BLVM_REQUIRE(S % 16 == 0 && H % 16 == 0 && Z % 16 == 0 && R % 16 == 0 && S > 0 && H > 0 && Z > 0 && R > 0,
+               "vrnn_decode: S, H, Z, R must be positive multiples of 16 (got %d, %d, %d, %d)", S, H, Z, R);
+  BLVM_REQUIRE(num_mix == VD_K, "vrnn_decode: the DMoL head has %d components", VD_K);
+  BLVM_REQUIRE((R / 16 + VD_NW - 1) / VD_NW <= 4, "vrnn_decode: recurrent size %d too large", R);
+  BLVM_REQUIRE((u == nullptr) == (v == nullptr), "vrnn_decode: u and v are given together (both NULL: the mode)");
+  BLVM_REQUIRE(aligned16(scratch), "vrnn_decode: scratch must be 16-byte aligned");
+  const size_t lds = vd_lds_bytes(S, H, Z, R);
+  BLVM_REQUIRE(lds <= 160 * 1024, "vrnn_decode: S=%d H=%d Z=%d R=%d need %zu bytes of LDS (> 160 KB)", S, H, Z, R, lds);
+  if (T == 0) return BLVM_OK;
+  const BlvmVrnnWeights* c = w->cell;
+  const VdPack p = vd_pack_layout(S, H, Z, R);
+  VDArgs a{};
+  int rc;
+#define PACK(dst, src, ld, rows, k)                               \
+  do {                                                            \
+    rc = t16_pack_rows(src, ld, rows, k, scratch + (dst), s);     \
+    if (rc) return rc;                                            \
+  } while (0)
+  PACK(p.enc[0], w->enc_w[0], S, H, S); PACK(p.enc[1], w->enc_w[1], H, H, H); PACK(p.enc[2], w->enc_w[2], H, H, H);
+  PACK(p.prior[0], c->prior_w[0], R, H, R); PACK(p.prior[1], c->prior_w[1], H, H, H); PACK(p.prior[2], c->prior_w[2], H, H, H);
+  PACK(p.prior_h, c->prior_hw, H, 2 * Z, H);
+  PACK(p.phi[0], c->phi_w[0], Z, H, Z);
+  for (int i = 1; i < 4; ++i) PACK(p.phi[i], c->phi_w[i], H, H, H);
+  PACK(p.wih, c->gru_wih, 2 * H, 3 * R, 2 * H); PACK(p.whh, c->gru_whh, R, 3 * R, R);
+  PACK(p.dec[0], w->dec_w[0], H + R, H, H + R); PACK(p.dec[1], w->dec_w[1], H, H, H); PACK(p.dec[2], w->dec_w[2], H, S * VD_F, H);
+#undef PACK
+  for (int i = 0; i < 3; ++i) {
+    a.enc_w[i] = scratch + p.enc[i]; a.enc_b[i] = w->enc_b[i];
+    a.prior_w[i] = scratch + p.prior[i]; a.prior_b[i] = c->prior_b[i];
+    a.dec_w[i] = scratch + p.dec[i]; a.dec_b[i] = w->dec_b[i];
+  }
+  for (int i = 0; i < 4; ++i) { a.phi_w[i] = scratch + p.phi[i]; a.phi_b[i] = c->phi_b[i]; }
+  a.prior_hw = scratch + p.prior_h; a.prior_hb = c->prior_hb;
+  a.wih = scratch + p.wih; a.whh = scratch + p.whh; a.bih = c->gru_bih; a.bhh = c->gru_bhh;
+  a.lik_w = w->lik_w; a.lik_b = w->lik_b;
+  a.x0 = x0; a.h0 = h0; a.eps = eps; a.u = u; a.v = v; a.x_out = x_out; a.h_out = h_out;
+  a.T = T; a.B = B; a.S = S; a.H = H; a.Z = Z; a.R = R;
+  a.sd_eps = sd_eps; a.beta = (float)(0.6931471805599453 / (1.0 - (double)sd_eps)); a.slope = slope; a.log_eps = log_eps;
+  BLVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vrnn_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(vrnn_decode_kernel, dim3((unsigned)((B + VD_ROWS - 1) / VD_ROWS)), dim3(VD_NW * 64), lds, s, a);
+  BLVM_CHECK_LAUNCH("vrnn_decode");
+  return BLVM_OK;
+}

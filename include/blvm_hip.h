@@ -162,6 +162,24 @@ typedef struct BlvmVrnnGrads { /* same shapes as the weights; ACCUMULATED into (
   float *gru_wih, *gru_whh, *gru_bih, *gru_bhh;
 } BlvmVrnnGrads;
 
+/* K1c  Ancestral sampling from VRNNAudio: every step of every utterance in ONE launch.  Replaces the loop of `VRNN.generate`
+ *   (`blvm/models/vrnn.py:371-434`): enc = encoder(x_t) -> `VRNNCell.generate` (`vrnn.py:143-164`: prior -> z = mu + sd eps ->
+ *   phi_z -> GRU) -> decoder(cat[phi_z, h_new]) -> DMoL head per sample -> draw -> x_{t+1}.  All weights in their PyTorch layouts;
+ *   the encoder / decoder are 3 x (Linear + LeakyReLU(slope)) as in `vrnn.py:487-505`, x_dim = H.
+ *   x0 [B,S] first frame stack; h0 [B,R] or NULL (zeros); eps [T,B,Z] standard normal; u [T,B,S,num_mix], v [T,B,S] uniforms of the
+ *   DMoL sampler as in blvm_mix_sample (both NULL: the mode); x_out [B,T,S]; h_out [B,R] or NULL.
+ *   scratch: blvm_vrnn_decode_scratch_floats(...) floats (operand-layout copies of the weights). */
+typedef struct BlvmVrnnDecodeWeights {
+  const float *enc_w[3], *enc_b[3]; /* [H,S], [H,H], [H,H] */
+  const BlvmVrnnWeights* cell;      /* prior_*, phi_*, gru_* are read (the posterior is not evaluated when z comes from the prior) */
+  const float *dec_w[3], *dec_b[3]; /* [H,H+R] (input order cat[phi_z, h]), [H,H], [S*3*num_mix,H] */
+  const float *lik_w, *lik_b;       /* [3*num_mix, 3*num_mix], [3*num_mix]: the head's Linear, applied per sample */
+} BlvmVrnnDecodeWeights;
+size_t blvm_vrnn_decode_scratch_floats(int S, int H, int Z, int R);
+int blvm_vrnn_decode(const BlvmVrnnDecodeWeights* w, const float* x0, const float* h0, const float* eps, const float* u,
+                     const float* v, int T, int B, int S, int H, int Z, int R, int num_mix, float sd_eps, float slope,
+                     float log_eps, float* x_out, float* h_out, float* scratch, void* stream);
+
 /* number of floats of `reserve` (activations kept for BPTT) / `workspace` (backward scratch). */
 size_t blvm_vrnn_reserve_floats(int Tp, int B, int X, int H, int Z, int R);
 size_t blvm_vrnn_bwd_workspace_floats(int Tp, int B, int X, int H, int Z, int R);

@@ -823,3 +823,23 @@ def test_upload_i32_carries_host_integers_in_kernel_arguments(n):
     d = ops.upload_i32(h.to(torch.int32), DEV)
     assert d.dtype == torch.int32 and d.device.type == "cuda"
     assert torch.equal(d.cpu(), h.to(torch.int32))
+
+
+@pytest.mark.parametrize("B,S,Hd,Z,use_mode", [(5, 16, 64, 32, False), (19, 64, 128, 48, False), (3, 16, 64, 32, True)])
+def test_vrnn_one_launch_decoder_matches_stepwise_generation(B, S, Hd, Z, use_mode):
+    """K1c (all steps of ancestral sampling in one launch) against the step-by-step `generate` on the same prior noise and sampler
+    draws: partial 16-utterance groups, two workgroups, the mode."""
+    torch.manual_seed(B + S)
+    m = VRNNAudio(likelihood="DMoL", input_size=S, hidden_size=Hd, latent_size=Z, residual_posterior=True).to(DEV)
+    T_ = 5
+    g = torch.Generator().manual_seed(3)
+    eps = torch.randn(T_, B, Z, generator=g).to(DEV)
+    u = torch.empty(T_, B, S, 10).uniform_(1e-5, 1 - 1e-5, generator=g).to(DEV)
+    v = torch.empty(T_, B, S).uniform_(1e-8, 1 - 1e-8, generator=g).to(DEV)
+    x0 = (torch.rand(B, S, 1, generator=g) * 0.2 - 0.1).to(DEV)
+    (a, a_sl), _ = m.generate(n_samples=B, max_timesteps=T_, x=x0, eps=eps, uniforms=(u, v), use_mode=use_mode)
+    (b, b_sl), _ = m.generate(n_samples=B, max_timesteps=T_, x=x0, eps=eps, uniforms=(u, v), use_mode=use_mode, fused=True)
+    assert tuple(a.shape) == tuple(b.shape) == (B, T_ + 1, S) and torch.equal(a_sl, b_sl)
+    assert torch.isfinite(b).all()
+    # a Gumbel-max tie or a sample on the clamp can flip an element; everything else agrees to fp32 round-off of the chain
+    assert float(((a - b).abs() > 2e-4).float().mean()) < 0.02, (a - b).abs().max()
