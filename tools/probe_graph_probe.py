@@ -1,0 +1,24 @@
+import os, sys, time, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "benchmarking-lvms_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+from blvm.models import VRNNAudio
+import blvm_oracle as O
+torch.manual_seed(0)
+m = VRNNAudio(likelihood="DMoL", input_size=64, hidden_size=256, latent_size=256, residual_posterior=True).cuda()
+x, x_sl = O.synth_batch(64, 16000, seed=0)
+x = x.cuda()
+def step(bwd):
+    loss, _, _ = m(x, x_sl)
+    if bwd:
+        m.zero_grad(set_to_none=True)
+        loss.backward()
+for bwd in (False, True):
+    for _ in range(4): step(bwd)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 8
+    for _ in range(n): step(bwd)
+    t_host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    print(f"graphs={os.environ.get('BLVM_GRAPHS', '1')} bwd={bwd}: host enqueue {t_host / n * 1e3:.2f} ms/step, total {t_all / n * 1e3:.2f} ms/step", flush=True)
