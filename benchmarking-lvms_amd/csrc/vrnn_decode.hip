@@ -80,15 +80,18 @@ __global__ __launch_bounds__(VD_NW * 64) void vrnn_decode_kernel(VDArgs a) {
   constexpr int NB = 8;  // k-chunks per item
   struct Item { const float* W; const float* A; int n, acc; bool last; int tile; };
   auto fetch = [&](float4 (&w)[NB], const Item& I) {
+    // unconditional loads (chunks beyond I.n re-read the last valid one; their A fragments are zeroed instead): the compiler
+    // can then count the loads in flight, and the wait before an item's MFMAs leaves the NEXT item's loads outstanding
 #pragma unroll
-    for (int j = 0; j < NB; ++j) w[j] = j < I.n ? *reinterpret_cast<const float4*>(I.W + 256 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < NB; ++j) w[j] = *reinterpret_cast<const float4*>(I.W + 256 * (j < I.n ? j : I.n - 1));
   };
   auto mac = [&](const float4 (&w)[NB], const Item& I, f32x4& acc) {
-    // unconditional: chunks beyond I.n carry zero weights (fetch) and re-read the item's last valid chunk, so the LDS reads
-    // of the whole item can be issued ahead of its MFMAs; two accumulator chains
     float4 x[NB];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) x[j] = *reinterpret_cast<const float4*>(I.A + 16 * (j < I.n ? j : I.n - 1));
+    for (int j = 0; j < NB; ++j) {
+      x[j] = *reinterpret_cast<const float4*>(I.A + 16 * (j < I.n ? j : I.n - 1));
+      if (j >= I.n) x[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     f32x4 c1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < NB; j += 2) {
