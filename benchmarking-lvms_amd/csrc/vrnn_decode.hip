@@ -107,31 +107,40 @@ __global__ __launch_bounds__(VD_NW * 64) void vrnn_decode_kernel(VDArgs a) {
     acc += c1;
   };
   f32x4 acc[6];
-  auto mac_sel = [&](const float4 (&w)[NB], const Item& I) {
-    switch (I.acc) {  // wave-uniform: keeps the accumulators in registers
-      case 0: mac(w, I, acc[0]); break;
-      case 1: mac(w, I, acc[1]); break;
-      case 2: mac(w, I, acc[2]); break;
-      case 3: mac(w, I, acc[3]); break;
-      case 4: mac(w, I, acc[4]); break;
-      default: mac(w, I, acc[5]); break;
+  auto mac_sel = [&](const float4 (&w)[NB], const Item& I, auto nacc) {
+    constexpr int NACC = decltype(nacc)::value;  // wave-uniform selection keeps the accumulators in registers
+    if constexpr (NACC == 1) {
+      mac(w, I, acc[0]);
+    } else if constexpr (NACC == 2) {
+      if (I.acc == 0) mac(w, I, acc[0]);
+      else mac(w, I, acc[1]);
+    } else {
+      switch (I.acc) {
+        case 0: mac(w, I, acc[0]); break;
+        case 1: mac(w, I, acc[1]); break;
+        case 2: mac(w, I, acc[2]); break;
+        case 3: mac(w, I, acc[3]); break;
+        case 4: mac(w, I, acc[4]); break;
+        default: mac(w, I, acc[5]); break;
+      }
     }
   };
-  auto run = [&](int nit, auto item, auto epi) {
+  auto run = [&](int nit, auto item, auto epi, auto nacc) {
     float4 w0[NB], w1[NB];
 #pragma unroll
     for (int g = 0; g < 6; ++g) acc[g] = zero4;
     if (nit > 0) {
       Item I0 = item(0), I1 = I0;
       fetch(w0, I0);
+#pragma nounroll
       for (int it = 0; it < nit; it += 2) {
         const bool two = it + 1 < nit;
         if (two) { I1 = item(it + 1); fetch(w1, I1); }
-        mac_sel(w0, I0);
+        mac_sel(w0, I0, nacc);
         if (I0.last) epi(I0.tile);
         if (it + 2 < nit) { I0 = item(it + 2); fetch(w0, I0); }
         if (two) {
-          mac_sel(w1, I1);
+          mac_sel(w1, I1, nacc);
           if (I1.last) epi(I1.tile);
         }
       }
@@ -140,8 +149,56 @@ __global__ __launch_bounds__(VD_NW * 64) void vrnn_decode_kernel(VDArgs a) {
   };
   const int a_off = (lane & 15), a_q = 4 * q;  // A fragment: row lane & 15, k = 4 (lane >> 4) .. + 3 of a chunk
   // items of a plain layer: tiles of this wave x segments (in0 | in1) x batches of 256 k
-  auto dense = [&](int N, const float* W, const float* bias, const float* in0, int ld0, int K0, const float* in1, int ld1, int K1,
-                   float* out, int ldo, float slope) {
+  // one step = a short PROGRAM of ops walked by a single loop, so that the layer pipeline below exists once in the code (as 13
+  // inlined copies the kernel was 100+ KB, more than the instruction cache holds)
+  struct Op { const float* W; const float* bias; int in0, ld0, K0, in1, ld1, K1, out, ldo, N, kind; float slope; int pad; };
+  enum { OP_DENSE = 0, OP_HEAD = 1, OP_GRU = 2, OP_SAMPLE = 3 };
+  Op* sProg = reinterpret_cast<Op*>(sPar + VD_ROWS * VD_CHUNK * 32);
+  const int N_OPS = 6 + 1 + 4 + 1 + 2 + 2 * (S / VD_CHUNK);  // <= 32 (checked on the host)
+  if (tid == 0) {
+    int n = 0;
+    auto D = [&](const float* W, const float* bias, float* in0, int ld0, int K0, float* in1, int ld1, int K1, float* out, int ldo, int N, float slope) {
+      Op o;
+      o.W = W; o.bias = bias; o.in0 = (int)(in0 - smem); o.ld0 = ld0; o.K0 = K0; o.in1 = in1 ? (int)(in1 - smem) : 0; o.ld1 = ld1; o.K1 = K1;
+      o.out = (int)(out - smem); o.ldo = ldo; o.N = N; o.kind = OP_DENSE; o.slope = slope; o.pad = 0;
+      sProg[n++] = o;
+    };
+    auto K = [&](int kind, int arg) { Op o{}; o.kind = kind; o.N = arg; sProg[n++] = o; };
+    D(a.enc_w[0], a.enc_b[0], sX, ldS, S, nullptr, 0, 0, sT0, ldH, H, a.slope);
+    D(a.enc_w[1], a.enc_b[1], sT0, ldH, H, nullptr, 0, 0, sT1, ldH, H, a.slope);
+    D(a.enc_w[2], a.enc_b[2], sT1, ldH, H, nullptr, 0, 0, sEnc, ldH, H, a.slope);
+    D(a.prior_w[0], a.prior_b[0], sH, ldR, R, nullptr, 0, 0, sT0, ldH, H, 0.f);
+    D(a.prior_w[1], a.prior_b[1], sT0, ldH, H, nullptr, 0, 0, sT1, ldH, H, 0.f);
+    D(a.prior_w[2], a.prior_b[2], sT1, ldH, H, nullptr, 0, 0, sT0, ldH, H, 0.f);
+    K(OP_HEAD, 0);
+    D(a.phi_w[0], a.phi_b[0], sZ, ldZ, Z, nullptr, 0, 0, sT1, ldH, H, 0.f);
+    D(a.phi_w[1], a.phi_b[1], sT1, ldH, H, nullptr, 0, 0, sT0, ldH, H, 0.f);
+    D(a.phi_w[2], a.phi_b[2], sT0, ldH, H, nullptr, 0, 0, sT1, ldH, H, 0.f);
+    D(a.phi_w[3], a.phi_b[3], sT1, ldH, H, nullptr, 0, 0, sPhi, ldH, H, 0.f);
+    K(OP_GRU, 0);
+    D(a.dec_w[0], a.dec_b[0], sPhi, ldH, H, sH, ldR, R, sT0, ldH, H, a.slope);
+    D(a.dec_w[1], a.dec_b[1], sT0, ldH, H, nullptr, 0, 0, sT1, ldH, H, a.slope);
+    for (int ch = 0; ch < S / VD_CHUNK; ++ch) {
+      const int c0 = ch * VD_CHUNK * VD_F;
+      D(a.dec_w[2] + (size_t)c0 * H, a.dec_b[2] + c0, sT1, ldH, H, nullptr, 0, 0, sDec, ldD, VD_CHUNK * VD_F, a.slope);
+      K(OP_SAMPLE, ch);
+    }
+  }
+  __syncthreads();
+  auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+  auto unip = [&](const float* p) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = uni((int)(unsigned)u), hi = uni((int)(unsigned)(u >> 32));
+    return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+  };
+  auto dense = [&](const Op& o) {
+    const int N = uni(o.N), ld0 = uni(o.ld0), K0 = uni(o.K0), ld1 = uni(o.ld1), K1 = uni(o.K1), ldo = uni(o.ldo);
+    const float* W = unip(o.W);
+    const float* bias = unip(o.bias);
+    const float* in0 = smem + uni(o.in0);
+    const float* in1 = smem + uni(o.in1);
+    float* out = smem + uni(o.out);
+    const float slope = __builtin_bit_cast(float, uni(__builtin_bit_cast(int, o.slope)));
     const int Kt = K0 + K1, nb0 = (K0 + 16 * NB - 1) / (16 * NB), nb1 = (K1 + 16 * NB - 1) / (16 * NB), ipt = nb0 + nb1;
     const int my_tiles = (N / 16 - wave + VD_NW - 1) / VD_NW;
     auto item = [&](int it) {
@@ -163,7 +220,7 @@ __global__ __launch_bounds__(VD_NW * 64) void vrnn_decode_kernel(VDArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) out[(4 * q + r) * ldo + tile * 16 + cc] = leaky(acc[0][r] + bv, slope);
       acc[0] = zero4;
-    });
+    }, std::integral_constant<int, 1>{});
   };
 
 #ifdef VD_PROF
@@ -173,176 +230,157 @@ __global__ __launch_bounds__(VD_NW * 64) void vrnn_decode_kernel(VDArgs a) {
 #define VD_TICK(k)
 #endif
   for (int t = 0; t < a.T; ++t) {
-    // encoder: 3 x (Linear + LeakyReLU)
-    dense(H, a.enc_w[0], a.enc_b[0], sX, ldS, S, nullptr, 0, 0, sT0, ldH, a.slope);
-    dense(H, a.enc_w[1], a.enc_b[1], sT0, ldH, H, nullptr, 0, 0, sT1, ldH, a.slope);
-    dense(H, a.enc_w[2], a.enc_b[2], sT1, ldH, H, nullptr, 0, 0, sEnc, ldH, a.slope);
-    VD_TICK(0)
-    // prior: 3 x (Linear + ReLU), Gaussian head, z = mu + sd * eps
-    dense(H, a.prior_w[0], a.prior_b[0], sH, ldR, R, nullptr, 0, 0, sT0, ldH, 0.f);
-    dense(H, a.prior_w[1], a.prior_b[1], sT0, ldH, H, nullptr, 0, 0, sT1, ldH, 0.f);
-    dense(H, a.prior_w[2], a.prior_b[2], sT1, ldH, H, nullptr, 0, 0, sT0, ldH, 0.f);
-    {  // head: mean tile (acc 0) and raw-scale tile (acc 1) of the same columns
-      const int nbh = (H + 16 * NB - 1) / (16 * NB), ipt = 2 * nbh;
-      const int my_tiles = (Z / 16 - wave + VD_NW - 1) / VD_NW;
-      auto item = [&](int it) {
-        Item I;
-        const int ti = it / ipt, r = it - ti * ipt;
-        I.tile = wave + ti * VD_NW;
-        const int half = r / nbh, kb = r - half * nbh, k0 = kb * 16 * NB;
-        I.n = (H - k0 < 16 * NB ? H - k0 : 16 * NB) / 16;
-        I.W = a.prior_hw + (size_t)(half * Z + I.tile * 16) * H + (size_t)k0 * 16 + 4 * lane;
-        I.A = sT0 + a_off * ldH + a_q + k0;
-        I.acc = half;
-        I.last = r == ipt - 1;
-        return I;
-      };
-      run(my_tiles > 0 ? my_tiles * ipt : 0, item, [&](int tile) {
-        const int col = tile * 16 + cc;
-        const float bm = a.prior_hb[col], br = a.prior_hb[Z + col];
+#pragma nounroll
+    for (int op = 0; op < N_OPS; ++op) {
+      const int kind = uni(sProg[op].kind);
+      if (kind == OP_DENSE) {
+        dense(sProg[op]);
+      } else if (kind == OP_HEAD) {
+        {  // head: mean tile (acc 0) and raw-scale tile (acc 1) of the same columns
+          const int nbh = (H + 16 * NB - 1) / (16 * NB), ipt = 2 * nbh;
+          const int my_tiles = (Z / 16 - wave + VD_NW - 1) / VD_NW;
+          auto item = [&](int it) {
+            Item I;
+            const int ti = it / ipt, r = it - ti * ipt;
+            I.tile = wave + ti * VD_NW;
+            const int half = r / nbh, kb = r - half * nbh, k0 = kb * 16 * NB;
+            I.n = (H - k0 < 16 * NB ? H - k0 : 16 * NB) / 16;
+            I.W = a.prior_hw + (size_t)(half * Z + I.tile * 16) * H + (size_t)k0 * 16 + 4 * lane;
+            I.A = sT0 + a_off * ldH + a_q + k0;
+            I.acc = half;
+            I.last = r == ipt - 1;
+            return I;
+          };
+          run(my_tiles > 0 ? my_tiles * ipt : 0, item, [&](int tile) {
+            const int col = tile * 16 + cc;
+            const float bm = a.prior_hb[col], br = a.prior_hb[Z + col];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = b0 + 4 * q + r < B ? a.eps[((size_t)t * B + b0 + 4 * q + r) * Z + col] : 0.f;
-          const float sd = softplus_beta(acc[1][r] + br, a.beta, 1.f / a.beta) + a.sd_eps;
-          sZ[(4 * q + r) * ldZ + col] = e * sd + (acc[0][r] + bm);
+            for (int r = 0; r < 4; ++r) {
+              const float e = b0 + 4 * q + r < B ? a.eps[((size_t)t * B + b0 + 4 * q + r) * Z + col] : 0.f;
+              const float sd = softplus_beta(acc[1][r] + br, a.beta, 1.f / a.beta) + a.sd_eps;
+              sZ[(4 * q + r) * ldZ + col] = e * sd + (acc[0][r] + bm);
+            }
+            acc[0] = zero4; acc[1] = zero4;
+          }, std::integral_constant<int, 2>{});
         }
-        acc[0] = zero4; acc[1] = zero4;
-      });
-    }
-    VD_TICK(1)
-    // phi_z: 4 x (Linear + ReLU)
-    dense(H, a.phi_w[0], a.phi_b[0], sZ, ldZ, Z, nullptr, 0, 0, sT1, ldH, 0.f);
-    dense(H, a.phi_w[1], a.phi_b[1], sT1, ldH, H, nullptr, 0, 0, sT0, ldH, 0.f);
-    dense(H, a.phi_w[2], a.phi_b[2], sT0, ldH, H, nullptr, 0, 0, sT1, ldH, 0.f);
-    dense(H, a.phi_w[3], a.phi_b[3], sT1, ldH, H, nullptr, 0, 0, sPhi, ldH, 0.f);
-    VD_TICK(2)
-    // GRU on cat[enc, phi_z] and h: per column tile 3 gates x (input projection over [enc | phi], hidden projection over h);
-    // the new state stays in registers until every wave has read the old one
-    {
-      const int KI = 2 * H;  // X = H in VRNNAudio
-      const int nbi = (H + 16 * NB - 1) / (16 * NB), nbh = (R + 16 * NB - 1) / (16 * NB), ipg = 2 * nbi + nbh, ipt = 3 * ipg;
-      const int my_tiles = (R / 16 - wave + VD_NW - 1) / VD_NW;
-      float hn[4][4];
-      auto item = [&](int it) {
-        Item I;
-        const int ti = it / ipt, r = it - ti * ipt, g = r / ipg, p = r - g * ipg;
-        I.tile = wave + ti * VD_NW;
-        const size_t wrow = (size_t)(g * R + I.tile * 16);
-        if (p < 2 * nbi) {  // input projection: enc then phi
-          const int seg = p / nbi, kb = p - seg * nbi, k0 = kb * 16 * NB;
-          I.n = (H - k0 < 16 * NB ? H - k0 : 16 * NB) / 16;
-          I.W = a.wih + wrow * KI + (size_t)(seg * H + k0) * 16 + 4 * lane;
-          I.A = (seg ? sPhi : sEnc) + a_off * ldH + a_q + k0;
-          I.acc = g;
-        } else {
-          const int kb = p - 2 * nbi, k0 = kb * 16 * NB;
-          I.n = (R - k0 < 16 * NB ? R - k0 : 16 * NB) / 16;
-          I.W = a.whh + wrow * R + (size_t)k0 * 16 + 4 * lane;
-          I.A = sH + a_off * ldR + a_q + k0;
-          I.acc = 3 + g;
-        }
-        I.last = r == ipt - 1;
-        return I;
-      };
-      int nt = 0;
-      // no barrier inside run() may separate the last read of sH from its update: run() ends with one
-      run(my_tiles > 0 ? my_tiles * ipt : 0, item, [&](int tile) {
-        const int col = tile * 16 + cc;
-        const float bir = a.bih[col], biu = a.bih[R + col], bin = a.bih[2 * R + col];
-        const float bhr = a.bhh[col], bhu = a.bhh[R + col], bhn = a.bhh[2 * R + col];
+      } else if (kind == OP_GRU) {
+        {
+          const int KI = 2 * H;  // X = H in VRNNAudio
+          const int nbi = (H + 16 * NB - 1) / (16 * NB), nbh = (R + 16 * NB - 1) / (16 * NB), ipg = 2 * nbi + nbh, ipt = 3 * ipg;
+          const int my_tiles = (R / 16 - wave + VD_NW - 1) / VD_NW;
+          float hn[4][4];
+          auto item = [&](int it) {
+            Item I;
+            const int ti = it / ipt, r = it - ti * ipt, g = r / ipg, p = r - g * ipg;
+            I.tile = wave + ti * VD_NW;
+            const size_t wrow = (size_t)(g * R + I.tile * 16);
+            if (p < 2 * nbi) {  // input projection: enc then phi
+              const int seg = p / nbi, kb = p - seg * nbi, k0 = kb * 16 * NB;
+              I.n = (H - k0 < 16 * NB ? H - k0 : 16 * NB) / 16;
+              I.W = a.wih + wrow * KI + (size_t)(seg * H + k0) * 16 + 4 * lane;
+              I.A = (seg ? sPhi : sEnc) + a_off * ldH + a_q + k0;
+              I.acc = g;
+            } else {
+              const int kb = p - 2 * nbi, k0 = kb * 16 * NB;
+              I.n = (R - k0 < 16 * NB ? R - k0 : 16 * NB) / 16;
+              I.W = a.whh + wrow * R + (size_t)k0 * 16 + 4 * lane;
+              I.A = sH + a_off * ldR + a_q + k0;
+              I.acc = 3 + g;
+            }
+            I.last = r == ipt - 1;
+            return I;
+          };
+          int nt = 0;
+          // no barrier inside run() may separate the last read of sH from its update: run() ends with one
+          run(my_tiles > 0 ? my_tiles * ipt : 0, item, [&](int tile) {
+            const int col = tile * 16 + cc;
+            const float bir = a.bih[col], biu = a.bih[R + col], bin = a.bih[2 * R + col];
+            const float bhr = a.bhh[col], bhu = a.bhh[R + col], bhn = a.bhh[2 * R + col];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float rg = sigmoidf_(acc[0][r] + bir + acc[3][r] + bhr);
-          const float ug = sigmoidf_(acc[1][r] + biu + acc[4][r] + bhu);
-          const float ng = tanhf(acc[2][r] + bin + rg * (acc[5][r] + bhn));
-          const float hv = (1.f - ug) * ng + ug * sH[(4 * q + r) * ldR + col];
-          switch (nt) {  // static register indices
-            case 0: hn[0][r] = hv; break;
-            case 1: hn[1][r] = hv; break;
-            case 2: hn[2][r] = hv; break;
-            default: hn[3][r] = hv; break;
+            for (int r = 0; r < 4; ++r) {
+              const float rg = sigmoidf_(acc[0][r] + bir + acc[3][r] + bhr);
+              const float ug = sigmoidf_(acc[1][r] + biu + acc[4][r] + bhu);
+              const float ng = tanhf(acc[2][r] + bin + rg * (acc[5][r] + bhn));
+              const float hv = (1.f - ug) * ng + ug * sH[(4 * q + r) * ldR + col];
+              switch (nt) {  // static register indices
+                case 0: hn[0][r] = hv; break;
+                case 1: hn[1][r] = hv; break;
+                case 2: hn[2][r] = hv; break;
+                default: hn[3][r] = hv; break;
+              }
+            }
+            ++nt;
+#pragma unroll
+            for (int g = 0; g < 6; ++g) acc[g] = zero4;
+          }, std::integral_constant<int, 6>{});
+          nt = 0;
+          for (int tile = wave; tile < R / 16; tile += VD_NW, ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float hv;
+              switch (nt) { case 0: hv = hn[0][r]; break; case 1: hv = hn[1][r]; break; case 2: hv = hn[2][r]; break; default: hv = hn[3][r]; break; }
+              sH[(4 * q + r) * ldR + tile * 16 + cc] = hv;
+            }
+          __syncthreads();
+        }
+      } else {
+        const int ch = uni(sProg[op].N);
+        // the sampler's draws of this chunk travel while the head runs
+        float uu[VD_K], vv = 0.5f;
+        if (tid < VD_ROWS * VD_CHUNK) {
+          const int r = tid / VD_CHUNK, sm = tid - r * VD_CHUNK;
+          const size_t f = ((size_t)t * B + (b0 + r < B ? b0 + r : 0)) * S + ch * VD_CHUNK + sm;
+          if (a.u != nullptr) {
+#pragma unroll
+            for (int m = 0; m < VD_K; ++m) uu[m] = a.u[f * VD_K + m];
+            vv = a.v[f];
           }
         }
-        ++nt;
+        // head Linear [30,30] per (utterance, sample) on the matrix pipe: K and N padded to 32 with zero weights; (sample, column
+        // tile) pairs over the waves.  A fragments start at 30 sm + 16 j + 4 q floats: 8-byte aligned
+        for (int w2 = wave; w2 < VD_CHUNK * 2; w2 += VD_NW) {
+          const int sm = w2 >> 1, ct = w2 & 1;
+          f32x4 c = zero4;
 #pragma unroll
-        for (int g = 0; g < 6; ++g) acc[g] = zero4;
-      });
-      nt = 0;
-      for (int tile = wave; tile < R / 16; tile += VD_NW, ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float hv;
-          switch (nt) { case 0: hv = hn[0][r]; break; case 1: hv = hn[1][r]; break; case 2: hv = hn[2][r]; break; default: hv = hn[3][r]; break; }
-          sH[(4 * q + r) * ldR + tile * 16 + cc] = hv;
-        }
-      __syncthreads();
-    }
-    VD_TICK(3)
-    // decoder on cat[phi_z, h_new]: 2 hidden layers, then the last layer in chunks of 8 samples with the head and the draw
-    dense(H, a.dec_w[0], a.dec_b[0], sPhi, ldH, H, sH, ldR, R, sT0, ldH, a.slope);
-    dense(H, a.dec_w[1], a.dec_b[1], sT0, ldH, H, nullptr, 0, 0, sT1, ldH, a.slope);
-    VD_TICK(4)
-    for (int ch = 0; ch < S / VD_CHUNK; ++ch) {
-      const int c0 = ch * VD_CHUNK * VD_F;  // first output column of the chunk (240 per chunk: a multiple of 16)
-      dense(VD_CHUNK * VD_F, a.dec_w[2] + (size_t)c0 * H, a.dec_b[2] + c0, sT1, ldH, H, nullptr, 0, 0, sDec, ldD, a.slope);
-      VD_TICK(5)
-      // the sampler's draws of this chunk travel while the head runs
-      float uu[VD_K], vv = 0.5f;
-      if (tid < VD_ROWS * VD_CHUNK) {
-        const int r = tid / VD_CHUNK, sm = tid - r * VD_CHUNK;
-        const size_t f = ((size_t)t * B + (b0 + r < B ? b0 + r : 0)) * S + ch * VD_CHUNK + sm;
-        if (a.u != nullptr) {
-#pragma unroll
-          for (int m = 0; m < VD_K; ++m) uu[m] = a.u[f * VD_K + m];
-          vv = a.v[f];
-        }
-      }
-      // head Linear [30,30] per (utterance, sample) on the matrix pipe: K and N padded to 32 with zero weights; (sample, column
-      // tile) pairs over the waves.  A fragments start at 30 sm + 16 j + 4 q floats: 8-byte aligned
-      for (int w2 = wave; w2 < VD_CHUNK * 2; w2 += VD_NW) {
-        const int sm = w2 >> 1, ct = w2 & 1;
-        f32x4 c = zero4;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const float* ap = sDec + (lane & 15) * ldD + sm * VD_F + 16 * j + 4 * q;
-          const float2 x01 = *reinterpret_cast<const float2*>(ap), x23 = *reinterpret_cast<const float2*>(ap + 2);
-          const float4 wf = *reinterpret_cast<const float4*>(sLik + ((ct * 2 + j) * 64 + lane) * 4);
-          c = __builtin_amdgcn_mfma_f32_16x16x4f32(x01.x, wf.x, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x4f32(x01.y, wf.y, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x4f32(x23.x, wf.z, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x4f32(x23.y, wf.w, c, 0, 0, 0);
-        }
-        const float bv = sLik[1024 + ct * 16 + cc];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sPar[((4 * q + r) * VD_CHUNK + sm) * 32 + ct * 16 + cc] = c[r] + bv;
-      }
-      __syncthreads();
-      if (tid < VD_ROWS * VD_CHUNK) {  // Gumbel-max component pick + clamped logistic draw (as mix_sample_kernel, dmol.hip)
-        const int r = tid / VD_CHUNK, sm = tid - r * VD_CHUNK, s_idx = ch * VD_CHUNK + sm;
-        if (b0 + r < B) {
-          const float* p = sPar + tid * 32;
-          const size_t f = ((size_t)t * B + b0 + r) * S + s_idx;
-          int best = 0;
-          float bvv = -INFINITY;
-          for (int m = 0; m < VD_K; ++m) {
-            float sc = p[m];
-            if (a.u != nullptr) sc -= logf(-logf(uu[m]));
-            if (sc > bvv) { bvv = sc; best = m; }
+          for (int j = 0; j < 2; ++j) {
+            const float* ap = sDec + (lane & 15) * ldD + sm * VD_F + 16 * j + 4 * q;
+            const float2 x01 = *reinterpret_cast<const float2*>(ap), x23 = *reinterpret_cast<const float2*>(ap + 2);
+            const float4 wf = *reinterpret_cast<const float4*>(sLik + ((ct * 2 + j) * 64 + lane) * 4);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(x01.x, wf.x, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(x01.y, wf.y, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(x23.x, wf.z, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(x23.y, wf.w, c, 0, 0, 0);
           }
-          float x = p[VD_K + best];
-          if (a.v != nullptr) {
-            x += expf(fmaxf(p[2 * VD_K + best], a.log_eps)) * (logf(vv) - logf(1.f - vv));
-            x = fminf(fmaxf(x, -1.f), 1.f);
-          }
-          a.x_out[((size_t)(b0 + r) * a.T + t) * S + s_idx] = x;
-          sX[r * ldS + s_idx] = x;
+          const float bv = sLik[1024 + ct * 16 + cc];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sPar[((4 * q + r) * VD_CHUNK + sm) * 32 + ct * 16 + cc] = c[r] + bv;
         }
+        __syncthreads();
+        if (tid < VD_ROWS * VD_CHUNK) {  // Gumbel-max component pick + clamped logistic draw (as mix_sample_kernel, dmol.hip)
+          const int r = tid / VD_CHUNK, sm = tid - r * VD_CHUNK, s_idx = ch * VD_CHUNK + sm;
+          if (b0 + r < B) {
+            const float* p = sPar + tid * 32;
+            const size_t f = ((size_t)t * B + b0 + r) * S + s_idx;
+            int best = 0;
+            float bvv = -INFINITY;
+            for (int m = 0; m < VD_K; ++m) {
+              float sc = p[m];
+              if (a.u != nullptr) sc -= logf(-logf(uu[m]));
+              if (sc > bvv) { bvv = sc; best = m; }
+            }
+            float x = p[VD_K + best];
+            if (a.v != nullptr) {
+              x += expf(fmaxf(p[2 * VD_K + best], a.log_eps)) * (logf(vv) - logf(1.f - vv));
+              x = fminf(fmaxf(x, -1.f), 1.f);
+            }
+            a.x_out[((size_t)(b0 + r) * a.T + t) * S + s_idx] = x;
+            sX[r * ldS + s_idx] = x;
+          }
+        }
+        __syncthreads();
       }
-      __syncthreads();
-      VD_TICK(6)
     }
   }
-
   if (a.h_out != nullptr)
     for (int i = tid; i < VD_ROWS * R; i += VD_NW * 64) {
       const int r = i / R, c = i - r * R;
@@ -356,7 +394,7 @@ __global__ __launch_bounds__(VD_NW * 64) void vrnn_decode_kernel(VDArgs a) {
 }
 
 size_t vd_lds_bytes(int S, int H, int Z, int R) {
-  return sizeof(float) * ((size_t)VD_ROWS * ((S + 4) + 4 * (H + 4) + (R + 4) + (Z + 4) + (VD_CHUNK * VD_F + 4)) + 1024 + 32 + VD_ROWS * VD_CHUNK * 32);
+  return sizeof(float) * ((size_t)VD_ROWS * ((S + 4) + 4 * (H + 4) + (R + 4) + (Z + 4) + (VD_CHUNK * VD_F + 4)) + 1024 + 32 + VD_ROWS * VD_CHUNK * 32 + 32 * 16);  // + the op program
 }
 
 struct VdPack { size_t enc[3], prior[3], prior_h, phi[4], wih, whh, dec[3], total; };
@@ -394,6 +432,7 @@ extern "C" int blvm_vrnn_decode(const BlvmVrnnDecodeWeights* w, const float* x0,
   BLVM_REQUIRE(S % 16 == 0 && H % 16 == 0 && Z % 16 == 0 && R % 16 == 0 && S > 0 && H > 0 && Z > 0 && R > 0,
                "vrnn_decode: S, H, Z, R must be positive multiples of 16 (got %d, %d, %d, %d)", S, H, Z, R);
   BLVM_REQUIRE(num_mix == VD_K, "vrnn_decode: the DMoL head has %d components", VD_K);
+  BLVM_REQUIRE(14 + 2 * (S / VD_CHUNK) <= 32, "vrnn_decode: frame stacks of more than %d samples are not supported", 9 * VD_CHUNK);
   BLVM_REQUIRE((R / 16 + VD_NW - 1) / VD_NW <= 4, "vrnn_decode: recurrent size %d too large", R);
   BLVM_REQUIRE((u == nullptr) == (v == nullptr), "vrnn_decode: u and v are given together (both NULL: the mode)");
   BLVM_REQUIRE(aligned16(scratch), "vrnn_decode: scratch must be 16-byte aligned");
