@@ -1,11 +1,12 @@
 import os, sys, time, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "benchmarking-lvms_amd"))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
 from blvm.models import VRNNAudio
-import blvm_oracle as O
 torch.manual_seed(0)
 m = VRNNAudio(likelihood="DMoL", input_size=64, hidden_size=256, latent_size=256, residual_posterior=True).cuda()
-x, x_sl = O.synth_batch(64, 16000, seed=0)
+import math
+_g = torch.Generator().manual_seed(0)
+_u = (torch.rand(64, 16000, generator=_g) * 2 - 1) * 0.5
+x, x_sl = _u.sign() * torch.log1p(65535 * _u.abs()) / math.log(65536), torch.full((64,), 16000, dtype=torch.int64)  # synthetic mu-law batch
 x = x.cuda()
 def step(bwd):
     loss, _, _ = m(x, x_sl)

@@ -1,9 +1,7 @@
 import os, sys, time, torch, collections
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "benchmarking-lvms_amd"))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
 from blvm.models import VRNNAudio
 import blvm._hip as H
-import blvm_oracle as O
 lib = H.load()
 acc = collections.defaultdict(float); cnt = collections.defaultdict(int)
 class Timed:
@@ -19,7 +17,10 @@ H._lib = Wrap(lib)
 torch.manual_seed(0)
 m = VRNNAudio(likelihood="DMoL", input_size=64, hidden_size=256, latent_size=256, residual_posterior=True).cuda()
 opt = torch.optim.Adam(m.parameters(), lr=3e-4)
-x, x_sl = O.synth_batch(64, 16000, seed=0); x = x.cuda()
+import math
+_g = torch.Generator().manual_seed(0)
+_u = (torch.rand(64, 16000, generator=_g) * 2 - 1) * 0.5
+x, x_sl = _u.sign() * torch.log1p(65535 * _u.abs()) / math.log(65536), torch.full((64,), 16000, dtype=torch.int64)  # synthetic mu-law batch; x = x.cuda()
 def step():
     loss, _, _ = m(x, x_sl)
     opt.zero_grad(set_to_none=True)
