@@ -20,7 +20,8 @@ opt = torch.optim.Adam(m.parameters(), lr=3e-4)
 import math
 _g = torch.Generator().manual_seed(0)
 _u = (torch.rand(64, 16000, generator=_g) * 2 - 1) * 0.5
-x, x_sl = _u.sign() * torch.log1p(65535 * _u.abs()) / math.log(65536), torch.full((64,), 16000, dtype=torch.int64)  # synthetic mu-law batch; x = x.cuda()
+x, x_sl = _u.sign() * torch.log1p(65535 * _u.abs()) / math.log(65536), torch.full((64,), 16000, dtype=torch.int64)  # synthetic mu-law batch
+x = x.cuda()
 def step():
     loss, _, _ = m(x, x_sl)
     opt.zero_grad(set_to_none=True)
