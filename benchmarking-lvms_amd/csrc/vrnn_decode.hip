@@ -78,8 +78,15 @@ __global__ __launch_bounds__(VD_NW * 64) void vrnn_decode_kernel(VDArgs a) {
   // sets that swap roles by position in the loop body), across tile and segment boundaries alike — with one wave per SIMD
   // nothing else hides the latency of a read that misses L2.
   constexpr int NB = 8;  // k-chunks per item
-  struct Item { const float* W; const float* A; int n, acc; bool last; int tile; };
-  auto fetch = [&](float4 (&w)[NB], const Item& I) {
+  struct Item { const float* W; const float* A; const float *bA, *bB; int bstride, n, acc; bool last; int tile; };
+  auto fetch = [&](float4 (&w)[NB], float (&bb)[6], const Item& I) {
+    // the tile's epilogue biases travel with the fragments (loaded for every item: an epilogue-time load would expose a full
+    // memory latency per tile)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      bb[k] = I.bA[k * I.bstride];
+      bb[3 + k] = I.bB[k * I.bstride];
+    }
     // unconditional loads (chunks beyond I.n re-read the last valid one; their A fragments are zeroed instead): the compiler
     // can then count the loads in flight, and the wait before an item's MFMAs leaves the NEXT item's loads outstanding
 #pragma unroll
@@ -127,21 +134,31 @@ __global__ __launch_bounds__(VD_NW * 64) void vrnn_decode_kernel(VDArgs a) {
   };
   auto run = [&](int nit, auto item, auto epi, auto nacc) {
     float4 w0[NB], w1[NB];
+    float bb0[6], bb1[6];
 #pragma unroll
     for (int g = 0; g < 6; ++g) acc[g] = zero4;
     if (nit > 0) {
+      // every fetch is unconditional (past the end: the last item again), so that between a fetch and the MFMAs that use the
+      // OTHER register set there is no branch with memory traffic — otherwise the compiler's wait before the MFMAs is vmcnt(0)
+      // and drains the prefetch it should overlap
       Item I0 = item(0), I1 = I0;
-      fetch(w0, I0);
+      fetch(w0, bb0, I0);
 #pragma nounroll
       for (int it = 0; it < nit; it += 2) {
-        const bool two = it + 1 < nit;
-        if (two) { I1 = item(it + 1); fetch(w1, I1); }
+        I1 = item(it + 1 < nit ? it + 1 : nit - 1);
+        fetch(w1, bb1, I1);
         mac_sel(w0, I0, nacc);
-        if (I0.last) epi(I0.tile);
-        if (it + 2 < nit) { I0 = item(it + 2); fetch(w0, I0); }
-        if (two) {
+        const bool l0 = I0.last;
+        const int t0 = I0.tile;
+        float be[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) be[k] = bb0[k];
+        I0 = item(it + 2 < nit ? it + 2 : nit - 1);
+        fetch(w0, bb0, I0);
+        if (l0) epi(t0, be);
+        if (it + 1 < nit) {
           mac_sel(w1, I1, nacc);
-          if (I1.last) epi(I1.tile);
+          if (I1.last) epi(I1.tile, bb1);
         }
       }
     }
@@ -213,10 +230,12 @@ __global__ __launch_bounds__(VD_NW * 64) void vrnn_decode_kernel(VDArgs a) {
       I.A = (second ? in1 + a_off * ld1 : in0 + a_off * ld0) + a_q + k0;
       I.acc = 0;
       I.last = r == ipt - 1;
+      I.bA = I.bB = bias + I.tile * 16 + cc;
+      I.bstride = 0;
       return I;
     };
-    run(my_tiles > 0 ? my_tiles * ipt : 0, item, [&](int tile) {
-      const float bv = bias[tile * 16 + cc];
+    run(my_tiles > 0 ? my_tiles * ipt : 0, item, [&](int tile, const float (&bb)[6]) {
+      const float bv = bb[0];
 #pragma unroll
       for (int r = 0; r < 4; ++r) out[(4 * q + r) * ldo + tile * 16 + cc] = leaky(acc[0][r] + bv, slope);
       acc[0] = zero4;
@@ -249,11 +268,13 @@ __global__ __launch_bounds__(VD_NW * 64) void vrnn_decode_kernel(VDArgs a) {
             I.A = sT0 + a_off * ldH + a_q + k0;
             I.acc = half;
             I.last = r == ipt - 1;
+            I.bA = I.bB = a.prior_hb + I.tile * 16 + cc;
+            I.bstride = Z;
             return I;
           };
-          run(my_tiles > 0 ? my_tiles * ipt : 0, item, [&](int tile) {
+          run(my_tiles > 0 ? my_tiles * ipt : 0, item, [&](int tile, const float (&bb)[6]) {
             const int col = tile * 16 + cc;
-            const float bm = a.prior_hb[col], br = a.prior_hb[Z + col];
+            const float bm = bb[0], br = bb[1];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float e = b0 + 4 * q + r < B ? a.eps[((size_t)t * B + b0 + 4 * q + r) * Z + col] : 0.f;
@@ -288,14 +309,17 @@ __global__ __launch_bounds__(VD_NW * 64) void vrnn_decode_kernel(VDArgs a) {
               I.acc = 3 + g;
             }
             I.last = r == ipt - 1;
+            I.bA = a.bih + I.tile * 16 + cc;
+            I.bB = a.bhh + I.tile * 16 + cc;
+            I.bstride = R;
             return I;
           };
           int nt = 0;
           // no barrier inside run() may separate the last read of sH from its update: run() ends with one
-          run(my_tiles > 0 ? my_tiles * ipt : 0, item, [&](int tile) {
+          run(my_tiles > 0 ? my_tiles * ipt : 0, item, [&](int tile, const float (&bb)[6]) {
             const int col = tile * 16 + cc;
-            const float bir = a.bih[col], biu = a.bih[R + col], bin = a.bih[2 * R + col];
-            const float bhr = a.bhh[col], bhu = a.bhh[R + col], bhn = a.bhh[2 * R + col];
+            const float bir = bb[0], biu = bb[1], bin = bb[2];
+            const float bhr = bb[3], bhu = bb[4], bhn = bb[5];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float rg = sigmoidf_(acc[0][r] + bir + acc[3][r] + bhr);
