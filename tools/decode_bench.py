@@ -29,7 +29,7 @@ def main():
             kw["smoothing"] = True
         m = cls(**kw).cuda()
         wbytes = sum(p.numel() for p in m.parameters()) * 4
-        for B in (2, 16, 64):
+        for B in (2, 16, 64, 1024):
             dt = timed(lambda n: m.generate(n_samples=B, max_timesteps=n), 60)
             print(f"{name} generate B={B}: {dt * 1e3:.3f} ms per 64-sample stack ({64 * B / dt:.3g} samples/s); parameters {wbytes / 1e6:.1f} MB "
                   f"-> {wbytes / dt / 1e9:.0f} GB/s of weights per step", flush=True)
