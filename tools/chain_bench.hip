@@ -106,6 +106,30 @@ __global__ __launch_bounds__(NW * 64) void k_small_noepi(Small a) {
   a.out[(size_t)row * a.ldo + col] = v[0] > 0.f ? v[0] : 0.f;
 }
 
+
+// output-store experiment: MODE 0 plain store, 1 nontemporal store, 2 agent-scope relaxed atomic store (sc1 write-through),
+// 3 no store at all (what the store + the kernel-end release of dirty L2 lines cost together), 4 = 16-byte stores by 64 threads
+template <int NW, int MODE>
+__global__ __launch_bounds__(NW * 64) void k_store(Small a) {
+  __shared__ float red[NW * 256];
+  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16;
+  const int t = threadIdx.x & 255;
+  const int row = r0 + (t >> 4), col = c0 + (t & 15);
+  const float e_bias = a.bias[col];
+  f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+  acc[0] = wave_gemm16<NW>(a.A, a.lda, r0, a.B, a.W, a.ldw, c0, a.K, threadIdx.x >> 6, acc[0]);
+  float v[1];
+  reduce_tiles<1, NW>(acc, red, v);
+  if (threadIdx.x >= 256 || row >= a.B) return;
+  float x = v[0] + e_bias;
+  x = x > 0.f ? x : 0.f;
+  float* o = a.out + (size_t)row * a.ldo + col;
+  if (MODE == 0) *o = x;
+  else if (MODE == 1) __builtin_nontemporal_store(x, o);
+  else if (MODE == 2) __hip_atomic_store(o, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else if (MODE == 3) { if (x == 12345.f) *o = x; }
+}
+
 int main() {
   const int B = 64, N = 512, K = 256, REP = 2000;
   float *act[2], *W, *bias, *add;
@@ -128,6 +152,16 @@ int main() {
   timeit("empty kernel, 128 WG x 256", [&](int) { hipLaunchKernelGGL(k_empty, dim3(128), dim3(256), 0, s); });
   timeit("empty kernel, 128 WG x 1024", [&](int) { hipLaunchKernelGGL(k_empty, dim3(128), dim3(1024), 0, s); });
   timeit("touch kernel (1 ptr arg), 128 WG x 256", [&](int i) { hipLaunchKernelGGL(k_touch, dim3(128), dim3(256), 0, s, act[i & 1]); });
+
+  for (int kk : {256}) {
+    Small a{}; a.W = W; a.bias = bias; a.add = add; a.lda = 2048; a.ldw = kk; a.ldadd = 2048; a.ldo = 2048; a.B = B; a.K = kk;
+    for (int rep = 0; rep < 2; ++rep) {
+      timeit("store mode 0 plain        N=512 K=256 NW=4", [&](int i) { a.A = act[i & 1]; a.out = act[(i + 1) & 1]; hipLaunchKernelGGL((k_store<4, 0>), dim3(N / 16, 4), dim3(256), 0, s, a); });
+      timeit("store mode 1 nontemporal  N=512 K=256 NW=4", [&](int i) { a.A = act[i & 1]; a.out = act[(i + 1) & 1]; hipLaunchKernelGGL((k_store<4, 1>), dim3(N / 16, 4), dim3(256), 0, s, a); });
+      timeit("store mode 2 agent atomic N=512 K=256 NW=4", [&](int i) { a.A = act[i & 1]; a.out = act[(i + 1) & 1]; hipLaunchKernelGGL((k_store<4, 2>), dim3(N / 16, 4), dim3(256), 0, s, a); });
+      timeit("store mode 3 no store     N=512 K=256 NW=4", [&](int i) { a.A = act[i & 1]; a.out = act[(i + 1) & 1]; hipLaunchKernelGGL((k_store<4, 3>), dim3(N / 16, 4), dim3(256), 0, s, a); });
+    }
+  }
   Big b{}; b.tiles[0] = 64; b.o[0] = act[0]; b.o[1] = act[1]; b.l[0] = 1; b.l[1] = 2;
   timeit("big kernarg (280 B) + select, 128 WG x 256", [&](int) { hipLaunchKernelGGL(k_bigarg, dim3(128), dim3(256), 0, s, b); });
   for (int kk : {256, 512, 1536}) {
