@@ -126,7 +126,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # BLVM_BENCH_FORCE_DIST=1 under torch.distributed.run with one rank walks the whole RCCL path (init, gradient all-reduce,
+    # barriers, MAX over ranks) on a one-GPU box; the numbers are those of N=1
+    use_dist = world > 1 or (os.environ.get("BLVM_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -159,7 +162,7 @@ def main():
         model = LSTMAudio(stack_size=S, hidden_size=H, num_layers=1, num_mix=10, num_bins=2**16).to(dev)
     params = list(model.parameters())
     opt = torch.optim.Adam(params, lr=3e-4)
-    reducer = FlatGradAllReduce(params) if world > 1 else None
+    reducer = FlatGradAllReduce(params) if use_dist else None
 
     # synthetic µ-law batch, resident in HBM before the timed region (rank-offset seed: different utterances per GPU)
     g = torch.Generator().manual_seed(1000 + rank)
@@ -214,7 +217,7 @@ def main():
             log("first step done")
     torch.cuda.synchronize()
     log("warm-up done, timing")
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -223,11 +226,11 @@ def main():
         step()
     cur["i"] = -1
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -313,7 +316,7 @@ def main():
             threads = max(1, min(16, os.cpu_count() or 1, len(os.sched_getaffinity(0))))
             res["cpu_baseline"] = cpu_baseline(args.cpu_batch, T, args.cpu_steps, threads)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

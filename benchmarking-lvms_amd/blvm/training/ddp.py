@@ -5,7 +5,7 @@ models are normalised by the batch's total number of frames (e.g. blvm/models/vr
 gradients is NOT the single-process gradient when shards hold different numbers of frames.  `FlatGradAllReduce`
 makes it exact with ONE collective per step: every rank sends [grad * n_local_frames ..., n_local_frames] in a
 single flat fp32 bucket (14.4 MB for VRNN — latency-bound on xGMI, no overlap needed), and divides the summed
-gradients by the summed frame count.
+gradients by the summed frame count.  After the call every `p.grad` IS a slice of that bucket (no copy back).
 """
 from typing import Iterable, List
 
@@ -30,13 +30,12 @@ class FlatGradAllReduce:
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
         torch._foreach_copy_(self.views, grads)
         self.flat[:-1].mul_(float(n_local_frames))
-        self.flat[-1] = float(n_local_frames)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        self.flat[-1:].fill_(float(n_local_frames))  # fill kernel; `flat[-1] = x` is a synchronising host-to-device copy
+        if dist.is_available() and dist.is_initialized():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.flat[:-1].div_(self.flat[-1])
+        # hand the bucket's slices out as the gradients (no copy back: 42 small dependent kernels were ~0.2 ms of a 21 ms
+        # VRNN step).  They are views of the bucket: valid until the next call, like DDP's gradient_as_bucket_view.
         for p, v in zip(self.params, self.views):
-            if p.grad is None:
-                p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
+            p.grad = v
         return self.flat[-1]
