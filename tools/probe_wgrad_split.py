@@ -9,12 +9,12 @@ from blvm import ops  # noqa: E402
 
 dev = "cuda:0"
 K = int(os.environ.get("ROWS", 16000))
-for M, N in [(256, 256), (512, 256), (768, 256), (768, 512), (256, 64), (128, 256)]:
+for M, N in [(256, 256), (512, 256), (768, 256), (768, 512), (256, 64), (128, 256), (1920, 256), (1536, 256), (1536, 512), (256, 768)]:
     A = torch.randn(K, M, device=dev)
     B = torch.randn(K, N, device=dev)
     C = torch.zeros(M, N, device=dev)
     line = f"M={M:4d} N={N:4d}:"
-    for sk in (4, 8, 16, 24, 32, 48, 64, 96, 128, 192):
+    for sk in (2, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128):
         f = lambda: ops.gemm(1, 1, M, N, K, A, M, B, N, C, N, accumulate=True, split_k=sk)  # noqa: E731
         for _ in range(3):
             f()
