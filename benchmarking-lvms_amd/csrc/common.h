@@ -133,6 +133,84 @@ __device__ __forceinline__ f32x4 wave_gemm16(const float* __restrict__ A, int ld
   return acc;
 }
 
+// ---- G products of the same K in ONE loop -----------------------------------------------------------------------------
+// acc[g] += A[g][r0+i][k] * W[g][c0[g]+j][k], W in T16.  A stage that needs several products (the 4 LSTM gates, the 3 GRU
+// gates, both Gaussian heads ...) must not call wave_gemm16 once per product: K is a run-time value, so every call is its own
+// loop nest and the loads of product g+1 are issued only after product g's MFMAs — G dependent memory round trips (~1 us each
+// from the Infinity Cache) instead of one.  Here all 2G (SAMEA: G+1) fragment loads of a k-chunk are issued together, two
+// chunks per trip.  Every acc[g] still sums its chunks in ascending order, element by element, exactly as wave_gemm16 does:
+// results are bit-identical.  The MFMAs of the G products are interleaved, so consecutive MFMAs are independent.
+template <int NW, int G, bool SAMEA>
+__device__ __forceinline__ void wave_gemm16_multi(const float* const (&A)[G], const int (&lda)[G], int r0, int nrows,
+                                                  const float* const (&W)[G], const int (&ldw)[G], const int (&c0)[G], int K,
+                                                  int wave, f32x4 (&acc)[G]) {
+  constexpr int STEP = NW * 16;
+  constexpr int GA = SAMEA ? 1 : G;
+  const int lane = threadIdx.x & 63;
+  const int rr = lane & 15, q = lane >> 4;
+  const bool aok = (r0 + rr) < nrows;
+  const float* ap[GA];
+  const float* wp[G];
+#pragma unroll
+  for (int g = 0; g < GA; ++g) ap[g] = A[g] + (size_t)(aok ? r0 + rr : 0) * lda[g] + 4 * q;
+#pragma unroll
+  for (int g = 0; g < G; ++g) wp[g] = W[g] + (size_t)c0[g] * ldw[g] + 4 * lane;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  int kc = wave * 16;
+  for (; kc + STEP < K; kc += 2 * STEP) {
+    float4 a0[GA], a1[GA], w0[G], w1[G];
+#pragma unroll
+    for (int g = 0; g < GA; ++g) {
+      a0[g] = *reinterpret_cast<const float4*>(ap[g] + kc);
+      a1[g] = *reinterpret_cast<const float4*>(ap[g] + kc + STEP);
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      w0[g] = *reinterpret_cast<const float4*>(wp[g] + 16 * (size_t)kc);
+      w1[g] = *reinterpret_cast<const float4*>(wp[g] + 16 * (size_t)(kc + STEP));
+    }
+    if (!aok) {
+#pragma unroll
+      for (int g = 0; g < GA; ++g) a0[g] = a1[g] = zero;
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[SAMEA ? 0 : g].x, w0[g].x, acc[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[SAMEA ? 0 : g].y, w0[g].y, acc[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[SAMEA ? 0 : g].z, w0[g].z, acc[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[SAMEA ? 0 : g].w, w0[g].w, acc[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[SAMEA ? 0 : g].x, w1[g].x, acc[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[SAMEA ? 0 : g].y, w1[g].y, acc[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[SAMEA ? 0 : g].z, w1[g].z, acc[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[SAMEA ? 0 : g].w, w1[g].w, acc[g], 0, 0, 0);
+  }
+  for (; kc < K; kc += STEP) {
+    float4 a0[GA], w0[G];
+#pragma unroll
+    for (int g = 0; g < GA; ++g) a0[g] = *reinterpret_cast<const float4*>(ap[g] + kc);
+#pragma unroll
+    for (int g = 0; g < G; ++g) w0[g] = *reinterpret_cast<const float4*>(wp[g] + 16 * (size_t)kc);
+    if (!aok) {
+#pragma unroll
+      for (int g = 0; g < GA; ++g) a0[g] = zero;
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[SAMEA ? 0 : g].x, w0[g].x, acc[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[SAMEA ? 0 : g].y, w0[g].y, acc[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[SAMEA ? 0 : g].z, w0[g].z, acc[g], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[SAMEA ? 0 : g].w, w0[g].w, acc[g], 0, 0, 0);
+  }
+}
+
 // ---- 32x32 output tile (large batches), K split over the NW waves of a workgroup ---------------------------------------
 // acc += A[r0+i][k] * W[c0+j][k] with v_mfma_f32_32x32x2_f32: lane (li = lane & 31, lh = lane >> 5) loads 4 consecutive k at
 // offset 4*lh of every 8-k chunk as one 16-byte load and feeds them to 4 MFMAs (MFMA c sums k = chunk + c and chunk + 4 + c;

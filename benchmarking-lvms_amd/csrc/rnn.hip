@@ -67,9 +67,12 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_kernel(LstmFwdArgs a) {
   const bool live = a.lens == nullptr || a.t < a.lens[rowc];
   f32x4 acc[4];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[g] = wave_gemm16<NW, true>(a.hprev, H, r0, a.B, a.Whh, H, g * H + c0, H, wave, acc[g]);
+  for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  {
+    const float* const As[4] = {a.hprev, a.hprev, a.hprev, a.hprev};
+    const float* const Ws[4] = {a.Whh, a.Whh, a.Whh, a.Whh};
+    const int ld[4] = {H, H, H, H}, cs[4] = {c0, H + c0, 2 * H + c0, 3 * H + c0};
+    wave_gemm16_multi<NW, 4, true>(As, ld, r0, a.B, Ws, ld, cs, H, wave, acc);
   }
   float v[4];
   reduce_tiles<4, NW>(acc, red, v);
@@ -189,9 +192,12 @@ __global__ __launch_bounds__(NW * 64) void gru_fwd_kernel(GruFwdArgs a) {
   const float hp = a.hprev[o];
   f32x4 acc[3];
 #pragma unroll
-  for (int g = 0; g < 3; ++g) {
-    acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[g] = wave_gemm16<NW, true>(a.hprev, R, r0, a.B, a.Whh, R, g * R + c0, R, wave, acc[g]);
+  for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  {
+    const float* const As[3] = {a.hprev, a.hprev, a.hprev};
+    const float* const Ws[3] = {a.Whh, a.Whh, a.Whh};
+    const int ld[3] = {R, R, R}, cs[3] = {c0, R + c0, 2 * R + c0};
+    wave_gemm16_multi<NW, 3, true>(As, ld, r0, a.B, Ws, ld, cs, R, wave, acc);
   }
   float v[3];
   reduce_tiles<3, NW>(acc, red, v);

@@ -41,9 +41,12 @@ __global__ __launch_bounds__(NW * 64) void gru_cell_stage_kernel(GruCellArgs a) 
   const float hp = a.hprev[(size_t)rowc * a.ldh + col];
   f32x4 acc[3];
 #pragma unroll
-  for (int g = 0; g < 3; ++g) {
-    acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[g] = wave_gemm16<NW, true>(a.A, a.lda, r0, a.B, a.Wih, a.ldw, g * H + c0, a.K, wave, acc[g]);
+  for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  {
+    const float* const As[3] = {a.A, a.A, a.A};
+    const float* const Ws[3] = {a.Wih, a.Wih, a.Wih};
+    const int la[3] = {a.lda, a.lda, a.lda}, lw[3] = {a.ldw, a.ldw, a.ldw}, cs[3] = {c0, H + c0, 2 * H + c0};
+    wave_gemm16_multi<NW, 3, true>(As, la, r0, a.B, Ws, lw, cs, a.K, wave, acc);
   }
   float v[3];
   reduce_tiles<3, NW>(acc, red, v);
@@ -82,8 +85,12 @@ __global__ __launch_bounds__(NW * 64) void rssm_dh_stage_kernel(RssmDhArgs a) {
   f32x4 acc[2];
   acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
   acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  acc[0] = wave_gemm16<NW, true>(a.DQ0, H, r0, a.B, a.WqT, H, c0, H, wave, acc[0]);
-  acc[1] = wave_gemm16<NW, true>(a.DP0, H, r0, a.B, a.WpT, H, c0, H, wave, acc[1]);
+  {
+    const float* const As[2] = {a.DQ0, a.DP0};
+    const float* const Ws[2] = {a.WqT, a.WpT};
+    const int ld[2] = {H, H}, cs[2] = {c0, c0};
+    wave_gemm16_multi<NW, 2, false>(As, ld, r0, a.B, Ws, ld, cs, H, wave, acc);
+  }
   float v[2];
   reduce_tiles<2, NW>(acc, red, v);
   if (!own) return;

@@ -157,10 +157,12 @@ __global__ __launch_bounds__(NW * 64) void head_stage_kernel(HeadArgs a) {
   f32x4 acc[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  acc[0] = wave_gemm16<NW, true>(a.P, a.H, r0, a.B, a.Wp, a.H, c0, a.H, wave, acc[0]);
-  acc[1] = wave_gemm16<NW, true>(a.P, a.H, r0, a.B, a.Wp, a.H, a.Z + c0, a.H, wave, acc[1]);
-  acc[2] = wave_gemm16<NW, true>(a.Q, a.H, r0, a.B, a.Wq, a.H, c0, a.H, wave, acc[2]);
-  acc[3] = wave_gemm16<NW, true>(a.Q, a.H, r0, a.B, a.Wq, a.H, a.Z + c0, a.H, wave, acc[3]);
+  {
+    const float* const As[4] = {a.P, a.P, a.Q, a.Q};
+    const float* const Ws[4] = {a.Wp, a.Wp, a.Wq, a.Wq};
+    const int ld[4] = {a.H, a.H, a.H, a.H}, cs[4] = {c0, a.Z + c0, c0, a.Z + c0};
+    wave_gemm16_multi<NW, 4, false>(As, ld, r0, a.B, Ws, ld, cs, a.H, wave, acc);
+  }
   float v[4];
   reduce_tiles<4, NW>(acc, red, v);
   if (!own) return;
@@ -231,8 +233,14 @@ __global__ __launch_bounds__(NW * 64) void dz_stage_kernel(DzArgs a) {
     f32x4 acc[2];
     acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[0] = wave_gemm16<NW, true>(a.D, a.H, r0, a.B, a.WT, a.H, c0, a.H, threadIdx.x >> 6, acc[0]);
-    if (a.D2 != nullptr) acc[1] = wave_gemm16<NW, true>(a.D2, a.H, r0, a.B, a.WT2, a.H, c0, a.H, threadIdx.x >> 6, acc[1]);
+    if (a.D2 != nullptr) {  // wave-uniform
+      const float* const As[2] = {a.D, a.D2};
+      const float* const Ws[2] = {a.WT, a.WT2};
+      const int ld[2] = {a.H, a.H}, cs[2] = {c0, c0};
+      wave_gemm16_multi<NW, 2, false>(As, ld, r0, a.B, Ws, ld, cs, a.H, threadIdx.x >> 6, acc);
+    } else {
+      acc[0] = wave_gemm16<NW, true>(a.D, a.H, r0, a.B, a.WT, a.H, c0, a.H, threadIdx.x >> 6, acc[0]);
+    }
     reduce_tiles<2, NW>(acc, red, v);
   }
   if (!own) return;

@@ -51,9 +51,12 @@ __global__ __launch_bounds__(NW * 64) void gru_stage_kernel(GruArgs a) {
   const float hp = a.decin_t[(size_t)rowc * ldd + a.H + col];
   f32x4 acc[3];
 #pragma unroll
-  for (int g = 0; g < 3; ++g) {
-    acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[g] = wave_gemm16<NW, true>(a.decin_t, ldd, r0, a.B, a.Wih, a.H, g * a.R + c0, a.H, wave, acc[g]);
+  for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  {
+    const float* const As[3] = {a.decin_t, a.decin_t, a.decin_t};
+    const float* const Ws[3] = {a.Wih, a.Wih, a.Wih};
+    const int la[3] = {ldd, ldd, ldd}, lw[3] = {a.H, a.H, a.H}, cs[3] = {c0, a.R + c0, 2 * a.R + c0};
+    wave_gemm16_multi<NW, 3, true>(As, la, r0, a.B, Ws, lw, cs, a.H, wave, acc);
   }
   float v[3];
   reduce_tiles<3, NW>(acc, red, v);
@@ -103,8 +106,12 @@ __global__ __launch_bounds__(NW * 64) void dh_stage_kernel(DhArgs a) {
     f32x4 acc[2];
     acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[0] = wave_gemm16<NW, true>(a.DP0, a.H, r0, a.B, a.WpT, a.H, c0, a.H, wave, acc[0]);
-    acc[1] = wave_gemm16<NW, true>(a.DQ0, a.H, r0, a.B, a.WqT, a.H, c0, a.H, wave, acc[1]);
+    {
+      const float* const As[2] = {a.DP0, a.DQ0};
+      const float* const Ws[2] = {a.WpT, a.WqT};
+      const int ld[2] = {a.H, a.H}, cs[2] = {c0, c0};
+      wave_gemm16_multi<NW, 2, false>(As, ld, r0, a.B, Ws, ld, cs, a.H, wave, acc);
+    }
     reduce_tiles<2, NW>(acc, red, v);
   }
   if (!own) return;
