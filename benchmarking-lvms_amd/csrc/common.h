@@ -80,6 +80,29 @@ inline int gemm_pick_split(int M, int N, int K) {
 // 1 KB read (~150 GB/s per workgroup, tools/cu_ingest.hip).  Block (row tile t, k chunk j) of a [R,K] matrix sits at
 // ((t * K/16 + j) * 256) floats, element (rr, 4q+e) of it at (rr + 16 q) * 4 + e: the fragment address of lane
 // (rr = lane & 15, q = lane >> 4) is W + c0 * ldw + 16 * k0 + 4 * lane with ldw = the packed matrix's K.
+// U consecutive k-chunks of one wave: all 2U fragment loads first, then the 4U MFMAs in ascending k
+template <int U, int STEP, int WS>
+__device__ __forceinline__ f32x4 gemm16_chunks(const float* __restrict__ ap, const float* __restrict__ wp, int kc, bool aok,
+                                                f32x4 acc) {
+  float4 a[U], w[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) a[u] = *reinterpret_cast<const float4*>(ap + kc + u * STEP);
+#pragma unroll
+  for (int u = 0; u < U; ++u) w[u] = *reinterpret_cast<const float4*>(wp + (size_t)WS * (kc + u * STEP));
+  if (!aok) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, w[u].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, w[u].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, w[u].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, w[u].w, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
 template <int NW, bool WT16 = false>
 __device__ __forceinline__ f32x4 wave_gemm16(const float* __restrict__ A, int lda, int r0, int nrows,
                                               const float* __restrict__ W, int ldw, int c0, int K, int wave,
@@ -91,45 +114,12 @@ __device__ __forceinline__ f32x4 wave_gemm16(const float* __restrict__ A, int ld
   const float* ap = A + (size_t)(aok ? r0 + rr : 0) * lda + 4 * q;
   const float* wp = WT16 ? W + (size_t)c0 * ldw + 4 * lane : W + (size_t)(c0 + rr) * ldw + 4 * q;
   constexpr int WS = WT16 ? 16 : 1;  // k stride of the W fragment address
-  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   int kc = wave * 16;
-  // 4 chunks per trip keeps 8 x 16-byte loads in flight
-  for (; kc + 3 * STEP < K; kc += 4 * STEP) {
-    float4 a0 = *reinterpret_cast<const float4*>(ap + kc);
-    float4 a1 = *reinterpret_cast<const float4*>(ap + kc + STEP);
-    float4 a2 = *reinterpret_cast<const float4*>(ap + kc + 2 * STEP);
-    float4 a3 = *reinterpret_cast<const float4*>(ap + kc + 3 * STEP);
-    const float4 w0 = *reinterpret_cast<const float4*>(wp + WS * (kc));
-    const float4 w1 = *reinterpret_cast<const float4*>(wp + WS * (kc + STEP));
-    const float4 w2 = *reinterpret_cast<const float4*>(wp + WS * (kc + 2 * STEP));
-    const float4 w3 = *reinterpret_cast<const float4*>(wp + WS * (kc + 3 * STEP));
-    if (!aok) { a0 = a1 = a2 = a3 = zero; }
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, w0.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, w0.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, w0.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, w0.w, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, w1.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, w1.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, w1.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, w1.w, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, w2.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, w2.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.z, w2.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.w, w2.w, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.x, w3.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.y, w3.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.z, w3.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.w, w3.w, acc, 0, 0, 0);
-  }
-  for (; kc < K; kc += STEP) {
-    float4 a0 = *reinterpret_cast<const float4*>(ap + kc);
-    const float4 w0 = *reinterpret_cast<const float4*>(wp + WS * (kc));
-    if (!aok) a0 = zero;
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, w0.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, w0.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, w0.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, w0.w, acc, 0, 0, 0);
-  }
+  // 4 chunks per trip keeps 8 x 16-byte loads in flight; left-over chunks are one dependent round trip EACH, so the host picks
+  // NW such that a wave owns 4 chunks or 1 (stages.h pick_nw).  Handling 2-3 left-over chunks in one trip here was tried: the
+  // extra code costs every link ~0.06 us (VRNN +0.3 ms/step) and only the 3-chunk shapes gain (tools/chain_bench.hip).
+  for (; kc + 3 * STEP < K; kc += 4 * STEP) acc = gemm16_chunks<4, STEP, WS>(ap, wp, kc, aok, acc);
+  for (; kc < K; kc += STEP) acc = gemm16_chunks<1, STEP, WS>(ap, wp, kc, aok, acc);
   return acc;
 }
 

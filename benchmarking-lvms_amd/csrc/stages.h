@@ -279,12 +279,18 @@ __global__ __launch_bounds__(NW * 64) void dz_stage_kernel(DzArgs a) {
   a.dph[o2 + a.Z] = g_sdp * sigmoidf_(a.beta * rp);
 }
 
-// number of waves for a K-deep reduction: <= 4 chunks of 16 per wave where possible
+// number of waves for a K-deep reduction.  One product (groups == 1, wave_gemm16): a wave's chunks cost one memory round trip
+// per 4 chunks plus one per left-over chunk, so take the NW with the fewest trips (K = 192: 12 chunks -> 16 waves x 1 chunk, not
+// 4 waves x 3), the size rule's choice on ties.  Several products (wave_gemm16_multi): <= 4 chunks of 16 per wave over all products.
 inline int pick_nw(int K, int groups) {
   const int chunks = (K / 16) * groups;
-  if (chunks > 32) return 16;
-  if (chunks > 16) return 8;
-  return 4;
+  const int by_size = chunks > 32 ? 16 : (chunks > 16 ? 8 : 4);  // <= 4 chunks per wave where possible
+  if (groups != 1) return by_size;
+  auto trips = [K](int nw) { const int cpw = (K / 16 + nw - 1) / nw; return cpw / 4 + cpw % 4; };
+  int best = by_size;
+  for (int nw = 4; nw <= 16; nw *= 2)
+    if (trips(nw) < trips(best)) best = nw;
+  return best;
 }
 
 #define LAUNCH_NW(kernel, nw, grid, stream, args)                                          \

@@ -194,7 +194,7 @@ int main() {
   }
   Big b{}; b.tiles[0] = 64; b.o[0] = act[0]; b.o[1] = act[1]; b.l[0] = 1; b.l[1] = 2;
   timeit("big kernarg (280 B) + select, 128 WG x 256", [&](int) { hipLaunchKernelGGL(k_bigarg, dim3(128), dim3(256), 0, s, b); });
-  for (int kk : {256, 512, 1536}) {
+  for (int kk : {192, 256, 512, 768, 1536}) {
     for (int nw : {4, 8, 16}) {
       Small a{}; a.W = W; a.bias = bias; a.add = add; a.lda = 2048; a.ldw = kk; a.ldadd = 2048; a.ldo = 2048; a.B = B; a.K = kk;
       a.a_split = 256; a.a_off = 0; a.add_c0 = 256; a.add_c1 = 512; a.relu_c1 = 512;
