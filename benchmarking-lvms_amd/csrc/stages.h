@@ -73,6 +73,38 @@ __global__ __launch_bounds__(NW * 64) void lin_stage_kernel(LinArgs<NSEG> a) {
   out[(size_t)row * ldo + col] = x;
 }
 
+// Single-segment link with SCALAR arguments: the command processor preloads the first 16 argument dwords into SGPRs before
+// the wave starts (-mllvm -amdgpu-kernarg-preload-count=16; struct arguments are never preloaded), so the operand loads do not
+// wait for a kernarg fetch from memory (0.16-0.2 us of a ~3 us link, tools/chain_bench.hip "scalar args").  Everything the
+// loads need sits in the 14 dwords that are preloaded (16 user SGPRs minus the kernarg pointer): five pointers and the leading
+// dimensions / K / B / flags packed two 16-bit values a dword; `out` and `slope`, needed last, come by s_load.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void lin1_stage_kernel(const float* A, const float* W, const float* bias,
+                                                             const float* add, const float* gate, unsigned lda_ldw,
+                                                             unsigned k_b, unsigned ldadd_ldgate, unsigned ldo_flags,
+                                                             float* out, float slope) {
+  __shared__ float red[NW * 256];
+  const int lda = lda_ldw & 0xffff, ldw = lda_ldw >> 16, K = k_b & 0xffff, B = k_b >> 16;
+  const int ldadd = ldadd_ldgate & 0xffff, ldgate = ldadd_ldgate >> 16, ldo = ldo_flags & 0xffff, flags = ldo_flags >> 16;
+  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16;
+  const int t = threadIdx.x & 255;
+  const int row = r0 + (t >> 4), col = c0 + (t & 15);
+  const bool own = threadIdx.x < 256 && row < B;
+  const int rowc = row < B ? row : r0;
+  const float e_bias = bias[(flags & LF_BIAS) ? col : 0];
+  const float e_add = add[(flags & LF_ADD) ? (size_t)rowc * ldadd + col : 0];
+  const float e_gate = gate[(flags & LF_GATE) ? (size_t)rowc * ldgate + col : 0];
+  f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+  acc[0] = wave_gemm16<NW, true>(A, lda, r0, B, W, ldw, c0, K, threadIdx.x >> 6, acc[0]);
+  float v[1];
+  reduce_tiles<1, NW>(acc, red, v);
+  if (!own) return;
+  float x = v[0] + ((flags & LF_BIAS) ? e_bias : 0.f) + ((flags & LF_ADD) ? e_add : 0.f);
+  if (flags & LF_RELU) x = x > 0.f ? x : x * slope;
+  if (flags & LF_GATE) x = e_gate > 0.f ? x : x * slope;
+  out[(size_t)row * ldo + col] = x;
+}
+
 // The same stage on 32x32 tiles for large batches (B >= 128): `tiles` counts 32-column tiles.  The NW partial tiles are
 // combined through LDS (row stride 33: conflict-free); threads 0..255 then own 4 output elements each.
 template <int NW, int NSEG>
@@ -359,6 +391,17 @@ inline void launch_lin_n(const LinLaunch& l, hipStream_t s) {
   }
   const int nw = pick_nw(kmax, 1);
   const dim3 grid(tiles, (l.B + 15) / 16);
+#ifndef BLVM_NO_LIN1
+  if (NSEG == 1 && l.B < 65536 && a.K[0] < 65536 && a.lda[0] < 65536 && a.ldw[0] < 65536 && a.ldadd[0] < 65536 &&
+      a.ldgate[0] < 65536 && a.ldo[0] < 65536) {
+    const unsigned p0 = (unsigned)a.lda[0] | ((unsigned)a.ldw[0] << 16), p1 = (unsigned)a.K[0] | ((unsigned)l.B << 16);
+    const unsigned p2 = (unsigned)a.ldadd[0] | ((unsigned)a.ldgate[0] << 16), p3 = (unsigned)a.ldo[0] | ((unsigned)a.flags[0] << 16);
+    if (nw == 16) hipLaunchKernelGGL((lin1_stage_kernel<16>), grid, dim3(1024), 0, s, a.A[0], a.W[0], a.bias[0], a.add[0], a.gate[0], p0, p1, p2, p3, a.out[0], a.slope);
+    else if (nw == 8) hipLaunchKernelGGL((lin1_stage_kernel<8>), grid, dim3(512), 0, s, a.A[0], a.W[0], a.bias[0], a.add[0], a.gate[0], p0, p1, p2, p3, a.out[0], a.slope);
+    else hipLaunchKernelGGL((lin1_stage_kernel<4>), grid, dim3(256), 0, s, a.A[0], a.W[0], a.bias[0], a.add[0], a.gate[0], p0, p1, p2, p3, a.out[0], a.slope);
+    return;
+  }
+#endif
   if (nw == 16) hipLaunchKernelGGL((lin_stage_kernel<16, NSEG>), grid, dim3(1024), 0, s, a);
   else if (nw == 8) hipLaunchKernelGGL((lin_stage_kernel<8, NSEG>), grid, dim3(512), 0, s, a);
   else hipLaunchKernelGGL((lin_stage_kernel<4, NSEG>), grid, dim3(256), 0, s, a);
