@@ -81,3 +81,33 @@ def test_two_rank_gradient_equals_single_process():
     assert n_global == n_full == 153.0
     assert err < 1e-5, err  # fp32 round-off only
     assert naive > 1e-2  # a rank's own gradient is NOT the global one: the exchange is doing real work
+
+
+def test_reducer_hands_out_bucket_slices_without_a_process_group():
+    """Single process, no process group: the exchange is the identity on the gradients, and afterwards every p.grad is a slice
+    of the flat bucket (no copy back) that clipping and the optimizer can work on in place."""
+    sys.path.insert(0, PKG)
+    from blvm.training.ddp import FlatGradAllReduce
+
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(3, 5)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(2, 2, 2))]
+    loss = sum((p * p).sum() * (i + 1) for i, p in enumerate(params))
+    loss.backward()
+    expect = [p.grad.clone() for p in params]
+    red = FlatGradAllReduce(params)
+    n = red(1234.0)
+    assert float(n) == 1234.0
+    lo, hi = red.flat.data_ptr(), red.flat.data_ptr() + red.flat.numel() * 4
+    for p, e in zip(params, expect):
+        assert lo <= p.grad.data_ptr() < hi, "gradient is not a slice of the bucket"
+        torch.testing.assert_close(p.grad, e, rtol=1e-6, atol=0)
+    torch.nn.utils.clip_grad_norm_(params, 1e-3)  # in place on the slices
+    assert float(red.flat[:-1].norm()) <= 1e-3 * 1.001
+    # a second step with fresh gradients (zero_grad(set_to_none=True) semantics) overwrites the bucket
+    for p in params:
+        p.grad = None
+    sum((p * p).sum() for p in params).backward()
+    expect2 = [p.grad.clone() for p in params]
+    red(10.0)
+    for p, e in zip(params, expect2):
+        torch.testing.assert_close(p.grad, e, rtol=1e-6, atol=0)
