@@ -105,6 +105,41 @@ __global__ __launch_bounds__(NW * 64) void lin1_stage_kernel(const float* A, con
   out[(size_t)row * ldo + col] = x;
 }
 
+// Two SYMMETRIC segments (prior | posterior layer of the same shape, forward with a bias or backward with a gate) with scalar
+// arguments: both segments share lda, K (= ldw, true for every T16 weight that is not a K-slice), ldo, the tile count and the
+// flags, and have at most ONE epilogue operand each (bias or gate), so all that the loads need fits the 14 preloaded dwords:
+// A0 A1 W0 W1 e0 e1 | lda/16:12 K/16:12 flags:4 | B:12 tiles:10 lde/4:10.  out0/out1, ldo, slope come by s_load.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void lin2s_stage_kernel(const float* A0, const float* A1, const float* W0, const float* W1,
+                                                              const float* e0, const float* e1, unsigned lda_k_flags,
+                                                              unsigned b_tiles_lde, float* out0, float* out1, int ldo,
+                                                              float slope) {
+  __shared__ float red[NW * 256];
+  const int lda = (lda_k_flags & 0xfff) * 16, K = ((lda_k_flags >> 12) & 0xfff) * 16, flags = lda_k_flags >> 24;
+  const int B = b_tiles_lde & 0xfff, tiles = (b_tiles_lde >> 12) & 0x3ff, lde = (b_tiles_lde >> 22) * 4;
+  const bool s1 = (int)blockIdx.x >= tiles;  // uniform
+  const int ct = (int)blockIdx.x - (s1 ? tiles : 0);
+  const float* A = s1 ? A1 : A0;
+  const float* W = s1 ? W1 : W0;
+  const float* e = s1 ? e1 : e0;
+  const int r0 = blockIdx.y * 16, c0 = ct * 16;
+  const int t = threadIdx.x & 255;
+  const int row = r0 + (t >> 4), col = c0 + (t & 15);
+  const bool own = threadIdx.x < 256 && row < B;
+  const int rowc = row < B ? row : r0;
+  // bias: e[col]; gate: e[row * lde + col]; neither: e is a valid dummy
+  const float e_val = e[(flags & LF_GATE) ? (size_t)rowc * lde + col : ((flags & LF_BIAS) ? col : 0)];
+  f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+  acc[0] = wave_gemm16<NW, true>(A, lda, r0, B, W, K, c0, K, threadIdx.x >> 6, acc[0]);
+  float v[1];
+  reduce_tiles<1, NW>(acc, red, v);
+  if (!own) return;
+  float x = v[0] + ((flags & LF_BIAS) ? e_val : 0.f);
+  if (flags & LF_RELU) x = x > 0.f ? x : x * slope;
+  if (flags & LF_GATE) x = e_val > 0.f ? x : x * slope;
+  (s1 ? out1 : out0)[(size_t)row * ldo + col] = x;
+}
+
 // The same stage on 32x32 tiles for large batches (B >= 128): `tiles` counts 32-column tiles.  The NW partial tiles are
 // combined through LDS (row stride 33: conflict-free); threads 0..255 then own 4 output elements each.
 template <int NW, int NSEG>
@@ -400,6 +435,27 @@ inline void launch_lin_n(const LinLaunch& l, hipStream_t s) {
     else if (nw == 8) hipLaunchKernelGGL((lin1_stage_kernel<8>), grid, dim3(512), 0, s, a.A[0], a.W[0], a.bias[0], a.add[0], a.gate[0], p0, p1, p2, p3, a.out[0], a.slope);
     else hipLaunchKernelGGL((lin1_stage_kernel<4>), grid, dim3(256), 0, s, a.A[0], a.W[0], a.bias[0], a.add[0], a.gate[0], p0, p1, p2, p3, a.out[0], a.slope);
     return;
+  }
+#endif
+#ifndef BLVM_NO_LIN2S
+  if (NSEG == 2) {
+    const int f = a.flags[0];
+    const bool one_operand = (f & LF_ADD) == 0 && ((f & LF_BIAS) == 0 || (f & LF_GATE) == 0);
+    const int lde = (f & LF_GATE) ? a.ldgate[0] : 0;
+    if (one_operand && a.flags[1 % NSEG] == f && a.lda[0] == a.lda[1 % NSEG] && a.K[0] == a.K[1 % NSEG] && a.ldw[0] == a.K[0] &&
+        a.ldw[1 % NSEG] == a.K[0] && a.ldo[0] == a.ldo[1 % NSEG] && a.tiles[0] == a.tiles[1 % NSEG] &&
+        (!(f & LF_GATE) || a.ldgate[1 % NSEG] == lde) && l.B < 4096 && a.lda[0] % 16 == 0 && a.lda[0] < 65536 &&
+        a.K[0] % 16 == 0 && a.K[0] < 65536 && lde % 4 == 0 && lde < 4096 && a.tiles[0] < 1024) {
+      const float* e0 = (f & LF_GATE) ? a.gate[0] : a.bias[0];
+      const float* e1 = (f & LF_GATE) ? a.gate[1 % NSEG] : a.bias[1 % NSEG];
+      const unsigned p0 = (unsigned)(a.lda[0] / 16) | ((unsigned)(a.K[0] / 16) << 12) | ((unsigned)f << 24);
+      const unsigned p1 = (unsigned)l.B | ((unsigned)a.tiles[0] << 12) | ((unsigned)(lde / 4) << 22);
+      const int p2 = a.ldo[0];
+      if (nw == 16) hipLaunchKernelGGL((lin2s_stage_kernel<16>), grid, dim3(1024), 0, s, a.A[0], a.A[1 % NSEG], a.W[0], a.W[1 % NSEG], e0, e1, p0, p1, a.out[0], a.out[1 % NSEG], p2, a.slope);
+      else if (nw == 8) hipLaunchKernelGGL((lin2s_stage_kernel<8>), grid, dim3(512), 0, s, a.A[0], a.A[1 % NSEG], a.W[0], a.W[1 % NSEG], e0, e1, p0, p1, a.out[0], a.out[1 % NSEG], p2, a.slope);
+      else hipLaunchKernelGGL((lin2s_stage_kernel<4>), grid, dim3(256), 0, s, a.A[0], a.A[1 % NSEG], a.W[0], a.W[1 % NSEG], e0, e1, p0, p1, a.out[0], a.out[1 % NSEG], p2, a.slope);
+      return;
+    }
   }
 #endif
   if (nw == 16) hipLaunchKernelGGL((lin_stage_kernel<16, NSEG>), grid, dim3(1024), 0, s, a);
