@@ -53,26 +53,31 @@ struct LstmFwdArgs {
 };
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void lstm_fwd_kernel(LstmFwdArgs a) {
+__global__ __launch_bounds__(NW * 64) void lstm_fwd_kernel(const float* hprev, const float* cprev, const float* Whh,
+                                                           const float* bhh, const float* xg, const int32_t* lens, unsigned b_h,
+                                                           int t_step, float* hnext, float* cnext, float* out, float* gates) {
+  // scalar arguments (LstmFwdArgs documents them): the 6 input pointers, B:16|H:16 and the step are the 14 dwords the command
+  // processor preloads into SGPRs (stages.h lin1_stage_kernel); the outputs come by s_load
+  const int B = b_h & 0xffff, H = b_h >> 16;
   __shared__ float red[4 * NW * 256];
-  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, wave = threadIdx.x >> 6, H = a.H;
+  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, wave = threadIdx.x >> 6;
   const int t = threadIdx.x & 255;
   const int row = r0 + (t >> 4), col = c0 + (t & 15);
-  const bool own = threadIdx.x < 256 && row < a.B;
-  const int rowc = row < a.B ? row : r0;
+  const bool own = threadIdx.x < 256 && row < B;
+  const int rowc = row < B ? row : r0;
   const size_t o = (size_t)rowc * H + col, o4 = (size_t)rowc * 4 * H + col;
-  const float x0 = a.xg[o4] + a.bhh[col], x1 = a.xg[o4 + H] + a.bhh[H + col];
-  const float x2 = a.xg[o4 + 2 * H] + a.bhh[2 * H + col], x3 = a.xg[o4 + 3 * H] + a.bhh[3 * H + col];
-  const float hp = a.hprev[o], cp = a.cprev[o];
-  const bool live = a.lens == nullptr || a.t < a.lens[rowc];
+  const float x0 = xg[o4] + bhh[col], x1 = xg[o4 + H] + bhh[H + col];
+  const float x2 = xg[o4 + 2 * H] + bhh[2 * H + col], x3 = xg[o4 + 3 * H] + bhh[3 * H + col];
+  const float hp = hprev[o], cp = cprev[o];
+  const bool live = lens == nullptr || t_step < lens[rowc];
   f32x4 acc[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
   {
-    const float* const As[4] = {a.hprev, a.hprev, a.hprev, a.hprev};
-    const float* const Ws[4] = {a.Whh, a.Whh, a.Whh, a.Whh};
+    const float* const As[4] = {hprev, hprev, hprev, hprev};
+    const float* const Ws[4] = {Whh, Whh, Whh, Whh};
     const int ld[4] = {H, H, H, H}, cs[4] = {c0, H + c0, 2 * H + c0, 3 * H + c0};
-    wave_gemm16_multi<NW, 4, true>(As, ld, r0, a.B, Ws, ld, cs, H, wave, acc);
+    wave_gemm16_multi<NW, 4, true>(As, ld, r0, B, Ws, ld, cs, H, wave, acc);
   }
   float v[4];
   reduce_tiles<4, NW>(acc, red, v);
@@ -80,13 +85,13 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_kernel(LstmFwdArgs a) {
   const float i = sigmoidf_(v[0] + x0), f = sigmoidf_(v[1] + x1), g = tanhf(v[2] + x2), og = sigmoidf_(v[3] + x3);
   const float c2 = f * cp + i * g;
   const float h2 = og * tanhf(c2);
-  a.cnext[o] = live ? c2 : cp;
-  a.hnext[o] = live ? h2 : hp;
-  a.out[o] = live ? h2 : 0.f;
-  a.gates[o4] = live ? i : 0.f;
-  a.gates[o4 + H] = live ? f : 0.f;
-  a.gates[o4 + 2 * H] = live ? g : 0.f;
-  a.gates[o4 + 3 * H] = live ? og : 0.f;
+  cnext[o] = live ? c2 : cp;
+  hnext[o] = live ? h2 : hp;
+  out[o] = live ? h2 : 0.f;
+  gates[o4] = live ? i : 0.f;
+  gates[o4 + H] = live ? f : 0.f;
+  gates[o4 + 2 * H] = live ? g : 0.f;
+  gates[o4 + 3 * H] = live ? og : 0.f;
 }
 
 struct LstmBwdArgs {
@@ -102,37 +107,43 @@ struct LstmBwdArgs {
 };
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(LstmBwdArgs a) {
+__global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(const float* DGn, const float* WhhT, const float* dout,
+                                                           const float* gates, const float* c_s, float* DC, unsigned b_h,
+                                                           unsigned has, float* DG, float* dh0) {
+  // scalar arguments (LstmBwdArgs documents them; c_s1 = c_s + B*H, consecutive steps of the saved cell states): 14 preloaded dwords
+  const int B = b_h & 0xffff, H0 = b_h >> 16;
+  const int has_gemm = has & 1, has_gates = (has >> 1) & 1;
+  const float* c_s1 = c_s + (size_t)B * H0;
   __shared__ float red[NW * 256];
-  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, H = a.H;
+  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, H = H0;
   const int t = threadIdx.x & 255;
   const int row = r0 + (t >> 4), col = c0 + (t & 15);
-  const bool own = threadIdx.x < 256 && row < a.B;
-  const int rowc = row < a.B ? row : r0;
+  const bool own = threadIdx.x < 256 && row < B;
+  const int rowc = row < B ? row : r0;
   const size_t o = (size_t)rowc * H + col, o4 = (size_t)rowc * 4 * H + col;
   float dh = 0.f, ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cs = 0.f, cs1 = 0.f, dc = 0.f;
-  if (a.has_gates) {  // wave-uniform
-    dh = a.dout[o];
-    ig = a.gates[o4]; fg = a.gates[o4 + H]; gg = a.gates[o4 + 2 * H]; og = a.gates[o4 + 3 * H];
-    cs = a.c_s[o]; cs1 = a.c_s1[o]; dc = a.DC[o];
+  if (has_gates) {  // wave-uniform
+    dh = dout[o];
+    ig = gates[o4]; fg = gates[o4 + H]; gg = gates[o4 + 2 * H]; og = gates[o4 + 3 * H];
+    cs = c_s[o]; cs1 = c_s1[o]; dc = DC[o];
   }
   float v[1] = {0.f};
-  if (a.has_gemm) {
+  if (has_gemm) {
     f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-    acc[0] = wave_gemm16<NW, true>(a.DGn, 4 * H, r0, a.B, a.WhhT, 4 * H, c0, 4 * H, threadIdx.x >> 6, acc[0]);
+    acc[0] = wave_gemm16<NW, true>(DGn, 4 * H, r0, B, WhhT, 4 * H, c0, 4 * H, threadIdx.x >> 6, acc[0]);
     reduce_tiles<1, NW>(acc, red, v);
   }
   if (!own) return;
   dh += v[0];
-  if (!a.has_gates) { a.dh0[o] = dh; return; }
+  if (!has_gates) { dh0[o] = dh; return; }
   const float tc = tanhf(cs1);
   const float d_o = dh * tc;
   const float dct = dc + dh * og * (1.f - tc * tc);
-  a.DG[o4] = dct * gg * ig * (1.f - ig);
-  a.DG[o4 + H] = dct * cs * fg * (1.f - fg);
-  a.DG[o4 + 2 * H] = dct * ig * (1.f - gg * gg);
-  a.DG[o4 + 3 * H] = d_o * og * (1.f - og);
-  a.DC[o] = dct * fg;
+  DG[o4] = dct * gg * ig * (1.f - ig);
+  DG[o4 + H] = dct * cs * fg * (1.f - fg);
+  DG[o4 + 2 * H] = dct * ig * (1.f - gg * gg);
+  DG[o4 + 3 * H] = d_o * og * (1.f - og);
+  DC[o] = dct * fg;
 }
 
 struct LstmReserve { float *XG, *Hs, *Cs, *GATES, *WhhP; };  // WhhP: T16 copy of Whh
@@ -312,6 +323,7 @@ extern "C" int blvm_lstm_seq_fwd(const float* Wih, const float* Whh, const float
   if (rc) return rc;
   BLVM_REQUIRE(Wih && Whh && bih && bhh && in && out && reserve, "lstm_fwd: null pointer");
   BLVM_REQUIRE(aligned16(reserve) && aligned16(Whh), "lstm_fwd: buffers must be 16-byte aligned");
+  BLVM_REQUIRE(B < 65536 && H < 65536, "lstm_fwd: B and H must be below 65536 (packed kernel arguments)");
   LstmReserve rs;
   carve_lstm(reserve, T, B, H, &rs);
   const size_t n = (size_t)T * B, bh = (size_t)B * H;
@@ -326,13 +338,12 @@ extern "C" int blvm_lstm_seq_fwd(const float* Wih, const float* Whh, const float
   const int nw = pick_nw(H, 4);
   const dim3 grid(H / 16, (B + 15) / 16);
   for (int t = 0; t < T; ++t) {
-    LstmFwdArgs a;
-    a.hprev = rs.Hs + t * bh; a.cprev = rs.Cs + t * bh; a.Whh = rs.WhhP; a.bhh = bhh;
-    a.xg = rs.XG + (size_t)t * B * 4 * H; a.lens = lens;
-    a.hnext = rs.Hs + (t + 1) * bh; a.cnext = rs.Cs + (t + 1) * bh;
-    a.out = out + t * bh; a.gates = rs.GATES + (size_t)t * B * 4 * H;
-    a.B = B; a.H = H; a.t = t;
-    LAUNCH_NW(lstm_fwd_kernel, nw, grid, s, a);
+    const float *hp = rs.Hs + t * bh, *cp = rs.Cs + t * bh, *xg_t = rs.XG + (size_t)t * B * 4 * H;
+    float *hnx = rs.Hs + (t + 1) * bh, *cnx = rs.Cs + (t + 1) * bh, *out_t = out + t * bh, *gates_t = rs.GATES + (size_t)t * B * 4 * H;
+    const unsigned b_h = (unsigned)B | ((unsigned)H << 16);
+    if (nw == 16) hipLaunchKernelGGL((lstm_fwd_kernel<16>), grid, dim3(1024), 0, s, hp, cp, (const float*)rs.WhhP, bhh, xg_t, lens, b_h, t, hnx, cnx, out_t, gates_t);
+    else if (nw == 8) hipLaunchKernelGGL((lstm_fwd_kernel<8>), grid, dim3(512), 0, s, hp, cp, (const float*)rs.WhhP, bhh, xg_t, lens, b_h, t, hnx, cnx, out_t, gates_t);
+    else hipLaunchKernelGGL((lstm_fwd_kernel<4>), grid, dim3(256), 0, s, hp, cp, (const float*)rs.WhhP, bhh, xg_t, lens, b_h, t, hnx, cnx, out_t, gates_t);
   }
   BLVM_CHECK_LAUNCH("lstm_seq_fwd");
   if (hn) BLVM_HIP(hipMemcpyAsync(hn, rs.Hs + T * bh, sizeof(float) * bh, hipMemcpyDeviceToDevice, s));
@@ -348,6 +359,7 @@ extern "C" int blvm_lstm_seq_bwd(const float* Wih, const float* Whh, const float
   if (rc) return rc;
   BLVM_REQUIRE(Wih && Whh && in && reserve && d_out && workspace, "lstm_bwd: null pointer");
   BLVM_REQUIRE(aligned16(reserve) && aligned16(workspace), "lstm_bwd: buffers must be 16-byte aligned");
+  BLVM_REQUIRE(B < 65536 && H < 65536, "lstm_bwd: B and H must be below 65536 (packed kernel arguments)");
   LstmReserve rs;
   carve_lstm(const_cast<float*>(reserve), T, B, H, &rs);
   LstmWs ws;
@@ -360,18 +372,16 @@ extern "C" int blvm_lstm_seq_bwd(const float* Wih, const float* Whh, const float
   const dim3 grid(H / 16, (B + 15) / 16);
   // scratch for dh0 when the caller does not want it
   for (int st = T - 1; st >= -1; --st) {
-    LstmBwdArgs a;
-    a.has_gemm = st < T - 1; a.has_gates = st >= 0;
-    a.DGn = ws.DG + (size_t)(st + 1 < T ? st + 1 : 0) * B * 4 * H;
-    a.WhhT = ws.WhhT;
+    const unsigned has = (st < T - 1 ? 1u : 0u) | (st >= 0 ? 2u : 0u);
     const int sg = st >= 0 ? st : 0;
-    a.dout = d_out + sg * bh; a.gates = rs.GATES + (size_t)sg * B * 4 * H;
-    a.c_s = rs.Cs + sg * bh; a.c_s1 = rs.Cs + (sg + 1) * bh;
-    a.DC = ws.DC; a.DG = ws.DG + (size_t)sg * B * 4 * H;
-    a.dh0 = d_h0;
-    a.B = B; a.H = H;
+    const float* DGn = ws.DG + (size_t)(st + 1 < T ? st + 1 : 0) * B * 4 * H;
+    const float *dout_s = d_out + sg * bh, *gates_s = rs.GATES + (size_t)sg * B * 4 * H, *c_s = rs.Cs + sg * bh;
+    float* DG_s = ws.DG + (size_t)sg * B * 4 * H;
+    const unsigned b_h = (unsigned)B | ((unsigned)H << 16);
     if (st == -1 && d_h0 == nullptr) break;
-    LAUNCH_NW(lstm_bwd_kernel, nw, grid, s, a);
+    if (nw == 16) hipLaunchKernelGGL((lstm_bwd_kernel<16>), grid, dim3(1024), 0, s, DGn, (const float*)ws.WhhT, dout_s, gates_s, c_s, ws.DC, b_h, has, DG_s, d_h0);
+    else if (nw == 8) hipLaunchKernelGGL((lstm_bwd_kernel<8>), grid, dim3(512), 0, s, DGn, (const float*)ws.WhhT, dout_s, gates_s, c_s, ws.DC, b_h, has, DG_s, d_h0);
+    else hipLaunchKernelGGL((lstm_bwd_kernel<4>), grid, dim3(256), 0, s, DGn, (const float*)ws.WhhT, dout_s, gates_s, c_s, ws.DC, b_h, has, DG_s, d_h0);
   }
   BLVM_CHECK_LAUNCH("lstm_seq_bwd");
   if (d_c0) BLVM_HIP(hipMemcpyAsync(d_c0, ws.DC, sizeof(float) * bh, hipMemcpyDeviceToDevice, s));

@@ -26,37 +26,34 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------
 // F9: GRU input projection of phi + gates + state update
 // ---------------------------------------------------------------------------------------------------------------
-struct GruArgs {
-  const float* decin_t;   // row block t of decin: [B, H+R] = [phi | h_prev]
-  float* decin_next;      // row block t+1 (h-part written)
-  const float* Wih;       // [3R,H]: the phi columns of the GRU input weight, in T16
-  const float* xg;        // [B,3R] x-part of the input projection incl. b_ih
-  const float* gh;        // [B,3R] hidden projection incl. b_hh
-  float *rg, *ug, *ng;    // [B,R] saved gates
-  int B, X, H, R;
-};
+// arguments: decin_t [B,H+R] row block t of decin = [phi | h_prev]; Wih [3R,H] the phi columns of the GRU input weight, in T16;
+// xg [B,3R] x-part of the input projection incl. b_ih; gh [B,3R] hidden projection incl. b_hh; decin_next = row block t+1 (h-part
+// written); rg, ug, ng [B,R] saved gates
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void gru_stage_kernel(GruArgs a) {
+__global__ __launch_bounds__(NW * 64) void gru_stage_kernel(const float* decin_t, const float* Wih, const float* xg,
+                                                            const float* gh, int B, int H, int R, float* decin_next,
+                                                            float* rg, float* ug, float* ng) {
+  // scalar arguments: the operand pointers and sizes are the first 11 dwords, preloaded into SGPRs (stages.h lin1_stage_kernel)
   __shared__ float red[3 * NW * 256];
   const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, wave = threadIdx.x >> 6;
-  const int ldd = a.H + a.R;
+  const int ldd = H + R;
   const int t = threadIdx.x & 255;
   const int row = r0 + (t >> 4), col = c0 + (t & 15);
-  const bool own = threadIdx.x < 256 && row < a.B;
-  const int rowc = row < a.B ? row : r0;  // clamped: unconditional prefetch
-  const size_t o3 = (size_t)rowc * 3 * a.R + col;
-  const float x0 = a.xg[o3], x1 = a.xg[o3 + a.R], x2 = a.xg[o3 + 2 * a.R];
-  const float hr = a.gh[o3], hz = a.gh[o3 + a.R], hn = a.gh[o3 + 2 * a.R];
-  const float hp = a.decin_t[(size_t)rowc * ldd + a.H + col];
+  const bool own = threadIdx.x < 256 && row < B;
+  const int rowc = row < B ? row : r0;  // clamped: unconditional prefetch
+  const size_t o3 = (size_t)rowc * 3 * R + col;
+  const float x0 = xg[o3], x1 = xg[o3 + R], x2 = xg[o3 + 2 * R];
+  const float hr = gh[o3], hz = gh[o3 + R], hn = gh[o3 + 2 * R];
+  const float hp = decin_t[(size_t)rowc * ldd + H + col];
   f32x4 acc[3];
 #pragma unroll
   for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
   {
-    const float* const As[3] = {a.decin_t, a.decin_t, a.decin_t};
-    const float* const Ws[3] = {a.Wih, a.Wih, a.Wih};
-    const int la[3] = {ldd, ldd, ldd}, lw[3] = {a.H, a.H, a.H}, cs[3] = {c0, a.R + c0, 2 * a.R + c0};
-    wave_gemm16_multi<NW, 3, true>(As, la, r0, a.B, Ws, lw, cs, a.H, wave, acc);
+    const float* const As[3] = {decin_t, decin_t, decin_t};
+    const float* const Ws[3] = {Wih, Wih, Wih};
+    const int la[3] = {ldd, ldd, ldd}, lw[3] = {H, H, H}, cs[3] = {c0, R + c0, 2 * R + c0};
+    wave_gemm16_multi<NW, 3, true>(As, la, r0, B, Ws, lw, cs, H, wave, acc);
   }
   float v[3];
   reduce_tiles<3, NW>(acc, red, v);
@@ -64,9 +61,9 @@ __global__ __launch_bounds__(NW * 64) void gru_stage_kernel(GruArgs a) {
   const float r = sigmoidf_(v[0] + x0 + hr);
   const float u = sigmoidf_(v[1] + x1 + hz);
   const float n = tanhf(v[2] + x2 + r * hn);
-  a.decin_next[(size_t)row * ldd + a.H + col] = (1.f - u) * n + u * hp;
-  const size_t o = (size_t)row * a.R + col;
-  a.rg[o] = r; a.ug[o] = u; a.ng[o] = n;
+  decin_next[(size_t)row * ldd + H + col] = (1.f - u) * n + u * hp;
+  const size_t o = (size_t)row * R + col;
+  rg[o] = r; ug[o] = u; ng[o] = n;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -319,12 +316,15 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     a.seg[0] = seg(rs.FZ[2] + oH, H, rs.Wf[3], H, w->phi_b[3], nullptr, 0, nullptr, 0, decin + (size_t)t * B * ldd, ldd, H, H, 1);
     launch_lin(a, s);
     // F9: GRU
-    GruArgs g;
-    g.decin_t = dec_t; g.decin_next = dec_n; g.Wih = rs.Wih;
-    g.xg = rs.XG + o3R; g.gh = rs.GHb + o3R;
-    g.rg = rs.RG + oR; g.ug = rs.UG + oR; g.ng = rs.NG + oR;
-    g.B = B; g.X = X; g.H = H; g.R = R;
-    LAUNCH_NW(gru_stage_kernel, pick_nw(H, 3), dim3(R / 16, rt), s, g);
+    {
+      const int nw = pick_nw(H, 3);
+      const dim3 grid(R / 16, rt);
+      const float *xg_t = rs.XG + o3R, *gh_t = rs.GHb + o3R;
+      float *rg_t = rs.RG + oR, *ug_t = rs.UG + oR, *ng_t = rs.NG + oR;
+      if (nw == 16) hipLaunchKernelGGL((gru_stage_kernel<16>), grid, dim3(1024), 0, s, dec_t, (const float*)rs.Wih, xg_t, gh_t, B, H, R, dec_n, rg_t, ug_t, ng_t);
+      else if (nw == 8) hipLaunchKernelGGL((gru_stage_kernel<8>), grid, dim3(512), 0, s, dec_t, (const float*)rs.Wih, xg_t, gh_t, B, H, R, dec_n, rg_t, ug_t, ng_t);
+      else hipLaunchKernelGGL((gru_stage_kernel<4>), grid, dim3(256), 0, s, dec_t, (const float*)rs.Wih, xg_t, gh_t, B, H, R, dec_n, rg_t, ug_t, ng_t);
+    }
   }
   BLVM_CHECK_LAUNCH("vrnn_seq_fwd");
   return BLVM_OK;
