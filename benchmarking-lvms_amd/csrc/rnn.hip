@@ -188,27 +188,33 @@ struct GruFwdArgs {
 };
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void gru_fwd_kernel(GruFwdArgs a) {
+__global__ __launch_bounds__(NW * 64) void gru_fwd_kernel(const float* hprev, const float* Whh, const float* bhh,
+                                                          const float* xg, const int32_t* lens, unsigned b_r, unsigned j_rev,
+                                                          float* hnext, float* out, float* rg, float* ug, float* ng, float* ghn,
+                                                          long long out_ts, int out_ld) {
+  // scalar arguments (GruFwdArgs documents them): the 5 input pointers, B:16|R:16 and j<<1|reverse are the first 12 dwords,
+  // preloaded into SGPRs (stages.h lin1_stage_kernel); the outputs come by s_load
+  const int B = b_r & 0xffff, R0 = b_r >> 16, j = j_rev >> 1, reverse = j_rev & 1;
   __shared__ float red[3 * NW * 256];
-  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, wave = threadIdx.x >> 6, R = a.R;
+  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, wave = threadIdx.x >> 6, R = R0;
   const int t = threadIdx.x & 255;
   const int row = r0 + (t >> 4), col = c0 + (t & 15);
-  const bool own = threadIdx.x < 256 && row < a.B;
-  const int rowc = row < a.B ? row : r0;
-  const int idx = time_index(a.j, a.reverse, a.lens, rowc);
+  const bool own = threadIdx.x < 256 && row < B;
+  const int rowc = row < B ? row : r0;
+  const int idx = time_index(j, reverse, lens, rowc);
   const size_t o = (size_t)rowc * R + col;
-  const size_t ox = ((size_t)idx * a.B + rowc) * 3 * R + col;
-  const float x0 = a.xg[ox], x1 = a.xg[ox + R], x2 = a.xg[ox + 2 * R];
-  const float b0 = a.bhh[col], b1 = a.bhh[R + col], b2 = a.bhh[2 * R + col];
-  const float hp = a.hprev[o];
+  const size_t ox = ((size_t)idx * B + rowc) * 3 * R + col;
+  const float x0 = xg[ox], x1 = xg[ox + R], x2 = xg[ox + 2 * R];
+  const float b0 = bhh[col], b1 = bhh[R + col], b2 = bhh[2 * R + col];
+  const float hp = hprev[o];
   f32x4 acc[3];
 #pragma unroll
   for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
   {
-    const float* const As[3] = {a.hprev, a.hprev, a.hprev};
-    const float* const Ws[3] = {a.Whh, a.Whh, a.Whh};
+    const float* const As[3] = {hprev, hprev, hprev};
+    const float* const Ws[3] = {Whh, Whh, Whh};
     const int ld[3] = {R, R, R}, cs[3] = {c0, R + c0, 2 * R + c0};
-    wave_gemm16_multi<NW, 3, true>(As, ld, r0, a.B, Ws, ld, cs, R, wave, acc);
+    wave_gemm16_multi<NW, 3, true>(As, ld, r0, B, Ws, ld, cs, R, wave, acc);
   }
   float v[3];
   reduce_tiles<3, NW>(acc, red, v);
@@ -218,9 +224,9 @@ __global__ __launch_bounds__(NW * 64) void gru_fwd_kernel(GruFwdArgs a) {
   const float u = sigmoidf_(x1 + v[1] + b1);
   const float n = tanhf(x2 + r * hn);
   const float h2 = (1.f - u) * n + u * hp;
-  a.hnext[o] = h2;
-  a.out[(size_t)idx * a.out_ts + (size_t)row * a.out_ld + col] = h2;
-  a.rg[o] = r; a.ug[o] = u; a.ng[o] = n; a.ghn[o] = hn;
+  hnext[o] = h2;
+  out[(size_t)idx * out_ts + (size_t)row * out_ld + col] = h2;
+  rg[o] = r; ug[o] = u; ng[o] = n; ghn[o] = hn;
 }
 
 struct GruBwdArgs {
@@ -409,6 +415,7 @@ extern "C" int blvm_gru_seq_fwd(const float* Wih, const float* Whh, const float*
   BLVM_REQUIRE(Wih && Whh && bih && bhh && in && out && reserve, "gru_fwd: null pointer");
   BLVM_REQUIRE(!reverse || lens, "gru_fwd: reverse needs lens");
   BLVM_REQUIRE(aligned16(reserve) && aligned16(Whh), "gru_fwd: buffers must be 16-byte aligned");
+  BLVM_REQUIRE(B < 65536 && R < 65536, "gru_fwd: B and R must be below 65536 (packed kernel arguments)");
   GruReserve rs;
   carve_gru(reserve, T, B, R, &rs);
   const size_t n = (size_t)T * B, br = (size_t)B * R;
@@ -421,12 +428,12 @@ extern "C" int blvm_gru_seq_fwd(const float* Wih, const float* Whh, const float*
   const int nw = pick_nw(R, 3);
   const dim3 grid(R / 16, (B + 15) / 16);
   for (int j = 0; j < T; ++j) {
-    GruFwdArgs a;
-    a.hprev = rs.Hs + j * br; a.Whh = rs.WhhP; a.bhh = bhh; a.xg = rs.XG; a.lens = lens;
-    a.hnext = rs.Hs + (j + 1) * br; a.out = out;
-    a.rg = rs.RG + j * br; a.ug = rs.UG + j * br; a.ng = rs.NG + j * br; a.ghn = rs.GHN + j * br;
-    a.out_ts = out_ts; a.out_ld = out_ld; a.B = B; a.R = R; a.j = j; a.reverse = reverse;
-    LAUNCH_NW(gru_fwd_kernel, nw, grid, s, a);
+    const float* hp = rs.Hs + j * br;
+    float *hnx = rs.Hs + (j + 1) * br, *rg_j = rs.RG + j * br, *ug_j = rs.UG + j * br, *ng_j = rs.NG + j * br, *ghn_j = rs.GHN + j * br;
+    const unsigned b_r = (unsigned)B | ((unsigned)R << 16), j_rev = ((unsigned)j << 1) | (reverse ? 1u : 0u);
+    if (nw == 16) hipLaunchKernelGGL((gru_fwd_kernel<16>), grid, dim3(1024), 0, s, hp, (const float*)rs.WhhP, bhh, (const float*)rs.XG, lens, b_r, j_rev, hnx, out, rg_j, ug_j, ng_j, ghn_j, out_ts, out_ld);
+    else if (nw == 8) hipLaunchKernelGGL((gru_fwd_kernel<8>), grid, dim3(512), 0, s, hp, (const float*)rs.WhhP, bhh, (const float*)rs.XG, lens, b_r, j_rev, hnx, out, rg_j, ug_j, ng_j, ghn_j, out_ts, out_ld);
+    else hipLaunchKernelGGL((gru_fwd_kernel<4>), grid, dim3(256), 0, s, hp, (const float*)rs.WhhP, bhh, (const float*)rs.XG, lens, b_r, j_rev, hnx, out, rg_j, ug_j, ng_j, ghn_j, out_ts, out_ld);
   }
   BLVM_CHECK_LAUNCH("gru_seq_fwd");
   if (hn) BLVM_HIP(hipMemcpyAsync(hn, rs.Hs + T * br, sizeof(float) * br, hipMemcpyDeviceToDevice, s));

@@ -28,25 +28,31 @@ struct GruCellArgs {
 };
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void gru_cell_stage_kernel(GruCellArgs a) {
+__global__ __launch_bounds__(NW * 64) void gru_cell_stage_kernel(const float* A, const float* Wih, const float* bih,
+                                                                 const float* gh, const float* hprev, unsigned lda_ldh,
+                                                                 unsigned b_h, int K, float* hnext, int ldn, float* rg, float* ug,
+                                                                 float* ng) {
+  // scalar arguments (GruCellArgs documents them; ldw = K for a T16 weight): 5 input pointers, lda:16|ldh:16, B:16|H:16 and K are
+  // the first 13 dwords, preloaded into SGPRs (stages.h lin1_stage_kernel)
+  const int lda = lda_ldh & 0xffff, ldh = lda_ldh >> 16, B = b_h & 0xffff, H0 = b_h >> 16, ldw = K;
   __shared__ float red[3 * NW * 256];
-  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, wave = threadIdx.x >> 6, H = a.H;
+  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, wave = threadIdx.x >> 6, H = H0;
   const int t = threadIdx.x & 255;
   const int row = r0 + (t >> 4), col = c0 + (t & 15);
-  const bool own = threadIdx.x < 256 && row < a.B;
-  const int rowc = row < a.B ? row : r0;
+  const bool own = threadIdx.x < 256 && row < B;
+  const int rowc = row < B ? row : r0;
   const size_t o3 = (size_t)rowc * 3 * H + col;
-  const float b0 = a.bih[col], b1 = a.bih[H + col], b2 = a.bih[2 * H + col];
-  const float hr = a.gh[o3], hz = a.gh[o3 + H], hn = a.gh[o3 + 2 * H];
-  const float hp = a.hprev[(size_t)rowc * a.ldh + col];
+  const float b0 = bih[col], b1 = bih[H + col], b2 = bih[2 * H + col];
+  const float hr = gh[o3], hz = gh[o3 + H], hn = gh[o3 + 2 * H];
+  const float hp = hprev[(size_t)rowc * ldh + col];
   f32x4 acc[3];
 #pragma unroll
   for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
   {
-    const float* const As[3] = {a.A, a.A, a.A};
-    const float* const Ws[3] = {a.Wih, a.Wih, a.Wih};
-    const int la[3] = {a.lda, a.lda, a.lda}, lw[3] = {a.ldw, a.ldw, a.ldw}, cs[3] = {c0, H + c0, 2 * H + c0};
-    wave_gemm16_multi<NW, 3, true>(As, la, r0, a.B, Ws, lw, cs, a.K, wave, acc);
+    const float* const As[3] = {A, A, A};
+    const float* const Ws[3] = {Wih, Wih, Wih};
+    const int la[3] = {lda, lda, lda}, lw[3] = {ldw, ldw, ldw}, cs[3] = {c0, H + c0, 2 * H + c0};
+    wave_gemm16_multi<NW, 3, true>(As, la, r0, B, Ws, lw, cs, K, wave, acc);
   }
   float v[3];
   reduce_tiles<3, NW>(acc, red, v);
@@ -54,9 +60,9 @@ __global__ __launch_bounds__(NW * 64) void gru_cell_stage_kernel(GruCellArgs a) 
   const float r = sigmoidf_(v[0] + b0 + hr);
   const float u = sigmoidf_(v[1] + b1 + hz);
   const float n = tanhf(v[2] + b2 + r * hn);
-  a.hnext[(size_t)row * a.ldn + col] = (1.f - u) * n + u * hp;
+  hnext[(size_t)row * ldn + col] = (1.f - u) * n + u * hp;
   const size_t o = (size_t)row * H + col;
-  a.rg[o] = r; a.ug[o] = u; a.ng[o] = n;
+  rg[o] = r; ug[o] = u; ng[o] = n;
 }
 
 // ---- backward GRU link: complete dL/dh_t, then the gate derivatives of step t -------------------------------------------
@@ -146,7 +152,7 @@ int check_rssm(int T, int B, int H, int Z, int C, int E) {
   BLVM_REQUIRE(T > 0 && B > 0, "rssm: bad T=%d B=%d", T, B);
   BLVM_REQUIRE(H > 0 && Z > 0 && H % 16 == 0 && Z % 16 == 0, "rssm: H, Z must be positive multiples of 16 (got %d, %d)", H, Z);
   BLVM_REQUIRE(C >= 0 && E > 0 && C % 4 == 0 && E % 4 == 0, "rssm: context / encoding sizes must be multiples of 4 (got %d, %d)", C, E);
-  BLVM_REQUIRE((B + 15) / 16 <= 65535, "rssm: batch too large");
+  BLVM_REQUIRE(B < 65536 && H < 65536, "rssm: B and H must be below 65536 (packed kernel arguments)");
   return BLVM_OK;
 }
 
@@ -209,11 +215,16 @@ extern "C" int blvm_rssm_seq_fwd(const BlvmRssmWeights* w, const float* enc, con
     l.seg[1] = seg(hprev, H, rs.Whh, H, w->gru_bhh, nullptr, 0, nullptr, 0, rs.GHb + o3, 3 * H, 3 * H, H, 0);
     launch_lin(l, s);
     // L2: GRU
-    GruCellArgs g;
-    g.A = rs.GIN + oH; g.lda = H; g.Wih = rs.Wih; g.ldw = H; g.bih = w->gru_bih; g.gh = rs.GHb + o3;
-    g.hprev = hprev; g.ldh = H; g.hnext = hnew; g.ldn = H;
-    g.rg = rs.RG + oH; g.ug = rs.UG + oH; g.ng = rs.NG + oH; g.B = B; g.H = H; g.K = H;
-    LAUNCH_NW(gru_cell_stage_kernel, pick_nw(H, 3), dim3(H / 16, rt), s, g);
+    {
+      const int nw = pick_nw(H, 3);
+      const dim3 grid(H / 16, rt);
+      const float *gin_t = rs.GIN + oH, *gh_t = rs.GHb + o3;
+      float *rg_t = rs.RG + oH, *ug_t = rs.UG + oH, *ng_t = rs.NG + oH;
+      const unsigned lda_ldh = (unsigned)H | ((unsigned)H << 16), b_h = (unsigned)B | ((unsigned)H << 16);
+      if (nw == 16) hipLaunchKernelGGL((gru_cell_stage_kernel<16>), grid, dim3(1024), 0, s, gin_t, (const float*)rs.Wih, w->gru_bih, gh_t, hprev, lda_ldh, b_h, H, hnew, H, rg_t, ug_t, ng_t);
+      else if (nw == 8) hipLaunchKernelGGL((gru_cell_stage_kernel<8>), grid, dim3(512), 0, s, gin_t, (const float*)rs.Wih, w->gru_bih, gh_t, hprev, lda_ldh, b_h, H, hnew, H, rg_t, ug_t, ng_t);
+      else hipLaunchKernelGGL((gru_cell_stage_kernel<4>), grid, dim3(256), 0, s, gin_t, (const float*)rs.Wih, w->gru_bih, gh_t, hprev, lda_ldh, b_h, H, hnew, H, rg_t, ug_t, ng_t);
+    }
     // L3..L5: posterior | prior MLPs on h_t
     l.seg[0] = seg(hnew, H, rs.Wq[0], H, nullptr, rs.XQ + oH, H, nullptr, 0, rs.Q[0] + oH, H, H, H, 1);
     l.seg[1] = seg(hnew, H, rs.Wp[0], H, w->prior_b[0], nullptr, 0, nullptr, 0, rs.P[0] + oH, H, H, H, 1);
