@@ -14,6 +14,8 @@ def per_kernel(db):
 if __name__ == "__main__":
     rows = per_kernel(sys.argv[1])
     steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
-    print("kernel,counter,dispatches,sum,sum_per_step")
+    import csv
+    out = csv.writer(sys.stdout)  # kernel names hold commas (argument lists)
+    out.writerow(["kernel", "counter", "dispatches", "sum", "sum_per_step"])
     for k, c, n, v in rows:
-        print(f"{k[:140]},{c},{n},{v:.1f},{v / steps:.1f}")
+        out.writerow([k[:140], c, n, f"{v:.1f}", f"{v / steps:.1f}"])
