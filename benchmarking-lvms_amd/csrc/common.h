@@ -130,10 +130,18 @@ __device__ __forceinline__ f32x4 wave_gemm16(const float* __restrict__ A, int ld
 // from the Infinity Cache) instead of one.  Here all 2G (SAMEA: G+1) fragment loads of a k-chunk are issued together, two
 // chunks per trip.  Every acc[g] still sums its chunks in ascending order, element by element, exactly as wave_gemm16 does:
 // results are bit-identical.  The MFMAs of the G products are interleaved, so consecutive MFMAs are independent.
-template <int NW, int G, bool SAMEA>
+//
+// `mid` runs once, right after the first trip's operand loads are issued (or at the end for a wave without chunks): a kernel
+// whose operand pointers are preloaded SGPRs (stages.h lin1_stage_kernel) puts there the epilogue prefetches whose pointers
+// still come by s_load, so the operand loads never wait for the argument fetch.
+struct NoMid {
+  __device__ __forceinline__ void operator()() const {}
+};
+template <int NW, int G, bool SAMEA, class Mid = NoMid>
 __device__ __forceinline__ void wave_gemm16_multi(const float* const (&A)[G], const int (&lda)[G], int r0, int nrows,
                                                   const float* const (&W)[G], const int (&ldw)[G], const int (&c0)[G], int K,
-                                                  int wave, f32x4 (&acc)[G]) {
+                                                  int wave, f32x4 (&acc)[G], Mid mid = Mid()) {
+  bool pending = true;
   constexpr int STEP = NW * 16;
   constexpr int GA = SAMEA ? 1 : G;
   const int lane = threadIdx.x & 63;
@@ -159,6 +167,7 @@ __device__ __forceinline__ void wave_gemm16_multi(const float* const (&A)[G], co
       w0[g] = *reinterpret_cast<const float4*>(wp[g] + 16 * (size_t)kc);
       w1[g] = *reinterpret_cast<const float4*>(wp[g] + 16 * (size_t)(kc + STEP));
     }
+    if (pending) { mid(); pending = false; }
     if (!aok) {
 #pragma unroll
       for (int g = 0; g < GA; ++g) a0[g] = a1[g] = zero;
@@ -186,6 +195,7 @@ __device__ __forceinline__ void wave_gemm16_multi(const float* const (&A)[G], co
     for (int g = 0; g < GA; ++g) a0[g] = *reinterpret_cast<const float4*>(ap[g] + kc);
 #pragma unroll
     for (int g = 0; g < G; ++g) w0[g] = *reinterpret_cast<const float4*>(wp[g] + 16 * (size_t)kc);
+    if (pending) { mid(); pending = false; }
     if (!aok) {
 #pragma unroll
       for (int g = 0; g < GA; ++g) a0[g] = zero;
@@ -199,6 +209,7 @@ __device__ __forceinline__ void wave_gemm16_multi(const float* const (&A)[G], co
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[SAMEA ? 0 : g].w, w0[g].w, acc[g], 0, 0, 0);
   }
+  if (pending) mid();
 }
 
 // ---- 32x32 output tile (large batches), K split over the NW waves of a workgroup ---------------------------------------

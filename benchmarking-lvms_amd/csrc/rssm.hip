@@ -244,7 +244,7 @@ extern "C" int blvm_rssm_seq_fwd(const BlvmRssmWeights* w, const float* enc, con
     h.raw_p = rs.RAWP + oZ; h.raw_q = rs.RAWQ + oZ; h.muq_raw = rs.MUQR + oZ;
     h.B = B; h.H = H; h.Z = Z; h.residual = mode;
     h.beta = beta; h.inv_beta = 1.f / beta; h.sd_eps = sd_eps;
-    LAUNCH_NW(head_stage_kernel, pick_nw(H, 4), dim3(Z / 16, rt), s, h);
+    launch_head(h, pick_nw(H, 4), dim3(Z / 16, rt), s);
   }
   BLVM_CHECK_LAUNCH("rssm_seq_fwd");
   return BLVM_OK;

@@ -122,7 +122,7 @@ extern "C" int blvm_srnn_latent_fwd(const BlvmSrnnWeights* w, const float* d, co
     h.raw_p = rs.RAWP + oZ; h.raw_q = rs.RAWQ + oZ;
     h.B = B; h.H = H; h.Z = Z; h.residual = residual_posterior;
     h.beta = beta; h.inv_beta = 1.f / beta; h.sd_eps = sd_eps; h.muq_raw = nullptr;
-    LAUNCH_NW(head_stage_kernel, pick_nw(H, 4), dim3(Z / 16, rt), s, h);
+    launch_head(h, pick_nw(H, 4), dim3(Z / 16, rt), s);
   }
   BLVM_CHECK_LAUNCH("srnn_latent_fwd");
   return BLVM_OK;

@@ -212,23 +212,28 @@ struct HeadArgs {
 };
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void head_stage_kernel(HeadArgs a) {
+__global__ __launch_bounds__(NW * 64) void head_stage_kernel(const float* P, const float* Q, const float* Wp, const float* Wq,
+                                                             const float* bp, const float* bq, unsigned b_h, int Z, HeadArgs a) {
+  // the leading scalars (14 dwords: what the operand and bias loads need) are preloaded into SGPRs, the struct comes by s_load
+  const int B = b_h & 0xffff, H = b_h >> 16;
   __shared__ float red[4 * NW * 256];
   const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, wave = threadIdx.x >> 6;
   const int t = threadIdx.x & 255;
   const int row = r0 + (t >> 4), col = c0 + (t & 15);
-  const bool own = threadIdx.x < 256 && row < a.B;
-  const size_t o = (size_t)row * a.Z + col;
-  const size_t oc = (size_t)(row < a.B ? row : r0) * a.Z + col;  // clamped: unconditional prefetch
-  const float b0 = a.bp[col], b1 = a.bp[a.Z + col], b2 = a.bq[col], b3 = a.bq[a.Z + col], e = a.eps[oc];
+  const bool own = threadIdx.x < 256 && row < B;
+  const size_t o = (size_t)row * Z + col;
+  const size_t oc = (size_t)(row < B ? row : r0) * Z + col;  // clamped: unconditional prefetch
+  const float b0 = bp[col], b1 = bp[Z + col], b2 = bq[col], b3 = bq[Z + col];
+  float e = 0.f;
   f32x4 acc[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
   {
-    const float* const As[4] = {a.P, a.P, a.Q, a.Q};
-    const float* const Ws[4] = {a.Wp, a.Wp, a.Wq, a.Wq};
-    const int ld[4] = {a.H, a.H, a.H, a.H}, cs[4] = {c0, a.Z + c0, c0, a.Z + c0};
-    wave_gemm16_multi<NW, 4, false>(As, ld, r0, a.B, Ws, ld, cs, a.H, wave, acc);
+    const float* const As[4] = {P, P, Q, Q};
+    const float* const Ws[4] = {Wp, Wp, Wq, Wq};
+    const int ld[4] = {H, H, H, H}, cs[4] = {c0, Z + c0, c0, Z + c0};
+    const float* eps = a.eps;
+    wave_gemm16_multi<NW, 4, false>(As, ld, r0, B, Ws, ld, cs, H, wave, acc, [&]() { e = eps[oc]; });
   }
   float v[4];
   reduce_tiles<4, NW>(acc, red, v);
@@ -255,6 +260,13 @@ __global__ __launch_bounds__(NW * 64) void head_stage_kernel(HeadArgs a) {
   a.mu_p[o] = mp; a.sd_p[o] = sp; a.mu_q[o] = mq; a.sd_q[o] = sqc;
   a.raw_p[o] = rp; a.raw_q[o] = rq;
   a.z[o] = e * sqc + mq;  // randn_like(mu).mul(sd).add(mu)
+}
+
+inline void launch_head(const HeadArgs& h, int nw, dim3 grid, hipStream_t s) {
+  const unsigned b_h = (unsigned)h.B | ((unsigned)h.H << 16);  // callers require B, H < 65536
+  if (nw == 16) hipLaunchKernelGGL((head_stage_kernel<16>), grid, dim3(1024), 0, s, h.P, h.Q, h.Wp, h.Wq, h.bp, h.bq, b_h, h.Z, h);
+  else if (nw == 8) hipLaunchKernelGGL((head_stage_kernel<8>), grid, dim3(512), 0, s, h.P, h.Q, h.Wp, h.Wq, h.bp, h.bq, b_h, h.Z, h);
+  else hipLaunchKernelGGL((head_stage_kernel<4>), grid, dim3(256), 0, s, h.P, h.Q, h.Wp, h.Wq, h.bp, h.bq, b_h, h.Z, h);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

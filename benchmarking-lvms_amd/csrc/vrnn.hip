@@ -304,7 +304,7 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     h.raw_p = rs.RAWP + oZ; h.raw_q = rs.RAWQ + oZ;
     h.B = B; h.H = H; h.Z = Z; h.residual = residual_posterior;
     h.beta = beta; h.inv_beta = 1.f / beta; h.sd_eps = sd_eps; h.muq_raw = nullptr;
-    LAUNCH_NW(head_stage_kernel, pick_nw(H, 4), dim3(Z / 16, rt), s, h);
+    launch_head(h, pick_nw(H, 4), dim3(Z / 16, rt), s);
     // F5..F8: phi_z MLP (last layer writes phi into decin row t)
     a.nseg = 1;
     a.seg[0] = seg(z + oZ, Z, rs.Wf[0], Z, w->phi_b[0], nullptr, 0, nullptr, 0, rs.FZ[0] + oH, H, H, Z, 1);
