@@ -80,15 +80,21 @@ inline int gemm_pick_split(int M, int N, int K) {
 // 1 KB read (~150 GB/s per workgroup, tools/cu_ingest.hip).  Block (row tile t, k chunk j) of a [R,K] matrix sits at
 // ((t * K/16 + j) * 256) floats, element (rr, 4q+e) of it at (rr + 16 q) * 4 + e: the fragment address of lane
 // (rr = lane & 15, q = lane >> 4) is W + c0 * ldw + 16 * k0 + 4 * lane with ldw = the packed matrix's K.
+// `mid` hook of the product helpers: runs once, right after the first trip's operand loads are issued (see wave_gemm16_multi)
+struct NoMid {
+  __device__ __forceinline__ void operator()() const {}
+};
+
 // U consecutive k-chunks of one wave: all 2U fragment loads first, then the 4U MFMAs in ascending k
-template <int U, int STEP, int WS>
+template <int U, int STEP, int WS, class Mid>
 __device__ __forceinline__ f32x4 gemm16_chunks(const float* __restrict__ ap, const float* __restrict__ wp, int kc, bool aok,
-                                                f32x4 acc) {
+                                                f32x4 acc, bool& pending, Mid& mid) {
   float4 a[U], w[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) a[u] = *reinterpret_cast<const float4*>(ap + kc + u * STEP);
 #pragma unroll
   for (int u = 0; u < U; ++u) w[u] = *reinterpret_cast<const float4*>(wp + (size_t)WS * (kc + u * STEP));
+  if (pending) { mid(); pending = false; }
   if (!aok) {
 #pragma unroll
     for (int u = 0; u < U; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -103,10 +109,11 @@ __device__ __forceinline__ f32x4 gemm16_chunks(const float* __restrict__ ap, con
   return acc;
 }
 
-template <int NW, bool WT16 = false>
+template <int NW, bool WT16 = false, class Mid = NoMid>
 __device__ __forceinline__ f32x4 wave_gemm16(const float* __restrict__ A, int lda, int r0, int nrows,
                                               const float* __restrict__ W, int ldw, int c0, int K, int wave,
-                                              f32x4 acc) {
+                                              f32x4 acc, Mid mid = Mid()) {
+  bool pending = true;
   constexpr int STEP = NW * 16;
   const int lane = threadIdx.x & 63;
   const int rr = lane & 15, q = lane >> 4;
@@ -118,8 +125,9 @@ __device__ __forceinline__ f32x4 wave_gemm16(const float* __restrict__ A, int ld
   // 4 chunks per trip keeps 8 x 16-byte loads in flight; left-over chunks are one dependent round trip EACH, so the host picks
   // NW such that a wave owns 4 chunks or 1 (stages.h pick_nw).  Handling 2-3 left-over chunks in one trip here was tried: the
   // extra code costs every link ~0.06 us (VRNN +0.3 ms/step) and only the 3-chunk shapes gain (tools/chain_bench.hip).
-  for (; kc + 3 * STEP < K; kc += 4 * STEP) acc = gemm16_chunks<4, STEP, WS>(ap, wp, kc, aok, acc);
-  for (; kc < K; kc += STEP) acc = gemm16_chunks<1, STEP, WS>(ap, wp, kc, aok, acc);
+  for (; kc + 3 * STEP < K; kc += 4 * STEP) acc = gemm16_chunks<4, STEP, WS>(ap, wp, kc, aok, acc, pending, mid);
+  for (; kc < K; kc += STEP) acc = gemm16_chunks<1, STEP, WS>(ap, wp, kc, aok, acc, pending, mid);
+  if (pending) mid();
   return acc;
 }
 
@@ -134,9 +142,6 @@ __device__ __forceinline__ f32x4 wave_gemm16(const float* __restrict__ A, int ld
 // `mid` runs once, right after the first trip's operand loads are issued (or at the end for a wave without chunks): a kernel
 // whose operand pointers are preloaded SGPRs (stages.h lin1_stage_kernel) puts there the epilogue prefetches whose pointers
 // still come by s_load, so the operand loads never wait for the argument fetch.
-struct NoMid {
-  __device__ __forceinline__ void operator()() const {}
-};
 template <int NW, int G, bool SAMEA, class Mid = NoMid>
 __device__ __forceinline__ void wave_gemm16_multi(const float* const (&A)[G], const int (&lda)[G], int r0, int nrows,
                                                   const float* const (&W)[G], const int (&ldw)[G], const int (&c0)[G], int K,

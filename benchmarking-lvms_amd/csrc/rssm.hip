@@ -299,7 +299,7 @@ extern "C" int blvm_rssm_seq_bwd(const BlvmRssmWeights* w, const float* enc, con
     dz.dqh = ws.DQH + o2Z; dz.dph = ws.DPH + o2Z;
     dz.B = B; dz.H = H; dz.Z = Z; dz.residual = mode; dz.t = t; dz.stride = stride;
     dz.fn_floor = fn_floor; dz.beta = beta; dz.sd_eps = sd_eps;
-    LAUNCH_NW(dz_stage_kernel, pick_nw(H, 1), dim3(Z / 16, rt), s, dz);
+    launch_dz(dz, pick_nw(H, 1), dim3(Z / 16, rt), s);
     // B2: heads -> third layers | G += DGH[t+1] Whh (the recurrent path of step t+1, off the critical chain)
     LinLaunch l;
     l.B = B; l.nseg = last ? 2 : 3;

@@ -51,7 +51,7 @@ int check_srnn(int Tp, int B, int H, int Z, int R) {
   BLVM_REQUIRE(Tp > 0 && B > 0, "srnn: bad Tp=%d B=%d", Tp, B);
   BLVM_REQUIRE(H > 0 && Z > 0 && R > 0 && H % 16 == 0 && Z % 16 == 0 && R % 16 == 0,
                "srnn: H,Z,R must be positive multiples of 16 (got %d,%d,%d)", H, Z, R);
-  BLVM_REQUIRE((B + 15) / 16 <= 65535, "srnn: batch too large");
+  BLVM_REQUIRE(B < 65536 && H < 65536, "srnn: B and H must be below 65536 (packed kernel arguments)");
   return BLVM_OK;
 }
 
@@ -171,7 +171,7 @@ extern "C" int blvm_srnn_latent_bwd(const BlvmSrnnWeights* w, const float* d, co
     dz.dqh = ws.DQH + o2Z; dz.dph = ws.DPH + o2Z;
     dz.B = B; dz.H = H; dz.Z = Z; dz.residual = residual_posterior; dz.t = t; dz.stride = stride;
     dz.fn_floor = fn_floor; dz.beta = beta; dz.sd_eps = sd_eps; dz.muq_raw = nullptr;
-    LAUNCH_NW(dz_stage_kernel, pick_nw(H, 2), dim3(Z / 16, rt), s, dz);
+    launch_dz(dz, pick_nw(H, 2), dim3(Z / 16, rt), s);
     // B2: heads -> third layers;  B3, B4: down to the first layers (LeakyReLU derivatives fused)
     LinLaunch l;
     l.B = B; l.slope = slope; l.nseg = 2;

@@ -289,38 +289,46 @@ struct DzArgs {
 };
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void dz_stage_kernel(DzArgs a) {
+__global__ __launch_bounds__(NW * 64) void dz_stage_kernel(const float* D, const float* WT, const float* D2, const float* WT2,
+                                                           unsigned b_h, int Z, int has_gemm, DzArgs a) {
+  // the leading scalars (what the operand loads need) are preloaded into SGPRs; the struct comes by s_load, and every saved
+  // value of the step is prefetched by `mid`, after the operand loads have been issued
+  const int B = b_h & 0xffff, H = b_h >> 16;
   __shared__ float red[2 * NW * 256];
   const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16;
   const int t = threadIdx.x & 255;
   const int row = r0 + (t >> 4), col = c0 + (t & 15);
-  const bool own = threadIdx.x < 256 && row < a.B;
-  const int rowc = row < a.B ? row : r0;  // clamped: unconditional prefetch
-  const size_t o = (size_t)rowc * a.Z + col;
-  const float mq = a.mu_q[o], sq = a.sd_q[o], mp = a.mu_p[o], sp = a.sd_p[o], e = a.eps[o], rq = a.raw_q[o], rp = a.raw_p[o];
-  float c_raw = 0.f, c_fn = 0.f;
-  if (a.c_fn != nullptr || a.c_raw != nullptr) {  // wave-uniform
-    const bool live = (long long)a.t * a.stride < a.x_sl[rowc];
-    const float cr = a.c_raw != nullptr ? a.c_raw[rowc] : 0.f;
-    const float cf = a.c_fn != nullptr ? a.c_fn[rowc] : 0.f;
-    c_raw = live ? cr : 0.f;
-    c_fn = live ? cf : 0.f;
-  }
-  const float e_add = a.dz_add != nullptr ? a.dz_add[(size_t)rowc * a.ld_add + col] : 0.f;
+  const bool own = threadIdx.x < 256 && row < B;
+  const int rowc = row < B ? row : r0;  // clamped: unconditional prefetch
+  const size_t o = (size_t)rowc * Z + col;
+  float mq = 0.f, sq = 1.f, mp = 0.f, sp = 1.f, e = 0.f, rq = 0.f, rp = 0.f, c_raw = 0.f, c_fn = 0.f, e_add = 0.f;
+  auto prefetch = [&]() {
+    mq = a.mu_q[o]; sq = a.sd_q[o]; mp = a.mu_p[o]; sp = a.sd_p[o]; e = a.eps[o]; rq = a.raw_q[o]; rp = a.raw_p[o];
+    if (a.c_fn != nullptr || a.c_raw != nullptr) {  // wave-uniform
+      const bool live = (long long)a.t * a.stride < a.x_sl[rowc];
+      const float cr = a.c_raw != nullptr ? a.c_raw[rowc] : 0.f;
+      const float cf = a.c_fn != nullptr ? a.c_fn[rowc] : 0.f;
+      c_raw = live ? cr : 0.f;
+      c_fn = live ? cf : 0.f;
+    }
+    e_add = a.dz_add != nullptr ? a.dz_add[(size_t)rowc * a.ld_add + col] : 0.f;
+  };
   float v[2] = {0.f, 0.f};
-  if (a.has_gemm) {  // wave-uniform
+  if (has_gemm) {  // wave-uniform
     f32x4 acc[2];
     acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (a.D2 != nullptr) {  // wave-uniform
-      const float* const As[2] = {a.D, a.D2};
-      const float* const Ws[2] = {a.WT, a.WT2};
-      const int ld[2] = {a.H, a.H}, cs[2] = {c0, c0};
-      wave_gemm16_multi<NW, 2, false>(As, ld, r0, a.B, Ws, ld, cs, a.H, threadIdx.x >> 6, acc);
+    if (D2 != nullptr) {  // wave-uniform
+      const float* const As[2] = {D, D2};
+      const float* const Ws[2] = {WT, WT2};
+      const int ld[2] = {H, H}, cs[2] = {c0, c0};
+      wave_gemm16_multi<NW, 2, false>(As, ld, r0, B, Ws, ld, cs, H, threadIdx.x >> 6, acc, prefetch);
     } else {
-      acc[0] = wave_gemm16<NW, true>(a.D, a.H, r0, a.B, a.WT, a.H, c0, a.H, threadIdx.x >> 6, acc[0]);
+      acc[0] = wave_gemm16<NW, true>(D, H, r0, B, WT, H, c0, H, threadIdx.x >> 6, acc[0], prefetch);
     }
     reduce_tiles<2, NW>(acc, red, v);
+  } else {
+    prefetch();
   }
   if (!own) return;
   const float dz = v[0] + v[1] + e_add;
@@ -351,11 +359,18 @@ __global__ __launch_bounds__(NW * 64) void dz_stage_kernel(DzArgs a) {
     g_sdq = g_pq * (-2.f * pq / sqr);
     g_muq = g_muq * var * pq;
   }
-  const size_t o2 = (size_t)row * 2 * a.Z + col;
+  const size_t o2 = (size_t)row * 2 * Z + col;
   a.dqh[o2] = g_muq;
-  a.dqh[o2 + a.Z] = g_sdq * sigmoidf_(a.beta * rq);
+  a.dqh[o2 + Z] = g_sdq * sigmoidf_(a.beta * rq);
   a.dph[o2] = g_mup;
-  a.dph[o2 + a.Z] = g_sdp * sigmoidf_(a.beta * rp);
+  a.dph[o2 + Z] = g_sdp * sigmoidf_(a.beta * rp);
+}
+
+inline void launch_dz(const DzArgs& d, int nw, dim3 grid, hipStream_t s) {
+  const unsigned b_h = (unsigned)d.B | ((unsigned)d.H << 16);  // callers require B, H < 65536
+  if (nw == 16) hipLaunchKernelGGL((dz_stage_kernel<16>), grid, dim3(1024), 0, s, d.D, d.WT, d.D2, d.WT2, b_h, d.Z, d.has_gemm, d);
+  else if (nw == 8) hipLaunchKernelGGL((dz_stage_kernel<8>), grid, dim3(512), 0, s, d.D, d.WT, d.D2, d.WT2, b_h, d.Z, d.has_gemm, d);
+  else hipLaunchKernelGGL((dz_stage_kernel<4>), grid, dim3(256), 0, s, d.D, d.WT, d.D2, d.WT2, b_h, d.Z, d.has_gemm, d);
 }
 
 // number of waves for a K-deep reduction.  One product (groups == 1, wave_gemm16): a wave's chunks cost one memory round trip

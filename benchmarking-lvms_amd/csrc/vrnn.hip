@@ -82,44 +82,53 @@ struct DhArgs {
 };
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void dh_stage_kernel(DhArgs a) {
+__global__ __launch_bounds__(NW * 64) void dh_stage_kernel(const float* DP0, const float* DQ0, const float* WpT, const float* WqT,
+                                                           float* G, unsigned b_h, int R, unsigned has, DhArgs a) {
+  // the leading scalars (operand pointers, G, sizes) are preloaded into SGPRs; the struct comes by s_load and the saved gates are
+  // prefetched by `mid`, after the operand loads have been issued (stages.h head_stage_kernel)
+  const int B = b_h & 0xffff, H = b_h >> 16;
+  const int has_gemm = has & 1, has_gates = (has >> 1) & 1;
   __shared__ float red[2 * NW * 256];
   const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, wave = threadIdx.x >> 6;
-  const int ldd = a.H + a.R;
+  const int ldd = H + R;
   const int t = threadIdx.x & 255;
   const int row = r0 + (t >> 4), col = c0 + (t & 15);
-  const bool own = threadIdx.x < 256 && row < a.B;
-  const int rowc = row < a.B ? row : r0;  // clamped: unconditional prefetch
-  const size_t o = (size_t)rowc * a.R + col, o3 = (size_t)rowc * 3 * a.R + col;
-  const float g0 = a.G[o];
+  const bool own = threadIdx.x < 256 && row < B;
+  const int rowc = row < B ? row : r0;  // clamped: unconditional prefetch
+  const size_t o = (size_t)rowc * R + col, o3 = (size_t)rowc * 3 * R + col;
+  const float g0 = G[o];
   float r = 0.f, u = 0.f, n = 0.f, hn = 0.f, hp = 0.f, dd = 0.f;
-  if (a.has_gates) {  // wave-uniform
-    r = a.rg[o]; u = a.ug[o]; n = a.ng[o]; hn = a.gh[o3 + 2 * a.R];
-    hp = a.decin_s[(size_t)rowc * ldd + a.H + col];
-    dd = a.ddecin_s[(size_t)rowc * ldd + a.H + col];
-  }
+  auto prefetch = [&]() {
+    if (has_gates) {  // wave-uniform
+      r = a.rg[o]; u = a.ug[o]; n = a.ng[o]; hn = a.gh[o3 + 2 * R];
+      hp = a.decin_s[(size_t)rowc * ldd + H + col];
+      dd = a.ddecin_s[(size_t)rowc * ldd + H + col];
+    }
+  };
   float v[2] = {0.f, 0.f};
-  if (a.has_gemm) {
+  if (has_gemm) {
     f32x4 acc[2];
     acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     {
-      const float* const As[2] = {a.DP0, a.DQ0};
-      const float* const Ws[2] = {a.WpT, a.WqT};
-      const int ld[2] = {a.H, a.H}, cs[2] = {c0, c0};
-      wave_gemm16_multi<NW, 2, false>(As, ld, r0, a.B, Ws, ld, cs, a.H, wave, acc);
+      const float* const As[2] = {DP0, DQ0};
+      const float* const Ws[2] = {WpT, WqT};
+      const int ld[2] = {H, H}, cs[2] = {c0, c0};
+      wave_gemm16_multi<NW, 2, false>(As, ld, r0, B, Ws, ld, cs, H, wave, acc, prefetch);
     }
     reduce_tiles<2, NW>(acc, red, v);
+  } else {
+    prefetch();
   }
   if (!own) return;
   const float g = g0 + v[0] + v[1];
-  if (!a.has_gates) { a.G[o] = g; return; }
+  if (!has_gates) { G[o] = g; return; }
   const float dn_pre = g * (1.f - u) * (1.f - n * n);
   const float du_pre = g * (hp - n) * u * (1.f - u);
   const float dr_pre = dn_pre * hn * r * (1.f - r);
-  a.dgi[o3] = dr_pre; a.dgi[o3 + a.R] = du_pre; a.dgi[o3 + 2 * a.R] = dn_pre;
-  a.dgh[o3] = dr_pre; a.dgh[o3 + a.R] = du_pre; a.dgh[o3 + 2 * a.R] = dn_pre * r;
-  a.G[o] = g * u + dd;
+  a.dgi[o3] = dr_pre; a.dgi[o3 + R] = du_pre; a.dgi[o3 + 2 * R] = dn_pre;
+  a.dgh[o3] = dr_pre; a.dgh[o3 + R] = du_pre; a.dgh[o3 + 2 * R] = dn_pre * r;
+  G[o] = g * u + dd;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -217,7 +226,7 @@ int check_dims(int Tp, int B, int X, int H, int Z, int R) {
   BLVM_REQUIRE(Tp > 0 && B > 0, "vrnn: bad Tp=%d B=%d", Tp, B);
   BLVM_REQUIRE(X > 0 && H > 0 && Z > 0 && R > 0 && X % 16 == 0 && H % 16 == 0 && Z % 16 == 0 && R % 16 == 0,
                "vrnn: X,H,Z,R must be positive multiples of 16 (got %d,%d,%d,%d)", X, H, Z, R);
-  BLVM_REQUIRE((B + 15) / 16 <= 65535, "vrnn: batch too large");
+  BLVM_REQUIRE(B < 65536 && H < 65536 && R < 65536, "vrnn: B, H and R must be below 65536 (packed kernel arguments)");
   return BLVM_OK;
 }
 
@@ -392,7 +401,14 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     d.decin_s = decin + sg * B * ldd; d.ddecin_s = d_decin + sg * B * ldd;
     d.dgi = ws.DGI + sg * B * 3 * R; d.dgh = ws.DGH + sg * B * 3 * R;
     d.B = B; d.H = H; d.R = R;
-    LAUNCH_NW(dh_stage_kernel, pick_nw(H, 2), dim3(R / 16, rt), s, d);
+    {
+      const int nw = pick_nw(H, 2);
+      const dim3 grid(R / 16, rt);
+      const unsigned b_h = (unsigned)B | ((unsigned)H << 16), has = (d.has_gemm ? 1u : 0u) | (d.has_gates ? 2u : 0u);
+      if (nw == 16) hipLaunchKernelGGL((dh_stage_kernel<16>), grid, dim3(1024), 0, s, d.DP0, d.DQ0, d.WpT, d.WqT, d.G, b_h, R, has, d);
+      else if (nw == 8) hipLaunchKernelGGL((dh_stage_kernel<8>), grid, dim3(512), 0, s, d.DP0, d.DQ0, d.WpT, d.WqT, d.G, b_h, R, has, d);
+      else hipLaunchKernelGGL((dh_stage_kernel<4>), grid, dim3(256), 0, s, d.DP0, d.DQ0, d.WpT, d.WqT, d.G, b_h, R, has, d);
+    }
   };
 
   // ---- batched, state-independent part: d(enc) and every weight gradient as large MFMA GEMMs over a row range ----
@@ -476,7 +492,7 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     d.dqh = ws.DQH + o2Z; d.dph = ws.DPH + o2Z;
     d.B = B; d.H = H; d.Z = Z; d.residual = residual_posterior; d.t = t; d.stride = stride;
     d.fn_floor = fn_floor; d.beta = beta; d.sd_eps = sd_eps; d.muq_raw = nullptr;
-    LAUNCH_NW(dz_stage_kernel, pick_nw(H, 1), dim3(Z / 16, rt), s, d);
+    launch_dz(d, pick_nw(H, 1), dim3(Z / 16, rt), s);
     // B7: heads -> last hidden layers
     a.nseg = 2;
     a.seg[0] = seg(ws.DPH + o2Z, 2 * Z, ws.phT, 2 * Z, nullptr, nullptr, 0, rs.P[2] + oH, H, ws.DP[2] + oH, H, H, 2 * Z, 0);
