@@ -85,6 +85,12 @@ struct NoMid {
   __device__ __forceinline__ void operator()() const {}
 };
 
+// keeps the scheduler from hoisting the hook's argument wait (s_waitcnt lgkmcnt) above the operand loads issued before it
+template <class Mid>
+__device__ __forceinline__ void mid_fence() {
+  if constexpr (!__is_same(Mid, NoMid)) __builtin_amdgcn_sched_barrier(0);
+}
+
 // U consecutive k-chunks of one wave: all 2U fragment loads first, then the 4U MFMAs in ascending k
 template <int U, int STEP, int WS, class Mid>
 __device__ __forceinline__ f32x4 gemm16_chunks(const float* __restrict__ ap, const float* __restrict__ wp, int kc, bool aok,
@@ -94,7 +100,7 @@ __device__ __forceinline__ f32x4 gemm16_chunks(const float* __restrict__ ap, con
   for (int u = 0; u < U; ++u) a[u] = *reinterpret_cast<const float4*>(ap + kc + u * STEP);
 #pragma unroll
   for (int u = 0; u < U; ++u) w[u] = *reinterpret_cast<const float4*>(wp + (size_t)WS * (kc + u * STEP));
-  if (pending) { mid(); pending = false; }
+  if (pending) { mid_fence<Mid>(); mid(); pending = false; }
   if (!aok) {
 #pragma unroll
     for (int u = 0; u < U; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -172,7 +178,7 @@ __device__ __forceinline__ void wave_gemm16_multi(const float* const (&A)[G], co
       w0[g] = *reinterpret_cast<const float4*>(wp[g] + 16 * (size_t)kc);
       w1[g] = *reinterpret_cast<const float4*>(wp[g] + 16 * (size_t)(kc + STEP));
     }
-    if (pending) { mid(); pending = false; }
+    if (pending) { mid_fence<Mid>(); mid(); pending = false; }
     if (!aok) {
 #pragma unroll
       for (int g = 0; g < GA; ++g) a0[g] = a1[g] = zero;
@@ -200,7 +206,7 @@ __device__ __forceinline__ void wave_gemm16_multi(const float* const (&A)[G], co
     for (int g = 0; g < GA; ++g) a0[g] = *reinterpret_cast<const float4*>(ap[g] + kc);
 #pragma unroll
     for (int g = 0; g < G; ++g) w0[g] = *reinterpret_cast<const float4*>(wp[g] + 16 * (size_t)kc);
-    if (pending) { mid(); pending = false; }
+    if (pending) { mid_fence<Mid>(); mid(); pending = false; }
     if (!aok) {
 #pragma unroll
       for (int g = 0; g < GA; ++g) a0[g] = zero;

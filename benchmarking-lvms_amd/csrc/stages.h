@@ -73,6 +73,68 @@ __global__ __launch_bounds__(NW * 64) void lin_stage_kernel(LinArgs<NSEG> a) {
   out[(size_t)row * ldo + col] = x;
 }
 
+// Multi-segment links with the OPERAND side of their arguments as preloaded scalars (see lin1_stage_kernel below) and the rest —
+// epilogue pointers, strides, flags, outputs — in the trailing struct, fetched by s_load while the operand loads are in flight:
+// the epilogue prefetch runs in wave_gemm16's `mid` hook.  Two segments: any shapes (16-bit fields).  Three segments: one shared
+// lda and K (= ldw), which is what VRNN's first link (three products of h_{t-1}) has; the host falls back to lin_stage_kernel.
+template <int NW, int NSEG>
+__device__ __forceinline__ void linp_body(const float* A, const float* W, int lda, int ldw, int K, int B, int ct, int s,
+                                          const LinArgs<NSEG>& a, float* red) {
+  const int r0 = blockIdx.y * 16, c0 = ct * 16;
+  const int t = threadIdx.x & 255;
+  const int row = r0 + (t >> 4), col = c0 + (t & 15);
+  const bool own = threadIdx.x < 256 && row < B;
+  const int rowc = row < B ? row : r0;
+  float e_bias = 0.f, e_add = 0.f, e_gate = 0.f;
+  int flags = 0;
+  auto prefetch = [&]() {
+    const float* bias = PICK(bias);
+    const float* add = PICK(add);
+    const float* gate = PICK(gate);
+    const int ldadd = PICK(ldadd), ldgate = PICK(ldgate);
+    flags = PICK(flags);
+    e_bias = bias[(flags & LF_BIAS) ? col : 0];
+    e_add = add[(flags & LF_ADD) ? (size_t)rowc * ldadd + col : 0];
+    e_gate = gate[(flags & LF_GATE) ? (size_t)rowc * ldgate + col : 0];
+  };
+  f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+  acc[0] = wave_gemm16<NW, true>(A, lda, r0, B, W, ldw, c0, K, threadIdx.x >> 6, acc[0], prefetch);
+  float v[1];
+  reduce_tiles<1, NW>(acc, red, v);
+  if (!own) return;
+  float* out = PICK(out);
+  const int ldo = PICK(ldo);
+  float x = v[0] + ((flags & LF_BIAS) ? e_bias : 0.f) + ((flags & LF_ADD) ? e_add : 0.f);
+  if (flags & LF_RELU) x = x > 0.f ? x : x * a.slope;
+  if (flags & LF_GATE) x = e_gate > 0.f ? x : x * a.slope;
+  out[(size_t)row * ldo + col] = x;
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void linp2_stage_kernel(const float* A0, const float* A1, const float* W0, const float* W1,
+                                                              unsigned lda01, unsigned ldw01, unsigned k01, unsigned tiles0_b,
+                                                              LinArgs<2> a) {
+  __shared__ float red[NW * 256];
+  const int tiles0 = tiles0_b & 0xffff, B = tiles0_b >> 16;
+  const bool s1 = (int)blockIdx.x >= tiles0;  // uniform
+  const int ct = (int)blockIdx.x - (s1 ? tiles0 : 0);
+  linp_body<NW, 2>(s1 ? A1 : A0, s1 ? W1 : W0, s1 ? lda01 >> 16 : lda01 & 0xffff, s1 ? ldw01 >> 16 : ldw01 & 0xffff,
+                   s1 ? k01 >> 16 : k01 & 0xffff, B, ct, s1 ? 1 : 0, a, red);
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void linp3_stage_kernel(const float* A0, const float* A1, const float* A2, const float* W0,
+                                                              const float* W1, const float* W2, unsigned lda_k,
+                                                              unsigned b_t0_t1, LinArgs<3> a) {
+  __shared__ float red[NW * 256];
+  const int lda = (lda_k & 0xffff), K = lda_k >> 16;
+  const int B = b_t0_t1 & 0xfff, t0 = (b_t0_t1 >> 12) & 0x3ff, t1 = b_t0_t1 >> 22;
+  const int bx = blockIdx.x;
+  const int s = (bx >= t0 ? 1 : 0) + (bx >= t0 + t1 ? 1 : 0);  // uniform
+  const int ct = bx - (s >= 1 ? t0 : 0) - (s >= 2 ? t1 : 0);
+  linp_body<NW, 3>(s == 0 ? A0 : (s == 1 ? A1 : A2), s == 0 ? W0 : (s == 1 ? W1 : W2), lda, K, K, B, ct, s, a, red);
+}
+
 // Single-segment link with SCALAR arguments: the command processor preloads the first 16 argument dwords into SGPRs before
 // the wave starts (-mllvm -amdgpu-kernarg-preload-count=16; struct arguments are never preloaded), so the operand loads do not
 // wait for a kernarg fetch from memory (0.16-0.2 us of a ~3 us link, tools/chain_bench.hip "scalar args").  Everything the
@@ -481,6 +543,35 @@ inline void launch_lin_n(const LinLaunch& l, hipStream_t s) {
       if (nw == 16) hipLaunchKernelGGL((lin2s_stage_kernel<16>), grid, dim3(1024), 0, s, a.A[0], a.A[1 % NSEG], a.W[0], a.W[1 % NSEG], e0, e1, p0, p1, a.out[0], a.out[1 % NSEG], p2, a.slope);
       else if (nw == 8) hipLaunchKernelGGL((lin2s_stage_kernel<8>), grid, dim3(512), 0, s, a.A[0], a.A[1 % NSEG], a.W[0], a.W[1 % NSEG], e0, e1, p0, p1, a.out[0], a.out[1 % NSEG], p2, a.slope);
       else hipLaunchKernelGGL((lin2s_stage_kernel<4>), grid, dim3(256), 0, s, a.A[0], a.A[1 % NSEG], a.W[0], a.W[1 % NSEG], e0, e1, p0, p1, a.out[0], a.out[1 % NSEG], p2, a.slope);
+      return;
+    }
+  }
+#endif
+#ifndef BLVM_NO_LINP
+  if (NSEG == 2) {
+    bool fits = l.B < 65536;
+    for (int i = 0; i < 2; ++i) fits = fits && a.lda[i % NSEG] < 65536 && a.ldw[i % NSEG] < 65536 && a.K[i % NSEG] < 65536;
+    fits = fits && a.tiles[0] < 65536;
+    if (fits) {
+      const LinArgs<2>& a2 = reinterpret_cast<const LinArgs<2>&>(a);  // NSEG == 2 here
+      const unsigned p0 = (unsigned)a2.lda[0] | ((unsigned)a2.lda[1] << 16), p1 = (unsigned)a2.ldw[0] | ((unsigned)a2.ldw[1] << 16);
+      const unsigned p2 = (unsigned)a2.K[0] | ((unsigned)a2.K[1] << 16), p3 = (unsigned)a2.tiles[0] | ((unsigned)l.B << 16);
+      if (nw == 16) hipLaunchKernelGGL((linp2_stage_kernel<16>), grid, dim3(1024), 0, s, a2.A[0], a2.A[1], a2.W[0], a2.W[1], p0, p1, p2, p3, a2);
+      else if (nw == 8) hipLaunchKernelGGL((linp2_stage_kernel<8>), grid, dim3(512), 0, s, a2.A[0], a2.A[1], a2.W[0], a2.W[1], p0, p1, p2, p3, a2);
+      else hipLaunchKernelGGL((linp2_stage_kernel<4>), grid, dim3(256), 0, s, a2.A[0], a2.A[1], a2.W[0], a2.W[1], p0, p1, p2, p3, a2);
+      return;
+    }
+  }
+  if (NSEG == 3) {
+    const LinArgs<3>& a3 = reinterpret_cast<const LinArgs<3>&>(a);  // NSEG == 3 here
+    bool fits = l.B < 4096 && a3.tiles[0] < 1024 && a3.tiles[1] < 1024 && a3.lda[0] < 65536 && a3.K[0] < 65536;
+    for (int i = 0; i < 3; ++i) fits = fits && a3.lda[i] == a3.lda[0] && a3.K[i] == a3.K[0] && a3.ldw[i] == a3.K[0];
+    if (fits) {
+      const unsigned p0 = (unsigned)a3.lda[0] | ((unsigned)a3.K[0] << 16);
+      const unsigned p1 = (unsigned)l.B | ((unsigned)a3.tiles[0] << 12) | ((unsigned)a3.tiles[1] << 22);
+      if (nw == 16) hipLaunchKernelGGL((linp3_stage_kernel<16>), grid, dim3(1024), 0, s, a3.A[0], a3.A[1], a3.A[2], a3.W[0], a3.W[1], a3.W[2], p0, p1, a3);
+      else if (nw == 8) hipLaunchKernelGGL((linp3_stage_kernel<8>), grid, dim3(512), 0, s, a3.A[0], a3.A[1], a3.A[2], a3.W[0], a3.W[1], a3.W[2], p0, p1, a3);
+      else hipLaunchKernelGGL((linp3_stage_kernel<4>), grid, dim3(256), 0, s, a3.A[0], a3.A[1], a3.A[2], a3.W[0], a3.W[1], a3.W[2], p0, p1, a3);
       return;
     }
   }
