@@ -244,38 +244,48 @@ struct GruBwdArgs {
 };
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void gru_bwd_kernel(GruBwdArgs a) {
+__global__ __launch_bounds__(NW * 64) void gru_bwd_kernel(const float* DGHn, const float* WhhT, float* G, unsigned b_r, unsigned has,
+                                                          GruBwdArgs a) {
+  // the leading scalars (operand pointers, G, sizes, flags) are preloaded into SGPRs; the struct comes by s_load and the saves of
+  // the step are prefetched by wave_gemm16's `mid` hook, after the operand loads have been issued (stages.h head_stage_kernel)
   __shared__ float red[NW * 256];
-  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, R = a.R;
+  const int B = b_r & 0xffff, R = b_r >> 16;
+  const int has_gemm = has & 1, has_gates = (has >> 1) & 1;
+  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16;
   const int t = threadIdx.x & 255;
   const int row = r0 + (t >> 4), col = c0 + (t & 15);
-  const bool own = threadIdx.x < 256 && row < a.B;
-  const int rowc = row < a.B ? row : r0;
+  const bool own = threadIdx.x < 256 && row < B;
+  const int rowc = row < B ? row : r0;
   const size_t o = (size_t)rowc * R + col;
-  float g = a.G[o];
-  float r = 0.f, u = 0.f, n = 0.f, hn = 0.f, hp = 0.f;
+  float g = G[o];
+  float dout = 0.f, r = 0.f, u = 0.f, n = 0.f, hn = 0.f, hp = 0.f;
   int idx = 0;
-  if (a.has_gates) {  // wave-uniform
-    idx = time_index(a.j, a.reverse, a.lens, rowc);
-    g += a.dout[(size_t)idx * a.out_ts + (size_t)rowc * a.out_ld + col];
-    r = a.rg[o]; u = a.ug[o]; n = a.ng[o]; hn = a.ghn[o]; hp = a.hprev[o];
-  }
+  auto prefetch = [&]() {
+    if (has_gates) {  // wave-uniform
+      idx = time_index(a.j, a.reverse, a.lens, rowc);
+      dout = a.dout[(size_t)idx * a.out_ts + (size_t)rowc * a.out_ld + col];
+      r = a.rg[o]; u = a.ug[o]; n = a.ng[o]; hn = a.ghn[o]; hp = a.hprev[o];
+    }
+  };
   float v[1] = {0.f};
-  if (a.has_gemm) {
+  if (has_gemm) {
     f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-    acc[0] = wave_gemm16<NW, true>(a.DGHn, 3 * R, r0, a.B, a.WhhT, 3 * R, c0, 3 * R, threadIdx.x >> 6, acc[0]);
+    acc[0] = wave_gemm16<NW, true>(DGHn, 3 * R, r0, B, WhhT, 3 * R, c0, 3 * R, threadIdx.x >> 6, acc[0], prefetch);
     reduce_tiles<1, NW>(acc, red, v);
+  } else {
+    prefetch();
   }
   if (!own) return;
+  g += dout;
   g += v[0];
-  if (!a.has_gates) { a.dh0[o] = g; return; }
+  if (!has_gates) { a.dh0[o] = g; return; }
   const float dn_pre = g * (1.f - u) * (1.f - n * n);
   const float du_pre = g * (hp - n) * u * (1.f - u);
   const float dr_pre = dn_pre * hn * r * (1.f - r);
-  const size_t oi = ((size_t)idx * a.B + row) * 3 * R + col, oh = (size_t)row * 3 * R + col;
+  const size_t oi = ((size_t)idx * B + row) * 3 * R + col, oh = (size_t)row * 3 * R + col;
   a.DGI[oi] = dr_pre; a.DGI[oi + R] = du_pre; a.DGI[oi + 2 * R] = dn_pre;
   a.DGH[oh] = dr_pre; a.DGH[oh + R] = du_pre; a.DGH[oh + 2 * R] = dn_pre * r;
-  a.G[o] = g * u;
+  G[o] = g * u;
 }
 
 struct GruReserve { float *XG, *Hs, *RG, *UG, *NG, *GHN, *WhhP; };  // WhhP: T16 copy of Whh
@@ -449,6 +459,7 @@ extern "C" int blvm_gru_seq_bwd(const float* Wih, const float* Whh, const float*
   if (rc) return rc;
   BLVM_REQUIRE(Wih && Whh && in && reserve && d_out && workspace, "gru_bwd: null pointer");
   BLVM_REQUIRE(!reverse || lens, "gru_bwd: reverse needs lens");
+  BLVM_REQUIRE(B < 65536 && R < 65536, "gru_bwd: B and R must be below 65536 (packed kernel arguments)");
   BLVM_REQUIRE(aligned16(reserve) && aligned16(workspace), "gru_bwd: buffers must be 16-byte aligned");
   GruReserve rs;
   carve_gru(const_cast<float*>(reserve), T, B, R, &rs);
@@ -471,7 +482,12 @@ extern "C" int blvm_gru_seq_bwd(const float* Wih, const float* Whh, const float*
     a.hprev = rs.Hs + jg * br; a.lens = lens;
     a.G = ws.G; a.DGI = ws.DGI; a.DGH = ws.DGH + (size_t)jg * B * 3 * R; a.dh0 = d_h0;
     a.out_ts = out_ts; a.out_ld = out_ld; a.B = B; a.R = R; a.j = jg; a.reverse = reverse;
-    LAUNCH_NW(gru_bwd_kernel, nw, grid, s, a);
+    {
+      const unsigned b_r = (unsigned)B | ((unsigned)R << 16), has = (a.has_gemm ? 1u : 0u) | (a.has_gates ? 2u : 0u);
+      if (nw == 16) hipLaunchKernelGGL((gru_bwd_kernel<16>), grid, dim3(1024), 0, s, a.DGHn, a.WhhT, a.G, b_r, has, a);
+      else if (nw == 8) hipLaunchKernelGGL((gru_bwd_kernel<8>), grid, dim3(512), 0, s, a.DGHn, a.WhhT, a.G, b_r, has, a);
+      else hipLaunchKernelGGL((gru_bwd_kernel<4>), grid, dim3(256), 0, s, a.DGHn, a.WhhT, a.G, b_r, has, a);
+    }
   }
   BLVM_CHECK_LAUNCH("gru_seq_bwd");
   if (d_in) {

@@ -78,35 +78,43 @@ struct RssmDhArgs {
 };
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void rssm_dh_stage_kernel(RssmDhArgs a) {
+__global__ __launch_bounds__(NW * 64) void rssm_dh_stage_kernel(const float* DQ0, const float* DP0, const float* WqT,
+                                                                const float* WpT, float* G, unsigned b_h, RssmDhArgs a) {
+  // leading scalars preloaded into SGPRs, the struct by s_load, the saves prefetched in the `mid` hook (stages.h head_stage_kernel)
   __shared__ float red[2 * NW * 256];
-  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, wave = threadIdx.x >> 6, H = a.H;
+  const int B = b_h & 0xffff, H = b_h >> 16;
+  const int r0 = blockIdx.y * 16, c0 = blockIdx.x * 16, wave = threadIdx.x >> 6;
   const int t = threadIdx.x & 255;
   const int row = r0 + (t >> 4), col = c0 + (t & 15);
-  const bool own = threadIdx.x < 256 && row < a.B;
-  const int rowc = row < a.B ? row : r0;
+  const bool own = threadIdx.x < 256 && row < B;
+  const int rowc = row < B ? row : r0;
   const size_t o = (size_t)rowc * H + col, o3 = (size_t)rowc * 3 * H + col;
-  const float g0 = a.G[o] + (a.dh_add != nullptr ? a.dh_add[o] : 0.f);
-  const float r = a.rg[o], u = a.ug[o], n = a.ng[o], hn = a.gh[o3 + 2 * H], hp = a.hprev[o];
+  const float gG = G[o];
+  float gadd = 0.f, r = 0.f, u = 0.f, n = 0.f, hn = 0.f, hp = 0.f;
+  auto prefetch = [&]() {
+    gadd = a.dh_add != nullptr ? a.dh_add[o] : 0.f;
+    r = a.rg[o]; u = a.ug[o]; n = a.ng[o]; hn = a.gh[o3 + 2 * H]; hp = a.hprev[o];
+  };
   f32x4 acc[2];
   acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
   acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   {
-    const float* const As[2] = {a.DQ0, a.DP0};
-    const float* const Ws[2] = {a.WqT, a.WpT};
+    const float* const As[2] = {DQ0, DP0};
+    const float* const Ws[2] = {WqT, WpT};
     const int ld[2] = {H, H}, cs[2] = {c0, c0};
-    wave_gemm16_multi<NW, 2, false>(As, ld, r0, a.B, Ws, ld, cs, H, wave, acc);
+    wave_gemm16_multi<NW, 2, false>(As, ld, r0, B, Ws, ld, cs, H, wave, acc, prefetch);
   }
   float v[2];
   reduce_tiles<2, NW>(acc, red, v);
   if (!own) return;
+  const float g0 = gG + gadd;
   const float g = g0 + v[0] + v[1];
   const float dn_pre = g * (1.f - u) * (1.f - n * n);
   const float du_pre = g * (hp - n) * u * (1.f - u);
   const float dr_pre = dn_pre * hn * r * (1.f - r);
   a.dgi[o3] = dr_pre; a.dgi[o3 + H] = du_pre; a.dgi[o3 + 2 * H] = dn_pre;
   a.dgh[o3] = dr_pre; a.dgh[o3 + H] = du_pre; a.dgh[o3 + 2 * H] = dn_pre * r;
-  a.G[o] = g * u;
+  G[o] = g * u;
 }
 
 struct RssmReserve {
@@ -320,7 +328,14 @@ extern "C" int blvm_rssm_seq_bwd(const BlvmRssmWeights* w, const float* enc, con
     d.dh_add = d_hs + oH + bh; d.G = ws.G;
     d.rg = rs.RG + oH; d.ug = rs.UG + oH; d.ng = rs.NG + oH; d.gh = rs.GHb + o3; d.hprev = hs + oH;
     d.dgi = ws.DGI + o3; d.dgh = ws.DGH + o3; d.B = B; d.H = H;
-    LAUNCH_NW(rssm_dh_stage_kernel, pick_nw(H, 2), dim3(H / 16, rt), s, d);
+    {
+      const int nw = pick_nw(H, 2);
+      const dim3 grid(H / 16, rt);
+      const unsigned b_h = (unsigned)B | ((unsigned)H << 16);
+      if (nw == 16) hipLaunchKernelGGL((rssm_dh_stage_kernel<16>), grid, dim3(1024), 0, s, d.DQ0, d.DP0, d.WqT, d.WpT, d.G, b_h, d);
+      else if (nw == 8) hipLaunchKernelGGL((rssm_dh_stage_kernel<8>), grid, dim3(512), 0, s, d.DQ0, d.DP0, d.WqT, d.WpT, d.G, b_h, d);
+      else hipLaunchKernelGGL((rssm_dh_stage_kernel<4>), grid, dim3(256), 0, s, d.DQ0, d.DP0, d.WqT, d.WpT, d.G, b_h, d);
+    }
     // B6: through the GRU input projection to the (ReLU) GRU input layer
     l.nseg = 1;
     l.seg[0] = seg(ws.DGI + o3, 3 * H, ws.wihT, 3 * H, nullptr, nullptr, 0, rs.GIN + oH, H, ws.DGIN + oH, H, H, 3 * H, 0);
