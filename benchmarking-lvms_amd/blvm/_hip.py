@@ -65,6 +65,10 @@ _SIGNATURES = {
     "blvm_version": (c_int, []),
     "blvm_last_error": (ctypes.c_char_p, []),
     "blvm_device_ok": (c_int, []),
+    "blvm_async_errors": (c_int, [c_void_p]),
+    "blvm_pchain_configure": (c_int, [c_int, c_int]),
+    "blvm_pchain_profile": (c_int, [c_void_p]),
+    "blvm_pchain_tune": (c_int, [c_int]),
     "blvm_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                               c_void_p, c_int, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
     "blvm_act_bwd_f32": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
@@ -166,6 +170,18 @@ def check(rc: int, what: str):
     if rc != 0:
         msg = load().blvm_last_error().decode(errors="replace")
         raise BlvmHipError(f"{what} failed (code {rc}): {msg}")
+
+
+def check_async(what: str = "a persistent recurrent launch"):
+    """Raise if a persistent chain launch of this process gave up on a bounded spin (its results are garbage).  Cheap (a read of
+    pinned host memory): called wherever the host has just synchronised with the device to read results back."""
+    code = ctypes.c_uint(0)
+    n = load().blvm_async_errors(ctypes.byref(code))
+    if n:
+        raise BlvmHipError(
+            f"{what}: {n} persistent launch(es) aborted on a bounded spin (last at step {code.value >> 4}, link {code.value & 15}): "
+            "a workgroup of the launch was not resident (is another process using this GPU?); results are invalid"
+        )
 
 
 def stream_ptr() -> int:

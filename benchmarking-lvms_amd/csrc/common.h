@@ -333,6 +333,16 @@ struct ChainKey {
 };
 int run_chain(const ChainKey& key, hipStream_t user, const std::function<int(hipStream_t)>& body);
 
+// persistent chains (pchain.h): the process-wide control block and a fresh launch epoch (core.hip)
+int pchain_ctl(unsigned** dev, unsigned** host_dev, unsigned* epoch);
+// largest batch the recurrent sequences run as ONE persistent launch for (0 = never; env BLVM_PCHAIN=0 / BLVM_PCHAIN_MAX_B=n, or
+// blvm_pchain_configure).  Beyond it the links are bound by MFMA / operand bytes, not latency, and the 32x32-tile launch-per-link
+// kernels fit better.  pchain_waves(): waves per workgroup of the persistent kernels (8 or 16; env BLVM_PCHAIN_NW).
+int pchain_max_batch();
+int pchain_waves();
+int pchain_tune();  // placement experiment bits (env BLVM_PCHAIN_TUNE / blvm_pchain_configure): see vrnn.hip
+unsigned long long* pchain_profile_buffer();  // diagnostics: null unless blvm_pchain_profile() installed a device buffer
+
 // internal launchers shared between translation units (defined in gemm.hip)
 int gemm_f32(int op_a, int op_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
              int ldc, const float* bias, int act, float slope, const float* gate, int ldg, int accumulate,

@@ -163,7 +163,103 @@ extern "C" int blvm_upload_i32(const int32_t* host, int n, int32_t* dst, void* s
   return BLVM_OK;
 }
 
-extern "C" int blvm_version(void) { return 100; /* 0.1.0 */ }
+// ---- persistent-chain control block (pchain.h) ---------------------------------------------------------------------------------
+// One per process and device: 64 bytes of device memory (word 0 = epoch of the last aborted launch) and 64 bytes of pinned host
+// memory mapped into the device (word 0 = aborted launches so far, word 1 = code of the last failed spin), written by a kernel
+// only when a bounded spin gives up — the normal path costs nothing and the API stays asynchronous.
+namespace blvm {
+namespace {
+struct PchainCtl {
+  std::mutex mu;
+  int device = -1;
+  unsigned* dev = nullptr;
+  unsigned* host = nullptr;      // host view
+  unsigned* host_dev = nullptr;  // device view of the same words
+  unsigned epoch = 0;
+};
+PchainCtl& pchain_ctl_state() {
+  static PchainCtl c;
+  return c;
+}
+}  // namespace
+
+namespace {
+int g_pchain_max_b = -1, g_pchain_nw = -1, g_pchain_tune = -1;
+unsigned long long* g_pchain_prof = nullptr;
+}
+unsigned long long* pchain_profile_buffer() { return g_pchain_prof; }
+int pchain_max_batch() {
+  if (g_pchain_max_b < 0) {
+    const char* e = getenv("BLVM_PCHAIN");
+    const char* m = getenv("BLVM_PCHAIN_MAX_B");
+    g_pchain_max_b = (e && atoi(e) == 0) ? 0 : (m ? atoi(m) : 128);
+  }
+  return g_pchain_max_b;
+}
+int pchain_waves() {
+  if (g_pchain_nw < 0) {
+    const char* e = getenv("BLVM_PCHAIN_NW");
+    g_pchain_nw = (e && atoi(e) == 16) ? 16 : 8;
+  }
+  return g_pchain_nw;
+}
+
+int pchain_tune() {
+  if (g_pchain_tune < 0) {
+    const char* e = getenv("BLVM_PCHAIN_TUNE");
+    g_pchain_tune = e ? atoi(e) : 22;
+  }
+  return g_pchain_tune;
+}
+
+int pchain_ctl(unsigned** dev, unsigned** host_dev, unsigned* epoch) {
+  PchainCtl& c = pchain_ctl_state();
+  std::lock_guard<std::mutex> lock(c.mu);
+  int d = 0;
+  BLVM_HIP(hipGetDevice(&d));
+  if (c.device != d) {  // one process per GPU; a device switch starts over (the old blocks are leaked on purpose: a kernel may still use them)
+    BLVM_HIP(hipMalloc(reinterpret_cast<void**>(&c.dev), 64));
+    BLVM_HIP(hipMemset(c.dev, 0, 64));
+    BLVM_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.host), 64, hipHostMallocMapped));
+    memset(c.host, 0, 64);
+    BLVM_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c.host_dev), c.host, 0));
+    c.device = d;
+    c.epoch = 0;
+  }
+  *dev = c.dev;
+  *host_dev = c.host_dev;
+  *epoch = ++c.epoch;
+  if (c.epoch == 0) *epoch = ++c.epoch;  // 0 is the block's reset value
+  return BLVM_OK;
+}
+}  // namespace blvm
+
+extern "C" int blvm_pchain_configure(int max_batch, int waves) {
+  if (max_batch >= 0) blvm::g_pchain_max_b = max_batch;
+  if (waves == 8 || waves == 16) blvm::g_pchain_nw = waves;
+  return BLVM_OK;
+}
+
+extern "C" int blvm_pchain_tune(int bits) {
+  blvm::g_pchain_tune = bits;
+  return BLVM_OK;
+}
+
+extern "C" int blvm_pchain_profile(unsigned long long* device_buffer) {
+  blvm::g_pchain_prof = device_buffer;
+  return BLVM_OK;
+}
+
+extern "C" int blvm_async_errors(unsigned* last_code) {
+  blvm::PchainCtl& c = blvm::pchain_ctl_state();
+  std::lock_guard<std::mutex> lock(c.mu);
+  if (!c.host) return 0;
+  const volatile unsigned* h = c.host;
+  if (last_code) *last_code = h[1];
+  return (int)h[0];
+}
+
+extern "C" int blvm_version(void) { return 110; /* 0.1.1 */ }
 
 extern "C" const char* blvm_last_error(void) { return blvm::g_err; }
 

@@ -16,7 +16,10 @@
 // Numerics: fp32 operands, fp32 MFMA accumulation (an exact fma chain), so a sequence is reproducible run-to-run.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "common.h"
+#include "pchain.h"
 
 namespace blvm {
 namespace {
@@ -165,6 +168,7 @@ size_t carve_reserve(float* base, int Tp, int B, int H, int Z, int R, Reserve* r
 struct BwdWs {
   float *pT[3], *phT, *qT[3], *qhT, *fT[4], *wihT, *whhT;   // transposed weights, T16
   float *DGI, *DGH, *DPHI[4], *DQH, *DPH, *DP[3], *DQ[3], *G;
+  float *GA, *GB;  // persistent backward: the running state gradient as per-step slabs (written once each), [T',B,R]
 };
 
 size_t carve_ws(float* base, int Tp, int B, int X, int H, int Z, int R, BwdWs* w) {
@@ -187,6 +191,7 @@ size_t carve_ws(float* base, int Tp, int B, int X, int H, int Z, int R, BwdWs* w
   for (int i = 0; i < 3; ++i) t.DP[i] = take(n * H);
   for (int i = 0; i < 3; ++i) t.DQ[i] = take(n * H);
   t.G = take((size_t)B * R);
+  t.GA = take(n * R); t.GB = take(n * R);
   if (w) *w = t;
   return off;
 }
@@ -221,6 +226,309 @@ inline int overlap_chunk_steps() {
   return v;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent forward: the WHOLE sequence in one launch (pchain.h).  The nine links of a step are the same as in the
+// launch-per-link path below (F1 .. F9); their 16x16 tiles are dealt over the resident workgroups:
+// consecutive links on alternating halves of the grid, the GRU's hidden projection behind the first three links (see the kernel).
+// Buffers polled inside the launch (sentinel-filled by the host): P, Q, FZ, GHb, z, decin.
+// ---------------------------------------------------------------------------------------------------------------
+struct VrnnPFwd {
+  const float *Wp[3], *Wq[3], *Wph, *Wqh, *Wf[4], *Wih, *Whh;                       // T16
+  const float *bp[3], *bq[3], *bph, *bqh, *bf[4], *bhh;                             // bq[0] unused (folded into XQ)
+  const float *XQ, *XG, *eps;
+  float *decin, *P[3], *Q[3], *FZ[3], *GHb, *RG, *UG, *NG, *RAWQ, *RAWP, *mu_p, *sd_p, *mu_q, *sd_q, *z;
+  int Tp, B, H, Z, R, residual;
+  float beta, inv_beta, sd_eps;
+  int g_set, nsets, g_def0, g_defn, tune;  // placement, see the kernel
+  pchain::Ctl ctl;
+  unsigned long long* prof;  // diagnostics (blvm_pchain_profile): per-link wall-clock ticks of workgroup 0 [0..15] and g_def0 [16..31]
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 1) void vrnn_pfwd_kernel(VrnnPFwd a) {
+  using namespace pchain;
+  extern __shared__ __attribute__((aligned(16))) float red_all[];  // 2 x (4 products x NW x 256) floats
+  float* const red0 = red_all;
+  float* const red1 = red_all + 4 * NW * 256;
+  int par = 0;
+  auto red = [&]() { par ^= 1; return par ? red0 : red1; };
+  Poll pl{a.ctl, 0u, false, 1};
+  const int w = blockIdx.x;
+  const int B = a.B, H = a.H, Z = a.Z, R = a.R, ldd = H + R;
+  const int rt = (B + 15) / 16, ctH = H / 16, ctZ = Z / 16, ctR = R / 16;
+  const size_t sH = (size_t)B * H, sZ = (size_t)B * Z, sR = (size_t)B * R, s3R = (size_t)B * 3 * R, sD = (size_t)B * ldd;
+  // Placement (host: vrnn_seq_fwd_impl): `nsets` ranges of `g_set` workgroups take the links in turn (2: while one range computes
+  // link l the other has fetched its weights for link l+1 and waits in the poll loop).  The GRU's hidden projection
+  // gh_t = h_{t-1} W_hh^T + b_hh (3R columns, first needed by F9) runs either on its own range [g_def0, g_def0 + g_defn), or in three
+  // batches behind the F1, F2, F3 tiles of the range that is idle next.
+  const int tune = a.tune;
+  const bool xcd = tune & 4, can = tune & 8, cand = tune & 16;
+  const int nset = a.g_set, nGH = 3 * ctR, bGH = (nGH + 2) / 3;
+  int phase = 0;
+  unsigned long long pacc[10] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+  const bool profiled = a.prof && (w == 0 || w == a.g_set);
+  unsigned long long tprev = profiled ? wall_clock64() : 0ull;
+  auto link_end = [&](int l) {
+    if (profiled) {
+      const unsigned long long now = wall_clock64();
+      pacc[l] += now - tprev;
+      tprev = now;
+    }
+  };
+  for (int t = 0; t < a.Tp; ++t) {
+    const float* dec_t = a.decin + (size_t)t * sD;
+    float* dec_tw = a.decin + (size_t)t * sD;
+    float* dec_n = a.decin + (size_t)(t + 1) * sD;
+    const float* hprev = dec_t + H;
+    const unsigned code = (unsigned)t << 4;
+    auto next_base = [&]() { return a.nsets == 2 ? (phase++ & 1) * nset : 0; };
+    auto gh_tiles = [&](int c_lo, int c_hi, int base, int n, bool canary) {  // column tiles [c_lo, c_hi) of the hidden projection
+      pl.code = code | 10u;
+      for (TileIter it(w, base, n, rt, c_hi - c_lo, xcd); it.valid(); it.next()) {
+        const int r0 = it.r0(), c0 = (c_lo + it.c()) * 16;
+        if (canary) canary_wait(hprev, ldd, r0, B, R, pl);
+        tile_lin<NW>(hprev, ldd, true, a.Whh, R, a.bhh, nullptr, 0, false, nullptr, 0, false, 0.f, a.GHb + t * s3R, 3 * R, true, r0, c0, B, red(), pl);
+      }
+    };
+    // F1: first prior layer | h-half of the first posterior layer
+    int base = next_base();
+    pl.code = code | 1u;
+    for (TileIter it(w, base, nset, rt, 2 * ctH, xcd); it.valid(); it.next()) {
+      const int r0 = it.r0(), cc = it.c(), sgm = cc >= ctH, c0 = (cc - (sgm ? ctH : 0)) * 16;
+      if (can) canary_wait(hprev, ldd, r0, B, R, pl);
+      if (!sgm) tile_lin<NW>(hprev, ldd, true, a.Wp[0], R, a.bp[0], nullptr, 0, false, nullptr, 0, true, 0.f, a.P[0] + t * sH, H, true, r0, c0, B, red(), pl);
+      else tile_lin<NW>(hprev, ldd, true, a.Wq[0], R, nullptr, a.XQ + t * sH, H, false, nullptr, 0, true, 0.f, a.Q[0] + t * sH, H, true, r0, c0, B, red(), pl);
+    }
+    if (a.g_defn > 0) { pl.nap = 16; gh_tiles(0, nGH, a.g_def0, a.g_defn, cand); pl.nap = 1; }
+    else gh_tiles(0, min(bGH, nGH), base, nset, false);
+    link_end(0);
+    // F2, F3
+    for (int l = 1; l < 3; ++l) {
+      base = next_base();
+      pl.code = code | (unsigned)(1 + l);
+      for (TileIter it(w, base, nset, rt, 2 * ctH, xcd); it.valid(); it.next()) {
+        const int r0 = it.r0(), cc = it.c(), sgm = cc >= ctH, c0 = (cc - (sgm ? ctH : 0)) * 16;
+        const float* A = (sgm ? a.Q[l - 1] : a.P[l - 1]) + t * sH;
+        if (can) canary_wait(A, H, r0, B, H, pl);
+        tile_lin<NW>(A, H, true, sgm ? a.Wq[l] : a.Wp[l], H, sgm ? a.bq[l] : a.bp[l], nullptr, 0, false, nullptr, 0, true, 0.f,
+                     (sgm ? a.Q[l] : a.P[l]) + t * sH, H, true, r0, c0, B, red(), pl);
+      }
+      if (a.g_defn == 0) gh_tiles(min(l * bGH, nGH), min((l + 1) * bGH, nGH), base, nset, false);
+      link_end(l);
+    }
+    // F4: heads + sample
+    base = next_base();
+    pl.code = code | 4u;
+    for (TileIter it(w, base, nset, rt, ctZ, xcd); it.valid(); it.next()) {
+      const int r0 = it.r0(), c0 = it.c() * 16;
+      const HeadOut o{a.mu_p + t * sZ, a.sd_p + t * sZ, a.mu_q + t * sZ, a.sd_q + t * sZ, a.z + t * sZ, a.RAWP + t * sZ, a.RAWQ + t * sZ, nullptr};
+      if (can) { canary_wait(a.P[2] + t * sH, H, r0, B, H, pl); canary_wait(a.Q[2] + t * sH, H, r0, B, H, pl); }
+      tile_head<NW>(a.P[2] + t * sH, a.Q[2] + t * sH, true, a.Wph, a.bph, a.Wqh, a.bqh, a.eps + t * sZ, o, H, Z, a.residual, a.beta, a.inv_beta,
+                    a.sd_eps, r0, c0, B, red(), pl);
+    }
+    link_end(3);
+    // F5..F8: phi_z MLP (last layer writes phi into decin row t)
+    for (int l = 0; l < 4; ++l) {
+      base = next_base();
+      pl.code = code | (unsigned)(5 + l);
+      const float* A = l == 0 ? a.z + t * sZ : a.FZ[l - 1] + t * sH;
+      const int K = l == 0 ? Z : H;
+      float* out = l == 3 ? dec_tw : a.FZ[l] + t * sH;
+      const int ldo = l == 3 ? ldd : H;
+      for (TileIter it(w, base, nset, rt, ctH, xcd); it.valid(); it.next()) {
+        const int r0 = it.r0(), c0 = it.c() * 16;
+        if (can) canary_wait(A, K, r0, B, K, pl);
+        tile_lin<NW>(A, K, true, a.Wf[l], K, a.bf[l], nullptr, 0, false, nullptr, 0, true, 0.f, out, ldo, true, r0, c0, B, red(), pl);
+      }
+      link_end(4 + l);
+    }
+    // F9: GRU
+    base = next_base();
+    pl.code = code | 9u;
+    for (TileIter it(w, base, nset, rt, ctR, xcd); it.valid(); it.next()) {
+      const int r0 = it.r0(), c0 = it.c() * 16;
+      if (can) canary_wait(dec_t, ldd, r0, B, H, pl);
+      tile_gru<NW>(dec_t, ldd, true, a.Wih, H, a.XG + t * s3R, a.GHb + t * s3R, hprev, ldd, R, dec_n + H, ldd, a.RG + t * sR, a.UG + t * sR,
+                   a.NG + t * sR, r0, c0, B, red(), pl);
+    }
+    link_end(8);
+  }
+  if (profiled && threadIdx.x == 0) {
+    for (int l = 0; l < 10; ++l) a.prof[(w == 0 ? 0 : 16) + l] += pacc[l];
+#ifdef PCHAIN_TPROF
+    if (w == 0) for (int l = 0; l < 8; ++l) a.prof[32 + l] += pl.tp[l];
+#endif
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent backward (BPTT): one launch for the whole sequence, steps T'-1 .. 0, nine links per step as in the
+// launch-per-link path below.  The running gradient wrt the recurrent state is kept as per-step slabs so that every
+// location is written once:  GA[t] = (gradient wrt h_t) * u_t + decoder gradient  (written by Ba of step t),
+// GB[t] = GA[t] + DGH[t] W_hh  (the K = 3R product that nothing needs before the next step's Ba: deferred range).
+// ---------------------------------------------------------------------------------------------------------------
+struct VrnnPBwd {
+  const float *pT[3], *phT, *qT[3], *qhT, *fT[4], *wihT, *whhT;                              // transposed weights, T16
+  const float *decin, *d_decin, *P[3], *Q[3], *FZ[3], *GHb, *RG, *UG, *NG;                     // saved by the forward
+  pchain::DzIn dz;                                                                             // step-0 slabs; the kernel offsets them
+  float *DGI, *DGH, *DPHI[4], *DQH, *DPH, *DP[3], *DQ[3], *GA, *GB, *G_out;
+  int Tp, B, H, Z, R;
+  int g_set, g_def0, g_defn, tune;
+  pchain::Ctl ctl;
+  unsigned long long* prof;
+};
+
+// Ba: g = GB[t+1] + DP0[t+1] W_p0 + DQ0[t+1] W_q0h  (the complete gradient wrt h_t), then the GRU gate derivatives of step t.
+// t == T'-1: g = 0 (no later step).  t == -1: only g, written to G_out (the gradient wrt the initial state).
+template <int NW>
+__device__ __forceinline__ void tile_dh(const VrnnPBwd& a, int t, int r0, int c0, float* red, pchain::Poll& pl) {
+  using namespace pchain;
+  const int B = a.B, H = a.H, R = a.R, ldd = H + R;
+  const size_t sH = (size_t)B * H, sR = (size_t)B * R, s3R = 3 * sR, sD = (size_t)B * ldd;
+  const int tt = threadIdx.x & 255;
+  const int row = r0 + (tt >> 4), col = c0 + (tt & 15);
+  const bool own = threadIdx.x < 256 && row < B;
+  const int rowc = row < B ? row : r0;
+  const size_t o = (size_t)rowc * R + col, o3 = (size_t)rowc * 3 * R + col;
+  const bool has_gemm = t + 1 < a.Tp, has_gates = t >= 0;
+  float r = 0.f, u = 0.f, n = 0.f, hn = 0.f, hp = 0.f, dd = 0.f;
+  if (has_gates) {
+    r = a.RG[t * sR + o]; u = a.UG[t * sR + o]; n = a.NG[t * sR + o]; hn = a.GHb[t * s3R + o3 + 2 * R];
+    hp = a.decin[t * sD + (size_t)rowc * ldd + H + col];
+    dd = a.d_decin[t * sD + (size_t)rowc * ldd + H + col];
+  }
+  float v[2] = {0.f, 0.f}, g0 = 0.f;
+  if (has_gemm) {
+    g0 = ld_sc1(a.GB + (t + 1) * sR + o);  // stored a step ago: request it under the operand wait
+    f32x4 acc[2];
+    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* const As[2] = {a.DP[0] + (t + 1) * sH, a.DQ[0] + (t + 1) * sH};
+    const float* const Ws[2] = {a.pT[0], a.qT[0]};
+    const int la[2] = {H, H}, cs[2] = {c0, c0};
+    mgemm16<NW, 2, 2, MapId>(As, la, true, r0, B, Ws, cs, H, acc, pl);
+    reduce_tiles<2, NW>(acc, red, v);
+    if (threadIdx.x >= 256) return;
+    wait_vm0(g0);
+    if (__any(own && is_sentinel(g0))) {
+      const float* const ps[1] = {a.GB + (t + 1) * sR + o};
+      float ws[1];
+      poll_words<1>(ps, ws, own, pl);
+      g0 = ws[0];
+    }
+  }
+  if (!own) return;
+  const float g = g0 + v[0] + v[1];
+  if (!has_gates) { a.G_out[(size_t)row * R + col] = g; return; }
+  const float dn_pre = g * (1.f - u) * (1.f - n * n);
+  const float du_pre = g * (hp - n) * u * (1.f - u);
+  const float dr_pre = dn_pre * hn * r * (1.f - r);
+  float* dgi = a.DGI + t * s3R + (size_t)row * 3 * R + col;
+  float* dgh = a.DGH + t * s3R + (size_t)row * 3 * R + col;
+  st_sc1(dgi, dr_pre); st_sc1(dgi + R, du_pre); st_sc1(dgi + 2 * R, dn_pre);
+  st_sc1(dgh, dr_pre); st_sc1(dgh + R, du_pre); st_sc1(dgh + 2 * R, dn_pre * r);
+  st_sc1(a.GA + t * sR + (size_t)row * R + col, g * u + dd);
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 1) void vrnn_pbwd_kernel(VrnnPBwd a) {
+  using namespace pchain;
+  extern __shared__ __attribute__((aligned(16))) float red_all[];  // 2 x (2 products x NW x 256) floats
+  float* const red0 = red_all;
+  float* const red1 = red_all + 2 * NW * 256;
+  int par = 0;
+  auto red = [&]() { par ^= 1; return par ? red0 : red1; };
+  Poll pl{a.ctl, 0u, false, 1};
+  const int w = blockIdx.x;
+  const int B = a.B, H = a.H, Z = a.Z, R = a.R, ldd = H + R;
+  const int rt = (B + 15) / 16, ctH = H / 16, ctZ = Z / 16, ctR = R / 16;
+  const size_t sH = (size_t)B * H, sZ = (size_t)B * Z, sR = (size_t)B * R, s3R = 3 * sR, s2Z = 2 * sZ, sD = (size_t)B * ldd;
+  const bool xcd = a.tune & 4, cand = a.tune & 16;
+  const int nset = a.g_set;
+  unsigned long long pacc[10] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+  const bool profiled = a.prof && (w == 0 || w == a.g_def0);
+  unsigned long long tprev = profiled ? wall_clock64() : 0ull;
+  auto link_end = [&](int l) {
+    if (profiled) {
+      const unsigned long long now = wall_clock64();
+      pacc[l] += now - tprev;
+      tprev = now;
+    }
+  };
+  for (int t = a.Tp - 1; t >= -1; --t) {
+    const unsigned code = (unsigned)(t + 1) << 4;
+    // Ba
+    pl.code = code | 1u;
+    for (TileIter it(w, 0, nset, rt, ctR, xcd); it.valid(); it.next()) tile_dh<NW>(a, t, it.r0(), it.c() * 16, red(), pl);
+    link_end(0);
+    if (t < 0) break;
+    const float* dec_t = a.decin + t * sD;
+    const float* ddec_t = a.d_decin + t * sD;
+    // Bb: dphi through the GRU input projection (critical) | GB[t] = GA[t] + DGH[t] W_hh (deferred)
+    pl.code = code | 2u;
+    for (TileIter it(w, 0, nset, rt, ctH, xcd); it.valid(); it.next())
+      tile_lin<NW>(a.DGI + t * s3R, 3 * R, true, a.wihT, 3 * R, nullptr, ddec_t, ldd, false, dec_t, ldd, false, 0.f, a.DPHI[3] + t * sH, H, true,
+                   it.r0(), it.c() * 16, B, red(), pl);
+    {
+      pl.nap = 16;
+      pl.code = code | 10u;
+      const bool own_range = a.g_defn > 0;
+      for (TileIter it(w, own_range ? a.g_def0 : 0, own_range ? a.g_defn : nset, rt, ctR, xcd); it.valid(); it.next()) {
+        if (cand && own_range) canary_wait(a.DGH + t * s3R, 3 * R, it.r0(), B, 3 * R, pl);
+        tile_lin<NW>(a.DGH + t * s3R, 3 * R, true, a.whhT, 3 * R, nullptr, a.GA + t * sR, R, true, nullptr, 0, false, 0.f, a.GB + t * sR, R, true,
+                     it.r0(), it.c() * 16, B, red(), pl);
+      }
+      pl.nap = 1;
+    }
+    link_end(1);
+    // B3..B5: back through phi_z layers 3, 2, 1
+    for (int l = 3; l >= 1; --l) {
+      pl.code = code | (unsigned)(6 - l);
+      for (TileIter it(w, 0, nset, rt, ctH, xcd); it.valid(); it.next())
+        tile_lin<NW>(a.DPHI[l] + t * sH, H, true, a.fT[l], H, nullptr, nullptr, 0, false, a.FZ[l - 1] + t * sH, H, false, 0.f, a.DPHI[l - 1] + t * sH, H,
+                     true, it.r0(), it.c() * 16, B, red(), pl);
+      link_end(5 - l);
+    }
+    // B6: dz and the heads
+    pl.code = code | 6u;
+    {
+      DzIn d = a.dz;
+      d.mu_q += t * sZ; d.sd_q += t * sZ; d.mu_p += t * sZ; d.sd_p += t * sZ; d.eps += t * sZ; d.raw_q += t * sZ; d.raw_p += t * sZ;
+      d.t = t;
+      for (TileIter it(w, 0, nset, rt, ctZ, xcd); it.valid(); it.next())
+        tile_dz<NW>(a.DPHI[0] + t * sH, a.fT[0], nullptr, nullptr, true, nullptr, 0, false, d, a.DQH + t * s2Z, a.DPH + t * s2Z, H, Z, it.r0(),
+                    it.c() * 16, B, red(), pl);
+    }
+    link_end(5);
+    // B7: heads -> last hidden layers;  B8, B9: hidden layers 2, 1
+    for (int l = 3; l >= 1; --l) {
+      pl.code = code | (unsigned)(10 - l);
+      for (TileIter it(w, 0, nset, rt, 2 * ctH, xcd); it.valid(); it.next()) {
+        const int cc = it.c(), sgm = cc >= ctH, c0 = (cc - (sgm ? ctH : 0)) * 16;
+        const float* A = l == 3 ? (sgm ? a.DQH : a.DPH) + t * s2Z : (sgm ? a.DQ[l] : a.DP[l]) + t * sH;
+        const int K = l == 3 ? 2 * Z : H;
+        const float* W = l == 3 ? (sgm ? a.qhT : a.phT) : (sgm ? a.qT[l] : a.pT[l]);
+        tile_lin<NW>(A, K, true, W, K, nullptr, nullptr, 0, false, (sgm ? a.Q[l - 1] : a.P[l - 1]) + t * sH, H, false, 0.f,
+                     (sgm ? a.DQ[l - 1] : a.DP[l - 1]) + t * sH, H, true, it.r0(), c0, B, red(), pl);
+      }
+      link_end(9 - l);
+    }
+  }
+  if (profiled && threadIdx.x == 0) {
+    for (int l = 0; l < 10; ++l) a.prof[(w == 0 ? 0 : 16) + l] += pacc[l];
+  }
+}
+
+inline int device_cus() {
+  static int v = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return n;
+  }();
+  return v;
+}
 
 int check_dims(int Tp, int B, int X, int H, int Z, int R) {
   BLVM_REQUIRE(Tp > 0 && B > 0, "vrnn: bad Tp=%d B=%d", Tp, B);
@@ -284,6 +592,48 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
   else BLVM_HIP(hipMemset2DAsync(decin + H, sizeof(float) * ldd, 0, sizeof(float) * R, B, s));
 
   const int rt = (B + 15) / 16;
+  if (B <= pchain_max_batch() && device_cus() >= 16) {
+    // persistent path: one launch for the whole sequence.  Sentinel-fill what the launch polls: P, Q, FZ, GHb (contiguous in the
+    // reserve), z, and decin (then the initial state goes into row 0).
+    VrnnPFwd a{};
+    for (int l = 0; l < 3; ++l) { a.Wp[l] = rs.Wp[l]; a.Wq[l] = rs.Wq[l]; a.bp[l] = w->prior_b[l]; a.bq[l] = w->post_b[l]; a.P[l] = rs.P[l]; a.Q[l] = rs.Q[l]; a.FZ[l] = rs.FZ[l]; }
+    for (int l = 0; l < 4; ++l) { a.Wf[l] = rs.Wf[l]; a.bf[l] = w->phi_b[l]; }
+    a.Wph = rs.Wph; a.Wqh = rs.Wqh; a.Wih = rs.Wih; a.Whh = rs.Whh; a.bph = w->prior_hb; a.bqh = w->post_hb; a.bhh = w->gru_bhh;
+    a.XQ = rs.XQ; a.XG = rs.XG; a.eps = eps;
+    a.decin = decin; a.GHb = rs.GHb; a.RG = rs.RG; a.UG = rs.UG; a.NG = rs.NG; a.RAWQ = rs.RAWQ; a.RAWP = rs.RAWP;
+    a.mu_p = mu_p; a.sd_p = sd_p; a.mu_q = mu_q; a.sd_q = sd_q; a.z = z;
+    a.Tp = Tp; a.B = B; a.H = H; a.Z = Z; a.R = R; a.residual = residual_posterior;
+    a.beta = beta; a.inv_beta = 1.f / beta; a.sd_eps = sd_eps;
+    const int n_crit = std::max(2 * (H / 16) * rt, (R / 16) * rt);  // tiles of the widest link
+    a.tune = pchain_tune();
+    a.nsets = (a.tune & 1) ? 2 : 1;
+    const bool dedicated = (a.tune & 2) != 0;
+    const int cus = device_cus() & ~7;
+    const int avail = dedicated ? std::max(16, cus - std::min(cus / 4, 64)) : cus;  // a dedicated range gets up to a quarter of the CUs ...
+    a.g_set = std::max(8, std::min(avail / a.nsets, (n_crit + 7) & ~7) & ~7);
+    a.g_def0 = a.nsets * a.g_set;
+    a.g_defn = dedicated ? std::max(8, std::min(cus - a.g_def0, (3 * (R / 16) * rt + 7) & ~7) & ~7) : 0;  // ... or what the sets leave
+    const int grid = a.g_def0 + a.g_defn;
+    rc = pchain_ctl(&a.ctl.dev, &a.ctl.host, &a.ctl.epoch);
+    if (rc) return rc;
+    a.prof = pchain_profile_buffer();
+    BLVM_HIP(hipMemsetAsync(rs.P[0], 0xFF, (size_t)(reinterpret_cast<char*>(rs.RG) - reinterpret_cast<char*>(rs.P[0])), s));
+    BLVM_HIP(hipMemsetAsync(z, 0xFF, sizeof(float) * n * Z, s));
+    BLVM_HIP(hipMemsetAsync(decin, 0xFF, sizeof(float) * n * ldd, s));  // rows 0..T'-1; row T' only receives h_n
+    if (h0) BLVM_HIP(hipMemcpy2DAsync(decin + H, sizeof(float) * ldd, h0, sizeof(float) * R, sizeof(float) * R, B, hipMemcpyDeviceToDevice, s));
+    else BLVM_HIP(hipMemset2DAsync(decin + H, sizeof(float) * ldd, 0, sizeof(float) * R, B, s));
+    const int nw = pchain_waves();
+    const size_t lds = sizeof(float) * 2 * 4 * nw * 256;
+    if (nw == 16) {
+      BLVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&vrnn_pfwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((vrnn_pfwd_kernel<16>), dim3(grid), dim3(1024), lds, s, a);
+    } else {
+      BLVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&vrnn_pfwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((vrnn_pfwd_kernel<8>), dim3(grid), dim3(512), lds, s, a);
+    }
+    BLVM_CHECK_LAUNCH("vrnn_seq_fwd (persistent)");
+    return BLVM_OK;
+  }
   for (int t = 0; t < Tp; ++t) {
     const size_t oH = (size_t)t * B * H, oZ = (size_t)t * B * Z, oR = (size_t)t * B * R, o3R = (size_t)t * B * 3 * R;
     const float* dec_t = decin + (size_t)t * B * ldd;
@@ -453,6 +803,46 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
 #undef TRY
     return BLVM_OK;
   };
+  if (B <= pchain_max_batch() && device_cus() >= 16) {
+    // persistent path: the whole BPTT chain in one launch, then the batched weight-gradient GEMMs
+    VrnnPBwd a{};
+    for (int l = 0; l < 3; ++l) { a.pT[l] = ws.pT[l]; a.qT[l] = ws.qT[l]; a.P[l] = rs.P[l]; a.Q[l] = rs.Q[l]; a.FZ[l] = rs.FZ[l]; a.DP[l] = ws.DP[l]; a.DQ[l] = ws.DQ[l]; }
+    for (int l = 0; l < 4; ++l) { a.fT[l] = ws.fT[l]; a.DPHI[l] = ws.DPHI[l]; }
+    a.phT = ws.phT; a.qhT = ws.qhT; a.wihT = ws.wihT; a.whhT = ws.whhT;
+    a.decin = decin; a.d_decin = d_decin; a.GHb = rs.GHb; a.RG = rs.RG; a.UG = rs.UG; a.NG = rs.NG;
+    a.dz.mu_q = mu_q; a.dz.sd_q = sd_q; a.dz.mu_p = mu_p; a.dz.sd_p = sd_p; a.dz.eps = eps; a.dz.raw_q = rs.RAWQ; a.dz.raw_p = rs.RAWP;
+    a.dz.muq_raw = nullptr; a.dz.x_sl = x_sl; a.dz.c_raw = c_raw; a.dz.c_fn = c_fn; a.dz.t = 0; a.dz.stride = stride;
+    a.dz.residual = residual_posterior; a.dz.fn_floor = fn_floor; a.dz.beta = beta; a.dz.sd_eps = sd_eps;
+    a.DGI = ws.DGI; a.DGH = ws.DGH; a.DQH = ws.DQH; a.DPH = ws.DPH; a.GA = ws.GA; a.GB = ws.GB; a.G_out = d_h0 ? d_h0 : ws.G;
+    a.Tp = Tp; a.B = B; a.H = H; a.Z = Z; a.R = R;
+    a.tune = pchain_tune();
+    const int cus = device_cus() & ~7;
+    const int n_crit = std::max(2 * (H / 16) * rt, (R / 16) * rt);
+    const bool dedicated = (a.tune & 2) != 0;
+    const int avail = dedicated ? std::max(16, cus - std::min(cus / 4, 64)) : cus;
+    a.g_set = std::max(8, std::min(avail, (n_crit + 7) & ~7) & ~7);
+    a.g_def0 = a.g_set;
+    a.g_defn = dedicated ? std::max(8, std::min(cus - a.g_def0, ((R / 16) * rt + 7) & ~7) & ~7) : 0;
+    const int grid = a.g_def0 + a.g_defn;
+    rc = pchain_ctl(&a.ctl.dev, &a.ctl.host, &a.ctl.epoch);
+    if (rc) return rc;
+    a.prof = pchain_profile_buffer();
+    if (a.prof) a.prof += 64;  // the backward's counters follow the forward's
+    float* const fill0 = ws.DGI;
+    float* const fill1 = ws.GB + n * R;
+    BLVM_HIP(hipMemsetAsync(fill0, 0xFF, (size_t)(reinterpret_cast<char*>(fill1) - reinterpret_cast<char*>(fill0)), s));
+    const int nw = pchain_waves();
+    const size_t lds = sizeof(float) * 2 * 2 * nw * 256;
+    if (nw == 16) {
+      BLVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&vrnn_pbwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((vrnn_pbwd_kernel<16>), dim3(grid), dim3(1024), lds, s, a);
+    } else {
+      BLVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&vrnn_pbwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((vrnn_pbwd_kernel<8>), dim3(grid), dim3(512), lds, s, a);
+    }
+    BLVM_CHECK_LAUNCH("vrnn_seq_bwd (persistent)");
+    return batched(0, n, s);
+  }
   const int chunk = overlap_chunk_steps();
   const bool overlap = chunk > 0 && Tp >= 2 * chunk;
   SideStream& side = side_stream();

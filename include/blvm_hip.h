@@ -32,6 +32,25 @@ int blvm_version(void);
 const char* blvm_last_error(void);
 /* 1 if a gfx950 device is visible to the HIP runtime, else 0 (never throws). */
 int blvm_device_ok(void);
+/* The recurrent sequences (K1-K5) run as ONE persistent launch whose workgroups wait for each other with BOUNDED spins.  A spin
+ * that gives up (a workgroup of the launch was not resident: another process holds CUs) drains its launch with garbage results; the
+ * call that enqueued it has long returned BLVM_OK.  This reports such launches: the number so far in this process (0 = none) and
+ * the code (step << 4 | link) of the last spin that failed.  Reads pinned host memory; never blocks.  Check it where results are
+ * read back (the reference's loops synchronise when they read the loss, `experiments/experiment_vrnn_audio.py:232`). */
+int blvm_async_errors(unsigned* last_code);
+/* Execution switch of K1-K5 (results agree to fp32 summation order): sequences with at most `max_batch` rows run as one
+ * persistent launch, larger ones as one launch per link (0 = always per link; < 0 = leave unchanged; default 128 or env
+ * BLVM_PCHAIN_MAX_B / BLVM_PCHAIN=0).  `waves` = 8 or 16 waves per workgroup of the persistent kernels (other values: unchanged). */
+int blvm_pchain_configure(int max_batch, int waves);
+/* Diagnostics: while `device_buffer` (64 zero-initialised uint64 in device memory, caller-owned) is installed, the persistent kernels
+ * add the 100 MHz wall-clock ticks two of their workgroups spend in every link of the step program (waits included): words
+ * [0..15] a workgroup on the critical path, [16..31] one that only runs deferred tiles ([64..95]: the same for backward kernels;
+ * pass 128 words).  NULL uninstalls. */
+int blvm_pchain_profile(unsigned long long* device_buffer);
+/* Diagnostics: placement experiment bits of the persistent kernels (results unchanged): 1 two workgroup ranges take the links in
+ * turn, 2 the GRU hidden projection on its own range, 4 XCD-aware column-tile placement, 8 / 16 one-word canary polls in front of
+ * the operand polls of the critical / deferred tiles. */
+int blvm_pchain_tune(int bits);
 /* n host integers -> device memory through kernel arguments (asynchronous on `stream`; a pageable hipMemcpy would block the host
  * until the stream has drained).  Carries the batch's lengths `x_sl` (`blvm/data/batchers.py:145-151` hands them over on the host). */
 int blvm_upload_i32(const int32_t* host, int n, int32_t* dst, void* stream);
