@@ -30,7 +30,10 @@ class BaseDataset(Dataset):
         return tuple(outs), tuple(metas)
 
     def collate(self, batch):
-        """[(outputs, metadata)] -> ((x, x_sl) per modality — unwrapped when there is one modality —, metadata)."""
+        """[(outputs, metadata)] -> ((x, x_sl) per modality — unwrapped when there is one modality —, metadata).
+        An empty shard of a data-parallel evaluation batch (length_samplers.py) collates to (None, None)."""
+        if len(batch) == 0:
+            return None, None
         if self.sort:
             batch = self.modalities[0][2].sort(batch, sort_modality_idx=0)
         outs, metas = zip(*batch)

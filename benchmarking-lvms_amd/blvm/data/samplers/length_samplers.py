@@ -1,7 +1,10 @@
 """Length-bucketed batch samplers with the reference's names, arguments and random-number consumption
 (blvm/data/samplers/length_samplers.py:48-300), plus rank sharding for the data-parallel path: every rank builds the SAME
 batches (same seed) and takes every `world_size`-th example of each, so one global batch is one optimizer step and the
-per-rank frame counts feed `FlatGradAllReduce`'s exact normalisation.  Host-side plumbing."""
+per-rank frame counts feed `FlatGradAllReduce`'s exact normalisation.  Every rank must take the SAME number of steps (each
+training step is a blocking all-reduce): a TRAINING batch with fewer examples than ranks is dropped on every rank alike; an
+EVALUATION batch is never dropped — ranks beyond its size get an empty shard (`[]`), which the loops skip (evaluation has no
+per-step collective; the metric sums are merged across ranks once, at the end).  Host-side plumbing."""
 import csv
 import random
 from typing import Iterator, List, Optional, Union
@@ -44,17 +47,25 @@ def _greedy_batches(order, lengths, budget):
 
 class _Sharded:
     rank, world_size = 0, 1
+    drop_small = False  # training: global batches smaller than the world are dropped identically on every rank
 
     def _shard(self, batch):
         return list(batch)[self.rank :: self.world_size] if self.world_size > 1 else batch
 
+    def _global_batches(self):
+        if self.drop_small and self.world_size > 1:
+            return [b for b in self.batches if len(b) >= self.world_size]
+        return self.batches
+
     def __len__(self):
-        return len(self.batches)
+        return len(self._global_batches())
 
 
 class LengthTrainSampler(_Sharded):
     """Pools of similar-length examples; every epoch each pool is shuffled, batches of total length <= batch_len are cut
     greedily across the concatenated pools and the batch order is shuffled (length_samplers.py:48-194)."""
+
+    drop_small = True
 
     def __init__(self, source: Union[str, List[int]], field: Optional[str] = "length", max_pool_difference: Optional[float] = None,
                  min_pool_size: int = 512, batch_len=None, batch_size=None, num_batches: Optional[int] = None, shuffle: bool = True,
@@ -112,7 +123,7 @@ class LengthTrainSampler(_Sharded):
 
     def __iter__(self) -> Iterator[List[int]]:
         try:
-            for batch in self.batches:
+            for batch in self._global_batches():
                 yield self._shard(batch)
         finally:
             if self.shuffle:

@@ -43,6 +43,30 @@ class Tracker:
             else:
                 src[m.name] = m.copy()
 
+    def all_reduce(self, source: str = None, group=None):
+        """Data-parallel runs: merge this epoch's metrics of `source` across ranks with each metric's own rule (the reference's
+        weighted running mean, blvm/evaluation/metrics.py:253-264), so that every rank — rank 0 decides about checkpoints — holds
+        the value of the WHOLE evaluation set, not of its shard.  One host-side collective; a rank whose shards were all empty
+        contributes nothing and still receives the result."""
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        src = self.metrics[source or self.source]
+        for m in src.values():
+            _ = m.value  # resolve deferred device scalars before pickling
+        gathered = [None] * dist.get_world_size(group)
+        dist.all_gather_object(gathered, {k: m.copy() for k, m in src.items()}, group=group)
+        merged = {}
+        for part in gathered:  # rank order: identical on every rank
+            for name, m in part.items():
+                if name in merged:
+                    merged[name].update(m)
+                else:
+                    merged[name] = m.copy()
+        src.clear()
+        src.update(merged)
+
     def values(self, source: str = None):
         return {k: m.value for k, m in self.metrics[source or self.source].items()}
 

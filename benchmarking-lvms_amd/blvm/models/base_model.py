@@ -23,7 +23,7 @@ def load_model(path, model_class_name: str = None, device: torch.device = torch.
         name_file = os.path.join(path, MODEL_CLASS_NAME_STR)
         if not os.path.exists(name_file):
             raise RuntimeError(f"Name of class of model to load was not given and not saved in checkpoint: {path}")
-        model_class_name = torch.load(name_file)
+        model_class_name = torch.load(name_file, weights_only=True)
     return getattr(blvm.models, model_class_name).load(path, device=device)
 
 
@@ -57,12 +57,12 @@ class BaseModel(nn.Module):
 
     @classmethod
     def load(cls, path, device: str = "cpu"):
-        kwargs = torch.load(os.path.join(path, MODEL_INIT_KWRGS_STR))
+        kwargs = torch.load(os.path.join(path, MODEL_INIT_KWRGS_STR), weights_only=True)
         extra = kwargs.pop("kwargs", {})
         args = kwargs.pop("args", [])
         model = cls(*args, **extra, **kwargs)
         model.to(device)
-        model.load_state_dict(torch.load(os.path.join(path, MODEL_STATE_DICT_STR), map_location=device))
+        model.load_state_dict(torch.load(os.path.join(path, MODEL_STATE_DICT_STR), map_location=device, weights_only=True))
         return model
 
     def extra_repr(self):

@@ -34,7 +34,7 @@ def load_run(directory: str, model: torch.nn.Module = None, optimizer=None, lr_s
         if raise_errors:
             raise FileNotFoundError(path)
         return model, None
-    checkpoint = torch.load(path, map_location=device, weights_only=False)  # written by save_run above
+    checkpoint = torch.load(path, map_location=device, weights_only=True)  # written by save_run above
     for obj, key in ((optimizer, "optimizer_state_dict"), (lr_scheduler, "lr_scheduler_state_dict"), (scaler, "scaler_state_dict")):
         if obj is not None and checkpoint.get(key) is not None:
             obj.load_state_dict(checkpoint[key])

@@ -340,7 +340,7 @@ int pchain_ctl(unsigned** dev, unsigned** host_dev, unsigned* epoch);
 // kernels fit better.  pchain_waves(): waves per workgroup of the persistent kernels (8 or 16; env BLVM_PCHAIN_NW).
 int pchain_max_batch();
 int pchain_waves();
-int pchain_tune();  // placement experiment bits (env BLVM_PCHAIN_TUNE / blvm_pchain_configure): see vrnn.hip
+int pchain_tune();  // placement bits (env BLVM_PCHAIN_TUNE / blvm_pchain_tune): 4 XCD-aware tile placement, 16 canary polls of deferred tiles
 unsigned long long* pchain_profile_buffer();  // diagnostics: null unless blvm_pchain_profile() installed a device buffer
 
 // internal launchers shared between translation units (defined in gemm.hip)

@@ -207,7 +207,7 @@ int pchain_waves() {
 int pchain_tune() {
   if (g_pchain_tune < 0) {
     const char* e = getenv("BLVM_PCHAIN_TUNE");
-    g_pchain_tune = e ? atoi(e) : 22;
+    g_pchain_tune = e ? atoi(e) : 20;
   }
   return g_pchain_tune;
 }

@@ -13,10 +13,15 @@
 //      0.8-1.0 us for <= 4 KB, cross-XCD +0.1-0.3) and the successful poll IS the operand fetch,
 //   3. MFMAs (K split over the NW waves), LDS reduction, fused epilogue, `sc1` stores.
 // Every buffer a link writes is a per-step slab ([T', B, F]: the activations kept for BPTT anyway), so no location is written
-// twice in a launch: no re-arming, no WAR hazard.  Progress: all G workgroups are resident and every workgroup processes its tiles
+// twice in a launch: no re-arming, no WAR hazard.  What the NEXT link multiplies is stored a second time in the T16 OPERAND LAYOUT
+// (common.h: a 16-row x 16-column output tile IS one 1 KB block of it), so the consumer's polled fragment loads are contiguous
+// 1 KB wave loads instead of 16 rows x 64 B (tools/cu_ingest.hip: 150 against 38 GB/s per workgroup); the row-major copy (plain
+// stores) serves everything that reads after the launch.  Progress: all G workgroups are resident and every workgroup processes its tiles
 // in (step, link) order, so the earliest unfinished tile never waits on a later one.  Every spin is bounded: a wave that gives up
 // raises the launch's abort word, every other spin sees it and the grid drains (the host reports BLVM_ELAUNCH).
 #pragma once
+#include <algorithm>
+
 #include "common.h"
 
 namespace blvm {
@@ -29,12 +34,6 @@ constexpr unsigned SPIN_LIMIT = 1u << 22;           // polls before a wave gives
 __device__ __forceinline__ f32x4 ld_sc1_x4(const float* p) {
   f32x4 v;
   asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-// L1-bypassing but L2-served: only for words whose producer runs on THIS XCD (same L2) and stores them plainly
-__device__ __forceinline__ f32x4 ld_nt_x4(const float* p) {
-  f32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
   return v;
 }
 __device__ __forceinline__ float ld_sc1(const float* p) {
@@ -92,9 +91,8 @@ struct Poll {
   unsigned code;
   bool dead;
   int nap;
-  bool local = false;  // operands come from workgroups on this XCD through its L2 (plain stores, nt loads) — probe only so far
 #ifdef PCHAIN_TPROF  // variant build: wall-clock anatomy of tile_lin (wave 0): see tile_lin
-  unsigned long long t_first = 0, t_ok = 0, tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_first = 0, t_ok = 0, t_end = 0, tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned polls = 0;
 #endif
   __device__ __forceinline__ void sleep() const {
@@ -110,44 +108,55 @@ struct MapPairs { static constexpr int of(int g) { return g >> 1; } };  // produ
 
 // ---- polled 16x16xK products ------------------------------------------------------------------------------------------------
 // acc[g] += A[AMap(g)][r0+i][k] W[g][c0[g]+j][k] over the k-chunks owned by `wave` (chunk = 16 k, waves interleave chunks), W in
-// the T16 operand layout with row length K.  When `polled`, the A operands are produced by other workgroups of this launch: their
-// fragments are re-read with sc1 loads until no word is the sentinel.  One trip = CH chunks: all weight fragments first (they do
+// the T16 operand layout with row length K.  When `polled`, the A operands are produced by other workgroups of this launch: A[g]
+// is then the T16 copy ([rt*16, K] as 1 KB blocks) of the activation, `lda` is ignored, and the fragments are re-read with sc1
+// loads until no word is the sentinel (rows >= nrows of the last row tile are never written and never looked at).  One trip = CH chunks: all weight fragments first (they do
 // not depend on the wait), then the activation fragments, then 4*CH*G MFMAs; a wave's chunk sum runs in ascending k.
 template <int NW, int GA, int G, class AMap, int CH>
-__device__ __forceinline__ void mgemm_trip(const float* const (&ap)[GA], const float* const (&wp)[G], int kc, bool aok, bool polled,
+__device__ __forceinline__ void mgemm_trip(const float* const (&ap)[GA], const float* const (&wp)[G], int kc, int n, bool aok, bool polled,
                                            f32x4 (&acc)[G], Poll& pl) {
+  // ONE body for 1 .. CH chunks (n, wave-uniform): chunk u exists when u < n.  Polled operands are T16 slabs (k advances by 16
+  // floats per k), plain ones row-major.
   constexpr int STEP = NW * 16;
   f32x4 w[G][CH], a[GA][CH];
 #pragma unroll
-  for (int g = 0; g < G; ++g)
+  for (int u = 0; u < CH; ++u)
+    if (u < n) {
 #pragma unroll
-    for (int u = 0; u < CH; ++u) w[g][u] = *reinterpret_cast<const f32x4*>(wp[g] + 16 * (size_t)(kc + u * STEP));
+      for (int g = 0; g < G; ++g) w[g][u] = *reinterpret_cast<const f32x4*>(wp[g] + 16 * (size_t)(kc + u * STEP));
+    }
   if (!polled) {
 #pragma unroll
-    for (int g = 0; g < GA; ++g)
+    for (int u = 0; u < CH; ++u)
+      if (u < n) {
 #pragma unroll
-      for (int u = 0; u < CH; ++u) a[g][u] = *reinterpret_cast<const f32x4*>(ap[g] + kc + u * STEP);
+        for (int g = 0; g < GA; ++g) a[g][u] = *reinterpret_cast<const f32x4*>(ap[g] + kc + u * STEP);
+      }
   } else {
     unsigned spins = 0;
     for (;;) {
 #pragma unroll
-      for (int g = 0; g < GA; ++g)
+      for (int u = 0; u < CH; ++u)
+        if (u < n) {
 #pragma unroll
-        for (int u = 0; u < CH; ++u) a[g][u] = pl.local ? ld_nt_x4(ap[g] + kc + u * STEP) : ld_sc1_x4(ap[g] + kc + u * STEP);
+          for (int g = 0; g < GA; ++g) a[g][u] = ld_sc1_x4(ap[g] + 16 * (size_t)(kc + u * STEP));
+        }
+      wait_vm0();
+      bool bad = false;
 #pragma unroll
-      for (int g = 0; g < GA; ++g)
+      for (int u = 0; u < CH; ++u)
+        if (u < n) {
 #pragma unroll
-        for (int u = 0; u < CH; ++u) wait_vm0(a[g][u]);
+          for (int g = 0; g < GA; ++g) { wait_vm0(a[g][u]); bad |= any_sentinel(a[g][u]); }
+        }
 #ifdef PCHAIN_TPROF
       if (spins == 0 && pl.t_first == 0) pl.t_first = wall_clock64();
       pl.polls++;
 #endif
-      bool bad = false;
-#pragma unroll
-      for (int g = 0; g < GA; ++g)
-#pragma unroll
-        for (int u = 0; u < CH; ++u) bad |= any_sentinel(a[g][u]);
       if (!__any(bad && aok) || pl.dead) break;
+#ifdef PCHAIN_NOWAIT  // timing experiment: never wait (results are garbage): what the tiles cost without the hand-offs
+      break;
+#endif
       if (spin_tick(spins, pl.ctl, pl.code, pl.dead)) break;
       pl.sleep();
     }
@@ -155,46 +164,37 @@ __device__ __forceinline__ void mgemm_trip(const float* const (&ap)[GA], const f
     pl.t_ok = wall_clock64();
 #endif
   }
-  if (!aok) {
-#pragma unroll
-    for (int g = 0; g < GA; ++g)
-#pragma unroll
-      for (int u = 0; u < CH; ++u) a[g][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
 #pragma unroll
   for (int u = 0; u < CH; ++u)
+    if (u < n) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[AMap::of(g)][u][e], w[g][u][e], acc[g], 0, 0, 0);
+        for (int g = 0; g < G; ++g)
+          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(aok ? a[AMap::of(g)][u][e] : 0.f, w[g][u][e], acc[g], 0, 0, 0);
+    }
 }
 
 template <int NW, int GA, int G, class AMap>
 __device__ __forceinline__ void mgemm16(const float* const (&A)[GA], const int (&lda)[GA], bool polled, int r0, int nrows,
                                         const float* const (&W)[G], const int (&c0)[G], int K, f32x4 (&acc)[G], Poll& pl) {
   constexpr int STEP = NW * 16;
-  // fragment registers of a trip: 4 * CH * (G + GA); keep it <= 64
-  constexpr int FR = (NW >= 16 ? 8 : 16) / (G + GA);  // 1024-thread workgroups have 128 VGPRs per lane
-  constexpr int MAXCH = FR >= 8 ? 8 : (FR >= 4 ? 4 : (FR >= 2 ? 2 : 1));
+  // fragment registers of a trip: 4 * CH * (G + GA); keep it <= 64 (32 for 1024-thread workgroups: 128 VGPRs per lane)
+  constexpr int FR = 12 / (G + GA);
+  constexpr int MAXCH = FR >= 6 ? 6 : (FR >= 4 ? 4 : (FR >= 2 ? 2 : 1));  // single products: 6 (K = 1536 on 8 waves is two trips)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rr = lane & 15, q = lane >> 4;
   const bool aok = (r0 + rr) < nrows;
   const float* ap[GA];
   const float* wp[G];
 #pragma unroll
-  for (int g = 0; g < GA; ++g) ap[g] = A[g] + (size_t)(aok ? r0 + rr : r0) * lda[g] + 4 * q;
+  for (int g = 0; g < GA; ++g)
+    ap[g] = polled ? A[g] + (size_t)(r0 >> 4) * 16 * K + 4 * lane : A[g] + (size_t)(aok ? r0 + rr : r0) * lda[g] + 4 * q;
 #pragma unroll
   for (int g = 0; g < G; ++g) wp[g] = W[g] + (size_t)c0[g] * K + 4 * lane;
   int nch = (K / 16 - wave + NW - 1) / NW;  // chunks wave, wave + NW, ... below K / 16 (wave-uniform)
-  int kc = wave * 16;
-  while (nch > 0) {
-    if (MAXCH >= 8 && nch >= 8) { mgemm_trip<NW, GA, G, AMap, (MAXCH >= 8 ? 8 : 1)>(ap, wp, kc, aok, polled, acc, pl); kc += 8 * STEP; nch -= 8; }
-    else if (MAXCH >= 8 && nch >= 6) { mgemm_trip<NW, GA, G, AMap, (MAXCH >= 8 ? 6 : 1)>(ap, wp, kc, aok, polled, acc, pl); kc += 6 * STEP; nch -= 6; }
-    else if (MAXCH >= 4 && nch >= 4) { mgemm_trip<NW, GA, G, AMap, (MAXCH >= 4 ? 4 : 1)>(ap, wp, kc, aok, polled, acc, pl); kc += 4 * STEP; nch -= 4; }
-    else if (MAXCH >= 4 && nch >= 3) { mgemm_trip<NW, GA, G, AMap, (MAXCH >= 4 ? 3 : 1)>(ap, wp, kc, aok, polled, acc, pl); kc += 3 * STEP; nch -= 3; }
-    else if (MAXCH >= 2 && nch >= 2) { mgemm_trip<NW, GA, G, AMap, (MAXCH >= 2 ? 2 : 1)>(ap, wp, kc, aok, polled, acc, pl); kc += 2 * STEP; nch -= 2; }
-    else { mgemm_trip<NW, GA, G, AMap, 1>(ap, wp, kc, aok, polled, acc, pl); kc += STEP; nch -= 1; }
-  }
+  for (int kc = wave * 16; nch > 0; nch -= MAXCH, kc += MAXCH * STEP)
+    mgemm_trip<NW, GA, G, AMap, MAXCH>(ap, wp, kc, nch < MAXCH ? nch : MAXCH, aok, polled, acc, pl);
 }
 
 // N epilogue words that other workgroups of this launch produce (sc1 loads until none is the sentinel); `need`: this lane uses them
@@ -210,6 +210,9 @@ __device__ __forceinline__ void poll_words(const float* const (&p)[N], float (&v
 #pragma unroll
     for (int i = 0; i < N; ++i) bad |= is_sentinel(v[i]);
     if (!__any(bad && need) || pl.dead) break;
+#ifdef PCHAIN_NOWAIT
+    break;
+#endif
     if (spin_tick(spins, pl.ctl, pl.code, pl.dead)) break;
     pl.sleep();
   }
@@ -246,28 +249,53 @@ struct TileIter {
   __host__ __device__ __forceinline__ int c() const { return xcd ? x + 8 * (j / rt) : j / rt; }
 };
 
-// Cheap wait in front of a polled product: ONE wave polls one word of every 16-column producer tile of A[r0 .. r0+15][0 .. K) (a
-// 4-byte sc1 load per producer and poll instead of the whole operand by every wave); the caller's barrier then releases the other
-// waves into the validating operand poll, which normally succeeds at once.  Trades one memory round trip for far less poll traffic.
-__device__ __forceinline__ void canary_wait(const float* A, int lda, int r0, int nrows, int K, Poll& pl) {
+// Cheap wait in front of a polled product for tiles OFF the critical path: one wave polls ONE word of every 1 KB block of the
+// T16 operand A16[r0 .. r0+15][0 .. K) instead of every wave polling its fragments; the barrier then releases the other waves into
+// the validating operand poll, which normally succeeds at once.  Costs a round trip, saves the fabric most of the idle polling.
+__device__ __forceinline__ void canary_wait(const float* A16, int r0, int K, Poll& pl) {
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x, np = K >> 4;
-    const int rl = min(r0 + 15, nrows - 1);
+    const float* base = A16 + (size_t)(r0 >> 4) * 16 * K;  // word 0 of a block = row r0, always written
     unsigned spins = 0;
     for (;;) {
       bool bad = false;
       for (int p0 = 0; p0 < np; p0 += 64) {
         const int pr = p0 + lane;
-        float v = ld_sc1(A + (size_t)rl * lda + 16 * (pr < np ? pr : 0) + 15);
+        float v = ld_sc1(base + 256 * (size_t)(pr < np ? pr : 0));
         wait_vm0(v);
         bad |= (pr < np) && is_sentinel(v);
       }
       if (!__any(bad) || pl.dead) break;
+#ifdef PCHAIN_NOWAIT
+      break;
+#endif
       if (spin_tick(spins, pl.ctl, pl.code, pl.dead)) break;
       pl.sleep();
     }
   }
   __syncthreads();
+}
+
+// Where a link's [16 x 16] output tile goes: a row-major copy (plain stores; `rm_sc1`: other workgroups poll single words of it)
+// and / or the T16 copy the next link multiplies (always sc1).  Either pointer may be null.
+struct Out {
+  float* rm;
+  int ld;
+  bool rm_sc1;
+  float* x16;  // [rt*16, 16*n16] in 1 KB blocks
+  int n16;
+};
+__device__ __forceinline__ Out out_rm(float* p, int ld, bool sc1 = false) { return Out{p, ld, sc1, nullptr, 0}; }
+__device__ __forceinline__ Out out_both(float* p, int ld, float* x16, int n16, bool sc1 = false) { return Out{p, ld, sc1, x16, n16}; }
+__device__ __forceinline__ void put(const Out& o, int r0, int c0, int row, int col, float x) {
+  if (o.rm != nullptr) {
+    if (o.rm_sc1) st_sc1(o.rm + (size_t)row * o.ld + col, x);
+    else o.rm[(size_t)row * o.ld + col] = x;
+  }
+  if (o.x16 != nullptr) {
+    const int rr = row - r0, cc = col - c0;
+    st_sc1(o.x16 + ((size_t)(r0 >> 4) * o.n16 + (c0 >> 4)) * 256 + (rr + 16 * (cc >> 2)) * 4 + (cc & 3), x);
+  }
 }
 
 // ---- link tiles -------------------------------------------------------------------------------------------------------------
@@ -276,12 +304,10 @@ __device__ __forceinline__ void canary_wait(const float* A, int lda, int r0, int
 
 // out = gate(act(A W^T + bias + add)):  bias [ncols] or null; add [B, ldadd] or null (add_polled: produced inside this launch);
 // relu: act = leaky ReLU with `slope`; gate [B, ldgate] or null: result *= (gate > 0 ? 1 : slope) — the backward of that activation.
-// out_sc1: the output is read by other workgroups of this launch.
 template <int NW>
 __device__ __forceinline__ void tile_lin(const float* A, int lda, bool a_polled, const float* W, int K, const float* bias,
                                          const float* add, int ldadd, bool add_polled, const float* gate, int ldgate, bool relu,
-                                         float slope, float* out, int ldo, bool out_sc1, int r0, int c0, int B, float* red,
-                                         Poll& pl) {
+                                         float slope, const Out& out, int r0, int c0, int B, float* red, Poll& pl) {
   const int t = threadIdx.x & 255;
   const int row = r0 + (t >> 4), col = c0 + (t & 15);
   const bool own = threadIdx.x < 256 && row < B;
@@ -306,6 +332,7 @@ __device__ __forceinline__ void tile_lin(const float* A, int lda, bool a_polled,
   if (a_polled && pl.nap == 1) {  // critical tiles only: [0] tiles, [1] start -> first poll back, [2] -> poll ok, [3] -> reduced, [4] polls
     const unsigned long long t3 = wall_clock64();
     pl.tp[0] += 1; pl.tp[1] += pl.t_first - t0; pl.tp[2] += pl.t_ok - pl.t_first; pl.tp[3] += t3 - pl.t_ok; pl.tp[4] += pl.polls;
+    if (pl.t_end != 0) pl.tp[6] += t0 - pl.t_end;  // end of the previous tile of any kind -> start of this one
   }
 #endif
   if (threadIdx.x >= 256) return;
@@ -319,15 +346,18 @@ __device__ __forceinline__ void tile_lin(const float* A, int lda, bool a_polled,
   float x = v[0] + e_bias + e_add;
   if (relu) x = x > 0.f ? x : x * slope;
   if (gate) x = e_gate > 0.f ? x : x * slope;
-  if (out_sc1) st_sc1(out + (size_t)row * ldo + col, x);
-  else out[(size_t)row * ldo + col] = x;
+  put(out, r0, c0, row, col, x);
+#ifdef PCHAIN_TPROF
+  if (a_polled && pl.nap == 1) { pl.t_end = wall_clock64(); }
+#endif
 }
 
 // Both Gaussian heads + posterior combination + reparameterised sample (stages.h head_stage_kernel): P, Q [B,H] are the last
 // hidden layers of the prior / posterior MLP (polled), Wp, Wq [2Z,H] in T16.  z is read by other workgroups (sc1); the statistics
 // are only read after the launch.  residual: 0 plain, 1 mu_q += mu_p, 2 precision-weighted, 3 generation (z ~ prior).
 struct HeadOut {
-  float *mu_p, *sd_p, *mu_q, *sd_q, *z, *raw_p, *raw_q, *muq_raw;  // [B,Z] slabs of this step; muq_raw may be null
+  float *mu_p, *sd_p, *mu_q, *sd_q, *raw_p, *raw_q, *muq_raw;  // [B,Z] slabs of this step; muq_raw may be null
+  Out z;
 };
 template <int NW>
 __device__ __forceinline__ void tile_head(const float* P, const float* Q, bool polled, const float* Wp, const float* bp, const float* Wq,
@@ -369,7 +399,7 @@ __device__ __forceinline__ void tile_head(const float* P, const float* Q, bool p
     mq = mp;
     sqc = sp;
   }
-  st_sc1(o.z + oo, e * sqc + mq);  // randn_like(mu).mul(sd).add(mu)
+  put(o.z, r0, c0, row, col, e * sqc + mq);  // randn_like(mu).mul(sd).add(mu)
   o.mu_p[oo] = mp; o.sd_p[oo] = sp; o.mu_q[oo] = mq; o.sd_q[oo] = sqc;
   o.raw_p[oo] = rp; o.raw_q[oo] = rq;
 }
@@ -379,7 +409,7 @@ __device__ __forceinline__ void tile_head(const float* P, const float* Q, bool p
 // by another link of this launch (polled words), h_prev likewise.  Writes h_new (sc1) and the gates r, u, n (read after the launch).
 template <int NW>
 __device__ __forceinline__ void tile_gru(const float* X, int ldx, bool polled, const float* Wih, int K, const float* xg, const float* gh,
-                                         const float* hprev, int ldh, int R, float* hnew, int ldn, float* rg, float* ug, float* ng,
+                                         const float* hprev, int ldh, int R, const Out& hnew, float* rg, float* ug, float* ng,
                                          int r0, int c0, int B, float* red, Poll& pl) {
   const int t = threadIdx.x & 255;
   const int row = r0 + (t >> 4), col = c0 + (t & 15);
@@ -411,14 +441,14 @@ __device__ __forceinline__ void tile_gru(const float* X, int ldx, bool polled, c
   const float r = sigmoidf_(v[0] + x0 + w[0]);
   const float u = sigmoidf_(v[1] + x1 + w[1]);
   const float n = tanhf(v[2] + x2 + r * w[2]);
-  st_sc1(hnew + (size_t)row * ldn + col, (1.f - u) * n + u * w[3]);
+  put(hnew, r0, c0, row, col, (1.f - u) * n + u * w[3]);
   const size_t o = (size_t)row * R + col;
   rg[o] = r; ug[o] = u; ng[o] = n;
 }
 
 // dz = D WT^T (+ D2 WT2^T) (+ dz_add), then back through rsample / posterior combination / KL (+ free nats) / softplus heads
 // (stages.h dz_stage_kernel): D [B,H] (and D2) polled, WT [Z,H] in T16; writes the gradients wrt both heads' Linear outputs
-// dqh, dph [B,2Z] (sc1: the next link multiplies them).
+// dqh, dph [B,2Z] (row-major for the weight gradients, T16 for the next link).
 struct DzIn {
   const float *mu_q, *sd_q, *mu_p, *sd_p, *eps, *raw_q, *raw_p, *muq_raw;  // [B,Z] slabs of this step (saved by the forward)
   const int32_t* x_sl;
@@ -428,7 +458,7 @@ struct DzIn {
 };
 template <int NW>
 __device__ __forceinline__ void tile_dz(const float* D, const float* WT, const float* D2, const float* WT2, bool polled, const float* dz_add,
-                                        int ld_add, bool add_polled, const DzIn& a, float* dqh, float* dph, int H, int Z, int r0, int c0,
+                                        int ld_add, bool add_polled, const DzIn& a, const Out& dqh, const Out& dph, int H, int Z, int r0, int c0,
                                         int B, float* red, Poll& pl) {
   const int t = threadIdx.x & 255;
   const int row = r0 + (t >> 4), col = c0 + (t & 15);
@@ -494,12 +524,141 @@ __device__ __forceinline__ void tile_dz(const float* D, const float* WT, const f
     g_sdq = g_pq * (-2.f * pq / sqr);
     g_muq = g_muq * var * pq;
   }
-  const size_t o2 = (size_t)row * 2 * Z + col;
-  st_sc1(dqh + o2, g_muq);
-  st_sc1(dqh + o2 + Z, g_sdq * sigmoidf_(a.beta * rq));
-  st_sc1(dph + o2, g_mup);
-  st_sc1(dph + o2 + Z, g_sdp * sigmoidf_(a.beta * rp));
+  // [B,2Z]: the mean half at column col, the scale half at Z + col (its T16 blocks follow the mean half's)
+  put(dqh, r0, c0, row, col, g_muq);
+  put(dqh, r0, Z + c0, row, Z + col, g_sdq * sigmoidf_(a.beta * rq));
+  put(dph, r0, c0, row, col, g_mup);
+  put(dph, r0, Z + c0, row, Z + col, g_sdp * sigmoidf_(a.beta * rp));
 }
 
+// Backward of a GRU state update fused with the products that complete the state gradient (vrnn.hip "B10"):
+//   g = g_in + D0 W0^T + D1 W1^T        (has_gemm; D0, D1 [B,K] polled, W0, W1 [R,K] T16; g_in: one polled word)
+//   gate derivatives of the step whose OUTPUT state g refers to (has_gates): r, u, n, hn = (h_prev W_hh^T + b_hh)_n, h_prev saved
+//   by the forward; writes dgi = [dr, du, dn], dgh = [dr, du, dn * r] ([B,3R], row-major + T16) and ga = g * u + dd (polled words;
+//   dd [B, ldh] = gradient reaching h_prev from outside the chain).  Without gates (the step before the first) g goes to g_out.
+struct GrubIn {
+  const float *D0, *D1, *W0, *W1, *g_in;
+  const float *rg, *ug, *ng, *gh, *hprev, *dd;
+  int ldh;
+  Out dgi, dgh;
+  float *ga, *g_out;
+  bool has_gemm, has_gates;
+};
+template <int NW>
+__device__ __forceinline__ void tile_grub(const GrubIn& a, int K, int R, int r0, int c0, int B, float* red, Poll& pl) {
+  const int tt = threadIdx.x & 255;
+  const int row = r0 + (tt >> 4), col = c0 + (tt & 15);
+  const bool own = threadIdx.x < 256 && row < B;
+  const int rowc = row < B ? row : r0;
+  const size_t o = (size_t)rowc * R + col, o3 = (size_t)rowc * 3 * R + col;
+  float r = 0.f, u = 0.f, n = 0.f, hn = 0.f, hp = 0.f, dd = 0.f;
+  if (a.has_gates) {
+    r = a.rg[o]; u = a.ug[o]; n = a.ng[o]; hn = a.gh[o3 + 2 * R];
+    hp = a.hprev[(size_t)rowc * a.ldh + col];
+    dd = a.dd[(size_t)rowc * a.ldh + col];
+  }
+  float v[2] = {0.f, 0.f}, g0 = 0.f;
+  if (a.has_gemm) {
+    g0 = ld_sc1(a.g_in + o);  // stored a step ago: request it under the operand wait
+    f32x4 acc[2];
+    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* const As[2] = {a.D0, a.D1};
+    const float* const Ws[2] = {a.W0, a.W1};
+    const int la[2] = {0, 0}, cs[2] = {c0, c0};
+    mgemm16<NW, 2, 2, MapId>(As, la, true, r0, B, Ws, cs, K, acc, pl);
+    reduce_tiles<2, NW>(acc, red, v);
+    if (threadIdx.x >= 256) return;
+    wait_vm0(g0);
+    if (__any(own && is_sentinel(g0))) {
+      const float* const ps[1] = {a.g_in + o};
+      float ws[1];
+      poll_words<1>(ps, ws, own, pl);
+      g0 = ws[0];
+    }
+  }
+  if (!own) return;
+  const float g = g0 + v[0] + v[1];
+  if (!a.has_gates) { a.g_out[(size_t)row * R + col] = g; return; }
+  const float dn_pre = g * (1.f - u) * (1.f - n * n);
+  const float du_pre = g * (hp - n) * u * (1.f - u);
+  const float dr_pre = dn_pre * hn * r * (1.f - r);
+  put(a.dgi, r0, c0, row, col, dr_pre); put(a.dgi, r0, R + c0, row, R + col, du_pre); put(a.dgi, r0, 2 * R + c0, row, 2 * R + col, dn_pre);
+  put(a.dgh, r0, c0, row, col, dr_pre); put(a.dgh, r0, R + c0, row, R + col, du_pre); put(a.dgh, r0, 2 * R + c0, row, 2 * R + col, dn_pre * r);
+  st_sc1(a.ga + (size_t)row * R + col, g * u + dd);
+}
+
+// =================================================================================================================================
+// The program a persistent launch executes (pchain.hip: ONE kernel, one copy of every tile kind — the step program of a model is
+// DATA, not code: with each link inlined at its own call site the VRNN kernel was 16 000 instructions, every link of a step ran
+// from a cold instruction cache and cost ~1 us more than the same tile in a small kernel, tools/pchain_probe.hip).
+// A launch walks steps s = 0 .. S-1; in every step each workgroup goes through the descriptors in order and runs the tiles that
+// are its own (TileIter over [wg0, wg0 + nwg)).  A pointer of a descriptor is `p[k] + s * stride[sidx[k]]` (stride table of the
+// program, entry 0 = 0: constants and null pointers); a backward sequence passes its last step's slabs and negative strides.
+// =================================================================================================================================
+enum Kind : int { K_LIN = 0, K_HEAD = 1, K_GRU = 2, K_DZ = 3, K_GRUB = 4 };
+enum DescFlag : int {
+  DF_RELU = 1,         // K_LIN: leaky ReLU (f[0] = slope) on the result
+  DF_A_PLAIN = 2,      // K_LIN: A is a row-major buffer written before the launch (ld[0]), not a polled T16 copy
+  DF_ADD_POLLED = 4,   // K_LIN: `add` words are produced inside the launch
+  DF_RM_SC1 = 8,       // the row-major output is polled word-wise by other workgroups
+  DF_GENTLE = 16,      // off the critical path: nap between polls
+  DF_CANARY = 32,      // one-word canary wait in front of the operand poll
+};
+constexpr int kMaxDesc = 13, kMaxPtr = 20;
+struct Desc {
+  int kind, ct, wg0, nwg, flags, K, s_begin, s_end;
+  int ld[4];                      // leading dimensions of row-major operands (per kind, see pchain.hip)
+  int n16[2];                     // 16-column chunks per row of the T16 outputs
+  int i[4];                       // per kind
+  float f[4];                     // per kind
+  unsigned char sidx[kMaxPtr];    // stride-table index of every pointer
+  const float* p[kMaxPtr];        // per kind
+};
+struct Program {
+  int ndesc, S, B, xcd;
+  long stride[16];
+  Ctl ctl;
+  unsigned long long* prof;       // diagnostics (blvm_pchain_profile): ticks per descriptor of workgroups 0 and prof_wg
+  int prof_wg, lds_products;      // lds_products: most products of any tile kind used (sizes the reduction scratch)
+  Desc d[kMaxDesc];
+};
+static_assert(sizeof(Program) <= 4096, "the program travels as a kernel argument");
+
+// host-side assembly of a program
+struct Builder {
+  Program p{};
+  int nstride = 1;
+  bool overflow = false;
+  int stride_index(long v) {
+    if (v == 0) return 0;
+    for (int i = 1; i < nstride; ++i)
+      if (p.stride[i] == v) return i;
+    if (nstride >= 16) { overflow = true; return 0; }
+    p.stride[nstride] = v;
+    return nstride++;
+  }
+  // a descriptor of `ct` column tiles (x all row tiles) on workgroups [wg0, wg0 + nwg), active in steps [s_begin, s_end)
+  Desc& add(int kind, int ct, int wg0, int nwg, int K, int flags, int s_begin, int s_end) {
+    static Desc dummy;
+    if (p.ndesc >= kMaxDesc) { overflow = true; return dummy; }
+    Desc& d = p.d[p.ndesc++];
+    d = Desc{};
+    d.kind = kind; d.ct = ct; d.wg0 = wg0; d.nwg = nwg; d.K = K; d.flags = flags; d.s_begin = s_begin; d.s_end = s_end;
+    return d;
+  }
+  void ptr(Desc& d, int k, const void* q, long stride = 0) {
+    d.p[k] = static_cast<const float*>(q);
+    d.sidx[k] = (unsigned char)(q ? stride_index(stride) : 0);
+  }
+};
+
+// workgroups for `tiles` tiles out of `avail` (a multiple of 8, at least 8): XCD-aware placement deals ranges in eights
+inline int range_for(int tiles, int avail) { return std::max(8, std::min(avail & ~7, (tiles + 7) & ~7)); }
+
 }  // namespace pchain
+
+// enqueue the persistent launch of a program (pchain.hip); grid = highest workgroup any descriptor names
+int pchain_launch(const pchain::Program& prog, hipStream_t stream);
+
 }  // namespace blvm

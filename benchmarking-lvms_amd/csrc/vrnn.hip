@@ -140,7 +140,10 @@ __global__ __launch_bounds__(NW * 64) void dh_stage_kernel(const float* DP0, con
 struct Reserve {
   float *P[3], *Q[3], *FZ[3], *GHb, *RG, *UG, *NG, *XQ, *XG, *RAWQ, *RAWP;
   float *Wp[3], *Wq[3], *Wph, *Wqh, *Wf[4], *Wih, *Whh;  // T16 copies of the weights the forward chain multiplies by
+  // persistent forward (B <= kPchainCarveMaxB): T16 copies of every activation a link multiplies, per step [rt*16, width]
+  float *H16, *P16[3], *Q16[3], *Z16, *FZ16[3], *PHI16, *x16_end;
 };
+constexpr int kPchainCarveMaxB = 128;  // the persistent kernels' extra buffers are carved for batches up to this size only
 
 size_t carve_reserve(float* base, int Tp, int B, int H, int Z, int R, Reserve* r) {
   const size_t n = (size_t)Tp * B;
@@ -161,6 +164,17 @@ size_t carve_reserve(float* base, int Tp, int B, int H, int Z, int R, Reserve* r
   tmp.Wf[0] = take((size_t)H * Z);
   for (int i = 1; i < 4; ++i) tmp.Wf[i] = take((size_t)H * H);
   tmp.Wih = take((size_t)3 * R * H); tmp.Whh = take((size_t)3 * R * R);
+  tmp.H16 = nullptr;
+  if (B <= kPchainCarveMaxB) {
+    const size_t rows = (size_t)((B + 15) / 16) * 16, m = (size_t)Tp * rows;
+    tmp.H16 = take((m + rows) * R);
+    for (int i = 0; i < 3; ++i) tmp.P16[i] = take(m * H);
+    for (int i = 0; i < 3; ++i) tmp.Q16[i] = take(m * H);
+    tmp.Z16 = take(m * Z);
+    for (int i = 0; i < 3; ++i) tmp.FZ16[i] = take(m * H);
+    tmp.PHI16 = take(m * H);
+    tmp.x16_end = take(0);
+  }
   if (r) *r = tmp;
   return off;
 }
@@ -168,7 +182,9 @@ size_t carve_reserve(float* base, int Tp, int B, int H, int Z, int R, Reserve* r
 struct BwdWs {
   float *pT[3], *phT, *qT[3], *qhT, *fT[4], *wihT, *whhT;   // transposed weights, T16
   float *DGI, *DGH, *DPHI[4], *DQH, *DPH, *DP[3], *DQ[3], *G;
-  float *GA, *GB;  // persistent backward: the running state gradient as per-step slabs (written once each), [T',B,R]
+  // persistent backward (B <= kPchainCarveMaxB): the running state gradient as per-step slabs (written once each), [T',B,R], and
+  // T16 copies of every gradient a link multiplies, per step [rt*16, width]
+  float *GA, *GB, *DP16[3], *DQ16[3], *DGI16, *DGH16, *DPHI16[4], *DPH16, *DQH16, *x16_end;
 };
 
 size_t carve_ws(float* base, int Tp, int B, int X, int H, int Z, int R, BwdWs* w) {
@@ -191,7 +207,16 @@ size_t carve_ws(float* base, int Tp, int B, int X, int H, int Z, int R, BwdWs* w
   for (int i = 0; i < 3; ++i) t.DP[i] = take(n * H);
   for (int i = 0; i < 3; ++i) t.DQ[i] = take(n * H);
   t.G = take((size_t)B * R);
-  t.GA = take(n * R); t.GB = take(n * R);
+  t.GA = nullptr;
+  if (B <= kPchainCarveMaxB) {
+    const size_t m = (size_t)Tp * ((B + 15) / 16) * 16;
+    t.GA = take(n * R); t.GB = take(n * R);
+    for (int i = 0; i < 3; ++i) { t.DP16[i] = take(m * H); t.DQ16[i] = take(m * H); }
+    t.DGI16 = take(m * 3 * R); t.DGH16 = take(m * 3 * R);
+    for (int i = 0; i < 4; ++i) t.DPHI16[i] = take(m * H);
+    t.DPH16 = take(m * 2 * Z); t.DQH16 = take(m * 2 * Z);
+    t.x16_end = take(0);
+  }
   if (w) *w = t;
   return off;
 }
@@ -227,297 +252,12 @@ inline int overlap_chunk_steps() {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// Persistent forward: the WHOLE sequence in one launch (pchain.h).  The nine links of a step are the same as in the
-// launch-per-link path below (F1 .. F9); their 16x16 tiles are dealt over the resident workgroups:
-// consecutive links on alternating halves of the grid, the GRU's hidden projection behind the first three links (see the kernel).
-// Buffers polled inside the launch (sentinel-filled by the host): P, Q, FZ, GHb, z, decin.
-// ---------------------------------------------------------------------------------------------------------------
-struct VrnnPFwd {
-  const float *Wp[3], *Wq[3], *Wph, *Wqh, *Wf[4], *Wih, *Whh;                       // T16
-  const float *bp[3], *bq[3], *bph, *bqh, *bf[4], *bhh;                             // bq[0] unused (folded into XQ)
-  const float *XQ, *XG, *eps;
-  float *decin, *P[3], *Q[3], *FZ[3], *GHb, *RG, *UG, *NG, *RAWQ, *RAWP, *mu_p, *sd_p, *mu_q, *sd_q, *z;
-  int Tp, B, H, Z, R, residual;
-  float beta, inv_beta, sd_eps;
-  int g_set, nsets, g_def0, g_defn, tune;  // placement, see the kernel
-  pchain::Ctl ctl;
-  unsigned long long* prof;  // diagnostics (blvm_pchain_profile): per-link wall-clock ticks of workgroup 0 [0..15] and g_def0 [16..31]
-};
-
-template <int NW>
-__global__ __launch_bounds__(NW * 64, 1) void vrnn_pfwd_kernel(VrnnPFwd a) {
-  using namespace pchain;
-  extern __shared__ __attribute__((aligned(16))) float red_all[];  // 2 x (4 products x NW x 256) floats
-  float* const red0 = red_all;
-  float* const red1 = red_all + 4 * NW * 256;
-  int par = 0;
-  auto red = [&]() { par ^= 1; return par ? red0 : red1; };
-  Poll pl{a.ctl, 0u, false, 1};
-  const int w = blockIdx.x;
-  const int B = a.B, H = a.H, Z = a.Z, R = a.R, ldd = H + R;
-  const int rt = (B + 15) / 16, ctH = H / 16, ctZ = Z / 16, ctR = R / 16;
-  const size_t sH = (size_t)B * H, sZ = (size_t)B * Z, sR = (size_t)B * R, s3R = (size_t)B * 3 * R, sD = (size_t)B * ldd;
-  // Placement (host: vrnn_seq_fwd_impl): `nsets` ranges of `g_set` workgroups take the links in turn (2: while one range computes
-  // link l the other has fetched its weights for link l+1 and waits in the poll loop).  The GRU's hidden projection
-  // gh_t = h_{t-1} W_hh^T + b_hh (3R columns, first needed by F9) runs either on its own range [g_def0, g_def0 + g_defn), or in three
-  // batches behind the F1, F2, F3 tiles of the range that is idle next.
-  const int tune = a.tune;
-  const bool xcd = tune & 4, can = tune & 8, cand = tune & 16;
-  const int nset = a.g_set, nGH = 3 * ctR, bGH = (nGH + 2) / 3;
-  int phase = 0;
-  unsigned long long pacc[10] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
-  const bool profiled = a.prof && (w == 0 || w == a.g_set);
-  unsigned long long tprev = profiled ? wall_clock64() : 0ull;
-  auto link_end = [&](int l) {
-    if (profiled) {
-      const unsigned long long now = wall_clock64();
-      pacc[l] += now - tprev;
-      tprev = now;
-    }
-  };
-  for (int t = 0; t < a.Tp; ++t) {
-    const float* dec_t = a.decin + (size_t)t * sD;
-    float* dec_tw = a.decin + (size_t)t * sD;
-    float* dec_n = a.decin + (size_t)(t + 1) * sD;
-    const float* hprev = dec_t + H;
-    const unsigned code = (unsigned)t << 4;
-    auto next_base = [&]() { return a.nsets == 2 ? (phase++ & 1) * nset : 0; };
-    auto gh_tiles = [&](int c_lo, int c_hi, int base, int n, bool canary) {  // column tiles [c_lo, c_hi) of the hidden projection
-      pl.code = code | 10u;
-      for (TileIter it(w, base, n, rt, c_hi - c_lo, xcd); it.valid(); it.next()) {
-        const int r0 = it.r0(), c0 = (c_lo + it.c()) * 16;
-        if (canary) canary_wait(hprev, ldd, r0, B, R, pl);
-        tile_lin<NW>(hprev, ldd, true, a.Whh, R, a.bhh, nullptr, 0, false, nullptr, 0, false, 0.f, a.GHb + t * s3R, 3 * R, true, r0, c0, B, red(), pl);
-      }
-    };
-    // F1: first prior layer | h-half of the first posterior layer
-    int base = next_base();
-    pl.code = code | 1u;
-    for (TileIter it(w, base, nset, rt, 2 * ctH, xcd); it.valid(); it.next()) {
-      const int r0 = it.r0(), cc = it.c(), sgm = cc >= ctH, c0 = (cc - (sgm ? ctH : 0)) * 16;
-      if (can) canary_wait(hprev, ldd, r0, B, R, pl);
-      if (!sgm) tile_lin<NW>(hprev, ldd, true, a.Wp[0], R, a.bp[0], nullptr, 0, false, nullptr, 0, true, 0.f, a.P[0] + t * sH, H, true, r0, c0, B, red(), pl);
-      else tile_lin<NW>(hprev, ldd, true, a.Wq[0], R, nullptr, a.XQ + t * sH, H, false, nullptr, 0, true, 0.f, a.Q[0] + t * sH, H, true, r0, c0, B, red(), pl);
-    }
-    if (a.g_defn > 0) { pl.nap = 16; gh_tiles(0, nGH, a.g_def0, a.g_defn, cand); pl.nap = 1; }
-    else gh_tiles(0, min(bGH, nGH), base, nset, false);
-    link_end(0);
-    // F2, F3
-    for (int l = 1; l < 3; ++l) {
-      base = next_base();
-      pl.code = code | (unsigned)(1 + l);
-      for (TileIter it(w, base, nset, rt, 2 * ctH, xcd); it.valid(); it.next()) {
-        const int r0 = it.r0(), cc = it.c(), sgm = cc >= ctH, c0 = (cc - (sgm ? ctH : 0)) * 16;
-        const float* A = (sgm ? a.Q[l - 1] : a.P[l - 1]) + t * sH;
-        if (can) canary_wait(A, H, r0, B, H, pl);
-        tile_lin<NW>(A, H, true, sgm ? a.Wq[l] : a.Wp[l], H, sgm ? a.bq[l] : a.bp[l], nullptr, 0, false, nullptr, 0, true, 0.f,
-                     (sgm ? a.Q[l] : a.P[l]) + t * sH, H, true, r0, c0, B, red(), pl);
-      }
-      if (a.g_defn == 0) gh_tiles(min(l * bGH, nGH), min((l + 1) * bGH, nGH), base, nset, false);
-      link_end(l);
-    }
-    // F4: heads + sample
-    base = next_base();
-    pl.code = code | 4u;
-    for (TileIter it(w, base, nset, rt, ctZ, xcd); it.valid(); it.next()) {
-      const int r0 = it.r0(), c0 = it.c() * 16;
-      const HeadOut o{a.mu_p + t * sZ, a.sd_p + t * sZ, a.mu_q + t * sZ, a.sd_q + t * sZ, a.z + t * sZ, a.RAWP + t * sZ, a.RAWQ + t * sZ, nullptr};
-      if (can) { canary_wait(a.P[2] + t * sH, H, r0, B, H, pl); canary_wait(a.Q[2] + t * sH, H, r0, B, H, pl); }
-      tile_head<NW>(a.P[2] + t * sH, a.Q[2] + t * sH, true, a.Wph, a.bph, a.Wqh, a.bqh, a.eps + t * sZ, o, H, Z, a.residual, a.beta, a.inv_beta,
-                    a.sd_eps, r0, c0, B, red(), pl);
-    }
-    link_end(3);
-    // F5..F8: phi_z MLP (last layer writes phi into decin row t)
-    for (int l = 0; l < 4; ++l) {
-      base = next_base();
-      pl.code = code | (unsigned)(5 + l);
-      const float* A = l == 0 ? a.z + t * sZ : a.FZ[l - 1] + t * sH;
-      const int K = l == 0 ? Z : H;
-      float* out = l == 3 ? dec_tw : a.FZ[l] + t * sH;
-      const int ldo = l == 3 ? ldd : H;
-      for (TileIter it(w, base, nset, rt, ctH, xcd); it.valid(); it.next()) {
-        const int r0 = it.r0(), c0 = it.c() * 16;
-        if (can) canary_wait(A, K, r0, B, K, pl);
-        tile_lin<NW>(A, K, true, a.Wf[l], K, a.bf[l], nullptr, 0, false, nullptr, 0, true, 0.f, out, ldo, true, r0, c0, B, red(), pl);
-      }
-      link_end(4 + l);
-    }
-    // F9: GRU
-    base = next_base();
-    pl.code = code | 9u;
-    for (TileIter it(w, base, nset, rt, ctR, xcd); it.valid(); it.next()) {
-      const int r0 = it.r0(), c0 = it.c() * 16;
-      if (can) canary_wait(dec_t, ldd, r0, B, H, pl);
-      tile_gru<NW>(dec_t, ldd, true, a.Wih, H, a.XG + t * s3R, a.GHb + t * s3R, hprev, ldd, R, dec_n + H, ldd, a.RG + t * sR, a.UG + t * sR,
-                   a.NG + t * sR, r0, c0, B, red(), pl);
-    }
-    link_end(8);
-  }
-  if (profiled && threadIdx.x == 0) {
-    for (int l = 0; l < 10; ++l) a.prof[(w == 0 ? 0 : 16) + l] += pacc[l];
-#ifdef PCHAIN_TPROF
-    if (w == 0) for (int l = 0; l < 8; ++l) a.prof[32 + l] += pl.tp[l];
-#endif
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Persistent backward (BPTT): one launch for the whole sequence, steps T'-1 .. 0, nine links per step as in the
-// launch-per-link path below.  The running gradient wrt the recurrent state is kept as per-step slabs so that every
-// location is written once:  GA[t] = (gradient wrt h_t) * u_t + decoder gradient  (written by Ba of step t),
-// GB[t] = GA[t] + DGH[t] W_hh  (the K = 3R product that nothing needs before the next step's Ba: deferred range).
-// ---------------------------------------------------------------------------------------------------------------
-struct VrnnPBwd {
-  const float *pT[3], *phT, *qT[3], *qhT, *fT[4], *wihT, *whhT;                              // transposed weights, T16
-  const float *decin, *d_decin, *P[3], *Q[3], *FZ[3], *GHb, *RG, *UG, *NG;                     // saved by the forward
-  pchain::DzIn dz;                                                                             // step-0 slabs; the kernel offsets them
-  float *DGI, *DGH, *DPHI[4], *DQH, *DPH, *DP[3], *DQ[3], *GA, *GB, *G_out;
-  int Tp, B, H, Z, R;
-  int g_set, g_def0, g_defn, tune;
-  pchain::Ctl ctl;
-  unsigned long long* prof;
-};
-
-// Ba: g = GB[t+1] + DP0[t+1] W_p0 + DQ0[t+1] W_q0h  (the complete gradient wrt h_t), then the GRU gate derivatives of step t.
-// t == T'-1: g = 0 (no later step).  t == -1: only g, written to G_out (the gradient wrt the initial state).
-template <int NW>
-__device__ __forceinline__ void tile_dh(const VrnnPBwd& a, int t, int r0, int c0, float* red, pchain::Poll& pl) {
-  using namespace pchain;
-  const int B = a.B, H = a.H, R = a.R, ldd = H + R;
-  const size_t sH = (size_t)B * H, sR = (size_t)B * R, s3R = 3 * sR, sD = (size_t)B * ldd;
-  const int tt = threadIdx.x & 255;
-  const int row = r0 + (tt >> 4), col = c0 + (tt & 15);
-  const bool own = threadIdx.x < 256 && row < B;
-  const int rowc = row < B ? row : r0;
-  const size_t o = (size_t)rowc * R + col, o3 = (size_t)rowc * 3 * R + col;
-  const bool has_gemm = t + 1 < a.Tp, has_gates = t >= 0;
-  float r = 0.f, u = 0.f, n = 0.f, hn = 0.f, hp = 0.f, dd = 0.f;
-  if (has_gates) {
-    r = a.RG[t * sR + o]; u = a.UG[t * sR + o]; n = a.NG[t * sR + o]; hn = a.GHb[t * s3R + o3 + 2 * R];
-    hp = a.decin[t * sD + (size_t)rowc * ldd + H + col];
-    dd = a.d_decin[t * sD + (size_t)rowc * ldd + H + col];
-  }
-  float v[2] = {0.f, 0.f}, g0 = 0.f;
-  if (has_gemm) {
-    g0 = ld_sc1(a.GB + (t + 1) * sR + o);  // stored a step ago: request it under the operand wait
-    f32x4 acc[2];
-    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* const As[2] = {a.DP[0] + (t + 1) * sH, a.DQ[0] + (t + 1) * sH};
-    const float* const Ws[2] = {a.pT[0], a.qT[0]};
-    const int la[2] = {H, H}, cs[2] = {c0, c0};
-    mgemm16<NW, 2, 2, MapId>(As, la, true, r0, B, Ws, cs, H, acc, pl);
-    reduce_tiles<2, NW>(acc, red, v);
-    if (threadIdx.x >= 256) return;
-    wait_vm0(g0);
-    if (__any(own && is_sentinel(g0))) {
-      const float* const ps[1] = {a.GB + (t + 1) * sR + o};
-      float ws[1];
-      poll_words<1>(ps, ws, own, pl);
-      g0 = ws[0];
-    }
-  }
-  if (!own) return;
-  const float g = g0 + v[0] + v[1];
-  if (!has_gates) { a.G_out[(size_t)row * R + col] = g; return; }
-  const float dn_pre = g * (1.f - u) * (1.f - n * n);
-  const float du_pre = g * (hp - n) * u * (1.f - u);
-  const float dr_pre = dn_pre * hn * r * (1.f - r);
-  float* dgi = a.DGI + t * s3R + (size_t)row * 3 * R + col;
-  float* dgh = a.DGH + t * s3R + (size_t)row * 3 * R + col;
-  st_sc1(dgi, dr_pre); st_sc1(dgi + R, du_pre); st_sc1(dgi + 2 * R, dn_pre);
-  st_sc1(dgh, dr_pre); st_sc1(dgh + R, du_pre); st_sc1(dgh + 2 * R, dn_pre * r);
-  st_sc1(a.GA + t * sR + (size_t)row * R + col, g * u + dd);
-}
-
-template <int NW>
-__global__ __launch_bounds__(NW * 64, 1) void vrnn_pbwd_kernel(VrnnPBwd a) {
-  using namespace pchain;
-  extern __shared__ __attribute__((aligned(16))) float red_all[];  // 2 x (2 products x NW x 256) floats
-  float* const red0 = red_all;
-  float* const red1 = red_all + 2 * NW * 256;
-  int par = 0;
-  auto red = [&]() { par ^= 1; return par ? red0 : red1; };
-  Poll pl{a.ctl, 0u, false, 1};
-  const int w = blockIdx.x;
-  const int B = a.B, H = a.H, Z = a.Z, R = a.R, ldd = H + R;
-  const int rt = (B + 15) / 16, ctH = H / 16, ctZ = Z / 16, ctR = R / 16;
-  const size_t sH = (size_t)B * H, sZ = (size_t)B * Z, sR = (size_t)B * R, s3R = 3 * sR, s2Z = 2 * sZ, sD = (size_t)B * ldd;
-  const bool xcd = a.tune & 4, cand = a.tune & 16;
-  const int nset = a.g_set;
-  unsigned long long pacc[10] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
-  const bool profiled = a.prof && (w == 0 || w == a.g_def0);
-  unsigned long long tprev = profiled ? wall_clock64() : 0ull;
-  auto link_end = [&](int l) {
-    if (profiled) {
-      const unsigned long long now = wall_clock64();
-      pacc[l] += now - tprev;
-      tprev = now;
-    }
-  };
-  for (int t = a.Tp - 1; t >= -1; --t) {
-    const unsigned code = (unsigned)(t + 1) << 4;
-    // Ba
-    pl.code = code | 1u;
-    for (TileIter it(w, 0, nset, rt, ctR, xcd); it.valid(); it.next()) tile_dh<NW>(a, t, it.r0(), it.c() * 16, red(), pl);
-    link_end(0);
-    if (t < 0) break;
-    const float* dec_t = a.decin + t * sD;
-    const float* ddec_t = a.d_decin + t * sD;
-    // Bb: dphi through the GRU input projection (critical) | GB[t] = GA[t] + DGH[t] W_hh (deferred)
-    pl.code = code | 2u;
-    for (TileIter it(w, 0, nset, rt, ctH, xcd); it.valid(); it.next())
-      tile_lin<NW>(a.DGI + t * s3R, 3 * R, true, a.wihT, 3 * R, nullptr, ddec_t, ldd, false, dec_t, ldd, false, 0.f, a.DPHI[3] + t * sH, H, true,
-                   it.r0(), it.c() * 16, B, red(), pl);
-    {
-      pl.nap = 16;
-      pl.code = code | 10u;
-      const bool own_range = a.g_defn > 0;
-      for (TileIter it(w, own_range ? a.g_def0 : 0, own_range ? a.g_defn : nset, rt, ctR, xcd); it.valid(); it.next()) {
-        if (cand && own_range) canary_wait(a.DGH + t * s3R, 3 * R, it.r0(), B, 3 * R, pl);
-        tile_lin<NW>(a.DGH + t * s3R, 3 * R, true, a.whhT, 3 * R, nullptr, a.GA + t * sR, R, true, nullptr, 0, false, 0.f, a.GB + t * sR, R, true,
-                     it.r0(), it.c() * 16, B, red(), pl);
-      }
-      pl.nap = 1;
-    }
-    link_end(1);
-    // B3..B5: back through phi_z layers 3, 2, 1
-    for (int l = 3; l >= 1; --l) {
-      pl.code = code | (unsigned)(6 - l);
-      for (TileIter it(w, 0, nset, rt, ctH, xcd); it.valid(); it.next())
-        tile_lin<NW>(a.DPHI[l] + t * sH, H, true, a.fT[l], H, nullptr, nullptr, 0, false, a.FZ[l - 1] + t * sH, H, false, 0.f, a.DPHI[l - 1] + t * sH, H,
-                     true, it.r0(), it.c() * 16, B, red(), pl);
-      link_end(5 - l);
-    }
-    // B6: dz and the heads
-    pl.code = code | 6u;
-    {
-      DzIn d = a.dz;
-      d.mu_q += t * sZ; d.sd_q += t * sZ; d.mu_p += t * sZ; d.sd_p += t * sZ; d.eps += t * sZ; d.raw_q += t * sZ; d.raw_p += t * sZ;
-      d.t = t;
-      for (TileIter it(w, 0, nset, rt, ctZ, xcd); it.valid(); it.next())
-        tile_dz<NW>(a.DPHI[0] + t * sH, a.fT[0], nullptr, nullptr, true, nullptr, 0, false, d, a.DQH + t * s2Z, a.DPH + t * s2Z, H, Z, it.r0(),
-                    it.c() * 16, B, red(), pl);
-    }
-    link_end(5);
-    // B7: heads -> last hidden layers;  B8, B9: hidden layers 2, 1
-    for (int l = 3; l >= 1; --l) {
-      pl.code = code | (unsigned)(10 - l);
-      for (TileIter it(w, 0, nset, rt, 2 * ctH, xcd); it.valid(); it.next()) {
-        const int cc = it.c(), sgm = cc >= ctH, c0 = (cc - (sgm ? ctH : 0)) * 16;
-        const float* A = l == 3 ? (sgm ? a.DQH : a.DPH) + t * s2Z : (sgm ? a.DQ[l] : a.DP[l]) + t * sH;
-        const int K = l == 3 ? 2 * Z : H;
-        const float* W = l == 3 ? (sgm ? a.qhT : a.phT) : (sgm ? a.qT[l] : a.pT[l]);
-        tile_lin<NW>(A, K, true, W, K, nullptr, nullptr, 0, false, (sgm ? a.Q[l - 1] : a.P[l - 1]) + t * sH, H, false, 0.f,
-                     (sgm ? a.DQ[l - 1] : a.DP[l - 1]) + t * sH, H, true, it.r0(), c0, B, red(), pl);
-      }
-      link_end(9 - l);
-    }
-  }
-  if (profiled && threadIdx.x == 0) {
-    for (int l = 0; l < 10; ++l) a.prof[(w == 0 ? 0 : 16) + l] += pacc[l];
-  }
+// [B, K] row-major (row stride ld) -> the T16 copy [rt*16, K] of the same rows (rows >= B are left alone: never read)
+__global__ void rows_to_t16_kernel(const float* src, int ld, int B, int K, float* dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * K) return;
+  const int row = i / K, k = i % K;
+  dst[((size_t)(row >> 4) * (K >> 4) + (k >> 4)) * 256 + ((row & 15) + 16 * ((k & 15) >> 2)) * 4 + (k & 3)] = src ? src[(size_t)row * ld + k] : 0.f;
 }
 
 inline int device_cus() {
@@ -592,47 +332,68 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
   else BLVM_HIP(hipMemset2DAsync(decin + H, sizeof(float) * ldd, 0, sizeof(float) * R, B, s));
 
   const int rt = (B + 15) / 16;
-  if (B <= pchain_max_batch() && device_cus() >= 16) {
-    // persistent path: one launch for the whole sequence.  Sentinel-fill what the launch polls: P, Q, FZ, GHb (contiguous in the
-    // reserve), z, and decin (then the initial state goes into row 0).
-    VrnnPFwd a{};
-    for (int l = 0; l < 3; ++l) { a.Wp[l] = rs.Wp[l]; a.Wq[l] = rs.Wq[l]; a.bp[l] = w->prior_b[l]; a.bq[l] = w->post_b[l]; a.P[l] = rs.P[l]; a.Q[l] = rs.Q[l]; a.FZ[l] = rs.FZ[l]; }
-    for (int l = 0; l < 4; ++l) { a.Wf[l] = rs.Wf[l]; a.bf[l] = w->phi_b[l]; }
-    a.Wph = rs.Wph; a.Wqh = rs.Wqh; a.Wih = rs.Wih; a.Whh = rs.Whh; a.bph = w->prior_hb; a.bqh = w->post_hb; a.bhh = w->gru_bhh;
-    a.XQ = rs.XQ; a.XG = rs.XG; a.eps = eps;
-    a.decin = decin; a.GHb = rs.GHb; a.RG = rs.RG; a.UG = rs.UG; a.NG = rs.NG; a.RAWQ = rs.RAWQ; a.RAWP = rs.RAWP;
-    a.mu_p = mu_p; a.sd_p = sd_p; a.mu_q = mu_q; a.sd_q = sd_q; a.z = z;
-    a.Tp = Tp; a.B = B; a.H = H; a.Z = Z; a.R = R; a.residual = residual_posterior;
-    a.beta = beta; a.inv_beta = 1.f / beta; a.sd_eps = sd_eps;
-    const int n_crit = std::max(2 * (H / 16) * rt, (R / 16) * rt);  // tiles of the widest link
-    a.tune = pchain_tune();
-    a.nsets = (a.tune & 1) ? 2 : 1;
-    const bool dedicated = (a.tune & 2) != 0;
-    const int cus = device_cus() & ~7;
-    const int avail = dedicated ? std::max(16, cus - std::min(cus / 4, 64)) : cus;  // a dedicated range gets up to a quarter of the CUs ...
-    a.g_set = std::max(8, std::min(avail / a.nsets, (n_crit + 7) & ~7) & ~7);
-    a.g_def0 = a.nsets * a.g_set;
-    a.g_defn = dedicated ? std::max(8, std::min(cus - a.g_def0, (3 * (R / 16) * rt + 7) & ~7) & ~7) : 0;  // ... or what the sets leave
-    const int grid = a.g_def0 + a.g_defn;
-    rc = pchain_ctl(&a.ctl.dev, &a.ctl.host, &a.ctl.epoch);
+  if (B <= pchain_max_batch() && B <= kPchainCarveMaxB && device_cus() >= 32) {
+    // Persistent path (pchain.h / pchain.hip): the nine links of a step as a program of 13 descriptors, one launch for the whole
+    // sequence.  Links on the critical path share the workgroups [0, g); the GRU's hidden projection gh_t = h_{t-1} W_hh^T + b_hh
+    // (3R columns, first needed by the GRU link's epilogue eight links later) has its own range behind them and polls gently.
+    using namespace pchain;
+    const int ctH = H / 16, ctZ = Z / 16, ctR = R / 16, cus = device_cus() & ~7;
+    const long sH = (long)B * H, sZ = (long)B * Z, sR = (long)B * R, s3R = 3 * sR, sD = (long)B * ldd;
+    const long xH = (long)rt * 16 * H, xZ = (long)rt * 16 * Z, xR = (long)rt * 16 * R;
+    const int def_n = range_for(3 * ctR * rt, std::min(cus / 4, 64));        // hidden projection: up to a quarter of the chip
+    const int half = range_for(ctH * rt, (cus - def_n) / 2);                   // prior | posterior halves of a link
+    const int g = 2 * half;
+    Builder bld;
+    bld.p.S = Tp; bld.p.B = B; bld.p.xcd = (pchain_tune() & 4) ? 1 : 0; bld.p.lds_products = 4;
+    bld.p.prof = pchain_profile_buffer(); bld.p.prof_wg = g;
+    auto lin = [&](const float* A16, long a_step, const float* W, int K, const float* bias, const float* add, long add_step, int ldadd, float* orm,
+                   long rm_step, int ldo, float* o16, long o16_step, int n16, int ct, int wg0, int nwg, int flags) {
+      Desc& d = bld.add(K_LIN, ct, wg0, nwg, K, flags, 0, Tp);
+      bld.ptr(d, 0, A16, a_step); bld.ptr(d, 1, W); bld.ptr(d, 2, bias); bld.ptr(d, 3, add, add_step);
+      bld.ptr(d, 5, orm, rm_step); bld.ptr(d, 6, o16, o16_step);
+      d.ld[1] = ldadd; d.ld[3] = ldo; d.n16[0] = n16; d.f[0] = 0.f;
+    };
+    // F1: first prior layer | h-half of the first posterior layer | hidden projection
+    lin(rs.H16, xR, rs.Wp[0], R, w->prior_b[0], nullptr, 0, 0, rs.P[0], sH, H, rs.P16[0], xH, ctH, ctH, 0, half, DF_RELU);
+    lin(rs.H16, xR, rs.Wq[0], R, nullptr, rs.XQ, sH, H, rs.Q[0], sH, H, rs.Q16[0], xH, ctH, ctH, half, half, DF_RELU);
+    lin(rs.H16, xR, rs.Whh, R, w->gru_bhh, nullptr, 0, 0, rs.GHb, s3R, 3 * R, nullptr, 0, 0, 3 * ctR, g, def_n,
+        DF_RM_SC1 | DF_GENTLE | ((pchain_tune() & 16) ? DF_CANARY : 0));
+    // F2, F3
+    for (int l = 1; l < 3; ++l) {
+      lin(rs.P16[l - 1], xH, rs.Wp[l], H, w->prior_b[l], nullptr, 0, 0, rs.P[l], sH, H, rs.P16[l], xH, ctH, ctH, 0, half, DF_RELU);
+      lin(rs.Q16[l - 1], xH, rs.Wq[l], H, w->post_b[l], nullptr, 0, 0, rs.Q[l], sH, H, rs.Q16[l], xH, ctH, ctH, half, half, DF_RELU);
+    }
+    {  // F4: heads + sample
+      Desc& d = bld.add(K_HEAD, ctZ, 0, range_for(ctZ * rt, g), H, 0, 0, Tp);
+      bld.ptr(d, 0, rs.P16[2], xH); bld.ptr(d, 1, rs.Q16[2], xH); bld.ptr(d, 2, rs.Wph); bld.ptr(d, 3, w->prior_hb); bld.ptr(d, 4, rs.Wqh);
+      bld.ptr(d, 5, w->post_hb); bld.ptr(d, 6, eps, sZ); bld.ptr(d, 7, mu_p, sZ); bld.ptr(d, 8, sd_p, sZ); bld.ptr(d, 9, mu_q, sZ);
+      bld.ptr(d, 10, sd_q, sZ); bld.ptr(d, 11, rs.RAWP, sZ); bld.ptr(d, 12, rs.RAWQ, sZ); bld.ptr(d, 13, nullptr);
+      bld.ptr(d, 14, z, sZ); bld.ptr(d, 15, rs.Z16, xZ);
+      d.ld[3] = Z; d.n16[0] = ctZ; d.i[0] = Z; d.i[1] = residual_posterior; d.f[0] = beta; d.f[1] = 1.f / beta; d.f[2] = sd_eps;
+    }
+    // F5..F8: phi_z MLP (the last layer writes phi into decin row t)
+    for (int l = 0; l < 4; ++l) {
+      const float* A = l == 0 ? rs.Z16 : rs.FZ16[l - 1];
+      lin(A, l == 0 ? xZ : xH, rs.Wf[l], l == 0 ? Z : H, w->phi_b[l], nullptr, 0, 0, l == 3 ? decin : rs.FZ[l], l == 3 ? sD : sH, l == 3 ? ldd : H,
+          l == 3 ? rs.PHI16 : rs.FZ16[l], xH, ctH, ctH, 0, range_for(ctH * rt, g), DF_RELU);
+    }
+    {  // F9: GRU
+      Desc& d = bld.add(K_GRU, ctR, 0, range_for(ctR * rt, g), H, 0, 0, Tp);
+      bld.ptr(d, 0, rs.PHI16, xH); bld.ptr(d, 1, rs.Wih); bld.ptr(d, 2, rs.XG, s3R); bld.ptr(d, 3, rs.GHb, s3R); bld.ptr(d, 4, decin + H, sD);
+      bld.ptr(d, 5, decin + sD + H, sD); bld.ptr(d, 6, rs.H16 + xR, xR); bld.ptr(d, 7, rs.RG, sR); bld.ptr(d, 8, rs.UG, sR); bld.ptr(d, 9, rs.NG, sR);
+      d.ld[0] = ldd; d.ld[3] = ldd; d.n16[0] = ctR; d.i[0] = R;
+    }
+    BLVM_REQUIRE(!bld.overflow, "vrnn_fwd: persistent program overflow");
+    rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
     if (rc) return rc;
-    a.prof = pchain_profile_buffer();
-    BLVM_HIP(hipMemsetAsync(rs.P[0], 0xFF, (size_t)(reinterpret_cast<char*>(rs.RG) - reinterpret_cast<char*>(rs.P[0])), s));
-    BLVM_HIP(hipMemsetAsync(z, 0xFF, sizeof(float) * n * Z, s));
+    // sentinel-fill what the launch polls: the T16 copies, the hidden projection, and decin (the GRU link polls words of h)
+    BLVM_HIP(hipMemsetAsync(rs.H16, 0xFF, (size_t)(reinterpret_cast<char*>(rs.x16_end) - reinterpret_cast<char*>(rs.H16)), s));
+    BLVM_HIP(hipMemsetAsync(rs.GHb, 0xFF, sizeof(float) * n * 3 * R, s));
     BLVM_HIP(hipMemsetAsync(decin, 0xFF, sizeof(float) * n * ldd, s));  // rows 0..T'-1; row T' only receives h_n
     if (h0) BLVM_HIP(hipMemcpy2DAsync(decin + H, sizeof(float) * ldd, h0, sizeof(float) * R, sizeof(float) * R, B, hipMemcpyDeviceToDevice, s));
     else BLVM_HIP(hipMemset2DAsync(decin + H, sizeof(float) * ldd, 0, sizeof(float) * R, B, s));
-    const int nw = pchain_waves();
-    const size_t lds = sizeof(float) * 2 * 4 * nw * 256;
-    if (nw == 16) {
-      BLVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&vrnn_pfwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((vrnn_pfwd_kernel<16>), dim3(grid), dim3(1024), lds, s, a);
-    } else {
-      BLVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&vrnn_pfwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((vrnn_pfwd_kernel<8>), dim3(grid), dim3(512), lds, s, a);
-    }
-    BLVM_CHECK_LAUNCH("vrnn_seq_fwd (persistent)");
-    return BLVM_OK;
+    hipLaunchKernelGGL(rows_to_t16_kernel, dim3((B * R + 255) / 256), dim3(256), 0, s, h0, R, B, R, rs.H16);
+    return pchain_launch(bld.p, s);
   }
   for (int t = 0; t < Tp; ++t) {
     const size_t oH = (size_t)t * B * H, oZ = (size_t)t * B * Z, oR = (size_t)t * B * R, o3R = (size_t)t * B * 3 * R;
@@ -803,44 +564,70 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
 #undef TRY
     return BLVM_OK;
   };
-  if (B <= pchain_max_batch() && device_cus() >= 16) {
-    // persistent path: the whole BPTT chain in one launch, then the batched weight-gradient GEMMs
-    VrnnPBwd a{};
-    for (int l = 0; l < 3; ++l) { a.pT[l] = ws.pT[l]; a.qT[l] = ws.qT[l]; a.P[l] = rs.P[l]; a.Q[l] = rs.Q[l]; a.FZ[l] = rs.FZ[l]; a.DP[l] = ws.DP[l]; a.DQ[l] = ws.DQ[l]; }
-    for (int l = 0; l < 4; ++l) { a.fT[l] = ws.fT[l]; a.DPHI[l] = ws.DPHI[l]; }
-    a.phT = ws.phT; a.qhT = ws.qhT; a.wihT = ws.wihT; a.whhT = ws.whhT;
-    a.decin = decin; a.d_decin = d_decin; a.GHb = rs.GHb; a.RG = rs.RG; a.UG = rs.UG; a.NG = rs.NG;
-    a.dz.mu_q = mu_q; a.dz.sd_q = sd_q; a.dz.mu_p = mu_p; a.dz.sd_p = sd_p; a.dz.eps = eps; a.dz.raw_q = rs.RAWQ; a.dz.raw_p = rs.RAWP;
-    a.dz.muq_raw = nullptr; a.dz.x_sl = x_sl; a.dz.c_raw = c_raw; a.dz.c_fn = c_fn; a.dz.t = 0; a.dz.stride = stride;
-    a.dz.residual = residual_posterior; a.dz.fn_floor = fn_floor; a.dz.beta = beta; a.dz.sd_eps = sd_eps;
-    a.DGI = ws.DGI; a.DGH = ws.DGH; a.DQH = ws.DQH; a.DPH = ws.DPH; a.GA = ws.GA; a.GB = ws.GB; a.G_out = d_h0 ? d_h0 : ws.G;
-    a.Tp = Tp; a.B = B; a.H = H; a.Z = Z; a.R = R;
-    a.tune = pchain_tune();
-    const int cus = device_cus() & ~7;
-    const int n_crit = std::max(2 * (H / 16) * rt, (R / 16) * rt);
-    const bool dedicated = (a.tune & 2) != 0;
-    const int avail = dedicated ? std::max(16, cus - std::min(cus / 4, 64)) : cus;
-    a.g_set = std::max(8, std::min(avail, (n_crit + 7) & ~7) & ~7);
-    a.g_def0 = a.g_set;
-    a.g_defn = dedicated ? std::max(8, std::min(cus - a.g_def0, ((R / 16) * rt + 7) & ~7) & ~7) : 0;
-    const int grid = a.g_def0 + a.g_defn;
-    rc = pchain_ctl(&a.ctl.dev, &a.ctl.host, &a.ctl.epoch);
-    if (rc) return rc;
-    a.prof = pchain_profile_buffer();
-    if (a.prof) a.prof += 64;  // the backward's counters follow the forward's
-    float* const fill0 = ws.DGI;
-    float* const fill1 = ws.GB + n * R;
-    BLVM_HIP(hipMemsetAsync(fill0, 0xFF, (size_t)(reinterpret_cast<char*>(fill1) - reinterpret_cast<char*>(fill0)), s));
-    const int nw = pchain_waves();
-    const size_t lds = sizeof(float) * 2 * 2 * nw * 256;
-    if (nw == 16) {
-      BLVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&vrnn_pbwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((vrnn_pbwd_kernel<16>), dim3(grid), dim3(1024), lds, s, a);
-    } else {
-      BLVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&vrnn_pbwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((vrnn_pbwd_kernel<8>), dim3(grid), dim3(512), lds, s, a);
+  if (B <= pchain_max_batch() && B <= kPchainCarveMaxB && device_cus() >= 32) {
+    // Persistent path: the whole BPTT chain as a program of 13 descriptors walked for s = 0 .. T' (t = T'-1-s: last-step slabs and
+    // negative strides), then the batched weight-gradient GEMMs.  The running gradient wrt the recurrent state lives in per-step
+    // slabs so that every location is written once: GA[t] = g_t * u_t + decoder gradient (written by the GRU-backward link),
+    // GB[t] = GA[t] + DGH[t] W_hh (a K = 3R product nothing needs before the NEXT step's GRU-backward link: own range, gentle polls).
+    using namespace pchain;
+    const int ctH = H / 16, ctZ = Z / 16, ctR = R / 16, cus = device_cus() & ~7, T = Tp;
+    const long sH = (long)B * H, sZ = (long)B * Z, sR = (long)B * R, s3R = 3 * sR, s2Z = 2 * sZ, sD = (long)B * ldd;
+    const long xH = (long)rt * 16 * H, x2Z = (long)rt * 16 * 2 * Z, x3R = (long)rt * 16 * 3 * R;
+    const int def_n = range_for(ctR * rt, std::min(cus / 4, 64));
+    const int half = range_for(ctH * rt, (cus - def_n) / 2), g = 2 * half;
+    Builder bld;
+    bld.p.S = T + 1; bld.p.B = B; bld.p.xcd = (pchain_tune() & 4) ? 1 : 0; bld.p.lds_products = 2;
+    bld.p.prof = pchain_profile_buffer() ? pchain_profile_buffer() + 64 : nullptr; bld.p.prof_wg = g;
+    auto last = [&](const float* base, long step) { return base ? base + (long)(T - 1) * step : nullptr; };  // slab of t = T'-1
+    {  // Ba: complete the gradient wrt h_t, GRU gate derivatives of step t (s = T': only the gradient wrt the initial state)
+      Desc& d = bld.add(K_GRUB, ctR, 0, range_for(ctR * rt, g), H, 0, 0, T + 1);
+      bld.ptr(d, 0, ws.DP16[0] + (long)T * xH, -xH); bld.ptr(d, 1, ws.DQ16[0] + (long)T * xH, -xH); bld.ptr(d, 2, ws.pT[0]); bld.ptr(d, 3, ws.qT[0]);
+      bld.ptr(d, 4, ws.GB + (long)T * sR, -sR);
+      bld.ptr(d, 5, last(rs.RG, sR), -sR); bld.ptr(d, 6, last(rs.UG, sR), -sR); bld.ptr(d, 7, last(rs.NG, sR), -sR); bld.ptr(d, 8, last(rs.GHb, s3R), -s3R);
+      bld.ptr(d, 9, last(decin, sD) + H, -sD); bld.ptr(d, 10, last(d_decin, sD) + H, -sD);
+      bld.ptr(d, 11, last(ws.DGI, s3R), -s3R); bld.ptr(d, 12, last(ws.DGI16, x3R), -x3R); bld.ptr(d, 13, last(ws.DGH, s3R), -s3R);
+      bld.ptr(d, 14, last(ws.DGH16, x3R), -x3R); bld.ptr(d, 15, last(ws.GA, sR), -sR); bld.ptr(d, 16, d_h0 ? d_h0 : ws.G);
+      d.ld[0] = ldd; d.ld[3] = 3 * R; d.n16[0] = 3 * ctR; d.i[0] = R; d.i[1] = 1; d.i[2] = T;
     }
-    BLVM_CHECK_LAUNCH("vrnn_seq_bwd (persistent)");
+    auto lin = [&](const float* A16, long a_x, const float* W, int K, const float* add, long add_step, int ldadd, const float* gate, long gate_step,
+                   int ldgate, float* orm, long rm_step, int ldo, float* o16, long o16_x, int n16, int ct, int wg0, int nwg, int flags) {
+      Desc& d = bld.add(K_LIN, ct, wg0, nwg, K, flags, 0, T);
+      bld.ptr(d, 0, last(A16, a_x), -a_x); bld.ptr(d, 1, W); bld.ptr(d, 3, last(add, add_step), -add_step); bld.ptr(d, 4, last(gate, gate_step), -gate_step);
+      bld.ptr(d, 5, last(orm, rm_step), -rm_step); bld.ptr(d, 6, last(o16, o16_x), -o16_x);
+      d.ld[1] = ldadd; d.ld[2] = ldgate; d.ld[3] = ldo; d.n16[0] = n16; d.f[0] = 0.f;
+    };
+    // Bb: dphi through the GRU input projection (+ the decoder's gradient, through phi's ReLU) | GB[t] = GA[t] + DGH[t] W_hh
+    lin(ws.DGI16, x3R, ws.wihT, 3 * R, d_decin, sD, ldd, decin, sD, ldd, ws.DPHI[3], sH, H, ws.DPHI16[3], xH, ctH, ctH, 0, range_for(ctH * rt, g), 0);
+    lin(ws.DGH16, x3R, ws.whhT, 3 * R, ws.GA, sR, R, nullptr, 0, 0, ws.GB, sR, R, nullptr, 0, 0, ctR, g, def_n,
+        DF_ADD_POLLED | DF_RM_SC1 | DF_GENTLE | ((pchain_tune() & 16) ? DF_CANARY : 0));
+    // B3..B5: back through phi_z layers 3, 2, 1
+    for (int l = 3; l >= 1; --l)
+      lin(ws.DPHI16[l], xH, ws.fT[l], H, nullptr, 0, 0, rs.FZ[l - 1], sH, H, ws.DPHI[l - 1], sH, H, ws.DPHI16[l - 1], xH, ctH, ctH, 0, range_for(ctH * rt, g), 0);
+    {  // B6: dz and the heads
+      Desc& d = bld.add(K_DZ, ctZ, 0, range_for(ctZ * rt, g), H, 0, 0, T);
+      bld.ptr(d, 0, last(ws.DPHI16[0], xH), -xH); bld.ptr(d, 1, ws.fT[0]); bld.ptr(d, 2, nullptr); bld.ptr(d, 3, nullptr); bld.ptr(d, 4, nullptr);
+      bld.ptr(d, 5, last(mu_q, sZ), -sZ); bld.ptr(d, 6, last(sd_q, sZ), -sZ); bld.ptr(d, 7, last(mu_p, sZ), -sZ); bld.ptr(d, 8, last(sd_p, sZ), -sZ);
+      bld.ptr(d, 9, last(eps, sZ), -sZ); bld.ptr(d, 10, last(rs.RAWQ, sZ), -sZ); bld.ptr(d, 11, last(rs.RAWP, sZ), -sZ); bld.ptr(d, 12, nullptr);
+      bld.ptr(d, 13, x_sl); bld.ptr(d, 14, c_raw); bld.ptr(d, 15, c_fn);
+      bld.ptr(d, 16, last(ws.DQH, s2Z), -s2Z); bld.ptr(d, 17, last(ws.DQH16, x2Z), -x2Z); bld.ptr(d, 18, last(ws.DPH, s2Z), -s2Z);
+      bld.ptr(d, 19, last(ws.DPH16, x2Z), -x2Z);
+      d.ld[3] = 2 * Z; d.n16[0] = 2 * ctZ; d.i[0] = Z; d.i[1] = residual_posterior; d.i[2] = stride; d.i[3] = T - 1;
+      d.f[0] = fn_floor; d.f[1] = beta; d.f[2] = sd_eps;
+    }
+    // B7: heads -> last hidden layers;  B8, B9: hidden layers 2, 1  (prior | posterior)
+    for (int l = 3; l >= 1; --l) {
+      lin(l == 3 ? ws.DPH16 : ws.DP16[l], l == 3 ? x2Z : xH, l == 3 ? ws.phT : ws.pT[l], l == 3 ? 2 * Z : H, nullptr, 0, 0, rs.P[l - 1], sH, H, ws.DP[l - 1], sH, H,
+          ws.DP16[l - 1], xH, ctH, ctH, 0, half, 0);
+      lin(l == 3 ? ws.DQH16 : ws.DQ16[l], l == 3 ? x2Z : xH, l == 3 ? ws.qhT : ws.qT[l], l == 3 ? 2 * Z : H, nullptr, 0, 0, rs.Q[l - 1], sH, H, ws.DQ[l - 1], sH, H,
+          ws.DQ16[l - 1], xH, ctH, ctH, half, half, 0);
+    }
+    BLVM_REQUIRE(!bld.overflow, "vrnn_bwd: persistent program overflow");
+    rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
+    if (rc) return rc;
+    // sentinel-fill what the launch polls: GA, GB (single words) and the T16 copies
+    BLVM_HIP(hipMemsetAsync(ws.GA, 0xFF, (size_t)(reinterpret_cast<char*>(ws.x16_end) - reinterpret_cast<char*>(ws.GA)), s));
+    rc = pchain_launch(bld.p, s);
+    if (rc) return rc;
     return batched(0, n, s);
   }
   const int chunk = overlap_chunk_steps();

@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "benchmarking-lvms_amd"))
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+from blvm import _hip  # noqa: E402
 from blvm.data.transforms import MuLawEncode  # noqa: E402
 from blvm.evaluation import Tracker  # noqa: E402
 from blvm.training.ddp import FlatGradAllReduce  # noqa: E402
@@ -22,7 +23,7 @@ class SyntheticUtterances:
     """Batches of synthetic mu-law waveforms with the shape of the reference's collated batches: x [B,T] float32 in
     (-1,1) zero-padded on the right, x_sl [B] int64 on the host, longest first (batchers.py:145-151)."""
 
-    def __init__(self, n_utterances, max_length, batch_size, batch_len, bits, seed, rank=0, world=1, min_frac=0.5):
+    def __init__(self, n_utterances, max_length, batch_size, batch_len, bits, seed, rank=0, world=1, min_frac=0.5, train=True):
         g = torch.Generator().manual_seed(seed)
         lens = (torch.rand(n_utterances, generator=g) * (1 - min_frac) + min_frac) * max_length
         lens = lens.long().clamp(min=1).sort(descending=True).values.tolist()
@@ -35,7 +36,12 @@ class SyntheticUtterances:
                 cur = []
         if cur:
             self.batches.append(cur)
-        self.batches = [b[rank::world] for b in self.batches if len(b[rank::world]) > 0]  # utterances shard by rank
+        # utterances shard by rank.  Every rank must take the same number of TRAINING steps (each one is a blocking all-reduce):
+        # a training batch with fewer utterances than ranks is dropped on every rank alike.  An evaluation batch is never dropped:
+        # ranks beyond its size get an empty shard and skip it (no per-step collective in evaluation).
+        if train:
+            self.batches = [b for b in self.batches if len(b) >= world]
+        self.batches = [b[rank::world] for b in self.batches]
         self.mulaw, self.seed, self.rank = MuLawEncode(bits), seed, rank
 
     def __len__(self):
@@ -43,6 +49,9 @@ class SyntheticUtterances:
 
     def __iter__(self):
         for i, lens in enumerate(self.batches):
+            if not lens:  # empty evaluation shard
+                yield None, None
+                continue
             g = torch.Generator().manual_seed(self.seed * 7919 + i * 31 + self.rank)
             T = max(lens)
             x = self.mulaw((torch.rand(len(lens), T, generator=g) * 2 - 1) * 0.5)
@@ -85,9 +94,8 @@ def real_data_loaders(args, num_bits, rank, world, mu_law=True):
             return len(self.loader)
 
         def __iter__(self):
-            for (x, x_sl), _ in self.loader:
-                if x.numel():
-                    yield x, x_sl
+            for xy, _ in self.loader:  # an empty evaluation shard collates to (None, None)
+                yield xy if xy is not None else (None, None)
 
     return _XY(mk(train_ds, tr_s)), _XY(mk(test_ds, te_s))
 
@@ -110,7 +118,7 @@ def setup(args):
     return rank, world, dev
 
 
-def run(args, model, forward_train, forward_eval, best_metric, num_bits, split_eval_fn=None, clip=True):
+def run(args, model, forward_train, forward_eval, best_metric, num_bits, split_eval_fn=None, clip=True, skip_nonfinite=False):
     """forward_train(model, x, x_sl) / forward_eval(model, x, x_sl) -> (loss, metrics, outputs)."""
     rank, world, dev = setup(args)
     model = model.to(dev)
@@ -121,7 +129,7 @@ def run(args, model, forward_train, forward_eval, best_metric, num_bits, split_e
     bs, bl = args.batch_size, (args.batch_len or (0 if args.batch_size else 64 * 16000))
     if args.dataset == "synthetic":
         train = SyntheticUtterances(args.synthetic_utterances, args.synthetic_length, bs, bl, num_bits, args.seed, rank, world)
-        test = SyntheticUtterances(max(args.synthetic_utterances // 8, 1), args.synthetic_length, bs, bl, num_bits, args.seed + 1, rank, world)
+        test = SyntheticUtterances(max(args.synthetic_utterances // 8, 1), args.synthetic_length, bs, bl, num_bits, args.seed + 1, rank, world, train=False)
     else:
         train, test = real_data_loaders(args, num_bits, rank, world, mu_law=getattr(args, "input_coding", "mu_law") == "mu_law")
     tracker = Tracker()
@@ -138,12 +146,17 @@ def run(args, model, forward_train, forward_eval, best_metric, num_bits, split_e
                 reducer(float(x_sl.sum()))
             if clip:
                 torch.nn.utils.clip_grad_value_(params, args.max_grad_value)
-                torch.nn.utils.clip_grad_norm_(params, args.max_grad_norm)
+                total_norm = torch.nn.utils.clip_grad_norm_(params, args.max_grad_norm)
+                if skip_nonfinite:  # experiment_srnn_audio.py:236-240 skips the update when the gradient norm is NaN / inf; here
+                    # the gradients are zeroed on the device instead (no host sync): Adam then sees a zero gradient for this step
+                    torch._foreach_mul_([p.grad for p in params if p.grad is not None], torch.isfinite(total_norm).to(torch.float32))
             optimizer.step()
             tracker.update(metrics)
             frames += int(x_sl.sum())
         scheduler.step()
         torch.cuda.synchronize()
+        _hip.check_async("training epoch")
+        tracker.all_reduce("train")
         if rank == 0:
             vals = ", ".join(f"{k} {v:.4f}" for k, v in tracker.values("train").items())
             print(f"epoch {epoch:4d} | {frames * world / (time.time() - t0):.3e} frames/s | {vals}", flush=True)
@@ -151,11 +164,14 @@ def run(args, model, forward_train, forward_eval, best_metric, num_bits, split_e
             model.eval()
             with torch.no_grad():
                 for x, x_sl in tracker.steps(test, source="test"):
+                    if x is None:  # this rank's shard of the batch is empty
+                        continue
                     x = x.to(dev, non_blocking=True)
                     if split_eval_fn is not None:
                         split_eval_fn(model, x, x_sl, tracker)
                     else:
                         tracker.update(forward_eval(model, x, x_sl)[1])
+            tracker.all_reduce("test")  # the whole test set's value on every rank (rank 0 decides about the checkpoint)
             value = tracker.values("test").get(best_metric)
             if rank == 0 and value is not None:
                 print(f"           test {best_metric} {value:.4f}", flush=True)

@@ -31,7 +31,7 @@ if __name__ == "__main__":
     args = parser.parse_args()
     model = SRNNAudio(likelihood=args.likelihood, input_size=args.stack_frames, hidden_size=args.hidden_size,
                       latent_size=args.latent_size, num_mix=args.num_mix, num_bins=2**args.num_bits,
-                      residual_posterior=args.residual_posterior, smoothing=args.smoothing)  # fmt: skip
+                      residual_posterior=args.residual_posterior, smoothing=args.smoothing, dropout=args.dropout)  # fmt: skip
     beta = CosineAnnealer(anneal_steps=args.beta_anneal_steps, start_value=args.beta_start_value, end_value=1)
     fn = CosineAnnealer(anneal_steps=args.free_nats_steps // 2, constant_steps=args.free_nats_steps // 2,
                         start_value=args.free_nats_start_value, end_value=0)  # fmt: skip
@@ -44,4 +44,4 @@ if __name__ == "__main__":
             state = dict(d_0=out.d_n, a_0=out.a_n, z_0=out.z_n)
 
     run(args, model, lambda m, x, sl: m(x, sl, beta=beta.step(), free_nats=fn.step()), lambda m, x, sl: m(x, sl), "elbo",
-        args.num_bits, split_eval if args.split_eval and args.random_segment_size else None)  # fmt: skip
+        args.num_bits, split_eval if args.split_eval and args.random_segment_size else None, skip_nonfinite=True)  # fmt: skip

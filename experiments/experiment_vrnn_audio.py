@@ -32,6 +32,8 @@ g.add_argument("--split_eval", default=False, type=str2bool)
 
 if __name__ == "__main__":
     args = parser.parse_args()
+    if args.dropout:  # the reference's VRNNAudio takes no dropout either (blvm/models/vrnn.py:437-447): the flag exists for CLI parity
+        parser.error("--dropout: VRNNAudio has no dropout; leave it at 0")
     model = VRNNAudio(likelihood=args.likelihood, input_size=args.stack_frames, hidden_size=args.hidden_size,
                       latent_size=args.latent_size, num_mix=args.num_mix, num_bins=2**args.num_bits,
                       condition_h_on_x=args.condition_h_on_x, condition_x_on_h=args.condition_x_on_h,

@@ -43,13 +43,13 @@ int blvm_async_errors(unsigned* last_code);
  * BLVM_PCHAIN_MAX_B / BLVM_PCHAIN=0).  `waves` = 8 or 16 waves per workgroup of the persistent kernels (other values: unchanged). */
 int blvm_pchain_configure(int max_batch, int waves);
 /* Diagnostics: while `device_buffer` (64 zero-initialised uint64 in device memory, caller-owned) is installed, the persistent kernels
- * add the 100 MHz wall-clock ticks two of their workgroups spend in every link of the step program (waits included): words
- * [0..15] a workgroup on the critical path, [16..31] one that only runs deferred tiles ([64..95]: the same for backward kernels;
- * pass 128 words).  NULL uninstalls. */
+ * add the 100 MHz wall-clock ticks two of their workgroups spend in every descriptor of the step program (waits included): words
+ * [0..15] workgroup 0 (critical path), [16..31] the first workgroup of the deferred range ([64..95]: the same for backward
+ * programs; pass 128 words).  NULL uninstalls. */
 int blvm_pchain_profile(unsigned long long* device_buffer);
-/* Diagnostics: placement experiment bits of the persistent kernels (results unchanged): 1 two workgroup ranges take the links in
- * turn, 2 the GRU hidden projection on its own range, 4 XCD-aware column-tile placement, 8 / 16 one-word canary polls in front of
- * the operand polls of the critical / deferred tiles. */
+/* Diagnostics: placement bits of the persistent programs (results unchanged; default 20): 4 XCD-aware column-tile placement (a
+ * column tile's row tiles on one XCD, so every XCD's L2 holds 1/8 of each weight matrix), 16 one-word canary poll in front of the
+ * operand polls of tiles off the critical path. */
 int blvm_pchain_tune(int bits);
 /* n host integers -> device memory through kernel arguments (asynchronous on `stream`; a pageable hipMemcpy would block the host
  * until the stream has drained).  Carries the batch's lengths `x_sl` (`blvm/data/batchers.py:145-151` hands them over on the host). */

@@ -111,3 +111,80 @@ def test_reducer_hands_out_bucket_slices_without_a_process_group():
     red(10.0)
     for p, e in zip(params, expect2):
         torch.testing.assert_close(p.grad, e, rtol=1e-6, atol=0)
+
+
+def _steps_worker(rank, world, port, q):
+    for p in (PKG, os.path.join(ROOT, "experiments"), ROOT):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from blvm.data.samplers import LengthEvalSampler, LengthTrainSampler
+    from blvm.evaluation import LossMetric, Tracker
+
+    import _common as C
+
+    # 5 utterances in batches of 2 -> a 1-utterance tail batch: fewer examples than ranks
+    train = C.SyntheticUtterances(5, 64, 2, 0, 8, seed=3, rank=rank, world=world, train=True)
+    test = C.SyntheticUtterances(5, 64, 2, 0, 8, seed=3, rank=rank, world=world, train=False)
+    n_train = sum(1 for _ in train)
+    shards = [None if x is None else int(x.shape[0]) for x, _ in test]
+    # the same rule in the length-bucketed samplers (lengths chosen so that the last batch holds one example)
+    lens = [10, 10, 10, 10, 10]
+    tr = LengthTrainSampler(lens, batch_len=20, min_pool_size=1, drop_last=False, shuffle=False, rank=rank, world_size=world)
+    ev = LengthEvalSampler(lens, batch_len=20, rank=rank, world_size=world)
+    tr_steps, ev_shards = [len(b) for b in tr], [len(b) for b in ev]
+    # every training step is a blocking collective: both ranks must reach it the same number of times
+    flat = torch.zeros(1)
+    for _ in range(n_train):
+        dist.all_reduce(flat)
+    # metric merge across ranks = the reference's weighted running mean over all examples
+    tracker = Tracker()
+    if rank == 0:
+        tracker.update([LossMetric(torch.tensor([1.0, 3.0]), weight_by=2)], source="test")
+    else:
+        tracker.update([LossMetric(torch.tensor([8.0]), weight_by=1)], source="test")
+    tracker.all_reduce("test")
+    q.put((rank, n_train, shards, tr_steps, ev_shards, len(tr), tracker.values("test")["loss"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_take_the_same_number_of_steps_with_a_one_example_tail_batch():
+    """a global batch with fewer examples than ranks must not leave a rank without a step (the other would hang in
+    the gradient all-reduce): training drops it on every rank, evaluation hands out an empty shard; metrics merge across ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_steps_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, n0, sh0, tr0, ev0, ltr0, v0), (_, n1, sh1, tr1, ev1, ltr1, v1) = res
+    assert n0 == n1 == 2  # the 1-utterance training batch is dropped on both ranks
+    assert sh0 == [1, 1, 1] and sh1 == [1, 1, None]  # evaluation keeps it: rank 1 gets an empty shard
+    assert tr0 == tr1 == [1, 1] and ltr0 == ltr1 == 2
+    assert sorted(ev0) == [1, 1, 1] and sorted(ev1) == [0, 1, 1]
+    assert v0 == v1 == pytest.approx((1.0 + 3.0 + 8.0) / 3)
+
+
+def test_bench_self_launches_two_ranks():
+    """`bench.py --gpus 2` run bare starts its own two ranks (before any GPU call) and counts them with an all-reduce; a world
+    size that differs from --gpus is refused in both directions."""
+    import json
+    import subprocess
+
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2
+    # a launcher-provided world that disagrees with --gpus is an error, not a silently mislabelled number
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], env=env2, capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in (bad.stderr + bad.stdout)

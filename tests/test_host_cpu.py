@@ -237,3 +237,47 @@ def test_host_helper_modules_the_entry_points_import(tmp_path):
     _, ck = load_run(str(tmp_path), model=m2, optimizer=opt2, lr_scheduler=sched2)
     assert all(torch.equal(p, q) for p, q in zip(m.state_dict().values(), m2.state_dict().values()))
     assert get_learning_rates_dict(opt2)["lr"] == get_learning_rates_dict(opt)["lr"] and "optimizer_state_dict" in ck
+
+
+def test_persistent_chain_tile_iterator_covers_every_tile_once(tmp_path):
+    """Host-side check of the placement logic of the persistent kernels (csrc/pchain.h TileIter): for plain and XCD-aware
+    placement, every (row tile, column tile) of a link is visited exactly once and only by workgroups of the link's range — a
+    workgroup outside the range must see no tile (an out-of-range tile index is an out-of-bounds access on the GPU)."""
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = tmp_path / "tile_iter_test"
+    src = os.path.join(ROOT, "tests", "host", "tile_iter_test.hip")
+    inc = [f"-I{os.path.join(ROOT, 'include')}", f"-I{os.path.join(ROOT, 'benchmarking-lvms_amd', 'csrc')}"]
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-w", *inc, src, "-o", str(exe)], check=True, timeout=600)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "0 errors" in out.stdout, out.stdout + out.stderr
+
+
+def test_save_run_load_run_round_trip_with_the_weights_only_loader(tmp_path):
+    """checkpoints are read back with loaders that execute nothing from the file."""
+    from blvm.training.restore import load_run, save_run
+
+    torch.manual_seed(0)
+    m = VRNNAudio(likelihood="DMoL", input_size=8, hidden_size=32, latent_size=16)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[2], gamma=0.5)
+    for p in m.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()
+    sched.step()
+    from types import SimpleNamespace
+
+    save_run(str(tmp_path), m, opt, sched, tracker=SimpleNamespace(epoch=3))
+    torch.manual_seed(1)
+    m2 = VRNNAudio(likelihood="DMoL", input_size=8, hidden_size=32, latent_size=16)
+    opt2 = torch.optim.Adam(m2.parameters(), lr=1e-3)
+    sched2 = torch.optim.lr_scheduler.MultiStepLR(opt2, milestones=[2], gamma=0.5)
+    m2, ck = load_run(str(tmp_path), m2, opt2, sched2)
+    assert ck["epoch"] == 3
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert opt2.state_dict()["state"][0]["step"] == opt.state_dict()["state"][0]["step"]
+    m3 = type(m).load(str(tmp_path))  # BaseModel.load: class name + kwargs + state dict, all through weights_only loads
+    assert torch.equal(m3.state_dict()["vrnn.encoder.2.weight"], m.state_dict()["vrnn.encoder.2.weight"])
