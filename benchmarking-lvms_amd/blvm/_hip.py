@@ -69,6 +69,8 @@ _SIGNATURES = {
     "blvm_pchain_configure": (c_int, [c_int, c_int]),
     "blvm_pchain_profile": (c_int, [c_void_p]),
     "blvm_pchain_tune": (c_int, [c_int]),
+    "blvm_pchain_chain_probe": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "blvm_pchain_rows_to_t16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "blvm_gemm_f32": (c_int, [c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                               c_void_p, c_int, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
     "blvm_act_bwd_f32": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),

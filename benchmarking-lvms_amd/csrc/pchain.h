@@ -31,27 +31,25 @@ constexpr unsigned SENTINEL = 0xFFFFFFFFu;          // hipMemsetAsync(buf, 0xFF,
 constexpr unsigned SPIN_LIMIT = 1u << 22;           // polls before a wave gives up (~seconds)
 
 // ---- write-through / L1-bypassing accesses ---------------------------------------------------------------------------------
-__device__ __forceinline__ f32x4 ld_sc1_x4(const float* p) {
-  f32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-  return v;
+// Buffer instructions with the sc1 cache bit through the compiler's builtins (aux = 16), NOT inline asm: the compiler then knows
+// when a loaded value is available and places the waits itself.  With asm loads it believed the destination registers valid at
+// issue: a copy it inserted between issue and wait (a loop-carried register, for one) read them early — results depended on timing.
+// A buffer resource is (base pointer, 4 GB range); the lane's address is base + a 32-bit byte offset.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr int AUX_SC1 = 16;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base) {  // base must be wave-uniform
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xFFFFFFFFu, 0x00020000);
 }
-__device__ __forceinline__ float ld_sc1(const float* p) {
-  float v;
-  asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-  return v;
+__device__ __forceinline__ f32x4 ld_sc1_x4(rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, AUX_SC1));
 }
-__device__ __forceinline__ void st_sc1(float* p, float v) {
-  asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+__device__ __forceinline__ float ld_sc1(rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, AUX_SC1));
 }
-__device__ __forceinline__ void st_sc1_x4(float* p, f32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+__device__ __forceinline__ void st_sc1(rsrc_t r, unsigned byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)byte_off, 0, AUX_SC1);
 }
-// the asm loads above are invisible to the compiler's own s_waitcnt insertion: wait explicitly, with the loaded registers as
-// operands so that no use of them can be scheduled above the wait
-__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void wait_vm0(f32x4& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)::"memory"); }
-__device__ __forceinline__ void wait_vm0(float& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)::"memory"); }
 
 __device__ __forceinline__ bool is_sentinel(float x) { return __float_as_uint(x) == SENTINEL; }
 __device__ __forceinline__ bool any_sentinel(const f32x4& v) {
@@ -112,43 +110,44 @@ struct MapPairs { static constexpr int of(int g) { return g >> 1; } };  // produ
 // is then the T16 copy ([rt*16, K] as 1 KB blocks) of the activation, `lda` is ignored, and the fragments are re-read with sc1
 // loads until no word is the sentinel (rows >= nrows of the last row tile are never written and never looked at).  One trip = CH chunks: all weight fragments first (they do
 // not depend on the wait), then the activation fragments, then 4*CH*G MFMAs; a wave's chunk sum runs in ascending k.
-template <int NW, int GA, int G, class AMap, int CH>
-__device__ __forceinline__ void mgemm_trip(const float* const (&ap)[GA], const float* const (&wp)[G], int kc, int n, bool aok, bool polled,
-                                           f32x4 (&acc)[G], Poll& pl) {
-  // ONE body for 1 .. CH chunks (n, wave-uniform): chunk u exists when u < n.  Polled operands are T16 slabs (k advances by 16
-  // floats per k), plain ones row-major.
+// `mid`: runs once per tile, right after the first trip's operand loads have been ISSUED and before anything waits on them: the
+// place for the epilogue's own operand loads (bias, addend, gate, saved values), so that they travel with the operands instead of
+// in front of them (a wait on them would also sit out the previous tile's write-through stores: gfx9 counts stores in vmcnt).
+struct NoMid {
+  __device__ __forceinline__ void operator()() const {}
+};
+
+template <int NW, int GA, int G, class AMap, int CH, class Mid>
+__device__ __forceinline__ void mgemm_trip(const rsrc_t (&ar)[GA], unsigned aoff, const float* const (&ap)[GA], const float* const (&wp)[G], int kc,
+                                           bool aok, bool polled, f32x4 (&acc)[G], Poll& pl, Mid& mid, bool& mid_pending) {
+  // Exactly CH chunks, no per-chunk guards: a guard around each chunk's load and the same guard around its sentinel check are one
+  // region to the compiler, which then waits after EVERY chunk's load (one memory round trip per chunk instead of one per trip).
+  // Polled operands are T16 slabs read through buffer resources (ar, byte offset aoff + 64 bytes per k), plain ones row-major (ap).
   constexpr int STEP = NW * 16;
   f32x4 w[G][CH], a[GA][CH];
 #pragma unroll
   for (int u = 0; u < CH; ++u)
-    if (u < n) {
 #pragma unroll
-      for (int g = 0; g < G; ++g) w[g][u] = *reinterpret_cast<const f32x4*>(wp[g] + 16 * (size_t)(kc + u * STEP));
-    }
+    for (int g = 0; g < G; ++g) w[g][u] = *reinterpret_cast<const f32x4*>(wp[g] + 16 * (size_t)(kc + u * STEP));
   if (!polled) {
 #pragma unroll
     for (int u = 0; u < CH; ++u)
-      if (u < n) {
 #pragma unroll
-        for (int g = 0; g < GA; ++g) a[g][u] = *reinterpret_cast<const f32x4*>(ap[g] + kc + u * STEP);
-      }
+      for (int g = 0; g < GA; ++g) a[g][u] = *reinterpret_cast<const f32x4*>(ap[g] + kc + u * STEP);
+    if (mid_pending) { mid(); mid_pending = false; }
   } else {
     unsigned spins = 0;
     for (;;) {
 #pragma unroll
       for (int u = 0; u < CH; ++u)
-        if (u < n) {
 #pragma unroll
-          for (int g = 0; g < GA; ++g) a[g][u] = ld_sc1_x4(ap[g] + 16 * (size_t)(kc + u * STEP));
-        }
-      wait_vm0();
+        for (int g = 0; g < GA; ++g) a[g][u] = ld_sc1_x4(ar[g], aoff + 64u * (unsigned)(kc + u * STEP));
+      if (mid_pending) { mid(); mid_pending = false; }  // behind the first poll's loads, in front of the first wait
       bool bad = false;
 #pragma unroll
       for (int u = 0; u < CH; ++u)
-        if (u < n) {
 #pragma unroll
-          for (int g = 0; g < GA; ++g) { wait_vm0(a[g][u]); bad |= any_sentinel(a[g][u]); }
-        }
+        for (int g = 0; g < GA; ++g) bad |= any_sentinel(a[g][u]);
 #ifdef PCHAIN_TPROF
       if (spins == 0 && pl.t_first == 0) pl.t_first = wall_clock64();
       pl.polls++;
@@ -166,46 +165,50 @@ __device__ __forceinline__ void mgemm_trip(const float* const (&ap)[GA], const f
   }
 #pragma unroll
   for (int u = 0; u < CH; ++u)
-    if (u < n) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+    for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int g = 0; g < G; ++g)
-          acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(aok ? a[AMap::of(g)][u][e] : 0.f, w[g][u][e], acc[g], 0, 0, 0);
-    }
+      for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(aok ? a[AMap::of(g)][u][e] : 0.f, w[g][u][e], acc[g], 0, 0, 0);
 }
 
-template <int NW, int GA, int G, class AMap>
+template <int NW, int GA, int G, class AMap, class Mid = NoMid>
 __device__ __forceinline__ void mgemm16(const float* const (&A)[GA], const int (&lda)[GA], bool polled, int r0, int nrows,
-                                        const float* const (&W)[G], const int (&c0)[G], int K, f32x4 (&acc)[G], Poll& pl) {
+                                        const float* const (&W)[G], const int (&c0)[G], int K, f32x4 (&acc)[G], Poll& pl, Mid mid = Mid()) {
   constexpr int STEP = NW * 16;
-  // fragment registers of a trip: 4 * CH * (G + GA); keep it <= 64 (32 for 1024-thread workgroups: 128 VGPRs per lane)
+  // fragment registers of a trip: 4 * CH * (G + GA); trips of 6 / 4 / 2 / 1 chunks (K = 256, 512, 1536 on 8 waves: 2, 4, 6 + 6)
   constexpr int FR = 12 / (G + GA);
-  constexpr int MAXCH = FR >= 6 ? 6 : (FR >= 4 ? 4 : (FR >= 2 ? 2 : 1));  // single products: 6 (K = 1536 on 8 waves is two trips)
+  constexpr int MAXCH = FR >= 6 ? 6 : (FR >= 4 ? 4 : (FR >= 2 ? 2 : 1));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rr = lane & 15, q = lane >> 4;
   const bool aok = (r0 + rr) < nrows;
+  rsrc_t ar[GA];
   const float* ap[GA];
   const float* wp[G];
 #pragma unroll
-  for (int g = 0; g < GA; ++g)
-    ap[g] = polled ? A[g] + (size_t)(r0 >> 4) * 16 * K + 4 * lane : A[g] + (size_t)(aok ? r0 + rr : r0) * lda[g] + 4 * q;
+  for (int g = 0; g < GA; ++g) {
+    ar[g] = make_rsrc(A[g]);
+    ap[g] = A[g] + (size_t)(aok ? r0 + rr : r0) * (polled ? 0 : lda[g]) + 4 * q;
+  }
+  const unsigned aoff = 4u * ((unsigned)(r0 >> 4) * 16u * (unsigned)K + 4u * (unsigned)lane);  // T16: row tile's slab + this lane's fragment
 #pragma unroll
   for (int g = 0; g < G; ++g) wp[g] = W[g] + (size_t)c0[g] * K + 4 * lane;
   int nch = (K / 16 - wave + NW - 1) / NW;  // chunks wave, wave + NW, ... below K / 16 (wave-uniform)
-  for (int kc = wave * 16; nch > 0; nch -= MAXCH, kc += MAXCH * STEP)
-    mgemm_trip<NW, GA, G, AMap, MAXCH>(ap, wp, kc, nch < MAXCH ? nch : MAXCH, aok, polled, acc, pl);
+  int kc = wave * 16;
+  bool mid_pending = true;
+  if constexpr (MAXCH >= 6) for (; nch >= 6; nch -= 6, kc += 6 * STEP) mgemm_trip<NW, GA, G, AMap, 6>(ar, aoff, ap, wp, kc, aok, polled, acc, pl, mid, mid_pending);
+  if constexpr (MAXCH >= 4) for (; nch >= 4; nch -= 4, kc += 4 * STEP) mgemm_trip<NW, GA, G, AMap, 4>(ar, aoff, ap, wp, kc, aok, polled, acc, pl, mid, mid_pending);
+  if constexpr (MAXCH >= 2) for (; nch >= 2; nch -= 2, kc += 2 * STEP) mgemm_trip<NW, GA, G, AMap, 2>(ar, aoff, ap, wp, kc, aok, polled, acc, pl, mid, mid_pending);
+  for (; nch >= 1; nch -= 1, kc += STEP) mgemm_trip<NW, GA, G, AMap, 1>(ar, aoff, ap, wp, kc, aok, polled, acc, pl, mid, mid_pending);
+  if (mid_pending) mid();  // a wave without chunks
 }
 
 // N epilogue words that other workgroups of this launch produce (sc1 loads until none is the sentinel); `need`: this lane uses them
 template <int N>
-__device__ __forceinline__ void poll_words(const float* const (&p)[N], float (&v)[N], bool need, Poll& pl) {
+__device__ __forceinline__ void poll_words(const rsrc_t (&r)[N], const unsigned (&off)[N], float (&v)[N], bool need, Poll& pl) {
   unsigned spins = 0;
   for (;;) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = ld_sc1(p[i]);
-#pragma unroll
-    for (int i = 0; i < N; ++i) wait_vm0(v[i]);
+    for (int i = 0; i < N; ++i) v[i] = ld_sc1(r[i], off[i]);
     bool bad = false;
 #pragma unroll
     for (int i = 0; i < N; ++i) bad |= is_sentinel(v[i]);
@@ -255,14 +258,13 @@ struct TileIter {
 __device__ __forceinline__ void canary_wait(const float* A16, int r0, int K, Poll& pl) {
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x, np = K >> 4;
-    const float* base = A16 + (size_t)(r0 >> 4) * 16 * K;  // word 0 of a block = row r0, always written
+    const rsrc_t r = make_rsrc(A16 + (size_t)(r0 >> 4) * 16 * K);  // word 0 of a block = row r0, always written
     unsigned spins = 0;
     for (;;) {
       bool bad = false;
       for (int p0 = 0; p0 < np; p0 += 64) {
         const int pr = p0 + lane;
-        float v = ld_sc1(base + 256 * (size_t)(pr < np ? pr : 0));
-        wait_vm0(v);
+        const float v = ld_sc1(r, 1024u * (unsigned)(pr < np ? pr : 0));
         bad |= (pr < np) && is_sentinel(v);
       }
       if (!__any(bad) || pl.dead) break;
@@ -289,12 +291,12 @@ __device__ __forceinline__ Out out_rm(float* p, int ld, bool sc1 = false) { retu
 __device__ __forceinline__ Out out_both(float* p, int ld, float* x16, int n16, bool sc1 = false) { return Out{p, ld, sc1, x16, n16}; }
 __device__ __forceinline__ void put(const Out& o, int r0, int c0, int row, int col, float x) {
   if (o.rm != nullptr) {
-    if (o.rm_sc1) st_sc1(o.rm + (size_t)row * o.ld + col, x);
+    if (o.rm_sc1) st_sc1(make_rsrc(o.rm), 4u * ((unsigned)row * (unsigned)o.ld + (unsigned)col), x);
     else o.rm[(size_t)row * o.ld + col] = x;
   }
   if (o.x16 != nullptr) {
     const int rr = row - r0, cc = col - c0;
-    st_sc1(o.x16 + ((size_t)(r0 >> 4) * o.n16 + (c0 >> 4)) * 256 + (rr + 16 * (cc >> 2)) * 4 + (cc & 3), x);
+    st_sc1(make_rsrc(o.x16), 4u * ((((unsigned)(r0 >> 4) * (unsigned)o.n16 + (unsigned)(c0 >> 4)) << 8) + (unsigned)((rr + 16 * (cc >> 2)) * 4 + (cc & 3))), x);
   }
 }
 
@@ -316,15 +318,18 @@ __device__ __forceinline__ void tile_lin(const float* A, int lda, bool a_polled,
   const unsigned long long t0 = wall_clock64();
   pl.t_first = 0; pl.polls = 0;
 #endif
-  const float e_bias = bias ? bias[col] : 0.f;
-  const float e_gate = gate ? gate[(size_t)rowc * ldgate + col] : 1.f;
-  float e_add = (add && !add_polled) ? add[(size_t)rowc * ldadd + col] : 0.f;
+  float e_bias = 0.f, e_gate = 1.f, e_add = 0.f;
+  auto prefetch = [&]() {  // the epilogue's operands, requested behind the product's operand loads
+    if (bias) e_bias = bias[col];
+    if (gate) e_gate = gate[(size_t)rowc * ldgate + col];
+    if (add && !add_polled) e_add = add[(size_t)rowc * ldadd + col];
+  };
   f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
   {
     const float* const As[1] = {A};
     const float* const Ws[1] = {W};
     const int la[1] = {lda}, cs[1] = {c0};
-    mgemm16<NW, 1, 1, MapSame>(As, la, a_polled, r0, B, Ws, cs, K, acc, pl);
+    mgemm16<NW, 1, 1, MapSame>(As, la, a_polled, r0, B, Ws, cs, K, acc, pl, prefetch);
   }
   float v[1];
   reduce_tiles<1, NW>(acc, red, v);
@@ -337,9 +342,10 @@ __device__ __forceinline__ void tile_lin(const float* A, int lda, bool a_polled,
 #endif
   if (threadIdx.x >= 256) return;
   if (add && add_polled) {
-    const float* const ps[1] = {add + (size_t)rowc * ldadd + col};
+    const rsrc_t rs[1] = {make_rsrc(add)};
+    const unsigned os[1] = {4u * ((unsigned)rowc * (unsigned)ldadd + (unsigned)col)};
     float ws[1];
-    poll_words<1>(ps, ws, own, pl);
+    poll_words<1>(rs, os, ws, own, pl);
     e_add = ws[0];
   }
   if (!own) return;
@@ -367,8 +373,8 @@ __device__ __forceinline__ void tile_head(const float* P, const float* Q, bool p
   const int row = r0 + (t >> 4), col = c0 + (t & 15);
   const bool own = threadIdx.x < 256 && row < B;
   const size_t oc = (size_t)(row < B ? row : r0) * Z + col;  // clamped: unconditional prefetch
-  const float b0 = bp[col], b1 = bp[Z + col], b2 = bq[col], b3 = bq[Z + col];
-  const float e = eps[oc];
+  float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f, e = 0.f;
+  auto prefetch = [&]() { b0 = bp[col]; b1 = bp[Z + col]; b2 = bq[col]; b3 = bq[Z + col]; e = eps[oc]; };
   f32x4 acc[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -376,7 +382,7 @@ __device__ __forceinline__ void tile_head(const float* P, const float* Q, bool p
     const float* const As[2] = {P, Q};
     const float* const Ws[4] = {Wp, Wp, Wq, Wq};
     const int la[2] = {H, H}, cs[4] = {c0, Z + c0, c0, Z + c0};
-    mgemm16<NW, 2, 4, MapPairs>(As, la, polled, r0, B, Ws, cs, H, acc, pl);
+    mgemm16<NW, 2, 4, MapPairs>(As, la, polled, r0, B, Ws, cs, H, acc, pl, prefetch);
   }
   float v[4];
   reduce_tiles<4, NW>(acc, red, v);
@@ -404,24 +410,31 @@ __device__ __forceinline__ void tile_head(const float* P, const float* Q, bool p
   o.raw_p[oo] = rp; o.raw_q[oo] = rq;
 }
 
-// GRU cell update of a [16 x 16] block of the state (vrnn.hip gru_stage_kernel): gi = X Wih^T (3 products, X [B,K] polled) + xg
-// (state-independent part of the input projection incl. b_ih, computed before the launch) ; gh = h_prev Whh^T + b_hh was produced
-// by another link of this launch (polled words), h_prev likewise.  Writes h_new (sc1) and the gates r, u, n (read after the launch).
+// GRU cell update of a [16 x 16] block of the state (vrnn.hip gru_stage_kernel, rssm.hip gru_cell_stage_kernel): gi = X Wih^T
+// (3 products, X [B,K] polled) + xg (state-independent part of the input projection incl. b_ih, computed before the launch) and /
+// or + b_ih ; gh = h_prev Whh^T + b_hh was produced by another link of this launch (polled words), h_prev likewise.  Writes h_new (sc1) and the gates r, u, n (read after the launch).
 template <int NW>
-__device__ __forceinline__ void tile_gru(const float* X, int ldx, bool polled, const float* Wih, int K, const float* xg, const float* gh,
-                                         const float* hprev, int ldh, int R, const Out& hnew, float* rg, float* ug, float* ng,
+__device__ __forceinline__ void tile_gru(const float* X, int ldx, bool polled, const float* Wih, int K, const float* xg, const float* bih,
+                                         const float* gh, const float* hprev, int ldh, int R, const Out& hnew, float* rg, float* ug, float* ng,
                                          int r0, int c0, int B, float* red, Poll& pl) {
   const int t = threadIdx.x & 255;
   const int row = r0 + (t >> 4), col = c0 + (t & 15);
   const bool own = threadIdx.x < 256 && row < B;
   const int rowc = row < B ? row : r0;
   const size_t o3 = (size_t)rowc * 3 * R + col;
-  const float x0 = xg ? xg[o3] : 0.f, x1 = xg ? xg[o3 + R] : 0.f, x2 = xg ? xg[o3 + 2 * R] : 0.f;
-  // gh and h_prev were stored links ago: request them NOW (under the operand wait) and only re-poll in the rare case one is missing
-  const float* const ps[4] = {gh + o3, gh + o3 + R, gh + o3 + 2 * R, hprev + (size_t)rowc * ldh + col};
-  float w[4];
+  // the state-independent part of the input projection: per row (xg, incl. b_ih: VRNN) and / or the bias alone (b_ih: RSSM);
+  // gh and h_prev were stored links ago: requested under the operand wait, re-polled only in the rare case one is missing
+  const rsrc_t rgh = make_rsrc(gh), rhp = make_rsrc(hprev);
+  const rsrc_t ps[4] = {rgh, rgh, rgh, rhp};
+  const unsigned po[4] = {4u * (unsigned)o3, 4u * (unsigned)(o3 + R), 4u * (unsigned)(o3 + 2 * R), 4u * ((unsigned)rowc * (unsigned)ldh + (unsigned)col)};
+  float w[4] = {0.f, 0.f, 0.f, 0.f}, x0 = 0.f, x1 = 0.f, x2 = 0.f;
+  auto prefetch = [&]() {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) w[i] = ld_sc1(ps[i]);
+    for (int i = 0; i < 4; ++i) w[i] = ld_sc1(ps[i], po[i]);
+    x0 = (xg ? xg[o3] : 0.f) + (bih ? bih[col] : 0.f);
+    x1 = (xg ? xg[o3 + R] : 0.f) + (bih ? bih[R + col] : 0.f);
+    x2 = (xg ? xg[o3 + 2 * R] : 0.f) + (bih ? bih[2 * R + col] : 0.f);
+  };
   f32x4 acc[3];
 #pragma unroll
   for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -429,14 +442,12 @@ __device__ __forceinline__ void tile_gru(const float* X, int ldx, bool polled, c
     const float* const As[1] = {X};
     const float* const Ws[3] = {Wih, Wih, Wih};
     const int la[1] = {ldx}, cs[3] = {c0, R + c0, 2 * R + c0};
-    mgemm16<NW, 1, 3, MapSame>(As, la, polled, r0, B, Ws, cs, K, acc, pl);
+    mgemm16<NW, 1, 3, MapSame>(As, la, polled, r0, B, Ws, cs, K, acc, pl, prefetch);
   }
   float v[3];
   reduce_tiles<3, NW>(acc, red, v);
   if (threadIdx.x >= 256) return;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) wait_vm0(w[i]);
-  if (__any(own && (is_sentinel(w[0]) | is_sentinel(w[1]) | is_sentinel(w[2]) | is_sentinel(w[3])))) poll_words<4>(ps, w, own, pl);
+  if (__any(own && (is_sentinel(w[0]) | is_sentinel(w[1]) | is_sentinel(w[2]) | is_sentinel(w[3])))) poll_words<4>(ps, po, w, own, pl);
   if (!own) return;
   const float r = sigmoidf_(v[0] + x0 + w[0]);
   const float u = sigmoidf_(v[1] + x1 + w[1]);
@@ -455,6 +466,7 @@ struct DzIn {
   const float *c_raw, *c_fn;  // [B] or null
   int t, stride, residual;
   float fn_floor, beta, sd_eps;
+  bool has_gemm = true;  // false: dz = dz_add alone (the last step of a chain whose z only feeds the next step)
 };
 template <int NW>
 __device__ __forceinline__ void tile_dz(const float* D, const float* WT, const float* D2, const float* WT2, bool polled, const float* dz_add,
@@ -465,37 +477,44 @@ __device__ __forceinline__ void tile_dz(const float* D, const float* WT, const f
   const bool own = threadIdx.x < 256 && row < B;
   const int rowc = row < B ? row : r0;
   const size_t o = (size_t)rowc * Z + col;
-  const float mq = a.mu_q[o], sq = a.sd_q[o], mp = a.mu_p[o], sp = a.sd_p[o], e = a.eps[o], rq = a.raw_q[o], rp = a.raw_p[o];
-  float c_raw = 0.f, c_fn = 0.f;
-  if (a.c_fn != nullptr || a.c_raw != nullptr) {
-    const bool live = (long long)a.t * a.stride < a.x_sl[rowc];
-    c_raw = (live && a.c_raw != nullptr) ? a.c_raw[rowc] : 0.f;
-    c_fn = (live && a.c_fn != nullptr) ? a.c_fn[rowc] : 0.f;
-  }
-  float e_add = (dz_add != nullptr && !add_polled) ? dz_add[(size_t)rowc * ld_add + col] : 0.f;
-  f32x4 acc[2];
-  acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (D2 != nullptr) {
-    const float* const As[2] = {D, D2};
-    const float* const Ws[2] = {WT, WT2};
-    const int la[2] = {H, H}, cs[2] = {c0, c0};
-    mgemm16<NW, 2, 2, MapId>(As, la, polled, r0, B, Ws, cs, H, acc, pl);
+  float mq = 0.f, sq = 1.f, mp = 0.f, sp = 1.f, e = 0.f, rq = 0.f, rp = 0.f, c_raw = 0.f, c_fn = 0.f, e_add = 0.f;
+  auto prefetch = [&]() {  // everything the forward saved for this step, requested behind the product's operand loads
+    mq = a.mu_q[o]; sq = a.sd_q[o]; mp = a.mu_p[o]; sp = a.sd_p[o]; e = a.eps[o]; rq = a.raw_q[o]; rp = a.raw_p[o];
+    if (a.c_fn != nullptr || a.c_raw != nullptr) {
+      const bool live = (long long)a.t * a.stride < a.x_sl[rowc];
+      c_raw = (live && a.c_raw != nullptr) ? a.c_raw[rowc] : 0.f;
+      c_fn = (live && a.c_fn != nullptr) ? a.c_fn[rowc] : 0.f;
+    }
+    if (dz_add != nullptr && !add_polled) e_add = dz_add[(size_t)rowc * ld_add + col];
+  };
+  float v[2] = {0.f, 0.f};
+  if (a.has_gemm) {  // uniform
+    f32x4 acc[2];
+    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (D2 != nullptr) {
+      const float* const As[2] = {D, D2};
+      const float* const Ws[2] = {WT, WT2};
+      const int la[2] = {H, H}, cs[2] = {c0, c0};
+      mgemm16<NW, 2, 2, MapId>(As, la, polled, r0, B, Ws, cs, H, acc, pl, prefetch);
+    } else {
+      f32x4 a1[1] = {acc[0]};
+      const float* const As[1] = {D};
+      const float* const Ws[1] = {WT};
+      const int la[1] = {H}, cs[1] = {c0};
+      mgemm16<NW, 1, 1, MapSame>(As, la, polled, r0, B, Ws, cs, H, a1, pl, prefetch);
+      acc[0] = a1[0];
+    }
+    reduce_tiles<2, NW>(acc, red, v);
   } else {
-    f32x4 a1[1] = {acc[0]};
-    const float* const As[1] = {D};
-    const float* const Ws[1] = {WT};
-    const int la[1] = {H}, cs[1] = {c0};
-    mgemm16<NW, 1, 1, MapSame>(As, la, polled, r0, B, Ws, cs, H, a1, pl);
-    acc[0] = a1[0];
+    prefetch();
   }
-  float v[2];
-  reduce_tiles<2, NW>(acc, red, v);
   if (threadIdx.x >= 256) return;
   if (dz_add != nullptr && add_polled) {
-    const float* const ps[1] = {dz_add + (size_t)rowc * ld_add + col};
+    const rsrc_t rs[1] = {make_rsrc(dz_add)};
+    const unsigned os[1] = {4u * ((unsigned)rowc * (unsigned)ld_add + (unsigned)col)};
     float ws[1];
-    poll_words<1>(ps, ws, own, pl);
+    poll_words<1>(rs, os, ws, own, pl);
     e_add = ws[0];
   }
   if (!own) return;
@@ -532,17 +551,18 @@ __device__ __forceinline__ void tile_dz(const float* D, const float* WT, const f
 }
 
 // Backward of a GRU state update fused with the products that complete the state gradient (vrnn.hip "B10"):
-//   g = g_in + D0 W0^T + D1 W1^T        (has_gemm; D0, D1 [B,K] polled, W0, W1 [R,K] T16; g_in: one polled word)
+//   g = g_in + g_add + D0 W0^T + D1 W1^T  (has_gemm: the products; D0, D1 [B,K] polled, W0, W1 [R,K] T16; has_gin: g_in, one polled
+//                                           word; g_add [B, ld_gadd]: a gradient reaching this state from outside the chain, or null)
 //   gate derivatives of the step whose OUTPUT state g refers to (has_gates): r, u, n, hn = (h_prev W_hh^T + b_hh)_n, h_prev saved
 //   by the forward; writes dgi = [dr, du, dn], dgh = [dr, du, dn * r] ([B,3R], row-major + T16) and ga = g * u + dd (polled words;
 //   dd [B, ldh] = gradient reaching h_prev from outside the chain).  Without gates (the step before the first) g goes to g_out.
 struct GrubIn {
-  const float *D0, *D1, *W0, *W1, *g_in;
-  const float *rg, *ug, *ng, *gh, *hprev, *dd;
-  int ldh;
+  const float *D0, *D1, *W0, *W1, *g_in, *g_add;
+  const float *rg, *ug, *ng, *gh, *hprev, *dd;  // dd may be null
+  int ldh, ld_gadd;
   Out dgi, dgh;
   float *ga, *g_out;
-  bool has_gemm, has_gates;
+  bool has_gemm, has_gin, has_gates;
 };
 template <int NW>
 __device__ __forceinline__ void tile_grub(const GrubIn& a, int K, int R, int r0, int c0, int B, float* red, Poll& pl) {
@@ -551,41 +571,45 @@ __device__ __forceinline__ void tile_grub(const GrubIn& a, int K, int R, int r0,
   const bool own = threadIdx.x < 256 && row < B;
   const int rowc = row < B ? row : r0;
   const size_t o = (size_t)rowc * R + col, o3 = (size_t)rowc * 3 * R + col;
-  float r = 0.f, u = 0.f, n = 0.f, hn = 0.f, hp = 0.f, dd = 0.f;
-  if (a.has_gates) {
-    r = a.rg[o]; u = a.ug[o]; n = a.ng[o]; hn = a.gh[o3 + 2 * R];
-    hp = a.hprev[(size_t)rowc * a.ldh + col];
-    dd = a.dd[(size_t)rowc * a.ldh + col];
-  }
-  float v[2] = {0.f, 0.f}, g0 = 0.f;
+  float r = 0.f, u = 0.f, n = 0.f, hn = 0.f, hp = 0.f, dd = 0.f, gadd = 0.f, g0 = 0.f;
+  auto prefetch = [&]() {  // g_in was stored a step ago: requested under the operand wait like the saved values
+    if (a.has_gin) g0 = ld_sc1(make_rsrc(a.g_in), 4u * (unsigned)o);
+    if (a.has_gates) {
+      r = a.rg[o]; u = a.ug[o]; n = a.ng[o]; hn = a.gh[o3 + 2 * R];
+      hp = a.hprev[(size_t)rowc * a.ldh + col];
+      if (a.dd != nullptr) dd = a.dd[(size_t)rowc * a.ldh + col];
+    }
+    if (a.g_add != nullptr) gadd = a.g_add[(size_t)rowc * a.ld_gadd + col];
+  };
+  float v[2] = {0.f, 0.f};
+  if (!a.has_gemm) prefetch();
   if (a.has_gemm) {
-    g0 = ld_sc1(a.g_in + o);  // stored a step ago: request it under the operand wait
     f32x4 acc[2];
     acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* const As[2] = {a.D0, a.D1};
     const float* const Ws[2] = {a.W0, a.W1};
     const int la[2] = {0, 0}, cs[2] = {c0, c0};
-    mgemm16<NW, 2, 2, MapId>(As, la, true, r0, B, Ws, cs, K, acc, pl);
+    mgemm16<NW, 2, 2, MapId>(As, la, true, r0, B, Ws, cs, K, acc, pl, prefetch);
     reduce_tiles<2, NW>(acc, red, v);
-    if (threadIdx.x >= 256) return;
-    wait_vm0(g0);
-    if (__any(own && is_sentinel(g0))) {
-      const float* const ps[1] = {a.g_in + o};
-      float ws[1];
-      poll_words<1>(ps, ws, own, pl);
-      g0 = ws[0];
-    }
+  }
+  if (threadIdx.x >= 256) return;
+  if (a.has_gin && __any(own && is_sentinel(g0))) {
+    const rsrc_t rs[1] = {make_rsrc(a.g_in)};
+    const unsigned os[1] = {4u * (unsigned)o};
+    float ws[1];
+    poll_words<1>(rs, os, ws, own, pl);
+    g0 = ws[0];
   }
   if (!own) return;
-  const float g = g0 + v[0] + v[1];
+  const float g = (g0 + gadd) + v[0] + v[1];
   if (!a.has_gates) { a.g_out[(size_t)row * R + col] = g; return; }
   const float dn_pre = g * (1.f - u) * (1.f - n * n);
   const float du_pre = g * (hp - n) * u * (1.f - u);
   const float dr_pre = dn_pre * hn * r * (1.f - r);
   put(a.dgi, r0, c0, row, col, dr_pre); put(a.dgi, r0, R + c0, row, R + col, du_pre); put(a.dgi, r0, 2 * R + c0, row, 2 * R + col, dn_pre);
   put(a.dgh, r0, c0, row, col, dr_pre); put(a.dgh, r0, R + c0, row, R + col, du_pre); put(a.dgh, r0, 2 * R + c0, row, 2 * R + col, dn_pre * r);
-  st_sc1(a.ga + (size_t)row * R + col, g * u + dd);
+  st_sc1(make_rsrc(a.ga), 4u * ((unsigned)row * (unsigned)R + (unsigned)col), g * u + dd);
 }
 
 // =================================================================================================================================
@@ -660,5 +684,18 @@ inline int range_for(int tiles, int avail) { return std::max(8, std::min(avail &
 
 // enqueue the persistent launch of a program (pchain.hip); grid = highest workgroup any descriptor names
 int pchain_launch(const pchain::Program& prog, hipStream_t stream);
+// dst = T16 copy [ceil(B/16)*16, K] of the rows of src [B, K] (row stride ld; null: zeros); rows >= B are left alone (never read)
+int pchain_rows_to_t16(const float* src, int ld, int B, int K, float* dst, hipStream_t stream);
+inline int device_cus() {
+  static int v = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return n;
+  }();
+  return v;
+}
+constexpr int kPchainCarveMaxB = 128;  // the persistent kernels' extra buffers are carved for batches up to this size only
+inline bool pchain_applies(int B) { return B <= pchain_max_batch() && B <= kPchainCarveMaxB; }
 
 }  // namespace blvm

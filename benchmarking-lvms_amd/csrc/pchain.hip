@@ -7,13 +7,13 @@
 //   K_HEAD  p: 0 P16  1 Q16  2 Wp  3 bp  4 Wq  5 bq  6 eps  7 mu_p  8 sd_p  9 mu_q  10 sd_q  11 raw_p  12 raw_q  13 muq_raw
 //              14 z row-major (ld[3])  15 z T16 (n16[0])               i: 0 Z  1 residual      f: 0 beta  1 1/beta  2 sd_eps
 //   K_GRU   p: 0 X16  1 Wih (T16)  2 xg  3 gh (polled words)  4 h_prev (polled words, ld[0])  5 h_new row-major (ld[3])
-//              6 h_new T16 (n16[0])  7 rg  8 ug  9 ng                   i: 0 R
+//              6 h_new T16 (n16[0])  7 rg  8 ug  9 ng  10 b_ih         i: 0 R
 //   K_DZ    p: 0 D16  1 WT  2 D2_16  3 WT2  4 dz_add (ld[1])  5 mu_q  6 sd_q  7 mu_p  8 sd_p  9 eps  10 raw_q  11 raw_p  12 muq_raw
 //              13 x_sl (int32)  14 c_raw  15 c_fn  16 dqh row-major  17 dqh T16  18 dph row-major  19 dph T16   (ld[3] = 2Z, n16[0])
-//              i: 0 Z  1 residual  2 stride  3 t at s = 0 (t = i[3] - s)   f: 0 fn_floor  1 beta  2 sd_eps
+//              i: 0 Z  1 residual  2 stride  3 t at s = 0 (t = i[3] - s)   f: 0 fn_floor  1 beta  2 sd_eps  3 first step with the product
 //   K_GRUB  p: 0 D0_16  1 D1_16  2 W0  3 W1  4 g_in (polled words)  5 rg  6 ug  7 ng  8 gh  9 h_prev (ld[0])  10 dd (ld[0])
-//              11 dgi row-major  12 dgi T16  13 dgh row-major  14 dgh T16  (ld[3] = 3R, n16[0])  15 ga  16 g_out
-//              i: 0 R  1 first step with the products  2 first step WITHOUT gates
+//              11 dgi row-major  12 dgi T16  13 dgh row-major  14 dgh T16  (ld[3] = 3R, n16[0])  15 ga  16 g_out  17 g_add (ld[1])
+//              i: 0 R  1 first step with the products  2 first step WITHOUT gates  3 first step with g_in
 #include <algorithm>
 #include <mutex>
 
@@ -24,129 +24,224 @@ namespace blvm {
 namespace {
 using namespace pchain;
 
-// A descriptor as the kernel reads it: strides resolved per pointer, in device memory written by pchain_resolve_kernel right before
-// the launch and never written again, so that the persistent kernel fetches a tile's operands with a handful of independent SCALAR
-// loads (s_load_dwordx8/x16 through the scalar cache, results uniform in SGPRs).  Read straight from the kernel argument it was a
-// chain of dependent scalar loads (descriptor -> stride index -> stride); from an LDS copy, ~15 vector LDS reads + readfirstlanes.
-struct RDesc {
-  int kind, ct, wg0, nwg, flags, K, s_begin, s_end;
-  int ld[4];
-  int n16[2];
-  int i[4];
-  float f[4];
-  int pad[2];
-  const float* p[kMaxPtr];
-  long st[kMaxPtr];
-};
+// A descriptor as the kernel reads it: 128 dwords, resolved (strides per pointer) by pchain_resolve_kernel right before the launch
+// and copied into LDS by every workgroup.  Every wave keeps the descriptor of its current tile in TWO VGPRs (lane l holds dword l /
+// 64 + l: two ds_read_b32) and reads a field with v_readlane; the NEXT descriptor's two LDS reads are issued at the top of the
+// current tile.  LDS, not global memory: on gfx9 vector loads AND stores share the vmcnt counter, so waiting for a prefetched
+// global load at the top of the next tile also sat out the previous tile's write-through stores (~0.9 us per tile, found with
+// blvm_pchain_chain_probe against tools/pchain_probe.hip); LDS reads are counted by lgkmcnt.
+//   dword 0 kind  1 ct  2 wg0  3 nwg  4 flags  5 K  6 s_begin  7 s_end  8..11 ld  12..13 n16  14..17 i  18..21 f
+//         24 + 2k, 25 + 2k: pointer k (k < 20)        64 + k: its per-step stride in floats (int32)
+//         84: number of tiles of THIS workgroup, 85 ..: its tiles as r0 | column tile << 16 — written once by each workgroup into
+//         its own LDS copy (TileIter involves integer divisions: ~0.5 us per tile when run inside the step loop)
+constexpr int kDescWords = 128;
+enum { RD_KIND = 0, RD_CT, RD_WG0, RD_NWG, RD_FLAGS, RD_K, RD_SBEGIN, RD_SEND, RD_LD = 8, RD_N16 = 12, RD_I = 14, RD_F = 18, RD_P = 24, RD_ST = 64,
+       RD_NT = 84, RD_TILE = 85 };
+constexpr int kMaxTilesPerWg = kDescWords - RD_TILE;
 struct Hdr {
   int ndesc, S, B, xcd, prof_wg, lds_products;
   Ctl ctl;
   unsigned long long* prof;
 };
 
-__global__ void pchain_resolve_kernel(Program a, RDesc* __restrict__ out) {
-  for (int e = threadIdx.x; e < a.ndesc * kMaxPtr; e += blockDim.x) {
-    const int i = e / kMaxPtr, k = e % kMaxPtr;
-    out[i].p[k] = a.d[i].p[k];
-    out[i].st[k] = a.stride[a.d[i].sidx[k]];
-  }
-  for (int i = threadIdx.x; i < a.ndesc; i += blockDim.x) {
+__global__ void pchain_resolve_kernel(Program a, int* __restrict__ out) {
+  for (int e = threadIdx.x; e < a.ndesc * kDescWords; e += blockDim.x) {
+    const int i = e / kDescWords, k = e % kDescWords;
     const Desc& d = a.d[i];
-    RDesc& l = out[i];
-    l.kind = d.kind; l.ct = d.ct; l.wg0 = d.wg0; l.nwg = d.nwg; l.flags = d.flags; l.K = d.K; l.s_begin = d.s_begin; l.s_end = d.s_end;
-    for (int k = 0; k < 4; ++k) { l.ld[k] = d.ld[k]; l.i[k] = d.i[k]; l.f[k] = d.f[k]; }
-    l.n16[0] = d.n16[0]; l.n16[1] = d.n16[1];
+    int v = 0;
+    if (k == RD_KIND) v = d.kind;
+    else if (k == RD_CT) v = d.ct;
+    else if (k == RD_WG0) v = d.wg0;
+    else if (k == RD_NWG) v = d.nwg;
+    else if (k == RD_FLAGS) v = d.flags;
+    else if (k == RD_K) v = d.K;
+    else if (k == RD_SBEGIN) v = d.s_begin;
+    else if (k == RD_SEND) v = d.s_end;
+    else if (k >= RD_LD && k < RD_LD + 4) v = d.ld[k - RD_LD];
+    else if (k >= RD_N16 && k < RD_N16 + 2) v = d.n16[k - RD_N16];
+    else if (k >= RD_I && k < RD_I + 4) v = d.i[k - RD_I];
+    else if (k >= RD_F && k < RD_F + 4) v = __float_as_int(d.f[k - RD_F]);
+    else if (k >= RD_P && k < RD_P + 2 * kMaxPtr) {
+      const unsigned long long q = reinterpret_cast<unsigned long long>(d.p[(k - RD_P) >> 1]);
+      v = (int)(((k - RD_P) & 1) ? (q >> 32) : (q & 0xffffffffull));
+    } else if (k >= RD_ST && k < RD_ST + kMaxPtr) {
+      v = (int)a.stride[d.sidx[k - RD_ST]];
+    }
+    out[e] = v;
   }
 }
 
+// the descriptor of the current tile, one dword per lane in two VGPRs, plus the pointers OF THE STEP it will be used in: lane k of
+// (plo, phi) = pointer k + step * stride k, computed for all twenty pointers at once by four vector instructions when the
+// descriptor is fetched (one tile ahead) — as scalar code in front of the tile it was ~7 dependent SALU instructions per pointer,
+// ~0.3 us of every link
+struct DescRegs {
+  int v0, v1;
+  unsigned plo, phi;
+  __device__ __forceinline__ void fetch(const int* tab_lds, int i, int step) {
+    const int lane = threadIdx.x & 63;
+    const int* q = tab_lds + i * kDescWords;
+    v0 = q[lane];
+    v1 = q[64 + lane];
+    const int k = lane < kMaxPtr ? lane : 0;
+    const unsigned long long base = ((unsigned long long)(unsigned)q[RD_P + 2 * k + 1] << 32) | (unsigned)q[RD_P + 2 * k];
+    const unsigned long long p = base + (unsigned long long)((long long)step * (long long)q[RD_ST + k] * 4);
+    plo = (unsigned)p;
+    phi = (unsigned)(p >> 32);
+  }
+  template <int IDX>
+  __device__ __forceinline__ int w() const {
+    return IDX < 64 ? __builtin_amdgcn_readlane(v0, IDX & 63) : __builtin_amdgcn_readlane(v1, IDX & 63);
+  }
+  __device__ __forceinline__ int tile(int k) const { return __builtin_amdgcn_readlane(v1, RD_TILE - 64 + k); }  // k wave-uniform
+  template <int IDX>
+  __device__ __forceinline__ float f() const { return __int_as_float(w<RD_F + IDX>()); }
+  template <int K>
+  __device__ __forceinline__ const float* base() const {
+    const unsigned long long lo = (unsigned)w<RD_P + 2 * K>(), hi = (unsigned)w<RD_P + 2 * K + 1>();
+    return reinterpret_cast<const float*>((hi << 32) | lo);
+  }
+  // pointer k at the step the descriptor was fetched for (null stays null: its stride is 0)
+  template <int K>
+  __device__ __forceinline__ const float* p(int) const {
+    const unsigned long long lo = (unsigned)__builtin_amdgcn_readlane((int)plo, K), hi = (unsigned)__builtin_amdgcn_readlane((int)phi, K);
+    return reinterpret_cast<const float*>((hi << 32) | lo);
+  }
+  template <int K>
+  __device__ __forceinline__ float* m(int s) const { return const_cast<float*>(p<K>(s)); }
+};
+
 template <int NW>
-__global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const RDesc* __restrict__ L, Hdr a) {
-  extern __shared__ __attribute__((aligned(16))) char lds_all[];  // [profile | 2 x (lds_products x NW x 256) floats]
-  unsigned long long* const pacc = reinterpret_cast<unsigned long long*>(lds_all);
-  float* const red0 = reinterpret_cast<float*>(lds_all + 16 * sizeof(unsigned long long));
+__global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restrict__ tab, Hdr a) {
+  extern __shared__ __attribute__((aligned(16))) char lds_all[];  // [descriptors | profile | 2 x (lds_products x NW x 256) floats]
+  int* const ltab = reinterpret_cast<int*>(lds_all);
+  unsigned long long* const pacc = reinterpret_cast<unsigned long long*>(lds_all + sizeof(int) * kDescWords * kMaxDesc);
+  float* const red0 = reinterpret_cast<float*>(lds_all + sizeof(int) * kDescWords * kMaxDesc + 16 * sizeof(unsigned long long));
   float* const red1 = red0 + a.lds_products * NW * 256;
   const int w = blockIdx.x, B = a.B, rt = (B + 15) / 16;
   const bool xcd = a.xcd != 0;
+  for (int e = threadIdx.x; e < a.ndesc * kDescWords; e += NW * 64) ltab[e] = tab[e];
   if (threadIdx.x < 16) pacc[threadIdx.x] = 0ull;
   unsigned mine = 0;  // the descriptors this workgroup has tiles of
-  for (int i = 0; i < a.ndesc; ++i)
-    if (TileIter(w, L[i].wg0, L[i].nwg, rt, L[i].ct, xcd).valid()) mine |= 1u << i;
+  for (int i = 0; i < a.ndesc; ++i) {
+    const int* q = tab + (size_t)i * kDescWords;
+    if (TileIter(w, q[RD_WG0], q[RD_NWG], rt, q[RD_CT], xcd).valid()) mine |= 1u << i;
+  }
   __syncthreads();
+  if (threadIdx.x < a.ndesc) {  // this workgroup's tiles of descriptor threadIdx.x, into its own copy of the table
+    int* q = ltab + threadIdx.x * kDescWords;
+    int k = 0;
+    for (TileIter it(w, q[RD_WG0], q[RD_NWG], rt, q[RD_CT], xcd); it.valid() && k < kMaxTilesPerWg; it.next()) q[RD_TILE + k++] = it.r0() | (it.c() << 16);
+    q[RD_NT] = k;
+  }
+  __syncthreads();
+  if (mine == 0) return;
   int par = 0;
   auto red = [&]() { par ^= 1; return par ? red0 : red1; };
   Poll pl{a.ctl, 0u, false, 1};
   const bool profiled = a.prof != nullptr && (w == 0 || w == a.prof_wg) && threadIdx.x == 0;
   unsigned long long tprev = profiled ? wall_clock64() : 0ull;
+#ifdef PCHAIN_TPROF2
+  unsigned long long tq[3] = {0ull, 0ull, 0ull}, tq_end = 0ull;
+#endif
+  DescRegs d, nx;
+  d.fetch(ltab, __builtin_ctz(mine), 0);
   for (int s = 0; s < a.S; ++s) {
     for (unsigned m = mine; m != 0; m &= m - 1) {
       const int i = __builtin_ctz(m);
-      const RDesc& d = L[i];
-      if (s < d.s_begin || s >= d.s_end) continue;
-      const int kind = d.kind, flags = d.flags, K = d.K;
-      TileIter it(w, d.wg0, d.nwg, rt, d.ct, xcd);
-      pl.nap = (flags & DF_GENTLE) ? 16 : 1;
-      pl.code = ((unsigned)s << 4) | (unsigned)i;
-      auto P = [&](int k) -> const float* { return d.p[k] + (long)s * d.st[k]; };
-      auto M = [&](int k) -> float* { return const_cast<float*>(d.p[k] + (long)s * d.st[k]); };
-      auto Pn = [&](int k) -> const float* { const float* q = d.p[k]; return q ? q + (long)s * d.st[k] : nullptr; };
-      auto Mn = [&](int k) -> float* { return const_cast<float*>(Pn(k)); };
-      switch (kind) {
-        case K_LIN: {
-          const bool a_polled = !(flags & DF_A_PLAIN);
-          const float *A = P(0), *W = d.p[1], *bias = d.p[2], *add = Pn(3), *gate = Pn(4);
-          const Out o{Mn(5), (d.ld[3]), (flags & DF_RM_SC1) != 0, Mn(6), (d.n16[0])};
-          const int lda = (d.ld[0]), ldadd = (d.ld[1]), ldgate = (d.ld[2]);
-          const float slope = d.f[0];
-          for (; it.valid(); it.next()) {
-            if ((flags & DF_CANARY) && a_polled) canary_wait(A, it.r0(), K, pl);
-            tile_lin<NW>(A, lda, a_polled, W, K, bias, add, ldadd, (flags & DF_ADD_POLLED) != 0, gate, ldgate, (flags & DF_RELU) != 0, slope, o, it.r0(),
-                         it.c() * 16, B, red(), pl);
-          }
-        } break;
-        case K_HEAD: {
-          const HeadOut o{M(7), M(8), M(9), M(10), M(11), M(12), Mn(13), Out{M(14), (d.ld[3]), false, M(15), (d.n16[0])}};
-          const int Z = (d.i[0]), residual = (d.i[1]);
-          for (; it.valid(); it.next())
-            tile_head<NW>(P(0), P(1), true, d.p[2], d.p[3], d.p[4], d.p[5], P(6), o, K, Z, residual, d.f[0], d.f[1], d.f[2], it.r0(), it.c() * 16, B, red(), pl);
-        } break;
-        case K_GRU: {
-          const Out o{M(5), (d.ld[3]), true, M(6), (d.n16[0])};
-          const int R = (d.i[0]), ldh = (d.ld[0]);
-          for (; it.valid(); it.next())
-            tile_gru<NW>(P(0), 0, true, d.p[1], K, Pn(2), P(3), P(4), ldh, R, o, M(7), M(8), M(9), it.r0(), it.c() * 16, B, red(), pl);
-        } break;
-        case K_DZ: {
-          DzIn z;
-          z.mu_q = P(5); z.sd_q = P(6); z.mu_p = P(7); z.sd_p = P(8); z.eps = P(9); z.raw_q = P(10); z.raw_p = P(11);
-          z.muq_raw = Pn(12);
-          z.x_sl = reinterpret_cast<const int32_t*>(d.p[13]); z.c_raw = d.p[14]; z.c_fn = d.p[15];
-          z.t = (d.i[3]) - s; z.stride = (d.i[2]); z.residual = (d.i[1]);
-          z.fn_floor = d.f[0]; z.beta = d.f[1]; z.sd_eps = d.f[2];
-          const int ldo = (d.ld[3]), n16 = (d.n16[0]), Z = (d.i[0]);
-          const Out oq{M(16), ldo, false, M(17), n16}, op{M(18), ldo, false, M(19), n16};
-          for (; it.valid(); it.next())
-            tile_dz<NW>(P(0), d.p[1], nullptr, nullptr, true, Pn(4), (d.ld[1]), (flags & DF_ADD_POLLED) != 0, z, oq, op, K, Z, it.r0(), it.c() * 16, B,
-                        red(), pl);
-        } break;
-        case K_GRUB: {
-          GrubIn g;
-          g.D0 = P(0); g.D1 = P(1); g.W0 = d.p[2]; g.W1 = d.p[3]; g.g_in = P(4);
-          g.rg = P(5); g.ug = P(6); g.ng = P(7); g.gh = P(8); g.hprev = P(9); g.dd = P(10); g.ldh = (d.ld[0]);
-          const int ldo = (d.ld[3]), n16 = (d.n16[0]);
-          g.dgi = Out{M(11), ldo, false, M(12), n16};
-          g.dgh = Out{M(13), ldo, false, M(14), n16};
-          g.ga = M(15); g.g_out = const_cast<float*>(d.p[16]);
-          g.has_gemm = s >= (d.i[1]); g.has_gates = s < (d.i[2]);
-          const int R = (d.i[0]);
-          for (; it.valid(); it.next()) tile_grub<NW>(g, K, R, it.r0(), it.c() * 16, B, red(), pl);
-        } break;
-        default: break;
+#ifdef PCHAIN_TPROF2
+      const unsigned long long tq0 = wall_clock64();
+      if (tq_end) tq[2] += tq0 - tq_end;
+#endif
+      // request the next descriptor of this workgroup's walk now; it lands while this tile runs
+      const unsigned rest = m & (m - 1);
+      nx.fetch(ltab, __builtin_ctz(rest != 0 ? rest : mine), rest != 0 ? s : s + 1);
+      const int kind = d.w<RD_KIND>(), flags = d.w<RD_FLAGS>(), K = d.w<RD_K>();
+      if (s >= d.w<RD_SBEGIN>() && s < d.w<RD_SEND>()) {
+        const int nt = d.w<RD_NT>();
+        pl.nap = (flags & DF_GENTLE) ? 16 : 1;
+        pl.code = ((unsigned)s << 4) | (unsigned)i;
+        const int ld0 = d.w<RD_LD + 0>(), ld1 = d.w<RD_LD + 1>(), ld2 = d.w<RD_LD + 2>(), ld3 = d.w<RD_LD + 3>(), n16 = d.w<RD_N16>();
+        switch (kind) {
+          case K_LIN: {
+            const bool a_polled = !(flags & DF_A_PLAIN);
+            const float *A = d.p<0>(s), *W = d.base<1>(), *bias = d.base<2>(), *add = d.p<3>(s), *gate = d.p<4>(s);
+            const Out o{d.m<5>(s), ld3, (flags & DF_RM_SC1) != 0, d.m<6>(s), n16};
+            const float slope = d.f<0>();
+            for (int tk = 0; tk < nt; ++tk) {
+              const int trc = d.tile(tk), tr0 = trc & 0xffff, tc0 = (trc >> 16) * 16;
+              if ((flags & DF_CANARY) && a_polled) canary_wait(A, tr0, K, pl);
+#ifdef PCHAIN_TPROF2
+              const unsigned long long tq1 = wall_clock64();
+              tq[0] += tq1 - tq0;
+#endif
+              tile_lin<NW>(A, ld0, a_polled, W, K, bias, add, ld1, (flags & DF_ADD_POLLED) != 0, gate, ld2, (flags & DF_RELU) != 0, slope, o, tr0, tc0, B,
+                           red(), pl);
+#ifdef PCHAIN_TPROF2
+              tq_end = wall_clock64();
+              tq[1] += tq_end - tq1;
+#endif
+            }
+          } break;
+#ifndef PCHAIN_ONLY_LIN
+          case K_HEAD: {
+            const HeadOut o{d.m<7>(s), d.m<8>(s), d.m<9>(s), d.m<10>(s), d.m<11>(s), d.m<12>(s), d.m<13>(s), Out{d.m<14>(s), ld3, false, d.m<15>(s), n16}};
+            const int Z = d.w<RD_I + 0>(), residual = d.w<RD_I + 1>();
+            for (int tk = 0; tk < nt; ++tk) {
+              const int trc = d.tile(tk);
+              tile_head<NW>(d.p<0>(s), d.p<1>(s), true, d.base<2>(), d.base<3>(), d.base<4>(), d.base<5>(), d.p<6>(s), o, K, Z, residual, d.f<0>(), d.f<1>(),
+                            d.f<2>(), trc & 0xffff, (trc >> 16) * 16, B, red(), pl);
+            }
+          } break;
+          case K_GRU: {
+            const Out o{d.m<5>(s), ld3, true, d.m<6>(s), n16};
+            const int R = d.w<RD_I + 0>();
+            for (int tk = 0; tk < nt; ++tk) {
+              const int trc = d.tile(tk);
+              tile_gru<NW>(d.p<0>(s), 0, true, d.base<1>(), K, d.p<2>(s), d.base<10>(), d.p<3>(s), d.p<4>(s), ld0, R, o, d.m<7>(s), d.m<8>(s), d.m<9>(s),
+                           trc & 0xffff, (trc >> 16) * 16, B, red(), pl);
+            }
+          } break;
+          case K_DZ: {
+            DzIn z;
+            z.mu_q = d.p<5>(s); z.sd_q = d.p<6>(s); z.mu_p = d.p<7>(s); z.sd_p = d.p<8>(s); z.eps = d.p<9>(s); z.raw_q = d.p<10>(s); z.raw_p = d.p<11>(s);
+            z.muq_raw = d.p<12>(s);
+            z.x_sl = reinterpret_cast<const int32_t*>(d.base<13>()); z.c_raw = d.base<14>(); z.c_fn = d.base<15>();
+            z.t = d.w<RD_I + 3>() - s; z.stride = d.w<RD_I + 2>(); z.residual = d.w<RD_I + 1>();
+            z.fn_floor = d.f<0>(); z.beta = d.f<1>(); z.sd_eps = d.f<2>();
+            z.has_gemm = s >= (int)d.f<3>();
+            const int Z = d.w<RD_I + 0>();
+            const Out oq{d.m<16>(s), ld3, false, d.m<17>(s), n16}, op{d.m<18>(s), ld3, false, d.m<19>(s), n16};
+            for (int tk = 0; tk < nt; ++tk) {
+              const int trc = d.tile(tk);
+              tile_dz<NW>(d.p<0>(s), d.base<1>(), nullptr, nullptr, true, d.p<4>(s), ld1, (flags & DF_ADD_POLLED) != 0, z, oq, op, K, Z, trc & 0xffff,
+                          (trc >> 16) * 16, B, red(), pl);
+            }
+          } break;
+          case K_GRUB: {
+            GrubIn g;
+            g.D0 = d.p<0>(s); g.D1 = d.p<1>(s); g.W0 = d.base<2>(); g.W1 = d.base<3>(); g.g_in = d.p<4>(s); g.g_add = d.p<17>(s); g.ld_gadd = ld1;
+            g.rg = d.p<5>(s); g.ug = d.p<6>(s); g.ng = d.p<7>(s); g.gh = d.p<8>(s); g.hprev = d.p<9>(s); g.dd = d.p<10>(s); g.ldh = ld0;
+            g.dgi = Out{d.m<11>(s), ld3, false, d.m<12>(s), n16};
+            g.dgh = Out{d.m<13>(s), ld3, false, d.m<14>(s), n16};
+            g.ga = d.m<15>(s); g.g_out = const_cast<float*>(d.base<16>());
+            g.has_gemm = s >= d.w<RD_I + 1>(); g.has_gates = s < d.w<RD_I + 2>(); g.has_gin = s >= d.w<RD_I + 3>();
+            const int R = d.w<RD_I + 0>();
+            for (int tk = 0; tk < nt; ++tk) {
+              const int trc = d.tile(tk);
+              tile_grub<NW>(g, K, R, trc & 0xffff, (trc >> 16) * 16, B, red(), pl);
+            }
+          } break;
+#endif
+          default: break;
+        }
+        if (profiled) {
+          const unsigned long long now = wall_clock64();
+          pacc[i] += now - tprev;
+          tprev = now;
+        }
       }
-      if (profiled) {
-        const unsigned long long now = wall_clock64();
-        pacc[i] += now - tprev;
-        tprev = now;
-      }
+      d = nx;
     }
   }
   if (profiled) {
@@ -154,10 +249,27 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const RDesc* __restr
 #ifdef PCHAIN_TPROF
     if (w == 0) for (int l = 0; l < 8; ++l) a.prof[32 + l] += pl.tp[l];
 #endif
+#ifdef PCHAIN_TPROF2
+    if (w == 0) for (int l = 0; l < 3; ++l) a.prof[40 + l] += tq[l];
+#endif
   }
 }
 
+__global__ void rows_to_t16_kernel(const float* src, int ld, int B, int K, float* dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * K) return;
+  const int row = i / K, k = i % K;
+  dst[((size_t)(row >> 4) * (K >> 4) + (k >> 4)) * 256 + ((row & 15) + 16 * ((k & 15) >> 2)) * 4 + (k & 3)] = src ? src[(size_t)row * ld + k] : 0.f;
+}
+
 }  // namespace
+
+int pchain_rows_to_t16(const float* src, int ld, int B, int K, float* dst, hipStream_t stream) {
+  BLVM_REQUIRE(B > 0 && K > 0 && K % 16 == 0 && dst != nullptr, "pchain_rows_to_t16: bad arguments");
+  hipLaunchKernelGGL(rows_to_t16_kernel, dim3((B * K + 255) / 256), dim3(256), 0, stream, src, ld, B, K, dst);
+  BLVM_CHECK_LAUNCH("pchain_rows_to_t16");
+  return BLVM_OK;
+}
 
 int pchain_launch(const pchain::Program& prog, hipStream_t stream) {
   BLVM_REQUIRE(prog.ndesc > 0 && prog.ndesc <= pchain::kMaxDesc && prog.S > 0 && prog.B > 0, "pchain: bad program (%d descriptors, %d steps)", prog.ndesc, prog.S);
@@ -167,6 +279,9 @@ int pchain_launch(const pchain::Program& prog, hipStream_t stream) {
     BLVM_REQUIRE(d.nwg > 0 && d.wg0 >= 0 && d.ct > 0 && d.K > 0 && d.K % 16 == 0, "pchain: bad descriptor %d", i);
     BLVM_REQUIRE(!prog.xcd || d.nwg % 8 == 0, "pchain: XCD-aware placement needs ranges of 8 k workgroups (descriptor %d has %d)", i, d.nwg);
     grid = std::max(grid, d.wg0 + d.nwg);
+    const int rt = (prog.B + 15) / 16;
+    const int per_wg = prog.xcd ? (((d.ct + 7) / 8) * rt + d.nwg / 8 - 1) / (d.nwg / 8) : (d.ct * rt + d.nwg - 1) / d.nwg;
+    BLVM_REQUIRE(per_wg <= kMaxTilesPerWg, "pchain: descriptor %d gives a workgroup %d tiles (at most %d)", i, per_wg, kMaxTilesPerWg);
   }
   int dev = 0, cus = 0;
   BLVM_HIP(hipGetDevice(&dev));
@@ -174,33 +289,70 @@ int pchain_launch(const pchain::Program& prog, hipStream_t stream) {
   BLVM_REQUIRE(grid <= cus, "pchain: the program names %d workgroups, the device has %d CUs (every workgroup must be resident)", grid, cus);
   // the resolved table: a slot of a small ring in library-owned device memory (launches on one stream are ordered; the ring keeps
   // launches that overlap on different streams apart)
-  RDesc* tab = nullptr;
+  int* tab = nullptr;
   {
     static std::mutex mu;
     static int tab_dev = -1;
-    static RDesc* ring = nullptr;
+    static int* ring = nullptr;
     static unsigned next = 0;
     constexpr unsigned kSlots = 8;
     std::lock_guard<std::mutex> lock(mu);
     if (tab_dev != dev) {
-      BLVM_HIP(hipMalloc(reinterpret_cast<void**>(&ring), sizeof(RDesc) * pchain::kMaxDesc * kSlots));
+      BLVM_HIP(hipMalloc(reinterpret_cast<void**>(&ring), sizeof(int) * kDescWords * pchain::kMaxDesc * kSlots));
       tab_dev = dev;
     }
-    tab = ring + (size_t)(next++ % kSlots) * pchain::kMaxDesc;
+    tab = ring + (size_t)(next++ % kSlots) * kDescWords * pchain::kMaxDesc;
   }
   hipLaunchKernelGGL(pchain_resolve_kernel, dim3(1), dim3(256), 0, stream, prog, tab);
   Hdr h{prog.ndesc, prog.S, prog.B, prog.xcd, prog.prof_wg, prog.lds_products, prog.ctl, prog.prof};
   const int nw = pchain_waves();
-  const size_t lds = 16 * sizeof(unsigned long long) + sizeof(float) * 2 * (size_t)prog.lds_products * nw * 256;
+  const size_t lds_fixed = sizeof(int) * kDescWords * pchain::kMaxDesc + 16 * sizeof(unsigned long long);
+  const size_t lds = lds_fixed + sizeof(float) * 2 * (size_t)prog.lds_products * nw * 256;
+  // the dynamic-LDS limit of the kernels is raised once per process and device (the call is far from free)
+  static int attr_dev[2] = {-1, -1};
+  const size_t lds_max = lds_fixed + sizeof(float) * 2 * 4 * (size_t)nw * 256;
+  BLVM_REQUIRE(lds <= lds_max, "pchain: %d products per tile exceed the reduction scratch", prog.lds_products);
   if (nw == 16) {
-    BLVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pchain_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((pchain_kernel<16>), dim3(grid), dim3(1024), lds, stream, (const RDesc*)tab, h);
+    if (attr_dev[1] != dev) {
+      BLVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pchain_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+      attr_dev[1] = dev;
+    }
+    hipLaunchKernelGGL((pchain_kernel<16>), dim3(grid), dim3(1024), lds, stream, (const int*)tab, h);
   } else {
-    BLVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pchain_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((pchain_kernel<8>), dim3(grid), dim3(512), lds, stream, (const RDesc*)tab, h);
+    if (attr_dev[0] != dev) {
+      BLVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pchain_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+      attr_dev[0] = dev;
+    }
+    hipLaunchKernelGGL((pchain_kernel<8>), dim3(grid), dim3(512), lds, stream, (const int*)tab, h);
   }
   BLVM_CHECK_LAUNCH("pchain_launch");
   return BLVM_OK;
 }
 
 }  // namespace blvm
+
+// Diagnostics / unit test of the engine: a chain of L links x_{s+1} = relu(x_s W^T + b), [B,N] x [N,N], as a one-descriptor program.
+// x16: (L+1) T16 slabs [ceil(B/16)*16, N] — slab 0 must hold x_0 (pchain_rows_to_t16 / blvm_pchain_rows_to_t16), slabs 1..L are
+// sentinel-filled here; xs: L row-major slabs [B,N] (outputs).  W in the T16 operand layout.
+extern "C" int blvm_pchain_chain_probe(const float* W16, const float* bias, float* x16, float* xs, int B, int N, int L, int nwg, void* stream_) {
+  using namespace blvm;
+  using namespace blvm::pchain;
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  BLVM_REQUIRE(W16 && bias && x16 && xs && B > 0 && N > 0 && N % 16 == 0 && L > 0, "pchain_chain_probe: bad arguments");
+  const int rt = (B + 15) / 16;
+  const long x = (long)rt * 16 * N, sN = (long)B * N;
+  Builder bld;
+  bld.p.S = L; bld.p.B = B; bld.p.xcd = (pchain_tune() & 4) ? 1 : 0; bld.p.lds_products = 1;
+  bld.p.prof = pchain_profile_buffer(); bld.p.prof_wg = 1;
+  Desc& d = bld.add(K_LIN, N / 16, 0, nwg > 0 ? nwg : range_for((N / 16) * rt, device_cus() & ~7), N, DF_RELU, 0, L);
+  bld.ptr(d, 0, x16, x); bld.ptr(d, 1, W16); bld.ptr(d, 2, bias); bld.ptr(d, 5, xs, sN); bld.ptr(d, 6, x16 + x, x);
+  d.ld[3] = N; d.n16[0] = N / 16; d.f[0] = 0.f;
+  int rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
+  if (rc) return rc;
+  BLVM_HIP(hipMemsetAsync(x16 + x, 0xFF, sizeof(float) * (size_t)x * L, s));
+  return pchain_launch(bld.p, s);
+}
+
+extern "C" int blvm_pchain_rows_to_t16(const float* src, int ld, int B, int K, float* dst, void* stream) {
+  return blvm::pchain_rows_to_t16(src, ld, B, K, dst, static_cast<hipStream_t>(stream));
+}

@@ -9,6 +9,7 @@
 // halves of the concatenated-input layers, every weight gradient and d(context), d(enc) are batched MFMA GEMMs
 // outside the loop.  Same design and numerics as vrnn.hip.
 #include "common.h"
+#include "pchain.h"
 
 namespace blvm {
 namespace {
@@ -120,6 +121,8 @@ __global__ __launch_bounds__(NW * 64) void rssm_dh_stage_kernel(const float* DQ0
 struct RssmReserve {
   float *GIN, *GHb, *RG, *UG, *NG, *Q[3], *P[3], *RAWQ, *RAWP, *MUQR, *XGIN, *XQ;
   float *Wgz, *Wih, *Whh, *Wq[3], *Wp[3], *Wqh, *Wph;  // T16 copies of the weights the forward chain multiplies by
+  // persistent forward (B <= kPchainCarveMaxB): T16 copies of every activation a link multiplies, per step [rt*16, width]
+  float *Z16, *H16, *GIN16, *Q16[3], *P16[3], *x16_end;
 };
 size_t carve_rssm(float* base, int T, int B, int H, int Z, RssmReserve* r) {
   const size_t n = (size_t)T * B;
@@ -135,11 +138,23 @@ size_t carve_rssm(float* base, int T, int B, int H, int Z, RssmReserve* r) {
   t.Wgz = take((size_t)H * Z); t.Wih = take((size_t)3 * H * H); t.Whh = take((size_t)3 * H * H);
   for (int i = 0; i < 3; ++i) { t.Wq[i] = take((size_t)H * H); t.Wp[i] = take((size_t)H * H); }
   t.Wqh = take((size_t)2 * Z * H); t.Wph = take((size_t)2 * Z * H);
+  t.Z16 = nullptr;
+  if (B <= kPchainCarveMaxB) {
+    const size_t rows = (size_t)((B + 15) / 16) * 16, m = (size_t)T * rows;
+    t.Z16 = take((m + rows) * Z); t.H16 = take((m + rows) * H); t.GIN16 = take(m * H);
+    for (int i = 0; i < 3; ++i) { t.Q16[i] = take(m * H); t.P16[i] = take(m * H); }
+    t.x16_end = take(0);
+  }
   if (r) *r = t;
   return off;
 }
 
-struct RssmWs { float *gzT, *wihT, *whhT, *qT[3], *pT[3], *qhT, *phT, *DGIN, *DGI, *DGH, *DQH, *DPH, *DQ[3], *DP[3], *G; };
+struct RssmWs {
+  float *gzT, *wihT, *whhT, *qT[3], *pT[3], *qhT, *phT, *DGIN, *DGI, *DGH, *DQH, *DPH, *DQ[3], *DP[3], *G;
+  // persistent backward (B <= kPchainCarveMaxB): the running state gradient as per-step slabs [T,B,H] and T16 copies of every
+  // gradient a link multiplies, per step [rt*16, width]
+  float *GA, *GB, *DGIN16, *DGI16, *DGH16, *DQH16, *DPH16, *DQ16[3], *DP16[3], *x16_end;
+};
 size_t carve_rssm_ws(float* base, int T, int B, int H, int Z, RssmWs* w) {
   const size_t n = (size_t)T * B;
   size_t off = 0;
@@ -152,6 +167,15 @@ size_t carve_rssm_ws(float* base, int T, int B, int H, int Z, RssmWs* w) {
   t.DQH = take(n * 2 * Z); t.DPH = take(n * 2 * Z);
   for (int i = 0; i < 3; ++i) { t.DQ[i] = take(n * H); t.DP[i] = take(n * H); }
   t.G = take((size_t)B * H);
+  t.GA = nullptr;
+  if (B <= kPchainCarveMaxB) {
+    const size_t m = (size_t)T * ((B + 15) / 16) * 16;
+    t.GA = take(n * H); t.GB = take(n * H);
+    t.DGIN16 = take(m * H); t.DGI16 = take(m * 3 * H); t.DGH16 = take(m * 3 * H);
+    t.DQH16 = take(m * 2 * Z); t.DPH16 = take(m * 2 * Z);
+    for (int i = 0; i < 3; ++i) { t.DQ16[i] = take(m * H); t.DP16[i] = take(m * H); }
+    t.x16_end = take(0);
+  }
   if (w) *w = t;
   return off;
 }
@@ -211,6 +235,59 @@ extern "C" int blvm_rssm_seq_fwd(const BlvmRssmWeights* w, const float* enc, con
   if (h0) BLVM_HIP(hipMemcpyAsync(hs, h0, sizeof(float) * (size_t)B * H, hipMemcpyDeviceToDevice, s));
   else BLVM_HIP(hipMemsetAsync(hs, 0, sizeof(float) * (size_t)B * H, s));
   const int rt = (B + 15) / 16;
+  if (pchain_applies(B) && device_cus() >= 32) {
+    // Persistent path (pchain.h / pchain.hip): the six links of a step as a program of 10 descriptors, one launch per sequence.
+    using namespace pchain;
+    const int ctH = H / 16, ctZ = Z / 16, cus = device_cus() & ~7;
+    const long sH = (long)B * H, sZ = (long)B * Z, s3H = 3 * sH, xH = (long)rt * 16 * H, xZ = (long)rt * 16 * Z;
+    const int r_h = range_for(ctH * rt, cus / 4);              // one H-wide link (or one half of a posterior | prior pair)
+    const int r_gh = range_for(3 * ctH * rt, cus - 2 * r_h);   // the hidden projection, beside the GRU input layer
+    Builder bld;
+    bld.p.S = T; bld.p.B = B; bld.p.xcd = (pchain_tune() & 4) ? 1 : 0; bld.p.lds_products = 4;
+    bld.p.prof = pchain_profile_buffer(); bld.p.prof_wg = r_h;
+    auto lin = [&](const float* A16, long a_step, const float* W, int K, const float* bias, const float* add, long add_step, float* orm, long rm_step,
+                   int ldo, bool rm_sc1, float* o16, long o16_step, int ct, int wg0, int nwg, int flags) {
+      Desc& d = bld.add(K_LIN, ct, wg0, nwg, K, flags | (rm_sc1 ? DF_RM_SC1 : 0), 0, T);
+      bld.ptr(d, 0, A16, a_step); bld.ptr(d, 1, W); bld.ptr(d, 2, bias); bld.ptr(d, 3, add, add_step); bld.ptr(d, 5, orm, rm_step);
+      bld.ptr(d, 6, o16, o16_step);
+      d.ld[1] = H; d.ld[3] = ldo; d.n16[0] = ctH; d.f[0] = 0.f;
+    };
+    // L1: GRU input layer (z half; the context half is hoisted) | hidden projection of the GRU
+    lin(rs.Z16, xZ, rs.Wgz, Z, C > 0 ? nullptr : w->gin_b, C > 0 ? rs.XGIN : nullptr, sH, rs.GIN, sH, H, false, rs.GIN16, xH, ctH, 0, r_h, DF_RELU);
+    lin(rs.H16, xH, rs.Whh, H, w->gru_bhh, nullptr, 0, rs.GHb, s3H, 3 * H, true, nullptr, 0, 3 * ctH, r_h, r_gh, 0);
+    {  // L2: GRU
+      Desc& d = bld.add(K_GRU, ctH, 0, r_h, H, 0, 0, T);
+      bld.ptr(d, 0, rs.GIN16, xH); bld.ptr(d, 1, rs.Wih); bld.ptr(d, 2, nullptr); bld.ptr(d, 3, rs.GHb, s3H); bld.ptr(d, 4, hs, sH);
+      bld.ptr(d, 5, hs + sH, sH); bld.ptr(d, 6, rs.H16 + xH, xH); bld.ptr(d, 7, rs.RG, sH); bld.ptr(d, 8, rs.UG, sH); bld.ptr(d, 9, rs.NG, sH);
+      bld.ptr(d, 10, w->gru_bih);
+      d.ld[0] = H; d.ld[3] = H; d.n16[0] = ctH; d.i[0] = H;
+    }
+    // L3..L5: posterior | prior MLPs on h_t
+    lin(rs.H16 + xH, xH, rs.Wq[0], H, nullptr, rs.XQ, sH, rs.Q[0], sH, H, false, rs.Q16[0], xH, ctH, 0, r_h, DF_RELU);
+    lin(rs.H16 + xH, xH, rs.Wp[0], H, w->prior_b[0], nullptr, 0, rs.P[0], sH, H, false, rs.P16[0], xH, ctH, r_h, r_h, DF_RELU);
+    for (int k = 1; k < 3; ++k) {
+      lin(rs.Q16[k - 1], xH, rs.Wq[k], H, w->post_b[k], nullptr, 0, rs.Q[k], sH, H, false, rs.Q16[k], xH, ctH, 0, r_h, DF_RELU);
+      lin(rs.P16[k - 1], xH, rs.Wp[k], H, w->prior_b[k], nullptr, 0, rs.P[k], sH, H, false, rs.P16[k], xH, ctH, r_h, r_h, DF_RELU);
+    }
+    {  // L6: heads, combination, sample
+      Desc& d = bld.add(K_HEAD, ctZ, 0, range_for(ctZ * rt, 2 * r_h), H, 0, 0, T);
+      bld.ptr(d, 0, rs.P16[2], xH); bld.ptr(d, 1, rs.Q16[2], xH); bld.ptr(d, 2, rs.Wph); bld.ptr(d, 3, w->prior_hb); bld.ptr(d, 4, rs.Wqh);
+      bld.ptr(d, 5, w->post_hb); bld.ptr(d, 6, eps, sZ); bld.ptr(d, 7, mu_p, sZ); bld.ptr(d, 8, sd_p, sZ); bld.ptr(d, 9, mu_q, sZ);
+      bld.ptr(d, 10, sd_q, sZ); bld.ptr(d, 11, rs.RAWP, sZ); bld.ptr(d, 12, rs.RAWQ, sZ); bld.ptr(d, 13, rs.MUQR, sZ);
+      bld.ptr(d, 14, zs + sZ, sZ); bld.ptr(d, 15, rs.Z16 + xZ, xZ);
+      d.ld[3] = Z; d.n16[0] = ctZ; d.i[0] = Z; d.i[1] = mode; d.f[0] = beta; d.f[1] = 1.f / beta; d.f[2] = sd_eps;
+    }
+    BLVM_REQUIRE(!bld.overflow, "rssm_fwd: persistent program overflow");
+    rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
+    if (rc) return rc;
+    // sentinel-fill what the launch polls: the T16 copies, the hidden projection, the states h_1 .. h_T (the GRU link polls words)
+    BLVM_HIP(hipMemsetAsync(rs.Z16, 0xFF, (size_t)(reinterpret_cast<char*>(rs.x16_end) - reinterpret_cast<char*>(rs.Z16)), s));
+    BLVM_HIP(hipMemsetAsync(rs.GHb, 0xFF, sizeof(float) * n * 3 * H, s));
+    BLVM_HIP(hipMemsetAsync(hs + sH, 0xFF, sizeof(float) * n * H, s));
+    rc = pchain_rows_to_t16(zs, Z, B, Z, rs.Z16, s); if (rc) return rc;
+    rc = pchain_rows_to_t16(hs, H, B, H, rs.H16, s); if (rc) return rc;
+    return pchain_launch(bld.p, s);
+  }
   for (int t = 0; t < T; ++t) {
     const size_t oH = (size_t)t * B * H, oZ = (size_t)t * B * Z, o3 = (size_t)t * B * 3 * H;
     const float* zprev = zs + oZ;
@@ -293,7 +370,74 @@ extern "C" int blvm_rssm_seq_bwd(const BlvmRssmWeights* w, const float* enc, con
   TRY(t16_pack_transposed(w->prior_hw, H, 2 * Z, H, ws.phT, s));
   BLVM_HIP(hipMemsetAsync(ws.G, 0, sizeof(float) * bh, s));
   const int rt = (B + 15) / 16;
-  for (int t = T - 1; t >= 0; --t) {
+  const bool persistent = pchain_applies(B) && device_cus() >= 32;
+  if (persistent) {
+    // Persistent path: the BPTT chain as a program of 12 descriptors walked for s = 0 .. T (t = T-1-s; s = T: the gradients wrt the
+    // initial state).  The running gradient wrt h lives in per-step slabs, each written once: GA[t] = g_t * u_t (GRU-backward link),
+    // GB[t] = GA[t+1] + DGH[t+1] W_hh (a K = 3H product nothing needs before the GRU-backward link three links later: own range).
+    using namespace pchain;
+    const int ctH = H / 16, ctZ = Z / 16, cus = device_cus() & ~7;
+    const long sH = (long)B * H, sZ = (long)B * Z, s3H = 3 * sH, s2Z = 2 * sZ;
+    const long xH = (long)rt * 16 * H, x3H = 3 * xH, x2Z = (long)rt * 16 * 2 * Z;
+    const int r_h = range_for(ctH * rt, cus / 4), r_gb = range_for(ctH * rt, cus - 2 * r_h);
+    Builder bld;
+    bld.p.S = T + 1; bld.p.B = B; bld.p.xcd = (pchain_tune() & 4) ? 1 : 0; bld.p.lds_products = 2;
+    bld.p.prof = pchain_profile_buffer() ? pchain_profile_buffer() + 64 : nullptr; bld.p.prof_wg = 2 * r_h;
+    auto at = [&](const float* base, long step, int t0) { return base ? base + (long)t0 * step : nullptr; };  // slab of step t0
+    auto lin = [&](const float* A16, long a_x, int a_t0, const float* W, int K, const float* add, long add_step, int add_t0, int ldadd, bool add_polled,
+                   const float* gate, long gate_step, float* orm, long rm_step, int ldo, bool rm_sc1, float* o16, long o16_x, int n16, int ct, int wg0,
+                   int nwg, int flags, int s0, int s1) {
+      Desc& d = bld.add(K_LIN, ct, wg0, nwg, K, flags | (add_polled ? DF_ADD_POLLED : 0) | (rm_sc1 ? DF_RM_SC1 : 0), s0, s1);
+      bld.ptr(d, 0, at(A16, a_x, a_t0), -a_x); bld.ptr(d, 1, W); bld.ptr(d, 3, at(add, add_step, add_t0), -add_step);
+      bld.ptr(d, 4, at(gate, gate_step, T - 1), -gate_step); bld.ptr(d, 5, rm_step ? at(orm, rm_step, T - 1) : orm, -rm_step);
+      bld.ptr(d, 6, at(o16, o16_x, T - 1), -o16_x);
+      d.ld[1] = ldadd; d.ld[2] = H; d.ld[3] = ldo; d.n16[0] = n16; d.f[0] = 0.f;
+    };
+    {  // B1: dz_t (direct + through the GRU input layer of step t+1), rsample / combination / KL / softplus heads
+      Desc& d = bld.add(K_DZ, ctZ, 0, range_for(ctZ * rt, 2 * r_h), H, 0, 0, T);
+      bld.ptr(d, 0, at(ws.DGIN16, xH, T), -xH); bld.ptr(d, 1, ws.gzT); bld.ptr(d, 4, at(d_zs, sZ, T), -sZ);
+      bld.ptr(d, 5, at(mu_q, sZ, T - 1), -sZ); bld.ptr(d, 6, at(sd_q, sZ, T - 1), -sZ); bld.ptr(d, 7, at(mu_p, sZ, T - 1), -sZ);
+      bld.ptr(d, 8, at(sd_p, sZ, T - 1), -sZ); bld.ptr(d, 9, at(eps, sZ, T - 1), -sZ); bld.ptr(d, 10, at(rs.RAWQ, sZ, T - 1), -sZ);
+      bld.ptr(d, 11, at(rs.RAWP, sZ, T - 1), -sZ); bld.ptr(d, 12, at(rs.MUQR, sZ, T - 1), -sZ);
+      bld.ptr(d, 13, x_sl); bld.ptr(d, 14, c_raw); bld.ptr(d, 15, c_fn);
+      bld.ptr(d, 16, at(ws.DQH, s2Z, T - 1), -s2Z); bld.ptr(d, 17, at(ws.DQH16, x2Z, T - 1), -x2Z); bld.ptr(d, 18, at(ws.DPH, s2Z, T - 1), -s2Z);
+      bld.ptr(d, 19, at(ws.DPH16, x2Z, T - 1), -x2Z);
+      d.ld[1] = Z; d.ld[3] = 2 * Z; d.n16[0] = 2 * ctZ; d.i[0] = Z; d.i[1] = mode; d.i[2] = stride; d.i[3] = T - 1;
+      d.f[0] = fn_floor; d.f[1] = beta; d.f[2] = sd_eps; d.f[3] = 1.f;
+    }
+    // B2: heads -> third layers (posterior | prior) | GB[t] = GA[t+1] + DGH[t+1] W_hh
+    lin(ws.DQH16, x2Z, T - 1, ws.qhT, 2 * Z, nullptr, 0, 0, 0, false, rs.Q[2], sH, ws.DQ[2], sH, H, false, ws.DQ16[2], xH, ctH, ctH, 0, r_h, 0, 0, T);
+    lin(ws.DPH16, x2Z, T - 1, ws.phT, 2 * Z, nullptr, 0, 0, 0, false, rs.P[2], sH, ws.DP[2], sH, H, false, ws.DP16[2], xH, ctH, ctH, r_h, r_h, 0, 0, T);
+    lin(ws.DGH16, x3H, T, ws.whhT, 3 * H, ws.GA, sH, T, H, true, nullptr, 0, ws.GB, sH, H, true, nullptr, 0, 0, ctH, 2 * r_h, r_gb, DF_GENTLE, 1, T);
+    // B3, B4
+    for (int k = 2; k >= 1; --k) {
+      lin(ws.DQ16[k], xH, T - 1, ws.qT[k], H, nullptr, 0, 0, 0, false, rs.Q[k - 1], sH, ws.DQ[k - 1], sH, H, false, ws.DQ16[k - 1], xH, ctH, ctH, 0, r_h, 0, 0, T);
+      lin(ws.DP16[k], xH, T - 1, ws.pT[k], H, nullptr, 0, 0, 0, false, rs.P[k - 1], sH, ws.DP[k - 1], sH, H, false, ws.DP16[k - 1], xH, ctH, ctH, r_h, r_h, 0, 0, T);
+    }
+    {  // B5: complete dL/dh_t, gate derivatives of step t
+      Desc& d = bld.add(K_GRUB, ctH, 0, r_h, H, 0, 0, T);
+      bld.ptr(d, 0, at(ws.DQ16[0], xH, T - 1), -xH); bld.ptr(d, 1, at(ws.DP16[0], xH, T - 1), -xH); bld.ptr(d, 2, ws.qT[0]); bld.ptr(d, 3, ws.pT[0]);
+      bld.ptr(d, 4, at(ws.GB, sH, T - 1), -sH);
+      bld.ptr(d, 5, at(rs.RG, sH, T - 1), -sH); bld.ptr(d, 6, at(rs.UG, sH, T - 1), -sH); bld.ptr(d, 7, at(rs.NG, sH, T - 1), -sH);
+      bld.ptr(d, 8, at(rs.GHb, s3H, T - 1), -s3H); bld.ptr(d, 9, at(hs, sH, T - 1), -sH); bld.ptr(d, 10, nullptr);
+      bld.ptr(d, 11, at(ws.DGI, s3H, T - 1), -s3H); bld.ptr(d, 12, at(ws.DGI16, x3H, T - 1), -x3H); bld.ptr(d, 13, at(ws.DGH, s3H, T - 1), -s3H);
+      bld.ptr(d, 14, at(ws.DGH16, x3H, T - 1), -x3H); bld.ptr(d, 15, at(ws.GA, sH, T - 1), -sH); bld.ptr(d, 16, ws.G);
+      bld.ptr(d, 17, at(d_hs, sH, T), -sH);
+      d.ld[0] = H; d.ld[1] = H; d.ld[3] = 3 * H; d.n16[0] = 3 * ctH; d.i[0] = H; d.i[1] = 0; d.i[2] = T; d.i[3] = 1;
+    }
+    // B6: through the GRU input projection to the (ReLU) GRU input layer
+    lin(ws.DGI16, x3H, T - 1, ws.wihT, 3 * H, nullptr, 0, 0, 0, false, rs.GIN, sH, ws.DGIN, sH, H, false, ws.DGIN16, xH, ctH, ctH, 0, r_h, 0, 0, T);
+    // s = T: gradients wrt the initial state: z0 through the GRU input layer of step 0 (+ its direct gradient), h0 through the GRU
+    // of step 0 (the caller adds the direct gradient d_hs[0])
+    if (d_z0) lin(ws.DGIN16, xH, T, ws.gzT, H, d_zs, sZ, T, Z, false, nullptr, 0, d_z0, 0, Z, false, nullptr, 0, 0, ctZ, 0, range_for(ctZ * rt, 2 * r_h), 0, T, T + 1);
+    if (d_h0) lin(ws.DGH16, x3H, T, ws.whhT, 3 * H, ws.GA, sH, T, H, true, nullptr, 0, d_h0, 0, H, false, nullptr, 0, 0, ctH, 2 * r_h, r_gb, 0, T, T + 1);
+    BLVM_REQUIRE(!bld.overflow, "rssm_bwd: persistent program overflow");
+    rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
+    if (rc) return rc;
+    BLVM_HIP(hipMemsetAsync(ws.GA, 0xFF, (size_t)(reinterpret_cast<char*>(ws.x16_end) - reinterpret_cast<char*>(ws.GA)), s));
+    TRY(pchain_launch(bld.p, s));
+  }
+  for (int t = T - 1; t >= 0 && !persistent; --t) {
     const size_t oH = (size_t)t * B * H, oZ = (size_t)t * B * Z, o3 = (size_t)t * B * 3 * H, o2Z = (size_t)t * B * 2 * Z;
     const bool last = t == T - 1;
     // B1: dz_t (direct + through the GRU input layer of step t+1), then rsample / combination / KL / softplus heads
@@ -344,13 +488,13 @@ extern "C" int blvm_rssm_seq_bwd(const BlvmRssmWeights* w, const float* enc, con
   BLVM_CHECK_LAUNCH("rssm_seq_bwd");
   // gradients wrt the initial state: z0 through the GRU input layer of step 0 (+ its direct gradient), h0 through the
   // GRU of step 0 (the caller adds the direct gradient d_hs[0])
-  if (d_z0) {
+  if (d_z0 && !persistent) {
     LinLaunch l;
     l.B = B; l.nseg = 1;
     l.seg[0] = seg(ws.DGIN, H, ws.gzT, H, nullptr, d_zs, Z, nullptr, 0, d_z0, Z, Z, H, 0);
     launch_lin(l, s);
   }
-  if (d_h0) {
+  if (d_h0 && !persistent) {
     LinLaunch l;
     l.B = B; l.nseg = 1;
     l.seg[0] = seg(ws.DGH, 3 * H, ws.whhT, 3 * H, nullptr, ws.G, H, nullptr, 0, d_h0, H, H, 3 * H, 0);

@@ -143,7 +143,6 @@ struct Reserve {
   // persistent forward (B <= kPchainCarveMaxB): T16 copies of every activation a link multiplies, per step [rt*16, width]
   float *H16, *P16[3], *Q16[3], *Z16, *FZ16[3], *PHI16, *x16_end;
 };
-constexpr int kPchainCarveMaxB = 128;  // the persistent kernels' extra buffers are carved for batches up to this size only
 
 size_t carve_reserve(float* base, int Tp, int B, int H, int Z, int R, Reserve* r) {
   const size_t n = (size_t)Tp * B;
@@ -252,24 +251,6 @@ inline int overlap_chunk_steps() {
 }
 
 
-// [B, K] row-major (row stride ld) -> the T16 copy [rt*16, K] of the same rows (rows >= B are left alone: never read)
-__global__ void rows_to_t16_kernel(const float* src, int ld, int B, int K, float* dst) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * K) return;
-  const int row = i / K, k = i % K;
-  dst[((size_t)(row >> 4) * (K >> 4) + (k >> 4)) * 256 + ((row & 15) + 16 * ((k & 15) >> 2)) * 4 + (k & 3)] = src ? src[(size_t)row * ld + k] : 0.f;
-}
-
-inline int device_cus() {
-  static int v = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    return n;
-  }();
-  return v;
-}
-
 int check_dims(int Tp, int B, int X, int H, int Z, int R) {
   BLVM_REQUIRE(Tp > 0 && B > 0, "vrnn: bad Tp=%d B=%d", Tp, B);
   BLVM_REQUIRE(X > 0 && H > 0 && Z > 0 && R > 0 && X % 16 == 0 && H % 16 == 0 && Z % 16 == 0 && R % 16 == 0,
@@ -332,7 +313,7 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
   else BLVM_HIP(hipMemset2DAsync(decin + H, sizeof(float) * ldd, 0, sizeof(float) * R, B, s));
 
   const int rt = (B + 15) / 16;
-  if (B <= pchain_max_batch() && B <= kPchainCarveMaxB && device_cus() >= 32) {
+  if (pchain_applies(B) && device_cus() >= 32) {
     // Persistent path (pchain.h / pchain.hip): the nine links of a step as a program of 13 descriptors, one launch for the whole
     // sequence.  Links on the critical path share the workgroups [0, g); the GRU's hidden projection gh_t = h_{t-1} W_hh^T + b_hh
     // (3R columns, first needed by the GRU link's epilogue eight links later) has its own range behind them and polls gently.
@@ -392,7 +373,8 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     BLVM_HIP(hipMemsetAsync(decin, 0xFF, sizeof(float) * n * ldd, s));  // rows 0..T'-1; row T' only receives h_n
     if (h0) BLVM_HIP(hipMemcpy2DAsync(decin + H, sizeof(float) * ldd, h0, sizeof(float) * R, sizeof(float) * R, B, hipMemcpyDeviceToDevice, s));
     else BLVM_HIP(hipMemset2DAsync(decin + H, sizeof(float) * ldd, 0, sizeof(float) * R, B, s));
-    hipLaunchKernelGGL(rows_to_t16_kernel, dim3((B * R + 255) / 256), dim3(256), 0, s, h0, R, B, R, rs.H16);
+    rc = pchain_rows_to_t16(h0, R, B, R, rs.H16, s);
+    if (rc) return rc;
     return pchain_launch(bld.p, s);
   }
   for (int t = 0; t < Tp; ++t) {
@@ -564,7 +546,7 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
 #undef TRY
     return BLVM_OK;
   };
-  if (B <= pchain_max_batch() && B <= kPchainCarveMaxB && device_cus() >= 32) {
+  if (pchain_applies(B) && device_cus() >= 32) {
     // Persistent path: the whole BPTT chain as a program of 13 descriptors walked for s = 0 .. T' (t = T'-1-s: last-step slabs and
     // negative strides), then the batched weight-gradient GEMMs.  The running gradient wrt the recurrent state lives in per-step
     // slabs so that every location is written once: GA[t] = g_t * u_t + decoder gradient (written by the GRU-backward link),
@@ -587,7 +569,7 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
       bld.ptr(d, 9, last(decin, sD) + H, -sD); bld.ptr(d, 10, last(d_decin, sD) + H, -sD);
       bld.ptr(d, 11, last(ws.DGI, s3R), -s3R); bld.ptr(d, 12, last(ws.DGI16, x3R), -x3R); bld.ptr(d, 13, last(ws.DGH, s3R), -s3R);
       bld.ptr(d, 14, last(ws.DGH16, x3R), -x3R); bld.ptr(d, 15, last(ws.GA, sR), -sR); bld.ptr(d, 16, d_h0 ? d_h0 : ws.G);
-      d.ld[0] = ldd; d.ld[3] = 3 * R; d.n16[0] = 3 * ctR; d.i[0] = R; d.i[1] = 1; d.i[2] = T;
+      d.ld[0] = ldd; d.ld[3] = 3 * R; d.n16[0] = 3 * ctR; d.i[0] = R; d.i[1] = 1; d.i[2] = T; d.i[3] = 1;
     }
     auto lin = [&](const float* A16, long a_x, const float* W, int K, const float* add, long add_step, int ldadd, const float* gate, long gate_step,
                    int ldgate, float* orm, long rm_step, int ldo, float* o16, long o16_x, int n16, int ct, int wg0, int nwg, int flags) {

@@ -51,6 +51,13 @@ int blvm_pchain_profile(unsigned long long* device_buffer);
  * column tile's row tiles on one XCD, so every XCD's L2 holds 1/8 of each weight matrix), 16 one-word canary poll in front of the
  * operand polls of tiles off the critical path. */
 int blvm_pchain_tune(int bits);
+/* Diagnostics / unit test of the persistent-chain engine on its own: L dependent links x_{s+1} = relu(x_s W^T + b), [B,N] x [N,N],
+ * as ONE launch.  W16: W [N,N] in the T16 operand layout (blvm_pchain_rows_to_t16 of W: a weight's rows are the "batch");
+ * x16: L+1 T16 slabs of ceil(B/16)*16 x N floats, slab 0 = x_0 in T16 (blvm_pchain_rows_to_t16); xs: L row-major [B,N] outputs.
+ * nwg: workgroups (0: one per tile, at most one per CU). */
+int blvm_pchain_chain_probe(const float* W16, const float* bias, float* x16, float* xs, int B, int N, int L, int nwg, void* stream);
+/* dst = T16 operand copy [ceil(B/16)*16, K] of the rows of src [B,K] (row stride ld). */
+int blvm_pchain_rows_to_t16(const float* src, int ld, int B, int K, float* dst, void* stream);
 /* n host integers -> device memory through kernel arguments (asynchronous on `stream`; a pageable hipMemcpy would block the host
  * until the stream has drained).  Carries the batch's lengths `x_sl` (`blvm/data/batchers.py:145-151` hands them over on the host). */
 int blvm_upload_i32(const int32_t* host, int n, int32_t* dst, void* stream);
