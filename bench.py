@@ -71,7 +71,7 @@ def pmc_traffic(model, B, T):
     """HBM-side bytes per train step of the dominant kernel, from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE in separate runs, FETCH_SIZE doubled on gfx950 per MI355X_MICROARCH.md) — counters cannot be read from inside
     the timed process, so this is the profile of the same command, valid for the workload it was taken on only."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_vrnn_pmc_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_vrnn_pmc_traffic.json")
     if model != "vrnn" or (B, T) != (64, 16000) or not os.path.exists(path):
         return None
     with open(path) as f:

@@ -80,75 +80,78 @@ class _Levels(nn.Sequential):
         return x
 
 
+def _per_level(value, num_levels: int, first_only: bool):
+    """Normalise a `channels_in` / `channels_out` argument to one entry per level: None -> no projection anywhere; an int -> that
+    width at the first level only (`first_only`: inputs enter at the bottom) or at every level; a list is taken as given."""
+    if value is None:
+        return [None] * num_levels
+    if isinstance(value, int):
+        return [value] + [None] * (num_levels - 1) if first_only else [value] * num_levels
+    return list(value)
+
+
+def _level_plan(level_stride: int, stride_per_block: int, num_blocks: int, dilation_factor: int, level: int):
+    """(stride, dilation) of the blocks of one level: the level's stride is spent `stride_per_block` at a time from the first block
+    on, the remaining blocks have stride 1; block b is dilated by dilation_factor**b (convolutional_coders.py:185-191)."""
+    plan, left = [], level_stride
+    for b in range(num_blocks):
+        take = stride_per_block if left >= stride_per_block else 1
+        if take == 1 and left != 1:
+            raise ValueError(f"remaining_stride={left} is not 1 at l={level}, b={b}.")
+        left //= take
+        plan.append((take, dilation_factor**b))
+    return plan
+
+
+def _receptive_field(plan, kernel_size: int, stride_in: int = 1, rf_in: int = 1):
+    """Accumulated (stride, receptive field) behind a sequence of (stride, dilation) convolutions."""
+    for stride, dilation in plan:
+        _, stride_in, rf_in, _ = compute_conv_attributes_single(i=1, k=kernel_size, p=0, s=stride, d=dilation, s_in=stride_in, r_in=rf_in)
+    return stride_in, rf_in
+
+
 class ConvCoder1d(nn.Module):
     def __init__(self, strides: List[int], channels: int = 128, kernel_size: Union[int, List[int]] = 5, stride_per_block: int = 2,
                  dilation_factor: int = 1, num_blocks: int = 8, channels_in: Optional[Union[int, List[Union[None, int]]]] = None,
                  channels_out: Optional[Union[int, List[Union[None, int]]]] = None, transposed: bool = False,
                  block_type: str = "BlockSeparable", activation: nn.Module = nn.PReLU):  # fmt: skip
-        """Same arguments as the reference (convolutional_coders.py:94-124)."""
+        """Same arguments, attributes, state_dict keys and parameter creation order as the reference's coder
+        (convolutional_coders.py:94-231).  Built in two passes: the (stride, dilation) plan and receptive fields of every level
+        are plain arithmetic (`_level_plan`, `_receptive_field`); the modules follow from the plans."""
         super().__init__()
-        if block_type not in ["BlockSeparable", "BlockSimple"]:
+        blocks_by_name = {"BlockSeparable": BlockSeparable, "BlockSimple": BlockSimple}
+        if block_type not in blocks_by_name:
             raise ValueError(f"Unknown {block_type=}.")
-        num_levels = len(strides)
-        overall_strides = np.cumprod(strides)
         assert all(stride_per_block**num_blocks >= s for s in strides), f"Not enough blocks per level for {strides=}"
-
         self.strides, self.channels, self.kernel_size, self.num_blocks = strides, channels, kernel_size, num_blocks
         self.transposed, self.stride_per_block, self.block_type, self.activation = transposed, stride_per_block, block_type, activation
-        self.num_levels, self.overall_strides, self.overall_stride = num_levels, overall_strides, overall_strides[-1]
+        self.num_levels = len(strides)
+        self.overall_strides = np.cumprod(strides)
+        self.overall_stride = self.overall_strides[-1]
+        self.channels_in = _per_level(channels_in, self.num_levels, first_only=True)
+        self.channels_out = _per_level(channels_out, self.num_levels, first_only=False)
+        self.e_size = [channels if c is None else c for c in self.channels_out]
 
-        if channels_in is None:
-            self.channels_in = [None] * num_levels
-        elif isinstance(channels_in, int):
-            self.channels_in = [channels_in] + [None] * (num_levels - 1)
-        else:
-            self.channels_in = channels_in
-        if channels_out is None:
-            self.channels_out = [None] * num_levels
-        elif isinstance(channels_out, int):
-            self.channels_out = [channels_out] * num_levels
-        else:
-            self.channels_out = channels_out
-        self.e_size = [c if c is not None else self.channels for c in self.channels_out]
-
-        block_cls = {"BlockSeparable": BlockSeparable, "BlockSimple": BlockSimple}[block_type]
-        self.overall_receptive_fields, self.receptive_fields = [], []
-        self.levels = nn.ModuleList()
-        self.out_projs = nn.ModuleDict()
-        self.in_projs = nn.ModuleDict()
-
-        overall_stride_in, overall_rf_in = 1, 1
-        for l in range(num_levels):
-            remaining_stride = self.strides[l]
-            stride_in, rf_in = 1, 1
-            blocks = []
-            for b in range(num_blocks):
-                dilation = dilation_factor**b
-                if remaining_stride >= self.stride_per_block:
-                    stride = self.stride_per_block
-                    remaining_stride = remaining_stride // self.stride_per_block
-                else:
-                    if remaining_stride != 1:
-                        raise ValueError(f"{remaining_stride=} is not 1 at {l=}, {b=}.")
-                    stride = 1
-                blocks.append(block_cls(channels, kernel_size, stride, dilation, activation, transposed, bias=True))
-                _, overall_stride_in, overall_rf_in, _ = compute_conv_attributes_single(
-                    i=1, k=kernel_size, p=0, s=stride, d=dilation, s_in=overall_stride_in, r_in=overall_rf_in)  # fmt: skip
-                _, stride_in, rf_in, _ = compute_conv_attributes_single(
-                    i=1, k=kernel_size, p=0, s=stride, d=dilation, s_in=stride_in, r_in=rf_in)  # fmt: skip
-            self.overall_receptive_fields.append(overall_rf_in)
-            self.receptive_fields.append(rf_in)
-            if transposed:  # mirrored stride order (convolutional_coders.py:227-231)
-                blocks = blocks[::-1]
-            self.levels.append(_Levels(*blocks))
-            # parameter creation order of the reference: out projection, then in projection
-            if self.channels_out[l] is not None:
-                self.out_projs[str(l)] = nn.Sequential(nn.Conv1d(channels, self.channels_out[l], 1), activation())
-                require_relu(self.out_projs[str(l)][1], "ConvCoder1d.out_projs")
-            if self.channels_in[l] is not None:
-                self.in_projs[str(l)] = nn.Sequential(nn.Conv1d(self.channels_in[l], channels, 1), activation())
-                require_relu(self.in_projs[str(l)][1], "ConvCoder1d.in_projs")
+        # pass 1: arithmetic
+        plans = [_level_plan(s, stride_per_block, num_blocks, dilation_factor, l) for l, s in enumerate(strides)]
+        self.receptive_fields = [_receptive_field(plan, kernel_size)[1] for plan in plans]
+        self.overall_receptive_fields, seen = [], (1, 1)
+        for plan in plans:  # through all levels below as well
+            seen = _receptive_field(plan, kernel_size, *seen)
+            self.overall_receptive_fields.append(seen[1])
         self.overall_receptive_field = self.overall_receptive_fields[-1]
+
+        # pass 2: modules, level by level (the reference creates a level's blocks, then its out projection, then its in projection:
+        # seeded initialisation and state_dict order depend on it)
+        self.levels, self.out_projs, self.in_projs = nn.ModuleList(), nn.ModuleDict(), nn.ModuleDict()
+        for l, plan in enumerate(plans):
+            blocks = [blocks_by_name[block_type](channels, kernel_size, stride, dilation, activation, transposed, bias=True) for stride, dilation in plan]
+            self.levels.append(_Levels(*(reversed(blocks) if transposed else blocks)))  # a transposed coder mirrors the stride order
+            for width, table, make in ((self.channels_out[l], self.out_projs, lambda c: nn.Conv1d(channels, c, 1)),
+                                       (self.channels_in[l], self.in_projs, lambda c: nn.Conv1d(c, channels, 1))):  # fmt: skip
+                if width is not None:
+                    table[str(l)] = nn.Sequential(make(width), activation())
+                    require_relu(table[str(l)][1], "ConvCoder1d.out_projs" if table is self.out_projs else "ConvCoder1d.in_projs")
 
     @property
     def device(self):

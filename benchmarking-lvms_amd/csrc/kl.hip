@@ -4,8 +4,11 @@
 // last dim) and the masked sums of VRNN/SRNN.compute_elbo (blvm/models/vrnn.py:271-276, srnn.py:150-156).
 // HBM-bound: 4 x 4 B read per latent element forward (64 B per audio frame at z=256, s=64 — SURVEY.md §8d).
 //
-// Mapping: one wave per latent row (t, b): 16-byte loads along Z, in-register KL, wave reduction in fp64, one
-// atomic per (row, output).  Rows are independent, so the grid is (rows / 4) workgroups of 4 waves.
+// Mapping (forward): a workgroup owns ONE utterance and a chunk of its latent steps — the four waves take steps in turn, a lane
+// 4 consecutive latent dimensions (16-byte loads: a 1 KB row per wave instruction at Z = 256) — and accumulates both sums in
+// float64 registers across its rows; wave shuffle + LDS reduction, then ONE fp64 atomic per workgroup and output.  (Round 1 had one
+// wave per row with an atomic per row and output: 32 000 fp64 atomics on 128 addresses at [64,16000] — 59 us for 65.5 MB, 14 % of
+// the HBM rate; the atomics, not the bytes, were the time.)  Backward: one wave per row, elementwise.
 #include "common.h"
 
 namespace blvm {
@@ -31,29 +34,48 @@ __device__ __forceinline__ float kl_elem(float mq, float sq, float mp, float sp)
   return log_(sp) - log_(sq) + (sq * sq + d * d) / (2.f * sp * sp) - 0.5f;
 }
 
-__global__ __launch_bounds__(256) void kl_fwd_kernel(KlArgs a) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (row >= a.B * a.Tp) return;
-  int b, t;
-  row_coord(a, row, b, t);
-  if ((long long)t * a.stride >= a.x_sl[b]) return;  // masked step: contributes nothing
-  const size_t base = (size_t)row * a.Z;
-  double s_raw = 0.0, s_fn = 0.0;
+// grid (B, ceil(Tp / chunk)); VEC: Z % 4 == 0 and 16-byte aligned rows
+template <bool VEC>
+__global__ __launch_bounds__(256) void kl_fwd_kernel(KlArgs a, int chunk) {
+  __shared__ double part[2][4];
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t0 = blockIdx.y * chunk, t1 = min(a.Tp, t0 + chunk);
+  const long long xs = a.x_sl[b];
   const bool use_fn = a.fn_floor > 0.f;
-  for (int c = lane; c < a.Z; c += 64) {
-    const float k = kl_elem(a.mu_q[base + c], a.sd_q[base + c], a.mu_p[base + c], a.sd_p[base + c]);
-    s_raw += (double)k;
-    s_fn += (double)(use_fn ? fmaxf(k, a.fn_floor) : k);
+  double s_raw = 0.0, s_fn = 0.0;
+  for (int t = t0 + wave; t < t1 && (long long)t * a.stride < xs; t += 4) {  // masked steps contribute nothing
+    const size_t base = ((a.layout == 0) ? (size_t)b * a.Tp + t : (size_t)t * a.B + b) * a.Z;
+    if (VEC) {
+      for (int c = lane * 4; c < a.Z; c += 256) {
+        const float4 mq = *reinterpret_cast<const float4*>(a.mu_q + base + c), sq = *reinterpret_cast<const float4*>(a.sd_q + base + c);
+        const float4 mp = *reinterpret_cast<const float4*>(a.mu_p + base + c), sp = *reinterpret_cast<const float4*>(a.sd_p + base + c);
+        const float k0 = kl_elem(mq.x, sq.x, mp.x, sp.x), k1 = kl_elem(mq.y, sq.y, mp.y, sp.y);
+        const float k2 = kl_elem(mq.z, sq.z, mp.z, sp.z), k3 = kl_elem(mq.w, sq.w, mp.w, sp.w);
+        s_raw += (double)k0; s_raw += (double)k1; s_raw += (double)k2; s_raw += (double)k3;
+        if (use_fn) { s_fn += (double)fmaxf(k0, a.fn_floor); s_fn += (double)fmaxf(k1, a.fn_floor); s_fn += (double)fmaxf(k2, a.fn_floor); s_fn += (double)fmaxf(k3, a.fn_floor); }
+      }
+    } else {
+      for (int c = lane; c < a.Z; c += 64) {
+        const float k = kl_elem(a.mu_q[base + c], a.sd_q[base + c], a.mu_p[base + c], a.sd_p[base + c]);
+        s_raw += (double)k;
+        if (use_fn) s_fn += (double)fmaxf(k, a.fn_floor);
+      }
+    }
   }
+  if (!use_fn) s_fn = s_raw;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     s_raw += __shfl_down(s_raw, off, 64);
     s_fn += __shfl_down(s_fn, off, 64);
   }
-  if (lane == 0) {
-    atomicAdd(a.kld + b, s_raw);
-    atomicAdd(a.kld_fn + b, s_fn);
+  if (lane == 0) { part[0][wave] = s_raw; part[1][wave] = s_fn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double r = (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]), f = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
+    if (r != 0.0 || f != 0.0) {
+      atomicAdd(a.kld + b, r);
+      atomicAdd(a.kld_fn + b, f);
+    }
   }
 }
 
@@ -205,7 +227,13 @@ extern "C" int blvm_kl_fwd(const float* mu_q, const float* sd_q, const float* mu
   a.mu_q = mu_q; a.sd_q = sd_q; a.mu_p = mu_p; a.sd_p = sd_p; a.x_sl = x_sl;
   a.kld = kld; a.kld_fn = kld_fn;
   a.layout = layout; a.B = B; a.Tp = Tp; a.Z = Z; a.stride = stride; a.fn_floor = fn_floor;
-  hipLaunchKernelGGL(kl_fwd_kernel, dim3((B * Tp + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  // chunk of steps per workgroup: ~1 000 workgroups, at least one step per wave
+  int chunk = (int)(((long long)B * Tp + 1023) / 1024);
+  chunk = chunk < 4 ? 4 : (chunk > 256 ? 256 : chunk);
+  const dim3 grid(B, (Tp + chunk - 1) / chunk);
+  const bool vec = Z % 4 == 0 && aligned16(mu_q) && aligned16(sd_q) && aligned16(mu_p) && aligned16(sd_p);
+  if (vec) hipLaunchKernelGGL((kl_fwd_kernel<true>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), a, chunk);
+  else hipLaunchKernelGGL((kl_fwd_kernel<false>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), a, chunk);
   BLVM_CHECK_LAUNCH("kl_fwd");
   return BLVM_OK;
 }

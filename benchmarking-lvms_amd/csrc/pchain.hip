@@ -214,7 +214,7 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
             const Out oq{d.m<16>(s), ld3, false, d.m<17>(s), n16}, op{d.m<18>(s), ld3, false, d.m<19>(s), n16};
             for (int tk = 0; tk < nt; ++tk) {
               const int trc = d.tile(tk);
-              tile_dz<NW>(d.p<0>(s), d.base<1>(), nullptr, nullptr, true, d.p<4>(s), ld1, (flags & DF_ADD_POLLED) != 0, z, oq, op, K, Z, trc & 0xffff,
+              tile_dz<NW>(d.p<0>(s), d.base<1>(), d.p<2>(s), d.base<3>(), true, d.p<4>(s), ld1, (flags & DF_ADD_POLLED) != 0, z, oq, op, K, Z, trc & 0xffff,
                           (trc >> 16) * 16, B, red(), pl);
             }
           } break;

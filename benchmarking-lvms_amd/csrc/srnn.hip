@@ -8,13 +8,17 @@
 // sample) forward and 4 backward, every element-wise piece fused into an epilogue (stages.h).  The KL(+free nats)
 // gradient is folded into the backward chain exactly as for the VRNN cell.
 #include "common.h"
+#include "pchain.h"
 
 namespace blvm {
 namespace {
 
 #include "stages.h"
 
-struct SrnnReserve { float *P[3], *Q[3], *XP, *XQ, *RAWP, *RAWQ, *Wp[3], *Wq[3], *Wph, *Wqh; };  // W*: T16 weight copies
+struct SrnnReserve {
+  float *P[3], *Q[3], *XP, *XQ, *RAWP, *RAWQ, *Wp[3], *Wq[3], *Wph, *Wqh;  // W*: T16 weight copies
+  float *Z16, *P16[3], *Q16[3], *x16_end;  // persistent forward (B <= kPchainCarveMaxB): T16 copies of what the links multiply
+};
 size_t carve_srnn(float* base, int Tp, int B, int H, int Z, SrnnReserve* r) {
   const size_t n = (size_t)Tp * B;
   size_t off = 0;
@@ -27,11 +31,21 @@ size_t carve_srnn(float* base, int Tp, int B, int H, int Z, SrnnReserve* r) {
   t.Wp[0] = take((size_t)H * Z); t.Wq[0] = take((size_t)H * Z);
   for (int i = 1; i < 3; ++i) { t.Wp[i] = take((size_t)H * H); t.Wq[i] = take((size_t)H * H); }
   t.Wph = take((size_t)2 * Z * H); t.Wqh = take((size_t)2 * Z * H);
+  t.Z16 = nullptr;
+  if (B <= kPchainCarveMaxB) {
+    const size_t rows = (size_t)((B + 15) / 16) * 16, m = (size_t)Tp * rows;
+    t.Z16 = take((m + rows) * Z);
+    for (int i = 0; i < 3; ++i) { t.P16[i] = take(m * H); t.Q16[i] = take(m * H); }
+    t.x16_end = take(0);
+  }
   if (r) *r = t;
   return off;
 }
 
-struct SrnnWs { float *pzT, *qzT, *pT[3], *qT[3], *phT, *qhT, *DPH, *DQH, *DP[3], *DQ[3]; };
+struct SrnnWs {
+  float *pzT, *qzT, *pT[3], *qT[3], *phT, *qhT, *DPH, *DQH, *DP[3], *DQ[3];
+  float *DZ0, *DPH16, *DQH16, *DP16[3], *DQ16[3], *x16_end;  // persistent backward (B <= kPchainCarveMaxB)
+};
 size_t carve_srnn_ws(float* base, int Tp, int B, int H, int Z, SrnnWs* w) {
   const size_t n = (size_t)Tp * B;
   size_t off = 0;
@@ -43,6 +57,14 @@ size_t carve_srnn_ws(float* base, int Tp, int B, int H, int Z, SrnnWs* w) {
   t.phT = take((size_t)H * 2 * Z); t.qhT = take((size_t)H * 2 * Z);
   t.DPH = take(n * 2 * Z); t.DQH = take(n * 2 * Z);
   for (int i = 0; i < 3; ++i) { t.DP[i] = take(n * H); t.DQ[i] = take(n * H); }
+  t.DZ0 = nullptr;
+  if (B <= kPchainCarveMaxB) {
+    const size_t m = (size_t)Tp * ((B + 15) / 16) * 16;
+    t.DZ0 = take((size_t)B * Z);
+    t.DPH16 = take(m * 2 * Z); t.DQH16 = take(m * 2 * Z);
+    for (int i = 0; i < 3; ++i) { t.DP16[i] = take(m * H); t.DQ16[i] = take(m * H); }
+    t.x16_end = take(0);
+  }
   if (w) *w = t;
   return off;
 }
@@ -100,6 +122,42 @@ extern "C" int blvm_srnn_latent_fwd(const BlvmSrnnWeights* w, const float* d, co
   if (z0) BLVM_HIP(hipMemcpyAsync(zs, z0, sizeof(float) * (size_t)B * Z, hipMemcpyDeviceToDevice, s));
   else BLVM_HIP(hipMemsetAsync(zs, 0, sizeof(float) * (size_t)B * Z, s));
   const int rt = (B + 15) / 16;
+  if (pchain_applies(B) && device_cus() >= 32) {
+    // Persistent path (pchain.h / pchain.hip): the four links of a step as a program of 7 descriptors, one launch per sequence
+    using namespace pchain;
+    const int ctH = H / 16, ctZ = Z / 16, cus = device_cus() & ~7;
+    const long sH = (long)B * H, sZ = (long)B * Z, xH = (long)rt * 16 * H, xZ = (long)rt * 16 * Z;
+    const int half = range_for(ctH * rt, cus / 2);
+    Builder bld;
+    bld.p.S = Tp; bld.p.B = B; bld.p.xcd = (pchain_tune() & 4) ? 1 : 0; bld.p.lds_products = 4;
+    bld.p.prof = pchain_profile_buffer(); bld.p.prof_wg = half;
+    auto lin = [&](const float* A16, long a_step, const float* W, int K, const float* bias, const float* add, float* orm, float* o16, int wg0) {
+      Desc& d = bld.add(K_LIN, ctH, wg0, half, K, DF_RELU, 0, Tp);
+      bld.ptr(d, 0, A16, a_step); bld.ptr(d, 1, W); bld.ptr(d, 2, bias); bld.ptr(d, 3, add, sH); bld.ptr(d, 5, orm, sH); bld.ptr(d, 6, o16, xH);
+      d.ld[1] = H; d.ld[3] = H; d.n16[0] = ctH; d.f[0] = slope;
+    };
+    lin(rs.Z16, xZ, rs.Wp[0], Z, nullptr, rs.XP, rs.P[0], rs.P16[0], 0);
+    lin(rs.Z16, xZ, rs.Wq[0], Z, nullptr, rs.XQ, rs.Q[0], rs.Q16[0], half);
+    for (int k = 1; k < 3; ++k) {
+      lin(rs.P16[k - 1], xH, rs.Wp[k], H, w->prior_b[k], nullptr, rs.P[k], rs.P16[k], 0);
+      lin(rs.Q16[k - 1], xH, rs.Wq[k], H, w->post_b[k], nullptr, rs.Q[k], rs.Q16[k], half);
+    }
+    {
+      Desc& d = bld.add(K_HEAD, ctZ, 0, range_for(ctZ * rt, 2 * half), H, 0, 0, Tp);
+      bld.ptr(d, 0, rs.P16[2], xH); bld.ptr(d, 1, rs.Q16[2], xH); bld.ptr(d, 2, rs.Wph); bld.ptr(d, 3, w->prior_hb); bld.ptr(d, 4, rs.Wqh);
+      bld.ptr(d, 5, w->post_hb); bld.ptr(d, 6, eps, sZ); bld.ptr(d, 7, mu_p, sZ); bld.ptr(d, 8, sd_p, sZ); bld.ptr(d, 9, mu_q, sZ);
+      bld.ptr(d, 10, sd_q, sZ); bld.ptr(d, 11, rs.RAWP, sZ); bld.ptr(d, 12, rs.RAWQ, sZ); bld.ptr(d, 13, nullptr);
+      bld.ptr(d, 14, zs + sZ, sZ); bld.ptr(d, 15, rs.Z16 + xZ, xZ);
+      d.ld[3] = Z; d.n16[0] = ctZ; d.i[0] = Z; d.i[1] = residual_posterior; d.f[0] = beta; d.f[1] = 1.f / beta; d.f[2] = sd_eps;
+    }
+    BLVM_REQUIRE(!bld.overflow, "srnn_fwd: persistent program overflow");
+    rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
+    if (rc) return rc;
+    BLVM_HIP(hipMemsetAsync(rs.Z16, 0xFF, (size_t)(reinterpret_cast<char*>(rs.x16_end) - reinterpret_cast<char*>(rs.Z16)), s));
+    rc = pchain_rows_to_t16(zs, Z, B, Z, rs.Z16, s);
+    if (rc) return rc;
+    return pchain_launch(bld.p, s);
+  }
   for (int t = 0; t < Tp; ++t) {
     const size_t oH = (size_t)t * B * H, oZ = (size_t)t * B * Z;
     const float* zprev = zs + oZ;
@@ -157,7 +215,58 @@ extern "C" int blvm_srnn_latent_bwd(const BlvmSrnnWeights* w, const float* d, co
   TRY(t16_pack_transposed(w->prior_hw, H, 2 * Z, H, ws.phT, s));
   TRY(t16_pack_transposed(w->post_hw, H, 2 * Z, H, ws.qhT, s));
   const int rt = (B + 15) / 16;
-  for (int t = Tp - 1; t >= 0; --t) {
+  const bool persistent = pchain_applies(B) && device_cus() >= 32;
+  if (persistent) {
+    // Persistent path: the BPTT chain as a program of 9 descriptors walked for s = 0 .. T' (t = T'-1-s; s = T': the gradient wrt z_0)
+    using namespace pchain;
+    const int ctH = H / 16, ctZ = Z / 16, cus = device_cus() & ~7, T = Tp;
+    const long sH = (long)B * H, sZ = (long)B * Z, s2Z = 2 * sZ, xH = (long)rt * 16 * H, x2Z = (long)rt * 16 * 2 * Z;
+    const int half = range_for(ctH * rt, cus / 2);
+    Builder bld;
+    bld.p.S = T + 1; bld.p.B = B; bld.p.xcd = (pchain_tune() & 4) ? 1 : 0; bld.p.lds_products = 2;
+    bld.p.prof = pchain_profile_buffer() ? pchain_profile_buffer() + 64 : nullptr; bld.p.prof_wg = half;
+    auto at = [&](const float* base, long step, int t0) { return base ? base + (long)t0 * step : nullptr; };
+    {  // B1: dz_t = decoder gradient + the two first layers of step t+1, then rsample / residual / KL / softplus heads
+      Desc& d = bld.add(K_DZ, ctZ, 0, range_for(ctZ * rt, 2 * half), H, 0, 0, T);
+      bld.ptr(d, 0, at(ws.DP16[0], xH, T), -xH); bld.ptr(d, 1, ws.pzT); bld.ptr(d, 2, at(ws.DQ16[0], xH, T), -xH); bld.ptr(d, 3, ws.qzT);
+      bld.ptr(d, 4, at(d_z, sZ, T - 1), -sZ);
+      bld.ptr(d, 5, at(mu_q, sZ, T - 1), -sZ); bld.ptr(d, 6, at(sd_q, sZ, T - 1), -sZ); bld.ptr(d, 7, at(mu_p, sZ, T - 1), -sZ);
+      bld.ptr(d, 8, at(sd_p, sZ, T - 1), -sZ); bld.ptr(d, 9, at(eps, sZ, T - 1), -sZ); bld.ptr(d, 10, at(rs.RAWQ, sZ, T - 1), -sZ);
+      bld.ptr(d, 11, at(rs.RAWP, sZ, T - 1), -sZ); bld.ptr(d, 12, nullptr); bld.ptr(d, 13, x_sl); bld.ptr(d, 14, c_raw); bld.ptr(d, 15, c_fn);
+      bld.ptr(d, 16, at(ws.DQH, s2Z, T - 1), -s2Z); bld.ptr(d, 17, at(ws.DQH16, x2Z, T - 1), -x2Z); bld.ptr(d, 18, at(ws.DPH, s2Z, T - 1), -s2Z);
+      bld.ptr(d, 19, at(ws.DPH16, x2Z, T - 1), -x2Z);
+      d.ld[1] = Z; d.ld[3] = 2 * Z; d.n16[0] = 2 * ctZ; d.i[0] = Z; d.i[1] = residual_posterior; d.i[2] = stride; d.i[3] = T - 1;
+      d.f[0] = fn_floor; d.f[1] = beta; d.f[2] = sd_eps; d.f[3] = 1.f;
+    }
+    auto lin = [&](const float* A16, long a_x, const float* W, int K, const float* gate, float* orm, float* o16, int wg0) {
+      Desc& d = bld.add(K_LIN, ctH, wg0, half, K, 0, 0, T);
+      bld.ptr(d, 0, at(A16, a_x, T - 1), -a_x); bld.ptr(d, 1, W); bld.ptr(d, 4, at(gate, sH, T - 1), -sH); bld.ptr(d, 5, at(orm, sH, T - 1), -sH);
+      bld.ptr(d, 6, at(o16, xH, T - 1), -xH);
+      d.ld[2] = H; d.ld[3] = H; d.n16[0] = ctH; d.f[0] = slope;
+    };
+    // B2: heads -> third layers;  B3, B4: down to the first layers (LeakyReLU derivatives fused)
+    lin(ws.DPH16, x2Z, ws.phT, 2 * Z, rs.P[2], ws.DP[2], ws.DP16[2], 0);
+    lin(ws.DQH16, x2Z, ws.qhT, 2 * Z, rs.Q[2], ws.DQ[2], ws.DQ16[2], half);
+    for (int k = 2; k >= 1; --k) {
+      lin(ws.DP16[k], xH, ws.pT[k], H, rs.P[k - 1], ws.DP[k - 1], ws.DP16[k - 1], 0);
+      lin(ws.DQ16[k], xH, ws.qT[k], H, rs.Q[k - 1], ws.DQ[k - 1], ws.DQ16[k - 1], half);
+    }
+    if (d_z0) {  // s = T': gradient wrt the initial latent through both first layers of step 0 (two links: every word written once)
+      const int r_z = range_for(ctZ * rt, half);
+      Desc& d1 = bld.add(K_LIN, ctZ, 0, r_z, H, DF_RM_SC1, T, T + 1);
+      bld.ptr(d1, 0, at(ws.DP16[0], xH, T), -xH); bld.ptr(d1, 1, ws.pzT); bld.ptr(d1, 5, ws.DZ0);
+      d1.ld[3] = Z;
+      Desc& d2 = bld.add(K_LIN, ctZ, half, r_z, H, DF_ADD_POLLED, T, T + 1);
+      bld.ptr(d2, 0, at(ws.DQ16[0], xH, T), -xH); bld.ptr(d2, 1, ws.qzT); bld.ptr(d2, 3, ws.DZ0); bld.ptr(d2, 5, d_z0);
+      d2.ld[1] = Z; d2.ld[3] = Z;
+    }
+    BLVM_REQUIRE(!bld.overflow, "srnn_bwd: persistent program overflow");
+    rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
+    if (rc) return rc;
+    BLVM_HIP(hipMemsetAsync(ws.DZ0, 0xFF, (size_t)(reinterpret_cast<char*>(ws.x16_end) - reinterpret_cast<char*>(ws.DZ0)), s));
+    TRY(pchain_launch(bld.p, s));
+  }
+  for (int t = Tp - 1; t >= 0 && !persistent; --t) {
     const size_t oH = (size_t)t * B * H, oZ = (size_t)t * B * Z, o2Z = (size_t)t * B * 2 * Z;
     // B1: dz_t = decoder gradient + the two first layers of step t+1, then rsample / residual / KL / softplus heads
     DzArgs dz;
@@ -185,7 +294,7 @@ extern "C" int blvm_srnn_latent_bwd(const BlvmSrnnWeights* w, const float* d, co
     }
   }
   BLVM_CHECK_LAUNCH("srnn_latent_bwd");
-  if (d_z0) {  // gradient wrt the initial latent: both first layers of step 0
+  if (d_z0 && !persistent) {  // gradient wrt the initial latent: both first layers of step 0
     LinLaunch l;
     l.B = B; l.slope = 0.f; l.nseg = 1;
     l.seg[0] = seg(ws.DP[0], H, ws.pzT, H, nullptr, nullptr, 0, nullptr, 0, d_z0, Z, Z, H, 0);
