@@ -67,6 +67,7 @@ _SIGNATURES = {
     "blvm_device_ok": (c_int, []),
     "blvm_async_errors": (c_int, [c_void_p]),
     "blvm_pchain_configure": (c_int, [c_int, c_int]),
+    "blvm_pchain_max_batch": (c_int, []),
     "blvm_pchain_profile": (c_int, [c_void_p]),
     "blvm_pchain_tune": (c_int, [c_int]),
     "blvm_pchain_chain_probe": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -85,6 +86,8 @@ _SIGNATURES = {
                             c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "blvm_vrnn_decode_scratch_floats": (c_size_t, [c_int] * 4),
     "blvm_vrnn_decode": (c_int, [ctypes.POINTER(VrnnDecodeWeights)] + [c_void_p] * 5 + [c_int] * 7 + [c_float] * 3 + [c_void_p] * 4),
+    "blvm_vrnn_generate_scratch_floats": (c_size_t, [c_int] * 6),
+    "blvm_vrnn_generate": (c_int, [ctypes.POINTER(VrnnDecodeWeights)] + [c_void_p] * 5 + [c_int] * 7 + [c_float] * 3 + [c_void_p] * 4),
     "blvm_vrnn_reserve_floats": (c_size_t, [c_int] * 6),
     "blvm_vrnn_bwd_workspace_floats": (c_size_t, [c_int] * 6),
     "blvm_vrnn_seq_fwd": (c_int, [ctypes.POINTER(VrnnWeights), c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

@@ -417,10 +417,12 @@ def _pack_weights(ts: Sequence[Optional[torch.Tensor]]) -> VrnnWeights:
 
 
 @torch.no_grad()
-def vrnn_decode(enc_lin, cell_params, dec_lin, lik_lin, x0, h0, eps, u, v, S, H, Z, R, num_mix, sd_eps, slope, log_eps):
+def vrnn_decode(enc_lin, cell_params, dec_lin, lik_lin, x0, h0, eps, u, v, S, H, Z, R, num_mix, sd_eps, slope, log_eps, whole_chip=None):
     """K1c: T = eps.shape[0] steps of ancestral sampling for all B utterances in one launch.  enc_lin / dec_lin: 3 nn.Linear each;
     cell_params in `_VRNN_PARAM_ORDER`; lik_lin the DMoL head's Linear.  x0 [B,S], h0 [B,R] or None, eps [T,B,Z],
-    u [T,B,S,num_mix] / v [T,B,S] uniforms (None: the mode).  -> (x [B,T,S], h_n [B,R])."""
+    u [T,B,S,num_mix] / v [T,B,S] uniforms (None: the mode).  -> (x [B,T,S], h_n [B,R]).
+    whole_chip: True = `blvm_vrnn_generate` (every layer of a step dealt over all CUs, B <= 128), False = `blvm_vrnn_decode`
+    (16 utterances per CU), None = the former whenever it applies."""
     from ._hip import VrnnDecodeWeights
 
     lib = load()
@@ -441,9 +443,16 @@ def vrnn_decode(enc_lin, cell_params, dec_lin, lik_lin, x0, h0, eps, u, v, S, H,
     h0 = _f32c(h0) if h0 is not None else None
     u = _f32c(u) if u is not None else None
     v = _f32c(v) if v is not None else None
-    scratch = torch.empty(lib.blvm_vrnn_decode_scratch_floats(S, H, Z, R), device=dev, dtype=torch.float32)
+    if whole_chip is None:
+        whole_chip = B <= lib.blvm_pchain_max_batch()
     x = torch.empty(B, T, S, device=dev, dtype=torch.float32)
     hn = torch.empty(B, R, device=dev, dtype=torch.float32)
+    if whole_chip:
+        scratch = torch.empty(lib.blvm_vrnn_generate_scratch_floats(T, B, S, H, Z, R), device=dev, dtype=torch.float32)
+        check(lib.blvm_vrnn_generate(ctypes.byref(w), ptr(x0), ptr(h0), ptr(eps), ptr(u), ptr(v), T, B, S, H, Z, R, num_mix, sd_eps,
+                                     slope, log_eps, ptr(x), ptr(hn), ptr(scratch), stream_ptr()), "blvm_vrnn_generate")  # fmt: skip
+        return x, hn
+    scratch = torch.empty(lib.blvm_vrnn_decode_scratch_floats(S, H, Z, R), device=dev, dtype=torch.float32)
     check(lib.blvm_vrnn_decode(ctypes.byref(w), ptr(x0), ptr(h0), ptr(eps), ptr(u), ptr(v), T, B, S, H, Z, R, num_mix, sd_eps, slope,
                                log_eps, ptr(x), ptr(hn), ptr(scratch), stream_ptr()), "blvm_vrnn_decode")  # fmt: skip
     return x, hn

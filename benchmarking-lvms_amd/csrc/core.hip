@@ -240,6 +240,8 @@ extern "C" int blvm_pchain_configure(int max_batch, int waves) {
   return BLVM_OK;
 }
 
+extern "C" int blvm_pchain_max_batch(void) { return std::min(blvm::pchain_max_batch(), 128); }
+
 extern "C" int blvm_pchain_tune(int bits) {
   blvm::g_pchain_tune = bits;
   return BLVM_OK;

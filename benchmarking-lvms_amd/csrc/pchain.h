@@ -286,6 +286,8 @@ struct Out {
   bool rm_sc1;
   float* x16;  // [rt*16, 16*n16] in 1 KB blocks
   int n16;
+  float* x16b = nullptr;  // a second consumer's T16 operand (a concatenated input, e.g. cat[phi, h]: the pointer starts at this
+  int n16b = 0;           // output's first block of a row tile, n16b = chunks per row of the whole concatenation)
 };
 __device__ __forceinline__ Out out_rm(float* p, int ld, bool sc1 = false) { return Out{p, ld, sc1, nullptr, 0}; }
 __device__ __forceinline__ Out out_both(float* p, int ld, float* x16, int n16, bool sc1 = false) { return Out{p, ld, sc1, x16, n16}; }
@@ -294,10 +296,10 @@ __device__ __forceinline__ void put(const Out& o, int r0, int c0, int row, int c
     if (o.rm_sc1) st_sc1(make_rsrc(o.rm), 4u * ((unsigned)row * (unsigned)o.ld + (unsigned)col), x);
     else o.rm[(size_t)row * o.ld + col] = x;
   }
-  if (o.x16 != nullptr) {
-    const int rr = row - r0, cc = col - c0;
-    st_sc1(make_rsrc(o.x16), 4u * ((((unsigned)(r0 >> 4) * (unsigned)o.n16 + (unsigned)(c0 >> 4)) << 8) + (unsigned)((rr + 16 * (cc >> 2)) * 4 + (cc & 3))), x);
-  }
+  const int rr = row - r0, cc = col - c0;
+  const unsigned in_block = (unsigned)((rr + 16 * ((cc & 15) >> 2)) * 4 + (cc & 3));
+  if (o.x16 != nullptr) st_sc1(make_rsrc(o.x16), 4u * ((((unsigned)(r0 >> 4) * (unsigned)o.n16 + (unsigned)((c0 + cc) >> 4)) << 8) + in_block), x);
+  if (o.x16b != nullptr) st_sc1(make_rsrc(o.x16b), 4u * ((((unsigned)(r0 >> 4) * (unsigned)o.n16b + (unsigned)((c0 + cc) >> 4)) << 8) + in_block), x);
 }
 
 // ---- link tiles -------------------------------------------------------------------------------------------------------------
@@ -612,6 +614,91 @@ __device__ __forceinline__ void tile_grub(const GrubIn& a, int K, int R, int r0,
   st_sc1(make_rsrc(a.ga), 4u * ((unsigned)row * (unsigned)R + (unsigned)col), g * u + dd);
 }
 
+// Sampling from a DMoL head during generation (`VRNN.generate`, blvm/models/vrnn.py:371-434: likelihood(dec) -> sample): a tile =
+// 16 utterances x 4 samples of one frame stack.  dec [B, S*F] (F = 3 * num_mix = 30 head inputs per sample, row-major, polled words:
+// the last decoder layer of this step) -> per sample the head's Linear(F -> F) -> Gumbel-max component pick with u, clamped
+// logistic draw with v (dmol.hip mix_sample_kernel; both null: the mode) -> x [B, ldx] (plain) and the T16 copy the next step's
+// encoder multiplies.  Wave w computes head outputs 4w .. 4w+3 of all 64 (utterance, sample) pairs (weights wave-uniform); wave 0
+// then draws.  `lds`: >= 16*4*F + 64*32 floats.
+template <int NW>
+__device__ __forceinline__ void tile_dmol_sample(const float* dec, int ldd, const float* Wl, const float* bl, const float* u, const float* v, int S, int F,
+                                                 int num_mix, float log_eps, const Out& xo, int r0, int s0, int B, float* lds, Poll& pl) {
+  static_assert(NW == 8 || NW == 16, "waves");
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  float* in = lds;               // [16 rows][4 * F]
+  float* outp = lds + 16 * 4 * F;  // [64 pairs][32]
+  const int rowlen = 4 * F;      // floats of a tile row (a multiple of 4: 16-byte pieces)
+  const int pieces = 16 * rowlen / 4;
+  const rsrc_t rd = make_rsrc(dec);
+  {  // polled cooperative load of the tile's head inputs
+    unsigned spins = 0;
+    for (;;) {
+      bool bad = false;
+      for (int q = tid; q < pieces; q += NW * 64) {
+        const int rr = q / (rowlen / 4), cq = q % (rowlen / 4);
+        const bool ok = r0 + rr < B;
+        const f32x4 x = ld_sc1_x4(rd, 4u * ((unsigned)(ok ? r0 + rr : r0) * (unsigned)ldd + (unsigned)(s0 * F + 4 * cq)));
+        bad |= ok && any_sentinel(x);
+        *reinterpret_cast<f32x4*>(in + rr * rowlen + 4 * cq) = x;
+      }
+      if (!__any(bad) || pl.dead) break;
+#ifdef PCHAIN_NOWAIT
+      break;
+#endif
+      if (spin_tick(spins, pl.ctl, pl.code, pl.dead)) break;
+      pl.sleep();
+    }
+  }
+  __syncthreads();  // (a wave that saw everything may pass while another still polls its pieces: the barrier orders them)
+  {
+    const int rr = lane >> 2, ss = lane & 3;
+    const float* a = in + rr * rowlen + ss * F;
+    if (wave * 4 < F) {
+      float acc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int jj = wave * 4 + j;
+        acc[j] = jj < F ? bl[jj] : 0.f;
+      }
+      for (int k = 0; k < F; ++k) {
+        const float ak = a[k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int jj = wave * 4 + j;
+          if (jj < F) acc[j] = fmaf(Wl[jj * F + k], ak, acc[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (wave * 4 + j < F) outp[lane * 32 + wave * 4 + j] = acc[j];
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int rr = lane >> 2, ss = lane & 3, row = r0 + rr, smp = s0 + ss;
+    if (row < B) {
+      const float* p = outp + lane * 32;
+      const size_t f = (size_t)row * S + smp;
+      int best = 0;
+      float bv = -INFINITY;
+      for (int m = 0; m < num_mix; ++m) {
+        float sc = p[m];
+        if (u != nullptr) sc -= logf(-logf(u[f * num_mix + m]));
+        if (sc > bv) { bv = sc; best = m; }  // first maximum, as torch.argmax
+      }
+      const float loc = p[num_mix + best], raw = p[2 * num_mix + best];
+      float x = loc;
+      if (v != nullptr) {
+        const float vv = v[f];
+        x = loc + expf(fmaxf(raw, log_eps)) * (logf(vv) - logf(1.f - vv));
+        x = fminf(fmaxf(x, -1.f), 1.f);
+      }
+      put(xo, r0, s0 & ~15, row, smp, x);
+    }
+  }
+  __syncthreads();  // the scratch is reused by the next tile
+}
+
 // =================================================================================================================================
 // The program a persistent launch executes (pchain.hip: ONE kernel, one copy of every tile kind — the step program of a model is
 // DATA, not code: with each link inlined at its own call site the VRNN kernel was 16 000 instructions, every link of a step ran
@@ -620,7 +707,7 @@ __device__ __forceinline__ void tile_grub(const GrubIn& a, int K, int R, int r0,
 // are its own (TileIter over [wg0, wg0 + nwg)).  A pointer of a descriptor is `p[k] + s * stride[sidx[k]]` (stride table of the
 // program, entry 0 = 0: constants and null pointers); a backward sequence passes its last step's slabs and negative strides.
 // =================================================================================================================================
-enum Kind : int { K_LIN = 0, K_HEAD = 1, K_GRU = 2, K_DZ = 3, K_GRUB = 4 };
+enum Kind : int { K_LIN = 0, K_HEAD = 1, K_GRU = 2, K_DZ = 3, K_GRUB = 4, K_DMOLS = 5 };
 enum DescFlag : int {
   DF_RELU = 1,         // K_LIN: leaky ReLU (f[0] = slope) on the result
   DF_A_PLAIN = 2,      // K_LIN: A is a row-major buffer written before the launch (ld[0]), not a polled T16 copy
@@ -629,7 +716,7 @@ enum DescFlag : int {
   DF_GENTLE = 16,      // off the critical path: nap between polls
   DF_CANARY = 32,      // one-word canary wait in front of the operand poll
 };
-constexpr int kMaxDesc = 13, kMaxPtr = 20;
+constexpr int kMaxDesc = 24, kMaxPtr = 20;
 struct Desc {
   int kind, ct, wg0, nwg, flags, K, s_begin, s_end;
   int ld[4];                      // leading dimensions of row-major operands (per kind, see pchain.hip)
@@ -647,7 +734,7 @@ struct Program {
   int prof_wg, lds_products;      // lds_products: most products of any tile kind used (sizes the reduction scratch)
   Desc d[kMaxDesc];
 };
-static_assert(sizeof(Program) <= 4096, "the program travels as a kernel argument");
+// (the program reaches the device through pchain_resolve_kernel, a few descriptors per launch: kernel arguments are limited to 4 KB)
 
 // host-side assembly of a program
 struct Builder {
@@ -665,7 +752,7 @@ struct Builder {
   // a descriptor of `ct` column tiles (x all row tiles) on workgroups [wg0, wg0 + nwg), active in steps [s_begin, s_end)
   Desc& add(int kind, int ct, int wg0, int nwg, int K, int flags, int s_begin, int s_end) {
     static Desc dummy;
-    if (p.ndesc >= kMaxDesc) { overflow = true; return dummy; }
+    if (p.ndesc >= kMaxDesc) { overflow = true; return dummy; }  // (callers check `overflow`)
     Desc& d = p.d[p.ndesc++];
     d = Desc{};
     d.kind = kind; d.ct = ct; d.wg0 = wg0; d.nwg = nwg; d.K = K; d.flags = flags; d.s_begin = s_begin; d.s_end = s_end;

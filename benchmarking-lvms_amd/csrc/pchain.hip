@@ -3,17 +3,19 @@
 // forward and one backward launch.  Pointer roles of a descriptor by tile kind:
 //
 //   K_LIN   p: 0 A (T16 copy, polled | row-major when DF_A_PLAIN, ld[0])  1 W (T16)  2 bias  3 add (ld[1])  4 gate (ld[2])
-//              5 out row-major (ld[3])  6 out T16 (n16[0])            f: 0 slope
+//              5 out row-major (ld[3])  6 out T16 (n16[0])  7 second out T16 (n16[1])            f: 0 slope
 //   K_HEAD  p: 0 P16  1 Q16  2 Wp  3 bp  4 Wq  5 bq  6 eps  7 mu_p  8 sd_p  9 mu_q  10 sd_q  11 raw_p  12 raw_q  13 muq_raw
 //              14 z row-major (ld[3])  15 z T16 (n16[0])               i: 0 Z  1 residual      f: 0 beta  1 1/beta  2 sd_eps
 //   K_GRU   p: 0 X16  1 Wih (T16)  2 xg  3 gh (polled words)  4 h_prev (polled words, ld[0])  5 h_new row-major (ld[3])
-//              6 h_new T16 (n16[0])  7 rg  8 ug  9 ng  10 b_ih         i: 0 R
+//              6 h_new T16 (n16[0])  7 rg  8 ug  9 ng  10 b_ih  11 second h_new T16 (n16[1])         i: 0 R
 //   K_DZ    p: 0 D16  1 WT  2 D2_16  3 WT2  4 dz_add (ld[1])  5 mu_q  6 sd_q  7 mu_p  8 sd_p  9 eps  10 raw_q  11 raw_p  12 muq_raw
 //              13 x_sl (int32)  14 c_raw  15 c_fn  16 dqh row-major  17 dqh T16  18 dph row-major  19 dph T16   (ld[3] = 2Z, n16[0])
 //              i: 0 Z  1 residual  2 stride  3 t at s = 0 (t = i[3] - s)   f: 0 fn_floor  1 beta  2 sd_eps  3 first step with the product
 //   K_GRUB  p: 0 D0_16  1 D1_16  2 W0  3 W1  4 g_in (polled words)  5 rg  6 ug  7 ng  8 gh  9 h_prev (ld[0])  10 dd (ld[0])
 //              11 dgi row-major  12 dgi T16  13 dgh row-major  14 dgh T16  (ld[3] = 3R, n16[0])  15 ga  16 g_out  17 g_add (ld[1])
 //              i: 0 R  1 first step with the products  2 first step WITHOUT gates  3 first step with g_in
+//   K_DMOLS p: 0 dec (row-major, polled words, ld[0])  1 head W [F,F]  2 head b  3 u  4 v  5 x row-major (ld[3])  6 x T16 (n16[0])
+//              i: 0 S  1 F  2 num_mix      f: 0 log_eps        (ct counts tiles of 4 samples)
 #include <algorithm>
 #include <mutex>
 
@@ -44,7 +46,17 @@ struct Hdr {
   unsigned long long* prof;
 };
 
-__global__ void pchain_resolve_kernel(Program a, int* __restrict__ out) {
+// descriptors reach the device a few per launch (kernel arguments are limited to 4 KB)
+constexpr int kResolveChunk = 12;
+struct ProgramPart {
+  int ndesc, first;
+  long stride[16];
+  Desc d[kResolveChunk];
+};
+static_assert(sizeof(ProgramPart) <= 4096, "kernel argument size");
+
+__global__ void pchain_resolve_kernel(ProgramPart a, int* __restrict__ out) {
+  out += (size_t)a.first * kDescWords;
   for (int e = threadIdx.x; e < a.ndesc * kDescWords; e += blockDim.x) {
     const int i = e / kDescWords, k = e % kDescWords;
     const Desc& d = a.d[i];
@@ -116,12 +128,12 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
   extern __shared__ __attribute__((aligned(16))) char lds_all[];  // [descriptors | profile | 2 x (lds_products x NW x 256) floats]
   int* const ltab = reinterpret_cast<int*>(lds_all);
   unsigned long long* const pacc = reinterpret_cast<unsigned long long*>(lds_all + sizeof(int) * kDescWords * kMaxDesc);
-  float* const red0 = reinterpret_cast<float*>(lds_all + sizeof(int) * kDescWords * kMaxDesc + 16 * sizeof(unsigned long long));
+  float* const red0 = reinterpret_cast<float*>(lds_all + sizeof(int) * kDescWords * kMaxDesc + 32 * sizeof(unsigned long long));
   float* const red1 = red0 + a.lds_products * NW * 256;
   const int w = blockIdx.x, B = a.B, rt = (B + 15) / 16;
   const bool xcd = a.xcd != 0;
   for (int e = threadIdx.x; e < a.ndesc * kDescWords; e += NW * 64) ltab[e] = tab[e];
-  if (threadIdx.x < 16) pacc[threadIdx.x] = 0ull;
+  if (threadIdx.x < 32) pacc[threadIdx.x] = 0ull;
   unsigned mine = 0;  // the descriptors this workgroup has tiles of
   for (int i = 0; i < a.ndesc; ++i) {
     const int* q = tab + (size_t)i * kDescWords;
@@ -166,7 +178,7 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
           case K_LIN: {
             const bool a_polled = !(flags & DF_A_PLAIN);
             const float *A = d.p<0>(s), *W = d.base<1>(), *bias = d.base<2>(), *add = d.p<3>(s), *gate = d.p<4>(s);
-            const Out o{d.m<5>(s), ld3, (flags & DF_RM_SC1) != 0, d.m<6>(s), n16};
+            const Out o{d.m<5>(s), ld3, (flags & DF_RM_SC1) != 0, d.m<6>(s), n16, d.m<7>(s), d.w<RD_N16 + 1>()};
             const float slope = d.f<0>();
             for (int tk = 0; tk < nt; ++tk) {
               const int trc = d.tile(tk), tr0 = trc & 0xffff, tc0 = (trc >> 16) * 16;
@@ -194,7 +206,7 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
             }
           } break;
           case K_GRU: {
-            const Out o{d.m<5>(s), ld3, true, d.m<6>(s), n16};
+            const Out o{d.m<5>(s), ld3, true, d.m<6>(s), n16, d.m<11>(s), d.w<RD_N16 + 1>()};
             const int R = d.w<RD_I + 0>();
             for (int tk = 0; tk < nt; ++tk) {
               const int trc = d.tile(tk);
@@ -232,6 +244,15 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
               tile_grub<NW>(g, K, R, trc & 0xffff, (trc >> 16) * 16, B, red(), pl);
             }
           } break;
+          case K_DMOLS: {
+            const Out o{d.m<5>(s), ld3, false, d.m<6>(s), n16};
+            const int S = d.w<RD_I + 0>(), F = d.w<RD_I + 1>(), nmix = d.w<RD_I + 2>();
+            for (int tk = 0; tk < nt; ++tk) {
+              const int trc = d.tile(tk);
+              tile_dmol_sample<NW>(d.p<0>(s), ld0, d.base<1>(), d.base<2>(), d.p<3>(s), d.p<4>(s), S, F, nmix, d.f<0>(), o, trc & 0xffff, (trc >> 16) * 4, B,
+                                   red0, pl);
+            }
+          } break;
 #endif
           default: break;
         }
@@ -245,12 +266,12 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
     }
   }
   if (profiled) {
-    for (int i = 0; i < a.ndesc; ++i) a.prof[(w == 0 ? 0 : 16) + i] += pacc[i];
+    for (int i = 0; i < a.ndesc; ++i) a.prof[(w == 0 ? 0 : 32) + i] += pacc[i];
 #ifdef PCHAIN_TPROF
-    if (w == 0) for (int l = 0; l < 8; ++l) a.prof[32 + l] += pl.tp[l];
+    if (w == 0) for (int l = 0; l < 8; ++l) a.prof[56 + l] += pl.tp[l];
 #endif
 #ifdef PCHAIN_TPROF2
-    if (w == 0) for (int l = 0; l < 3; ++l) a.prof[40 + l] += tq[l];
+    if (w == 0) for (int l = 0; l < 3; ++l) a.prof[60 + l] += tq[l];
 #endif
   }
 }
@@ -303,10 +324,17 @@ int pchain_launch(const pchain::Program& prog, hipStream_t stream) {
     }
     tab = ring + (size_t)(next++ % kSlots) * kDescWords * pchain::kMaxDesc;
   }
-  hipLaunchKernelGGL(pchain_resolve_kernel, dim3(1), dim3(256), 0, stream, prog, tab);
+  for (int first = 0; first < prog.ndesc; first += kResolveChunk) {
+    ProgramPart part;
+    part.ndesc = std::min(kResolveChunk, prog.ndesc - first);
+    part.first = first;
+    for (int k = 0; k < 16; ++k) part.stride[k] = prog.stride[k];
+    for (int k = 0; k < part.ndesc; ++k) part.d[k] = prog.d[first + k];
+    hipLaunchKernelGGL(pchain_resolve_kernel, dim3(1), dim3(256), 0, stream, part, tab);
+  }
   Hdr h{prog.ndesc, prog.S, prog.B, prog.xcd, prog.prof_wg, prog.lds_products, prog.ctl, prog.prof};
   const int nw = pchain_waves();
-  const size_t lds_fixed = sizeof(int) * kDescWords * pchain::kMaxDesc + 16 * sizeof(unsigned long long);
+  const size_t lds_fixed = sizeof(int) * kDescWords * pchain::kMaxDesc + 32 * sizeof(unsigned long long);
   const size_t lds = lds_fixed + sizeof(float) * 2 * (size_t)prog.lds_products * nw * 256;
   // the dynamic-LDS limit of the kernels is raised once per process and device (the call is far from free)
   static int attr_dev[2] = {-1, -1};

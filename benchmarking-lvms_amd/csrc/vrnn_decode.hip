@@ -8,6 +8,7 @@
 // every activation in LDS and walks the layers itself: the only traffic is the weight stream (T16 operand layout: one
 // contiguous 1 KB read per fragment), the noise and the samples — the decode step is bound by how fast one CU ingests weights.
 #include "common.h"
+#include "pchain.h"
 
 namespace blvm {
 namespace {
@@ -495,5 +496,153 @@ extern "C" int blvm_vrnn_decode(const BlvmVrnnDecodeWeights* w, const float* x0,
   BLVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(vrnn_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(vrnn_decode_kernel, dim3((unsigned)((B + VD_ROWS - 1) / VD_ROWS)), dim3(VD_NW * 64), lds, s, a);
   BLVM_CHECK_LAUNCH("vrnn_decode");
+  return BLVM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same sampling loop on the persistent-chain engine (pchain.h / pchain.hip): K1c above keeps 16 utterances on ONE CU (0.37 ms per
+// step at any batch size: the fp32 matrix pipe of one CU); here every layer of a step is a link whose 16x16 tiles are dealt over the
+// whole chip — 17 descriptors per step, the weights (12.5 MB) stay in the L2s, activations travel as sentinel-polled T16 copies.
+// Nothing is kept for a backward pass, but every buffer is still a per-step slab (every word is written once per launch).
+// ---------------------------------------------------------------------------------------------------------------------------------
+namespace blvm {
+namespace {
+struct VgBufs {
+  size_t X16, E16[2], CAT16, H16, HS, P16[3], GHb, Z16, F16[3], DC16, D16[2], DEC, dummyZ, dummyR, end;
+};
+VgBufs vg_layout(size_t base, int T, int B, int S, int H, int Z, int R) {
+  VgBufs b;
+  size_t o = base;
+  auto take = [&](size_t n) { size_t at = o; o += (n + 3) & ~(size_t)3; return at; };
+  const size_t rows = (size_t)((B + 15) / 16) * 16, m = (size_t)T * rows, X = H;
+  b.X16 = take((m + rows) * S);
+  b.E16[0] = take(m * H); b.E16[1] = take(m * H);
+  b.CAT16 = take(m * (X + H));
+  b.H16 = take((m + rows) * R);
+  b.HS = take((size_t)(T + 1) * B * R);
+  for (int i = 0; i < 3; ++i) b.P16[i] = take(m * H);
+  b.GHb = take((size_t)T * B * 3 * R);
+  b.Z16 = take(m * Z);
+  for (int i = 0; i < 3; ++i) b.F16[i] = take(m * H);
+  b.DC16 = take(m * (H + R));
+  b.D16[0] = take(m * H); b.D16[1] = take(m * H);
+  b.DEC = take((size_t)T * B * S * VD_F);
+  b.dummyZ = take((size_t)B * Z);
+  b.dummyR = take((size_t)B * R);
+  b.end = o;
+  return b;
+}
+}  // namespace
+}  // namespace blvm
+
+extern "C" size_t blvm_vrnn_generate_scratch_floats(int T, int B, int S, int H, int Z, int R) {
+  if (T <= 0 || B <= 0 || S <= 0 || H <= 0 || Z <= 0 || R <= 0) return 0;
+  return vg_layout(vd_pack_layout(S, H, Z, R).total, T, B, S, H, Z, R).end;
+}
+
+extern "C" int blvm_vrnn_generate(const BlvmVrnnDecodeWeights* w, const float* x0, const float* h0, const float* eps, const float* u,
+                                  const float* v, int T, int B, int S, int H, int Z, int R, int num_mix, float sd_eps, float slope,
+                                  float log_eps, float* x_out, float* h_out, float* scratch, void* stream_) {
+  using namespace pchain;
+  hipStream_t s = static_cast<hipStream_t>(stream_);
+  BLVM_REQUIRE(w && w->cell && x0 && eps && x_out && scratch, "vrnn_generate: null pointer");
+  BLVM_REQUIRE(T >= 0 && B > 0 && B <= kPchainCarveMaxB, "vrnn_generate: bad T=%d B=%d (at most %d utterances)", T, B, kPchainCarveMaxB);
+  BLVM_REQUIRE(S % 16 == 0 && H % 16 == 0 && Z % 16 == 0 && R % 16 == 0 && S > 0 && H > 0 && Z > 0 && R > 0,
+               "vrnn_generate: S, H, Z, R must be positive multiples of 16 (got %d, %d, %d, %d)", S, H, Z, R);
+  BLVM_REQUIRE(num_mix == VD_K, "vrnn_generate: the DMoL head has %d components", VD_K);
+  BLVM_REQUIRE((u == nullptr) == (v == nullptr), "vrnn_generate: u and v are given together (both NULL: the mode)");
+  BLVM_REQUIRE(aligned16(scratch), "vrnn_generate: scratch must be 16-byte aligned");
+  if (T == 0) return BLVM_OK;
+  const BlvmVrnnWeights* c = w->cell;
+  const VdPack p = vd_pack_layout(S, H, Z, R);
+  const VgBufs b = vg_layout(p.total, T, B, S, H, Z, R);
+  int rc;
+#define PACK(dst, src, ld, rows, k)                               \
+  do {                                                            \
+    rc = t16_pack_rows(src, ld, rows, k, scratch + (dst), s);     \
+    if (rc) return rc;                                            \
+  } while (0)
+  PACK(p.enc[0], w->enc_w[0], S, H, S); PACK(p.enc[1], w->enc_w[1], H, H, H); PACK(p.enc[2], w->enc_w[2], H, H, H);
+  PACK(p.prior[0], c->prior_w[0], R, H, R); PACK(p.prior[1], c->prior_w[1], H, H, H); PACK(p.prior[2], c->prior_w[2], H, H, H);
+  PACK(p.prior_h, c->prior_hw, H, 2 * Z, H);
+  PACK(p.phi[0], c->phi_w[0], Z, H, Z);
+  for (int i = 1; i < 4; ++i) PACK(p.phi[i], c->phi_w[i], H, H, H);
+  PACK(p.wih, c->gru_wih, 2 * H, 3 * R, 2 * H); PACK(p.whh, c->gru_whh, R, 3 * R, R);
+  PACK(p.dec[0], w->dec_w[0], H + R, H, H + R); PACK(p.dec[1], w->dec_w[1], H, H, H); PACK(p.dec[2], w->dec_w[2], H, S * VD_F, H);
+#undef PACK
+  const int rt = (B + 15) / 16, ctS = S / 16, ctH = H / 16, ctZ = Z / 16, ctR = R / 16, X = H, cus = device_cus() & ~7;
+  const long rows = (long)rt * 16, xS = rows * S, xH = rows * H, xZ = rows * Z, xR = rows * R, xC = rows * (X + H), xD = rows * (H + R);
+  const long sR = (long)B * R, s3R = 3 * sR, sZ = (long)B * Z, sF = (long)B * S * VD_F;
+  float* const sc = scratch;
+  const float beta = (float)(0.6931471805599453 / (1.0 - (double)sd_eps));
+  // ranges: the hidden projection and the wide last decoder layer off to the side of the critical links
+  const int r_side = range_for(3 * ctR * rt, std::min(cus / 4, 64));
+  const int r_main = range_for(std::max(ctR * rt, ctH * rt), cus - r_side);
+  Builder bld;
+  bld.p.S = T; bld.p.B = B; bld.p.xcd = (pchain_tune() & 4) ? 1 : 0; bld.p.lds_products = 4;
+  bld.p.prof = pchain_profile_buffer(); bld.p.prof_wg = r_main;
+  auto lin = [&](size_t A16, long a_step, size_t W, int K, const float* bias, int ct, int flags, float sl, float* orm, long rm_step, int ldo, size_t o16,
+                 long o16_step, int n16, size_t o16b, long o16b_step, int n16b, int wg0, int nwg) -> Desc& {
+    Desc& d = bld.add(K_LIN, ct, wg0, nwg, K, flags, 0, T);
+    bld.ptr(d, 0, sc + A16, a_step); bld.ptr(d, 1, sc + W); bld.ptr(d, 2, bias); bld.ptr(d, 5, orm, rm_step);
+    bld.ptr(d, 6, o16 ? sc + o16 : nullptr, o16_step); bld.ptr(d, 7, o16b ? sc + o16b : nullptr, o16b_step);
+    d.ld[3] = ldo; d.n16[0] = n16; d.n16[1] = n16b; d.f[0] = sl;
+    return d;
+  };
+  const int rH = range_for(ctH * rt, r_main);
+  // encoder(x_t)
+  lin(b.X16, xS, p.enc[0], S, w->enc_b[0], ctH, DF_RELU, slope, nullptr, 0, 0, b.E16[0], xH, ctH, 0, 0, 0, 0, rH);
+  lin(b.E16[0], xH, p.enc[1], H, w->enc_b[1], ctH, DF_RELU, slope, nullptr, 0, 0, b.E16[1], xH, ctH, 0, 0, 0, 0, rH);
+  lin(b.E16[1], xH, p.enc[2], H, w->enc_b[2], ctH, DF_RELU, slope, nullptr, 0, 0, b.CAT16, xC, (X + H) / 16, 0, 0, 0, 0, rH);
+  // prior(h_{t-1}) | hidden projection of the GRU
+  lin(b.H16, xR, p.prior[0], R, c->prior_b[0], ctH, DF_RELU, 0.f, nullptr, 0, 0, b.P16[0], xH, ctH, 0, 0, 0, 0, rH);
+  lin(b.H16, xR, p.whh, R, c->gru_bhh, 3 * ctR, DF_RM_SC1 | DF_GENTLE | ((pchain_tune() & 16) ? DF_CANARY : 0), 0.f, sc + b.GHb, s3R, 3 * R, 0, 0, 0, 0, 0, 0,
+      r_main, r_side);
+  lin(b.P16[0], xH, p.prior[1], H, c->prior_b[1], ctH, DF_RELU, 0.f, nullptr, 0, 0, b.P16[1], xH, ctH, 0, 0, 0, 0, rH);
+  lin(b.P16[1], xH, p.prior[2], H, c->prior_b[2], ctH, DF_RELU, 0.f, nullptr, 0, 0, b.P16[2], xH, ctH, 0, 0, 0, 0, rH);
+  {  // z ~ prior (head in generation mode: the posterior operands are the prior's)
+    Desc& d = bld.add(K_HEAD, ctZ, 0, range_for(ctZ * rt, r_main), H, 0, 0, T);
+    bld.ptr(d, 0, sc + b.P16[2], xH); bld.ptr(d, 1, sc + b.P16[2], xH); bld.ptr(d, 2, sc + p.prior_h); bld.ptr(d, 3, c->prior_hb);
+    bld.ptr(d, 4, sc + p.prior_h); bld.ptr(d, 5, c->prior_hb); bld.ptr(d, 6, eps, sZ);
+    for (int k = 7; k <= 12; ++k) bld.ptr(d, k, sc + b.dummyZ);
+    bld.ptr(d, 13, nullptr); bld.ptr(d, 14, sc + b.dummyZ); bld.ptr(d, 15, sc + b.Z16, xZ);
+    d.ld[3] = Z; d.n16[0] = ctZ; d.i[0] = Z; d.i[1] = 3; d.f[0] = beta; d.f[1] = 1.f / beta; d.f[2] = sd_eps;
+  }
+  // phi_z(z): the last layer feeds the GRU input cat[enc, phi] and the decoder input cat[phi, h_new]
+  lin(b.Z16, xZ, p.phi[0], Z, c->phi_b[0], ctH, DF_RELU, 0.f, nullptr, 0, 0, b.F16[0], xH, ctH, 0, 0, 0, 0, rH);
+  lin(b.F16[0], xH, p.phi[1], H, c->phi_b[1], ctH, DF_RELU, 0.f, nullptr, 0, 0, b.F16[1], xH, ctH, 0, 0, 0, 0, rH);
+  lin(b.F16[1], xH, p.phi[2], H, c->phi_b[2], ctH, DF_RELU, 0.f, nullptr, 0, 0, b.F16[2], xH, ctH, 0, 0, 0, 0, rH);
+  lin(b.F16[2], xH, p.phi[3], H, c->phi_b[3], ctH, DF_RELU, 0.f, nullptr, 0, 0, b.CAT16 + (size_t)(X / 16) * 256, xC, (X + H) / 16, b.DC16, xD,
+      (H + R) / 16, 0, rH);
+  {  // GRU(cat[enc, phi], h_{t-1}) -> h_t: row-major (polled words of the next step), T16 for the next step, T16 into cat[phi, h_t]
+    Desc& d = bld.add(K_GRU, ctR, 0, range_for(ctR * rt, r_main), X + H, 0, 0, T);
+    bld.ptr(d, 0, sc + b.CAT16, xC); bld.ptr(d, 1, sc + p.wih); bld.ptr(d, 2, nullptr); bld.ptr(d, 3, sc + b.GHb, s3R); bld.ptr(d, 4, sc + b.HS, sR);
+    bld.ptr(d, 5, sc + b.HS + sR, sR); bld.ptr(d, 6, sc + b.H16 + xR, xR); bld.ptr(d, 7, sc + b.dummyR); bld.ptr(d, 8, sc + b.dummyR);
+    bld.ptr(d, 9, sc + b.dummyR); bld.ptr(d, 10, c->gru_bih); bld.ptr(d, 11, sc + b.DC16 + (size_t)(H / 16) * 256, xD);
+    d.ld[0] = R; d.ld[3] = R; d.n16[0] = ctR; d.n16[1] = (H + R) / 16; d.i[0] = R;
+  }
+  // decoder(cat[phi, h_t]); the last layer (S * F columns) on every workgroup
+  lin(b.DC16, xD, p.dec[0], H + R, w->dec_b[0], ctH, DF_RELU, slope, nullptr, 0, 0, b.D16[0], xH, ctH, 0, 0, 0, 0, rH);
+  lin(b.D16[0], xH, p.dec[1], H, w->dec_b[1], ctH, DF_RELU, slope, nullptr, 0, 0, b.D16[1], xH, ctH, 0, 0, 0, 0, rH);
+  lin(b.D16[1], xH, p.dec[2], H, w->dec_b[2], S * VD_F / 16, DF_RELU | DF_RM_SC1, slope, sc + b.DEC, sF, S * VD_F, 0, 0, 0, 0, 0, 0, 0,
+      range_for(S * VD_F / 16 * rt, cus));
+  {  // per sample: head Linear -> DMoL draw -> x_{t+1}
+    Desc& d = bld.add(K_DMOLS, S / 4, 0, range_for(S / 4 * rt, r_main), 16, 0, 0, T);
+    bld.ptr(d, 0, sc + b.DEC, sF); bld.ptr(d, 1, w->lik_w); bld.ptr(d, 2, w->lik_b); bld.ptr(d, 3, u, (long)B * S * VD_K); bld.ptr(d, 4, v, (long)B * S);
+    bld.ptr(d, 5, x_out, S); bld.ptr(d, 6, sc + b.X16 + xS, xS);
+    d.ld[0] = S * VD_F; d.ld[3] = T * S; d.n16[0] = ctS; d.i[0] = S; d.i[1] = VD_F; d.i[2] = VD_K; d.f[0] = log_eps;
+  }
+  BLVM_REQUIRE(!bld.overflow, "vrnn_generate: persistent program overflow");
+  rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
+  if (rc) return rc;
+  // sentinel-fill everything the launch polls (all step slabs), then the initial frame stack and state
+  BLVM_HIP(hipMemsetAsync(sc + b.X16, 0xFF, sizeof(float) * (b.dummyZ - b.X16), s));
+  rc = pchain_rows_to_t16(x0, S, B, S, sc + b.X16, s); if (rc) return rc;
+  rc = pchain_rows_to_t16(h0, R, B, R, sc + b.H16, s); if (rc) return rc;
+  if (h0) BLVM_HIP(hipMemcpyAsync(sc + b.HS, h0, sizeof(float) * (size_t)B * R, hipMemcpyDeviceToDevice, s));
+  else BLVM_HIP(hipMemsetAsync(sc + b.HS, 0, sizeof(float) * (size_t)B * R, s));
+  rc = pchain_launch(bld.p, s);
+  if (rc) return rc;
+  if (h_out) BLVM_HIP(hipMemcpyAsync(h_out, sc + b.HS + (size_t)T * sR, sizeof(float) * (size_t)B * R, hipMemcpyDeviceToDevice, s));
   return BLVM_OK;
 }

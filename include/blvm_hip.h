@@ -42,9 +42,10 @@ int blvm_async_errors(unsigned* last_code);
  * persistent launch, larger ones as one launch per link (0 = always per link; < 0 = leave unchanged; default 128 or env
  * BLVM_PCHAIN_MAX_B / BLVM_PCHAIN=0).  `waves` = 8 or 16 waves per workgroup of the persistent kernels (other values: unchanged). */
 int blvm_pchain_configure(int max_batch, int waves);
+int blvm_pchain_max_batch(void); /* the current limit (at most 128) */
 /* Diagnostics: while `device_buffer` (64 zero-initialised uint64 in device memory, caller-owned) is installed, the persistent kernels
  * add the 100 MHz wall-clock ticks two of their workgroups spend in every descriptor of the step program (waits included): words
- * [0..15] workgroup 0 (critical path), [16..31] the first workgroup of the deferred range ([64..95]: the same for backward
+ * [0..31] workgroup 0 (critical path), [32..55] the first workgroup of the deferred range ([64..127]: the same for backward
  * programs; pass 128 words).  NULL uninstalls. */
 int blvm_pchain_profile(unsigned long long* device_buffer);
 /* Diagnostics: placement bits of the persistent programs (results unchanged; default 20): 4 XCD-aware column-tile placement (a
@@ -205,6 +206,14 @@ size_t blvm_vrnn_decode_scratch_floats(int S, int H, int Z, int R);
 int blvm_vrnn_decode(const BlvmVrnnDecodeWeights* w, const float* x0, const float* h0, const float* eps, const float* u,
                      const float* v, int T, int B, int S, int H, int Z, int R, int num_mix, float sd_eps, float slope,
                      float log_eps, float* x_out, float* h_out, float* scratch, void* stream);
+
+/* K1c on the whole chip: the same sampling loop (same arguments and draws, B <= 128) as ONE persistent launch whose every layer is a
+ * link dealt over all CUs (csrc/pchain.hip) instead of 16 utterances per CU: 17 links per step.  scratch:
+ * blvm_vrnn_generate_scratch_floats(T, B, ...) floats (weight copies + one slab per step of every activation). */
+size_t blvm_vrnn_generate_scratch_floats(int T, int B, int S, int H, int Z, int R);
+int blvm_vrnn_generate(const BlvmVrnnDecodeWeights* w, const float* x0, const float* h0, const float* eps, const float* u,
+                       const float* v, int T, int B, int S, int H, int Z, int R, int num_mix, float sd_eps, float slope,
+                       float log_eps, float* x_out, float* h_out, float* scratch, void* stream);
 
 /* number of floats of `reserve` (activations kept for BPTT) / `workspace` (backward scratch). */
 size_t blvm_vrnn_reserve_floats(int Tp, int B, int X, int H, int Z, int R);

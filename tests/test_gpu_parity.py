@@ -825,10 +825,13 @@ def test_upload_i32_carries_host_integers_in_kernel_arguments(n):
     assert torch.equal(d.cpu(), h.to(torch.int32))
 
 
-@pytest.mark.parametrize("B,S,Hd,Z,use_mode", [(5, 16, 64, 32, False), (19, 64, 128, 48, False), (3, 16, 64, 32, True)])
-def test_vrnn_one_launch_decoder_matches_stepwise_generation(B, S, Hd, Z, use_mode):
-    """K1c (all steps of ancestral sampling in one launch) against the step-by-step `generate` on the same prior noise and sampler
-    draws: partial 16-utterance groups, two workgroups, the mode."""
+@pytest.mark.parametrize("whole_chip", [False, True])
+@pytest.mark.parametrize("B,S,Hd,Z,use_mode", [(5, 16, 64, 32, False), (19, 64, 128, 48, False), (3, 16, 64, 32, True), (64, 64, 256, 256, False)])
+def test_vrnn_one_launch_decoder_matches_stepwise_generation(B, S, Hd, Z, use_mode, whole_chip, monkeypatch):
+    """K1c (all steps of ancestral sampling in one launch: 16 utterances per CU, or every layer dealt over the whole chip) against the
+    step-by-step `generate` on the same prior noise and sampler draws: partial 16-utterance groups, several groups, the mode."""
+    real = ops.vrnn_decode
+    monkeypatch.setattr(ops, "vrnn_decode", lambda *a, **k: real(*a, whole_chip=whole_chip, **k))
     torch.manual_seed(B + S)
     m = VRNNAudio(likelihood="DMoL", input_size=S, hidden_size=Hd, latent_size=Z, residual_posterior=True).to(DEV)
     T_ = 5
@@ -843,3 +846,4 @@ def test_vrnn_one_launch_decoder_matches_stepwise_generation(B, S, Hd, Z, use_mo
     assert torch.isfinite(b).all()
     # a Gumbel-max tie or a sample on the clamp can flip an element; everything else agrees to fp32 round-off of the chain
     assert float(((a - b).abs() > 2e-4).float().mean()) < 0.02, (a - b).abs().max()
+    _hip.check_async()
