@@ -27,6 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "benchmarking-lvms_amd"))
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 (--dtype bf16 only)
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_*_f32 dense peak (= fp32 vector peak)
 _T0 = time.time()
 
@@ -287,6 +288,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default 64 = the reference's --batch_len 64 s of audio; cwvae: 8)")
     ap.add_argument("--length", type=int, default=None, help="samples per utterance (default 16000 = 1 s at 16 kHz; cwvae: 49152)")
     ap.add_argument("--model", default="vrnn", choices=["vrnn", "srnn", "lstm", "wavenet", "cwvae", "stcn"], help="vrnn = BASELINE headline (configs[1])")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="operand type of the matrix products: f32 (headline) or bf16 operands / fp32 "
+                    "accumulation for the persistent chains and K6 (the reference's --use_amp regime; a separate mode, never the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=10)
@@ -320,6 +323,7 @@ def main():
     from blvm.training.ddp import FlatGradAllReduce
 
     assert _hip.load().blvm_device_ok() == 1, "libblvm_hip: no gfx950 device"
+    _hip.set_operand_dtype(args.dtype)
     if args.batch is None:
         args.batch = 8 if args.model == "cwvae" else 64  # SURVEY §8d shapes per config (C4: [8, 49152] per GPU)
     if args.length is None:
@@ -337,6 +341,7 @@ def main():
     flops_fb = 3 * 2 * macs  # forward + dgrad + wgrad
     achieved = flops_fb / ((m["fwd_ms"] + m["bwd_ms"]) * 1e-3) / 1e12
 
+    peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
     if rank == 0:
         res = {
             "metric": f"audio frames/sec training ({args.model.upper()}, 16 kHz mu-law)",
@@ -352,7 +357,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
             "bits_per_dim": m["bpd_step0"],
             "bits_per_dim_note": f"ELBO bits/dim of the first forward (random-init weights, seeded); after {args.warmup + args.steps} Adam updates on this one fixed batch: {m['bpd_last']:.4f}",
@@ -370,9 +375,9 @@ def main():
                 "kernel": kname,
                 "bound": "mfma",
                 "achieved": achieved,
-                "peak": PEAK_F32_MFMA_TFLOPS,
+                "peak": peak,
                 "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                "frac": achieved / peak,
                 "traffic": pmc_traffic(args.model, B, T),
                 "flops_per_call": flops_fb,
                 "fwd_ms": m["fwd_ms"],
@@ -382,12 +387,12 @@ def main():
         if n_ranks == 1 and not use_dist and not args.no_sweep and args.model == "vrnn" and (B, T) == (64, 16000):
             # the large-batch regime of the same kernels (the chain's cost per link does not depend on B until B ~ 256): same
             # model, same step, fewer timed steps.  Not the headline: `value` above stays the B = 64 configuration.
-            sweep = [dict(batch_per_gpu=B, ms_per_step=m["ms_median"], frames_per_s=B * T / (m["ms_median"] * 1e-3), roofline_frac=achieved / PEAK_F32_MFMA_TFLOPS)]
+            sweep = [dict(batch_per_gpu=B, ms_per_step=m["ms_median"], frames_per_s=B * T / (m["ms_median"] * 1e-3), roofline_frac=achieved / peak)]
             for Bs in (256, 1024):
                 ms_ = measure(args.model, model, Bs, T, 5, 2, rank, dev, False, FlatGradAllReduce)
                 mc, _ = model_macs(args.model, model, Bs, T)
                 tf = 6 * mc / ((ms_["fwd_ms"] + ms_["bwd_ms"]) * 1e-3) / 1e12
-                sweep.append(dict(batch_per_gpu=Bs, ms_per_step=ms_["ms_median"], frames_per_s=Bs * T / (ms_["ms_median"] * 1e-3), roofline_frac=tf / PEAK_F32_MFMA_TFLOPS))
+                sweep.append(dict(batch_per_gpu=Bs, ms_per_step=ms_["ms_median"], frames_per_s=Bs * T / (ms_["ms_median"] * 1e-3), roofline_frac=tf / peak))
                 log(f"sweep B={Bs}: {ms_['ms_median']:.1f} ms/step, cell {tf:.1f} TF/s")
             res["sweep"] = sweep
         if n_ranks == 1 and not args.no_cpu_baseline and args.model == "vrnn":

@@ -68,6 +68,8 @@ _SIGNATURES = {
     "blvm_async_errors": (c_int, [c_void_p]),
     "blvm_pchain_configure": (c_int, [c_int, c_int]),
     "blvm_pchain_max_batch": (c_int, []),
+    "blvm_set_operand_dtype": (c_int, [c_int]),
+    "blvm_get_operand_dtype": (c_int, []),
     "blvm_pchain_profile": (c_int, [c_void_p]),
     "blvm_pchain_tune": (c_int, [c_int]),
     "blvm_pchain_chain_probe": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -187,6 +189,22 @@ def check_async(what: str = "a persistent recurrent launch"):
             f"{what}: {n} persistent launch(es) aborted on a bounded spin (last at step {code.value >> 4}, link {code.value & 15}): "
             "a workgroup of the launch was not resident (is another process using this GPU?); results are invalid"
         )
+
+
+DTYPES = {"f32": 0, "bf16": 1}
+
+
+def set_operand_dtype(name: str):
+    """Operand type of the matrix products: "f32" (default) or "bf16" (bf16 operands, fp32 accumulation, for the persistent
+    recurrent chains and the K6 GEMMs) — what the reference's `--use_amp True` selects with torch.autocast
+    (`experiments/experiment_vrnn_audio.py:219-230`).  Process-wide."""
+    if name not in DTYPES:
+        raise ValueError(f"operand dtype {name!r}: one of {sorted(DTYPES)}")
+    check(load().blvm_set_operand_dtype(DTYPES[name]), "blvm_set_operand_dtype")
+
+
+def get_operand_dtype() -> str:
+    return "bf16" if load().blvm_get_operand_dtype() == 1 else "f32"
 
 
 def stream_ptr() -> int:

@@ -349,6 +349,19 @@ int gemm_f32(int op_a, int op_b, int M, int N, int K, const float* A, int lda, c
              int split_k, hipStream_t stream);
 int colsum_f32(int M, int N, const float* X, int ldx, float* out, int accumulate, hipStream_t stream);
 int transpose_f32(int M, int N, const float* X, int ldx, float* out, int ldo, hipStream_t stream);
+// Operand type of the matrix products (core.hip; blvm_set_operand_dtype / env BLVM_DTYPE=bf16): false = fp32 (the default), true =
+// bf16 operands with fp32 accumulation for the persistent chains and K6 — the reference's `--use_amp True` regime
+// (experiments/experiment_vrnn_audio.py:219-230).  Everything stored, every epilogue and every reduction stays fp32.
+bool operand_bf16();
+// while one is alive on this thread with bf16 = true, t16_pack writes bf16 elements (the first half of dst)
+struct T16PackScope {
+  explicit T16PackScope(bool bf16);
+  ~T16PackScope();
+  T16PackScope(const T16PackScope&) = delete;
+  T16PackScope& operator=(const T16PackScope&) = delete;
+ private:
+  bool prev_;
+};
 // dst = T16 operand layout (see wave_gemm16) of the [R,K] matrix M[r][k] = src[r * rs + k * cs]; R, K multiples of 16.
 int t16_pack(const float* src, long rs, long cs, int R, int K, float* dst, hipStream_t stream);
 inline int t16_pack_rows(const float* W, int ldw, int R, int K, float* dst, hipStream_t s) { return t16_pack(W, ldw, 1, R, K, dst, s); }

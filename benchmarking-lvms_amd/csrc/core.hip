@@ -196,6 +196,14 @@ int pchain_max_batch() {
   }
   return g_pchain_max_b;
 }
+static int g_operand_dtype = -1;
+bool operand_bf16() {
+  if (g_operand_dtype < 0) {
+    const char* e = getenv("BLVM_DTYPE");
+    g_operand_dtype = (e && (strcmp(e, "bf16") == 0 || strcmp(e, "1") == 0)) ? 1 : 0;
+  }
+  return g_operand_dtype == 1;
+}
 int pchain_waves() {
   if (g_pchain_nw < 0) {
     const char* e = getenv("BLVM_PCHAIN_NW");
@@ -239,6 +247,16 @@ extern "C" int blvm_pchain_configure(int max_batch, int waves) {
   if (waves == 8 || waves == 16) blvm::g_pchain_nw = waves;
   return BLVM_OK;
 }
+
+extern "C" int blvm_set_operand_dtype(int dtype) {
+  if (dtype != BLVM_DTYPE_F32 && dtype != BLVM_DTYPE_BF16) {
+    blvm::set_error("blvm_set_operand_dtype: %d is neither BLVM_DTYPE_F32 nor BLVM_DTYPE_BF16", dtype);
+    return BLVM_EINVAL;
+  }
+  blvm::g_operand_dtype = dtype;
+  return BLVM_OK;
+}
+extern "C" int blvm_get_operand_dtype(void) { return blvm::operand_bf16() ? BLVM_DTYPE_BF16 : BLVM_DTYPE_F32; }
 
 extern "C" int blvm_pchain_max_batch(void) { return std::min(blvm::pchain_max_batch(), 128); }
 

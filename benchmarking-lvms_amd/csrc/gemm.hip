@@ -9,6 +9,8 @@
 // done by the global->LDS stage.  Next tile is prefetched into registers while the current one is multiplied.
 // f32-in MFMA is an exact fp32 fma chain (guide §3 'FP32-input MFMA'), so results are bit-reproducible except
 // for split-K (atomic) accumulation order.
+#include <type_traits>
+
 #include "common.h"
 
 namespace blvm {
@@ -186,8 +188,151 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 }
 
+// ---- bf16-operand variant (operand_bf16(): the reference's --use_amp regime) -----------------------------------------------------
+// Same tiling, arguments and epilogue; the global -> LDS stage rounds both operands to bf16 (nearest even) and lays them out
+// k-group-major — element (m, k) at ((k / 8) * LD + m) * 8 + k % 8 — so that the 8 consecutive k a lane feeds
+// v_mfma_f32_32x32x16_bf16 (gfx950's full-rate form) are one ds_read_b128.  BK = 32: two MFMAs per 32x32 tile and staged k-tile
+// (16x the fp32 pipe's rate, so this kernel is bound by the operand stream: what it buys is the matrix pipe's time).
+// Accumulation and epilogue are fp32.
+constexpr int BKB = 32;
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk2(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector((f2_t){a, b}, b2_t)); }
+
+template <int BM, int BN, int OPA, int OPB>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
+  constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD;
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int KVB = BKB / 4;
+  constexpr int A_V = BM * BKB / 4 / 256;  // float4 per thread per stage (2, 4 or 6)
+  constexpr int B_V = BN * BKB / 4 / 256;
+  static_assert(A_V % 2 == 0 && B_V % 2 == 0, "pairs of k rows");
+  __shared__ __attribute__((aligned(16))) unsigned short As[(BKB / 8) * LDA_S * 8];
+  __shared__ __attribute__((aligned(16))) unsigned short Bs[(BKB / 8) * LDB_S * 8];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * g.k_per_split;
+  const int kend = min(g.K, kbeg + g.k_per_split);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[A_V], rb[B_V];
+  // operand X (rows of length `ext` along m or n): OP == 0: X[row][k], a thread holds 4 consecutive k of one row;
+  // OP == 1: X[k][row], a thread holds 4 consecutive rows of k rows 2p and 2p + 1 (items v, v + 1)
+  auto load_op = [&](auto op_tag, const float* X, int ldx, int ext, int base, bool vec, int BT, float4* r, int NV, int k0) {
+    constexpr int OP = decltype(op_tag)::value;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      if (OP == 0) {
+        const int id = tid + v * 256;
+        const int m = id / KVB, k4 = (id % KVB) * 4;
+        const int gm = base + m, gk = k0 + k4;
+        const int nv = (gm < ext) ? max(0, min(4, kend - gk)) : 0;
+        r[v] = ld4(X + (size_t)(gm < ext ? gm : 0) * ldx + gk, nv, vec);
+      } else {
+        const int id = tid + (v >> 1) * 256;
+        const int k = 2 * (id / (BT / 4)) + (v & 1), m4 = (id % (BT / 4)) * 4;
+        const int gm = base + m4, gk = k0 + k;
+        const int nv = (gk < kend) ? max(0, min(4, ext - gm)) : 0;
+        r[v] = ld4(X + (size_t)(gk < kend ? gk : 0) * ldx + gm, nv, vec);
+      }
+    }
+  };
+  auto store_op = [&](auto op_tag, unsigned short* S, int LD, int BT, const float4* r, int NV) {
+    constexpr int OP = decltype(op_tag)::value;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      if (OP == 0) {
+        const int id = tid + v * 256;
+        const int m = id / KVB, k4 = (id % KVB) * 4;
+        uint2 q;
+        q.x = pk2(r[v].x, r[v].y); q.y = pk2(r[v].z, r[v].w);
+        *reinterpret_cast<uint2*>(&S[((k4 >> 3) * LD + m) * 8 + (k4 & 7)]) = q;
+      } else if ((v & 1) == 0) {
+        const int id = tid + (v >> 1) * 256;
+        const int k = 2 * (id / (BT / 4)), m4 = (id % (BT / 4)) * 4;
+        unsigned short* d = &S[((k >> 3) * LD + m4) * 8 + (k & 7)];
+        *reinterpret_cast<unsigned*>(d + 0) = pk2(r[v].x, r[v + 1].x);
+        *reinterpret_cast<unsigned*>(d + 8) = pk2(r[v].y, r[v + 1].y);
+        *reinterpret_cast<unsigned*>(d + 16) = pk2(r[v].z, r[v + 1].z);
+        *reinterpret_cast<unsigned*>(d + 24) = pk2(r[v].w, r[v + 1].w);
+      }
+    }
+  };
+  using OA = std::integral_constant<int, OPA>;
+  using OB = std::integral_constant<int, OPB>;
+  auto load_tiles = [&](int k0) {
+    load_op(OA{}, g.A, g.lda, g.M, m0, g.a_vec != 0, BM, ra, A_V, k0);
+    load_op(OB{}, g.B, g.ldb, g.N, n0, g.b_vec != 0, BN, rb, B_V, k0);
+  };
+  auto store_tiles = [&]() {
+    store_op(OA{}, As, LDA_S, BM, ra, A_V);
+    store_op(OB{}, Bs, LDB_S, BN, rb, B_V);
+  };
+
+  if (kbeg < kend) load_tiles(kbeg);
+  const int li = lane & 31, lh = lane >> 5;
+  for (int k0 = kbeg; k0 < kend; k0 += BKB) {
+    __syncthreads();
+    store_tiles();
+    __syncthreads();
+    if (k0 + BKB < kend) load_tiles(k0 + BKB);
+#pragma unroll
+    for (int st = 0; st < BKB / 16; ++st) {
+      bf16x8_t a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(&As[((2 * st + lh) * LDA_S + wm * (BM / 2) + i * 32 + li) * 8]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(&Bs[((2 * st + lh) * LDB_S + wn * (BN / 2) + j * 32 + li) * 8]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  const bool atomic = gridDim.z > 1;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (BN / 2) + j * 32 + li;
+      if (n >= g.N) continue;
+      const float bv = (g.bias != nullptr && blockIdx.z == 0) ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= g.M) continue;
+        float v = acc[i][j][r] + bv;
+        if (g.act == 1) v = v > 0.f ? v : 0.f;
+        else if (g.act == 2) v = v > 0.f ? v : v * g.slope;
+        if (g.gate != nullptr) v *= (g.gate[(size_t)m * g.ldg + n] > 0.f) ? 1.f : g.slope;
+        float* cp = g.C + (size_t)m * g.ldc + n;
+        if (atomic) atomicAdd(cp, v);
+        else if (g.accumulate) *cp += v;
+        else *cp = v;
+      }
+    }
+}
+
 template <int BM, int BN>
-void launch_gemm(const GemmArgs& g, int op_a, int op_b, dim3 grid, hipStream_t s) {
+void launch_gemm(const GemmArgs& g, int op_a, int op_b, dim3 grid, hipStream_t s, bool bf16) {
+  if (bf16) {
+    if (op_a == 0 && op_b == 0) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, 0, 0>), grid, dim3(256), 0, s, g);
+    else if (op_a == 0 && op_b == 1) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, 0, 1>), grid, dim3(256), 0, s, g);
+    else if (op_a == 1 && op_b == 0) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, 1, 0>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, 1, 1>), grid, dim3(256), 0, s, g);
+    return;
+  }
   if (op_a == 0 && op_b == 0) hipLaunchKernelGGL((gemm_kernel<BM, BN, 0, 0>), grid, dim3(256), 0, s, g);
   else if (op_a == 0 && op_b == 1) hipLaunchKernelGGL((gemm_kernel<BM, BN, 0, 1>), grid, dim3(256), 0, s, g);
   else if (op_a == 1 && op_b == 0) hipLaunchKernelGGL((gemm_kernel<BM, BN, 1, 0>), grid, dim3(256), 0, s, g);
@@ -296,10 +441,12 @@ int gemm_f32(int op_a, int op_b, int M, int N, int K, const float* A, int lda, c
   const bool m192 = big && !n192 && M % 192 == 0 && M % 128 != 0;
   const int bm = big ? (m192 ? 192 : 128) : 64;
   const int bn = big ? (n192 ? 192 : 128) : 64;
-  int ksteps = (K + BK - 1) / BK;
+  const bool bf16 = operand_bf16();
+  const int bk = bf16 ? BKB : BK;
+  int ksteps = (K + bk - 1) / bk;
   if (split_k > ksteps) split_k = ksteps > 0 ? ksteps : 1;
-  g.k_per_split = ((ksteps + split_k - 1) / split_k) * BK;
-  if (g.k_per_split == 0) g.k_per_split = BK;
+  g.k_per_split = ((ksteps + split_k - 1) / split_k) * bk;
+  if (g.k_per_split == 0) g.k_per_split = bk;
   split_k = (K + g.k_per_split - 1) / g.k_per_split;
   if (split_k < 1) split_k = 1;
   BLVM_REQUIRE(split_k == 1 || (act == 0 && gate == nullptr), "gemm: split-K needs a linear epilogue");
@@ -307,10 +454,10 @@ int gemm_f32(int op_a, int op_b, int M, int N, int K, const float* A, int lda, c
   BLVM_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
   if (split_k > 1 && !accumulate)  // atomic accumulation needs a zeroed destination
     BLVM_HIP(hipMemset2DAsync(C, sizeof(float) * (size_t)ldc, 0, sizeof(float) * (size_t)N, (size_t)M, stream));
-  if (n192) launch_gemm<128, 192>(g, op_a, op_b, grid, stream);
-  else if (m192) launch_gemm<192, 128>(g, op_a, op_b, grid, stream);
-  else if (big) launch_gemm<128, 128>(g, op_a, op_b, grid, stream);
-  else launch_gemm<64, 64>(g, op_a, op_b, grid, stream);
+  if (n192) launch_gemm<128, 192>(g, op_a, op_b, grid, stream, bf16);
+  else if (m192) launch_gemm<192, 128>(g, op_a, op_b, grid, stream, bf16);
+  else if (big) launch_gemm<128, 128>(g, op_a, op_b, grid, stream, bf16);
+  else launch_gemm<64, 64>(g, op_a, op_b, grid, stream, bf16);
   BLVM_CHECK_LAUNCH("gemm_f32");
   return BLVM_OK;
 }
@@ -367,9 +514,38 @@ __global__ __launch_bounds__(256) void t16_pack_kernel(const float* __restrict__
   dst[i] = src[r * rs + (size_t)k * cs];
 }
 
+// the same block order with bf16 elements (two per 32-bit word, round to nearest even): the weights of the bf16-operand chains
+__global__ __launch_bounds__(256) void t16_pack_bf16_kernel(const float* __restrict__ src, long rs, long cs, int KB, size_t n2,
+                                                            unsigned* __restrict__ dst) {
+  const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;  // output word = elements 2w, 2w + 1
+  if (w >= n2) return;
+  const size_t i = 2 * w;
+  const int e = (int)(i & 3), lane = (int)((i >> 2) & 63);
+  const size_t blk = i >> 8;
+  const int j = (int)(blk % KB);
+  const size_t t = blk / KB;
+  const size_t r = 16 * t + (lane & 15);
+  const int k = 16 * j + 4 * (lane >> 4) + e;
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  const f2 v = {src[r * rs + (size_t)k * cs], src[r * rs + (size_t)(k + 1) * cs]};
+  dst[w] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2));
+}
+
+namespace {
+thread_local bool g_pack_bf16 = false;
+}
+T16PackScope::T16PackScope(bool bf16) : prev_(g_pack_bf16) { g_pack_bf16 = bf16; }
+T16PackScope::~T16PackScope() { g_pack_bf16 = prev_; }
+
 int t16_pack(const float* src, long rs, long cs, int R, int K, float* dst, hipStream_t stream) {
   BLVM_REQUIRE(src && dst && R > 0 && K > 0 && R % 16 == 0 && K % 16 == 0 && aligned16(dst), "t16_pack: R=%d, K=%d must be multiples of 16", R, K);
   const size_t n = (size_t)R * K;
+  if (g_pack_bf16) {
+    hipLaunchKernelGGL(t16_pack_bf16_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, stream, src, rs, cs, K / 16, n / 2, reinterpret_cast<unsigned*>(dst));
+    BLVM_CHECK_LAUNCH("t16_pack_bf16");
+    return BLVM_OK;
+  }
   hipLaunchKernelGGL(t16_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, rs, cs, K / 16, n, dst);
   BLVM_CHECK_LAUNCH("t16_pack");
   return BLVM_OK;

@@ -117,18 +117,34 @@ struct NoMid {
   __device__ __forceinline__ void operator()() const {}
 };
 
-template <int NW, int GA, int G, class AMap, int CH, class Mid>
-__device__ __forceinline__ void mgemm_trip(const rsrc_t (&ar)[GA], unsigned aoff, const float* const (&ap)[GA], const float* const (&wp)[G], int kc,
+// BF (the bf16-operand mode, blvm_set_operand_dtype): the weights were packed as bf16 (same T16 block order, 512 B per block) and the
+// activation fragments are rounded to bf16 in registers — a lane's 4 floats of a chunk ARE the 4 k-values a lane feeds
+// v_mfma_f32_16x16x16_bf16, so one MFMA replaces the four fp32 ones; accumulation, epilogues and everything stored stay fp32.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32 (round to nearest even)
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
+}
+template <bool BF> struct WFrag { typedef f32x4 type; };
+template <> struct WFrag<true> { typedef u32x2 type; };
+
+template <int NW, bool BF, int GA, int G, class AMap, int CH, class Mid>
+__device__ __forceinline__ void mgemm_trip(const rsrc_t (&ar)[GA], unsigned aoff, const float* const (&ap)[GA], const char* const (&wp)[G], int kc,
                                            bool aok, bool polled, f32x4 (&acc)[G], Poll& pl, Mid& mid, bool& mid_pending) {
   // Exactly CH chunks, no per-chunk guards: a guard around each chunk's load and the same guard around its sentinel check are one
   // region to the compiler, which then waits after EVERY chunk's load (one memory round trip per chunk instead of one per trip).
   // Polled operands are T16 slabs read through buffer resources (ar, byte offset aoff + 64 bytes per k), plain ones row-major (ap).
   constexpr int STEP = NW * 16;
-  f32x4 w[G][CH], a[GA][CH];
+  typedef typename WFrag<BF>::type wfrag;
+  constexpr int ES = BF ? 2 : 4;  // bytes per weight element
+  wfrag w[G][CH];
+  f32x4 a[GA][CH];
 #pragma unroll
   for (int u = 0; u < CH; ++u)
 #pragma unroll
-    for (int g = 0; g < G; ++g) w[g][u] = *reinterpret_cast<const f32x4*>(wp[g] + 16 * (size_t)(kc + u * STEP));
+    for (int g = 0; g < G; ++g) w[g][u] = *reinterpret_cast<const wfrag*>(wp[g] + (size_t)ES * 16 * (size_t)(kc + u * STEP));
   if (!polled) {
 #pragma unroll
     for (int u = 0; u < CH; ++u)
@@ -163,15 +179,30 @@ __device__ __forceinline__ void mgemm_trip(const rsrc_t (&ar)[GA], unsigned aoff
     pl.t_ok = wall_clock64();
 #endif
   }
+  if constexpr (BF) {
 #pragma unroll
-  for (int u = 0; u < CH; ++u)
+    for (int u = 0; u < CH; ++u) {
+      s16x4 ab[GA];
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+      for (int ga = 0; ga < GA; ++ga) {
+        const f32x4 x = a[ga][u];
+        const u32x2 q = {aok ? pk_bf16(x[0], x[1]) : 0u, aok ? pk_bf16(x[2], x[3]) : 0u};
+        ab[ga] = __builtin_bit_cast(s16x4, q);
+      }
 #pragma unroll
-      for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(aok ? a[AMap::of(g)][u][e] : 0.f, w[g][u][e], acc[g], 0, 0, 0);
+      for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ab[AMap::of(g)], __builtin_bit_cast(s16x4, w[g][u]), acc[g], 0, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < CH; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(aok ? a[AMap::of(g)][u][e] : 0.f, w[g][u][e], acc[g], 0, 0, 0);
+  }
 }
 
-template <int NW, int GA, int G, class AMap, class Mid = NoMid>
+template <int NW, bool BF, int GA, int G, class AMap, class Mid = NoMid>
 __device__ __forceinline__ void mgemm16(const float* const (&A)[GA], const int (&lda)[GA], bool polled, int r0, int nrows,
                                         const float* const (&W)[G], const int (&c0)[G], int K, f32x4 (&acc)[G], Poll& pl, Mid mid = Mid()) {
   constexpr int STEP = NW * 16;
@@ -183,7 +214,7 @@ __device__ __forceinline__ void mgemm16(const float* const (&A)[GA], const int (
   const bool aok = (r0 + rr) < nrows;
   rsrc_t ar[GA];
   const float* ap[GA];
-  const float* wp[G];
+  const char* wp[G];
 #pragma unroll
   for (int g = 0; g < GA; ++g) {
     ar[g] = make_rsrc(A[g]);
@@ -191,14 +222,14 @@ __device__ __forceinline__ void mgemm16(const float* const (&A)[GA], const int (
   }
   const unsigned aoff = 4u * ((unsigned)(r0 >> 4) * 16u * (unsigned)K + 4u * (unsigned)lane);  // T16: row tile's slab + this lane's fragment
 #pragma unroll
-  for (int g = 0; g < G; ++g) wp[g] = W[g] + (size_t)c0[g] * K + 4 * lane;
+  for (int g = 0; g < G; ++g) wp[g] = reinterpret_cast<const char*>(W[g]) + (BF ? 2 : 4) * ((size_t)c0[g] * K + 4 * lane);
   int nch = (K / 16 - wave + NW - 1) / NW;  // chunks wave, wave + NW, ... below K / 16 (wave-uniform)
   int kc = wave * 16;
   bool mid_pending = true;
-  if constexpr (MAXCH >= 6) for (; nch >= 6; nch -= 6, kc += 6 * STEP) mgemm_trip<NW, GA, G, AMap, 6>(ar, aoff, ap, wp, kc, aok, polled, acc, pl, mid, mid_pending);
-  if constexpr (MAXCH >= 4) for (; nch >= 4; nch -= 4, kc += 4 * STEP) mgemm_trip<NW, GA, G, AMap, 4>(ar, aoff, ap, wp, kc, aok, polled, acc, pl, mid, mid_pending);
-  if constexpr (MAXCH >= 2) for (; nch >= 2; nch -= 2, kc += 2 * STEP) mgemm_trip<NW, GA, G, AMap, 2>(ar, aoff, ap, wp, kc, aok, polled, acc, pl, mid, mid_pending);
-  for (; nch >= 1; nch -= 1, kc += STEP) mgemm_trip<NW, GA, G, AMap, 1>(ar, aoff, ap, wp, kc, aok, polled, acc, pl, mid, mid_pending);
+  if constexpr (MAXCH >= 6) for (; nch >= 6; nch -= 6, kc += 6 * STEP) mgemm_trip<NW, BF, GA, G, AMap, 6>(ar, aoff, ap, wp, kc, aok, polled, acc, pl, mid, mid_pending);
+  if constexpr (MAXCH >= 4) for (; nch >= 4; nch -= 4, kc += 4 * STEP) mgemm_trip<NW, BF, GA, G, AMap, 4>(ar, aoff, ap, wp, kc, aok, polled, acc, pl, mid, mid_pending);
+  if constexpr (MAXCH >= 2) for (; nch >= 2; nch -= 2, kc += 2 * STEP) mgemm_trip<NW, BF, GA, G, AMap, 2>(ar, aoff, ap, wp, kc, aok, polled, acc, pl, mid, mid_pending);
+  for (; nch >= 1; nch -= 1, kc += STEP) mgemm_trip<NW, BF, GA, G, AMap, 1>(ar, aoff, ap, wp, kc, aok, polled, acc, pl, mid, mid_pending);
   if (mid_pending) mid();  // a wave without chunks
 }
 
@@ -308,7 +339,7 @@ __device__ __forceinline__ void put(const Out& o, int r0, int c0, int row, int c
 
 // out = gate(act(A W^T + bias + add)):  bias [ncols] or null; add [B, ldadd] or null (add_polled: produced inside this launch);
 // relu: act = leaky ReLU with `slope`; gate [B, ldgate] or null: result *= (gate > 0 ? 1 : slope) — the backward of that activation.
-template <int NW>
+template <int NW, bool BF = false>
 __device__ __forceinline__ void tile_lin(const float* A, int lda, bool a_polled, const float* W, int K, const float* bias,
                                          const float* add, int ldadd, bool add_polled, const float* gate, int ldgate, bool relu,
                                          float slope, const Out& out, int r0, int c0, int B, float* red, Poll& pl) {
@@ -331,7 +362,7 @@ __device__ __forceinline__ void tile_lin(const float* A, int lda, bool a_polled,
     const float* const As[1] = {A};
     const float* const Ws[1] = {W};
     const int la[1] = {lda}, cs[1] = {c0};
-    mgemm16<NW, 1, 1, MapSame>(As, la, a_polled, r0, B, Ws, cs, K, acc, pl, prefetch);
+    mgemm16<NW, BF, 1, 1, MapSame>(As, la, a_polled, r0, B, Ws, cs, K, acc, pl, prefetch);
   }
   float v[1];
   reduce_tiles<1, NW>(acc, red, v);
@@ -367,7 +398,7 @@ struct HeadOut {
   float *mu_p, *sd_p, *mu_q, *sd_q, *raw_p, *raw_q, *muq_raw;  // [B,Z] slabs of this step; muq_raw may be null
   Out z;
 };
-template <int NW>
+template <int NW, bool BF = false>
 __device__ __forceinline__ void tile_head(const float* P, const float* Q, bool polled, const float* Wp, const float* bp, const float* Wq,
                                           const float* bq, const float* eps, const HeadOut& o, int H, int Z, int residual, float beta,
                                           float inv_beta, float sd_eps, int r0, int c0, int B, float* red, Poll& pl) {
@@ -384,7 +415,7 @@ __device__ __forceinline__ void tile_head(const float* P, const float* Q, bool p
     const float* const As[2] = {P, Q};
     const float* const Ws[4] = {Wp, Wp, Wq, Wq};
     const int la[2] = {H, H}, cs[4] = {c0, Z + c0, c0, Z + c0};
-    mgemm16<NW, 2, 4, MapPairs>(As, la, polled, r0, B, Ws, cs, H, acc, pl, prefetch);
+    mgemm16<NW, BF, 2, 4, MapPairs>(As, la, polled, r0, B, Ws, cs, H, acc, pl, prefetch);
   }
   float v[4];
   reduce_tiles<4, NW>(acc, red, v);
@@ -415,7 +446,7 @@ __device__ __forceinline__ void tile_head(const float* P, const float* Q, bool p
 // GRU cell update of a [16 x 16] block of the state (vrnn.hip gru_stage_kernel, rssm.hip gru_cell_stage_kernel): gi = X Wih^T
 // (3 products, X [B,K] polled) + xg (state-independent part of the input projection incl. b_ih, computed before the launch) and /
 // or + b_ih ; gh = h_prev Whh^T + b_hh was produced by another link of this launch (polled words), h_prev likewise.  Writes h_new (sc1) and the gates r, u, n (read after the launch).
-template <int NW>
+template <int NW, bool BF = false>
 __device__ __forceinline__ void tile_gru(const float* X, int ldx, bool polled, const float* Wih, int K, const float* xg, const float* bih,
                                          const float* gh, const float* hprev, int ldh, int R, const Out& hnew, float* rg, float* ug, float* ng,
                                          int r0, int c0, int B, float* red, Poll& pl) {
@@ -444,7 +475,7 @@ __device__ __forceinline__ void tile_gru(const float* X, int ldx, bool polled, c
     const float* const As[1] = {X};
     const float* const Ws[3] = {Wih, Wih, Wih};
     const int la[1] = {ldx}, cs[3] = {c0, R + c0, 2 * R + c0};
-    mgemm16<NW, 1, 3, MapSame>(As, la, polled, r0, B, Ws, cs, K, acc, pl, prefetch);
+    mgemm16<NW, BF, 1, 3, MapSame>(As, la, polled, r0, B, Ws, cs, K, acc, pl, prefetch);
   }
   float v[3];
   reduce_tiles<3, NW>(acc, red, v);
@@ -470,7 +501,7 @@ struct DzIn {
   float fn_floor, beta, sd_eps;
   bool has_gemm = true;  // false: dz = dz_add alone (the last step of a chain whose z only feeds the next step)
 };
-template <int NW>
+template <int NW, bool BF = false>
 __device__ __forceinline__ void tile_dz(const float* D, const float* WT, const float* D2, const float* WT2, bool polled, const float* dz_add,
                                         int ld_add, bool add_polled, const DzIn& a, const Out& dqh, const Out& dph, int H, int Z, int r0, int c0,
                                         int B, float* red, Poll& pl) {
@@ -498,13 +529,13 @@ __device__ __forceinline__ void tile_dz(const float* D, const float* WT, const f
       const float* const As[2] = {D, D2};
       const float* const Ws[2] = {WT, WT2};
       const int la[2] = {H, H}, cs[2] = {c0, c0};
-      mgemm16<NW, 2, 2, MapId>(As, la, polled, r0, B, Ws, cs, H, acc, pl, prefetch);
+      mgemm16<NW, BF, 2, 2, MapId>(As, la, polled, r0, B, Ws, cs, H, acc, pl, prefetch);
     } else {
       f32x4 a1[1] = {acc[0]};
       const float* const As[1] = {D};
       const float* const Ws[1] = {WT};
       const int la[1] = {H}, cs[1] = {c0};
-      mgemm16<NW, 1, 1, MapSame>(As, la, polled, r0, B, Ws, cs, H, a1, pl, prefetch);
+      mgemm16<NW, BF, 1, 1, MapSame>(As, la, polled, r0, B, Ws, cs, H, a1, pl, prefetch);
       acc[0] = a1[0];
     }
     reduce_tiles<2, NW>(acc, red, v);
@@ -566,7 +597,7 @@ struct GrubIn {
   float *ga, *g_out;
   bool has_gemm, has_gin, has_gates;
 };
-template <int NW>
+template <int NW, bool BF = false>
 __device__ __forceinline__ void tile_grub(const GrubIn& a, int K, int R, int r0, int c0, int B, float* red, Poll& pl) {
   const int tt = threadIdx.x & 255;
   const int row = r0 + (tt >> 4), col = c0 + (tt & 15);
@@ -592,7 +623,7 @@ __device__ __forceinline__ void tile_grub(const GrubIn& a, int K, int R, int r0,
     const float* const As[2] = {a.D0, a.D1};
     const float* const Ws[2] = {a.W0, a.W1};
     const int la[2] = {0, 0}, cs[2] = {c0, c0};
-    mgemm16<NW, 2, 2, MapId>(As, la, true, r0, B, Ws, cs, K, acc, pl, prefetch);
+    mgemm16<NW, BF, 2, 2, MapId>(As, la, true, r0, B, Ws, cs, K, acc, pl, prefetch);
     reduce_tiles<2, NW>(acc, red, v);
   }
   if (threadIdx.x >= 256) return;
@@ -727,6 +758,7 @@ struct Desc {
   const float* p[kMaxPtr];        // per kind
 };
 struct Program {
+  int bf16 = 0;  // weights are bf16 T16 packs, products on the bf16 matrix pipe (see mgemm_trip)
   int ndesc, S, B, xcd;
   long stride[16];
   Ctl ctl;
@@ -784,5 +816,7 @@ inline int device_cus() {
 }
 constexpr int kPchainCarveMaxB = 128;  // the persistent kernels' extra buffers are carved for batches up to this size only
 inline bool pchain_applies(int B) { return B <= pchain_max_batch() && B <= kPchainCarveMaxB; }
+// the bf16-operand mode (common.h operand_bf16) of a sequence that runs as a persistent launch: its weights are packed as bf16
+inline bool pchain_bf16(int B) { return operand_bf16() && pchain_applies(B) && device_cus() >= 32; }
 
 }  // namespace blvm

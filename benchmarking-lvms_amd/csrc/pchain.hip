@@ -123,7 +123,7 @@ struct DescRegs {
   __device__ __forceinline__ float* m(int s) const { return const_cast<float*>(p<K>(s)); }
 };
 
-template <int NW>
+template <int NW, bool BF>
 __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restrict__ tab, Hdr a) {
   extern __shared__ __attribute__((aligned(16))) char lds_all[];  // [descriptors | profile | 2 x (lds_products x NW x 256) floats]
   int* const ltab = reinterpret_cast<int*>(lds_all);
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
               const unsigned long long tq1 = wall_clock64();
               tq[0] += tq1 - tq0;
 #endif
-              tile_lin<NW>(A, ld0, a_polled, W, K, bias, add, ld1, (flags & DF_ADD_POLLED) != 0, gate, ld2, (flags & DF_RELU) != 0, slope, o, tr0, tc0, B,
+              tile_lin<NW, BF>(A, ld0, a_polled, W, K, bias, add, ld1, (flags & DF_ADD_POLLED) != 0, gate, ld2, (flags & DF_RELU) != 0, slope, o, tr0, tc0, B,
                            red(), pl);
 #ifdef PCHAIN_TPROF2
               tq_end = wall_clock64();
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
             const int Z = d.w<RD_I + 0>(), residual = d.w<RD_I + 1>();
             for (int tk = 0; tk < nt; ++tk) {
               const int trc = d.tile(tk);
-              tile_head<NW>(d.p<0>(s), d.p<1>(s), true, d.base<2>(), d.base<3>(), d.base<4>(), d.base<5>(), d.p<6>(s), o, K, Z, residual, d.f<0>(), d.f<1>(),
+              tile_head<NW, BF>(d.p<0>(s), d.p<1>(s), true, d.base<2>(), d.base<3>(), d.base<4>(), d.base<5>(), d.p<6>(s), o, K, Z, residual, d.f<0>(), d.f<1>(),
                             d.f<2>(), trc & 0xffff, (trc >> 16) * 16, B, red(), pl);
             }
           } break;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
             const int R = d.w<RD_I + 0>();
             for (int tk = 0; tk < nt; ++tk) {
               const int trc = d.tile(tk);
-              tile_gru<NW>(d.p<0>(s), 0, true, d.base<1>(), K, d.p<2>(s), d.base<10>(), d.p<3>(s), d.p<4>(s), ld0, R, o, d.m<7>(s), d.m<8>(s), d.m<9>(s),
+              tile_gru<NW, BF>(d.p<0>(s), 0, true, d.base<1>(), K, d.p<2>(s), d.base<10>(), d.p<3>(s), d.p<4>(s), ld0, R, o, d.m<7>(s), d.m<8>(s), d.m<9>(s),
                            trc & 0xffff, (trc >> 16) * 16, B, red(), pl);
             }
           } break;
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
             const Out oq{d.m<16>(s), ld3, false, d.m<17>(s), n16}, op{d.m<18>(s), ld3, false, d.m<19>(s), n16};
             for (int tk = 0; tk < nt; ++tk) {
               const int trc = d.tile(tk);
-              tile_dz<NW>(d.p<0>(s), d.base<1>(), d.p<2>(s), d.base<3>(), true, d.p<4>(s), ld1, (flags & DF_ADD_POLLED) != 0, z, oq, op, K, Z, trc & 0xffff,
+              tile_dz<NW, BF>(d.p<0>(s), d.base<1>(), d.p<2>(s), d.base<3>(), true, d.p<4>(s), ld1, (flags & DF_ADD_POLLED) != 0, z, oq, op, K, Z, trc & 0xffff,
                           (trc >> 16) * 16, B, red(), pl);
             }
           } break;
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
             const int R = d.w<RD_I + 0>();
             for (int tk = 0; tk < nt; ++tk) {
               const int trc = d.tile(tk);
-              tile_grub<NW>(g, K, R, trc & 0xffff, (trc >> 16) * 16, B, red(), pl);
+              tile_grub<NW, BF>(g, K, R, trc & 0xffff, (trc >> 16) * 16, B, red(), pl);
             }
           } break;
           case K_DMOLS: {
@@ -337,22 +337,21 @@ int pchain_launch(const pchain::Program& prog, hipStream_t stream) {
   const size_t lds_fixed = sizeof(int) * kDescWords * pchain::kMaxDesc + 32 * sizeof(unsigned long long);
   const size_t lds = lds_fixed + sizeof(float) * 2 * (size_t)prog.lds_products * nw * 256;
   // the dynamic-LDS limit of the kernels is raised once per process and device (the call is far from free)
-  static int attr_dev[2] = {-1, -1};
+  static int attr_dev[4] = {-1, -1, -1, -1};
   const size_t lds_max = lds_fixed + sizeof(float) * 2 * 4 * (size_t)nw * 256;
   BLVM_REQUIRE(lds <= lds_max, "pchain: %d products per tile exceed the reduction scratch", prog.lds_products);
-  if (nw == 16) {
-    if (attr_dev[1] != dev) {
-      BLVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pchain_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-      attr_dev[1] = dev;
+  auto go = [&](auto kernel, int slot, int threads) -> int {
+    if (attr_dev[slot] != dev) {
+      BLVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+      attr_dev[slot] = dev;
     }
-    hipLaunchKernelGGL((pchain_kernel<16>), dim3(grid), dim3(1024), lds, stream, (const int*)tab, h);
-  } else {
-    if (attr_dev[0] != dev) {
-      BLVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pchain_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-      attr_dev[0] = dev;
-    }
-    hipLaunchKernelGGL((pchain_kernel<8>), dim3(grid), dim3(512), lds, stream, (const int*)tab, h);
-  }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, stream, (const int*)tab, h);
+    return BLVM_OK;
+  };
+  int rc;
+  if (nw == 16) rc = prog.bf16 ? go(&pchain_kernel<16, true>, 3, 1024) : go(&pchain_kernel<16, false>, 1, 1024);
+  else rc = prog.bf16 ? go(&pchain_kernel<8, true>, 2, 512) : go(&pchain_kernel<8, false>, 0, 512);
+  if (rc) return rc;
   BLVM_CHECK_LAUNCH("pchain_launch");
   return BLVM_OK;
 }

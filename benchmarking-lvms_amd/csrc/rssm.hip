@@ -219,6 +219,7 @@ extern "C" int blvm_rssm_seq_fwd(const BlvmRssmWeights* w, const float* enc, con
   rc = gemm_f32(0, 0, (int)n, H, E, enc, E, w->post_w[0] + H, ldq, rs.XQ, H, w->post_b[0], 0, 0.f, nullptr, 0, 0, 1, s);
   if (rc) return rc;
   // T16 operand copies of the chain's weights (once per sequence): z columns of the GRU input layer, h columns of post_w0
+  const T16PackScope pack_scope(pchain_bf16(B));  // bf16-operand mode: the persistent launch multiplies bf16 weight packs
   rc = t16_pack_rows(w->gin_w, ldg, H, Z, rs.Wgz, s); if (rc) return rc;
   rc = t16_pack_rows(w->gru_wih, H, 3 * H, H, rs.Wih, s); if (rc) return rc;
   rc = t16_pack_rows(w->gru_whh, H, 3 * H, H, rs.Whh, s); if (rc) return rc;
@@ -243,6 +244,7 @@ extern "C" int blvm_rssm_seq_fwd(const BlvmRssmWeights* w, const float* enc, con
     const int r_h = range_for(ctH * rt, cus / 4);              // one H-wide link (or one half of a posterior | prior pair)
     const int r_gh = range_for(3 * ctH * rt, cus - 2 * r_h);   // the hidden projection, beside the GRU input layer
     Builder bld;
+    bld.p.bf16 = pchain_bf16(B);
     bld.p.S = T; bld.p.B = B; bld.p.xcd = (pchain_tune() & 4) ? 1 : 0; bld.p.lds_products = 4;
     bld.p.prof = pchain_profile_buffer(); bld.p.prof_wg = r_h;
     auto lin = [&](const float* A16, long a_step, const float* W, int K, const float* bias, const float* add, long add_step, float* orm, long rm_step,
@@ -357,6 +359,7 @@ extern "C" int blvm_rssm_seq_bwd(const BlvmRssmWeights* w, const float* enc, con
   const int ldg = Z + C, ldq = H + E;
   const float beta = (float)(0.6931471805599453 / (1.0 - (double)sd_eps));
 #define TRY(x) do { rc = (x); if (rc) return rc; } while (0)
+  const T16PackScope pack_scope(pchain_bf16(B));  // bf16-operand mode: the persistent launch multiplies bf16 weight packs
   TRY(t16_pack_transposed(w->gin_w, ldg, H, Z, ws.gzT, s));
   TRY(t16_pack_transposed(w->gru_wih, H, 3 * H, H, ws.wihT, s));
   TRY(t16_pack_transposed(w->gru_whh, H, 3 * H, H, ws.whhT, s));
@@ -381,6 +384,7 @@ extern "C" int blvm_rssm_seq_bwd(const BlvmRssmWeights* w, const float* enc, con
     const long xH = (long)rt * 16 * H, x3H = 3 * xH, x2Z = (long)rt * 16 * 2 * Z;
     const int r_h = range_for(ctH * rt, cus / 4), r_gb = range_for(ctH * rt, cus - 2 * r_h);
     Builder bld;
+    bld.p.bf16 = pchain_bf16(B);
     bld.p.S = T + 1; bld.p.B = B; bld.p.xcd = (pchain_tune() & 4) ? 1 : 0; bld.p.lds_products = 2;
     bld.p.prof = pchain_profile_buffer() ? pchain_profile_buffer() + 64 : nullptr; bld.p.prof_wg = 2 * r_h;
     auto at = [&](const float* base, long step, int t0) { return base ? base + (long)t0 * step : nullptr; };  // slab of step t0

@@ -111,6 +111,7 @@ extern "C" int blvm_srnn_latent_fwd(const BlvmSrnnWeights* w, const float* d, co
   rc = gemm_f32(0, 0, (int)n, H, R, a, R, w->post_w[0], ldw0, rs.XQ, H, w->post_b[0], 0, 0.f, nullptr, 0, 0, 1, s);
   if (rc) return rc;
   // T16 operand copies of the chain's weights (once per sequence); layer 0: the z columns
+  const T16PackScope pack_scope(pchain_bf16(B));  // bf16-operand mode: the persistent launch multiplies bf16 weight packs
   rc = t16_pack_rows(w->prior_w[0] + R, ldw0, H, Z, rs.Wp[0], s); if (rc) return rc;
   rc = t16_pack_rows(w->post_w[0] + R, ldw0, H, Z, rs.Wq[0], s); if (rc) return rc;
   for (int k = 1; k < 3; ++k) {
@@ -129,6 +130,7 @@ extern "C" int blvm_srnn_latent_fwd(const BlvmSrnnWeights* w, const float* d, co
     const long sH = (long)B * H, sZ = (long)B * Z, xH = (long)rt * 16 * H, xZ = (long)rt * 16 * Z;
     const int half = range_for(ctH * rt, cus / 2);
     Builder bld;
+    bld.p.bf16 = pchain_bf16(B);
     bld.p.S = Tp; bld.p.B = B; bld.p.xcd = (pchain_tune() & 4) ? 1 : 0; bld.p.lds_products = 4;
     bld.p.prof = pchain_profile_buffer(); bld.p.prof_wg = half;
     auto lin = [&](const float* A16, long a_step, const float* W, int K, const float* bias, const float* add, float* orm, float* o16, int wg0) {
@@ -206,6 +208,7 @@ extern "C" int blvm_srnn_latent_bwd(const BlvmSrnnWeights* w, const float* d, co
   const int ldw0 = R + Z;
   const float beta = (float)(0.6931471805599453 / (1.0 - (double)sd_eps));
 #define TRY(x) do { rc = (x); if (rc) return rc; } while (0)
+  const T16PackScope pack_scope(pchain_bf16(B));  // bf16-operand mode: the persistent launch multiplies bf16 weight packs
   TRY(t16_pack_transposed(w->prior_w[0] + R, ldw0, H, Z, ws.pzT, s));
   TRY(t16_pack_transposed(w->post_w[0] + R, ldw0, H, Z, ws.qzT, s));
   for (int k = 1; k < 3; ++k) {
@@ -223,6 +226,7 @@ extern "C" int blvm_srnn_latent_bwd(const BlvmSrnnWeights* w, const float* d, co
     const long sH = (long)B * H, sZ = (long)B * Z, s2Z = 2 * sZ, xH = (long)rt * 16 * H, x2Z = (long)rt * 16 * 2 * Z;
     const int half = range_for(ctH * rt, cus / 2);
     Builder bld;
+    bld.p.bf16 = pchain_bf16(B);
     bld.p.S = T + 1; bld.p.B = B; bld.p.xcd = (pchain_tune() & 4) ? 1 : 0; bld.p.lds_products = 2;
     bld.p.prof = pchain_profile_buffer() ? pchain_profile_buffer() + 64 : nullptr; bld.p.prof_wg = half;
     auto at = [&](const float* base, long step, int t0) { return base ? base + (long)t0 * step : nullptr; };

@@ -295,6 +295,7 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
   if (rc) return rc;
 
   // T16 operand copies of the chain's weights (once per sequence)
+  const T16PackScope pack_scope(pchain_bf16(B));  // bf16-operand mode: the persistent launch multiplies bf16 weight packs
   rc = t16_pack_rows(w->prior_w[0], R, H, R, rs.Wp[0], s); if (rc) return rc;
   rc = t16_pack_rows(w->post_w[0], R + X, H, R, rs.Wq[0], s); if (rc) return rc;  // the h columns
   for (int l = 1; l < 3; ++l) {
@@ -325,6 +326,7 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     const int half = range_for(ctH * rt, (cus - def_n) / 2);                   // prior | posterior halves of a link
     const int g = 2 * half;
     Builder bld;
+    bld.p.bf16 = pchain_bf16(B);
     bld.p.S = Tp; bld.p.B = B; bld.p.xcd = (pchain_tune() & 4) ? 1 : 0; bld.p.lds_products = 4;
     bld.p.prof = pchain_profile_buffer(); bld.p.prof_wg = g;
     auto lin = [&](const float* A16, long a_step, const float* W, int K, const float* bias, const float* add, long add_step, int ldadd, float* orm,
@@ -466,6 +468,7 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
   const float beta = (float)(0.6931471805599453 / (1.0 - (double)sd_eps));
 
   // transposed T16 operand copies of every weight the chain multiplies from the right
+  const T16PackScope pack_scope(pchain_bf16(B));  // bf16-operand mode: the persistent launch multiplies bf16 weight packs
   rc = t16_pack_transposed(w->prior_w[0], R, H, R, ws.pT[0], s); if (rc) return rc;
   rc = t16_pack_transposed(w->prior_w[1], H, H, H, ws.pT[1], s); if (rc) return rc;
   rc = t16_pack_transposed(w->prior_w[2], H, H, H, ws.pT[2], s); if (rc) return rc;
@@ -558,6 +561,7 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     const int def_n = range_for(ctR * rt, std::min(cus / 4, 64));
     const int half = range_for(ctH * rt, (cus - def_n) / 2), g = 2 * half;
     Builder bld;
+    bld.p.bf16 = pchain_bf16(B);
     bld.p.S = T + 1; bld.p.B = B; bld.p.xcd = (pchain_tune() & 4) ? 1 : 0; bld.p.lds_products = 2;
     bld.p.prof = pchain_profile_buffer() ? pchain_profile_buffer() + 64 : nullptr; bld.p.prof_wg = g;
     auto last = [&](const float* base, long step) { return base ? base + (long)(T - 1) * step : nullptr; };  // slab of t = T'-1

@@ -557,6 +557,7 @@ extern "C" int blvm_vrnn_generate(const BlvmVrnnDecodeWeights* w, const float* x
   const VdPack p = vd_pack_layout(S, H, Z, R);
   const VgBufs b = vg_layout(p.total, T, B, S, H, Z, R);
   int rc;
+  const T16PackScope pack_scope(pchain_bf16(B));
 #define PACK(dst, src, ld, rows, k)                               \
   do {                                                            \
     rc = t16_pack_rows(src, ld, rows, k, scratch + (dst), s);     \
@@ -579,6 +580,7 @@ extern "C" int blvm_vrnn_generate(const BlvmVrnnDecodeWeights* w, const float* x
   const int r_side = range_for(3 * ctR * rt, std::min(cus / 4, 64));
   const int r_main = range_for(std::max(ctR * rt, ctH * rt), cus - r_side);
   Builder bld;
+    bld.p.bf16 = pchain_bf16(B);
   bld.p.S = T; bld.p.B = B; bld.p.xcd = (pchain_tune() & 4) ? 1 : 0; bld.p.lds_products = 4;
   bld.p.prof = pchain_profile_buffer(); bld.p.prof_wg = r_main;
   auto lin = [&](size_t A16, long a_step, size_t W, int K, const float* bias, int ct, int flags, float sl, float* orm, long rm_step, int ldo, size_t o16,

@@ -111,8 +111,14 @@ def setup(args):
             os.environ.setdefault("MASTER_PORT", args.ddp_master_port)
         dist.init_process_group("nccl", device_id=dev)
     torch.manual_seed(args.seed)  # same weights on every rank
-    if args.use_amp and rank == 0:
-        print("note: --use_amp is accepted for CLI parity; libblvm_hip computes in fp32", file=sys.stderr)
+    if args.use_amp:
+        # the reference wraps forward in torch.autocast (experiment_vrnn_audio.py:219-230); here: bf16 operands / fp32 accumulation
+        # for the persistent recurrent chains and the K6 GEMMs, everything else (and everything stored) fp32
+        from blvm import _hip
+
+        _hip.set_operand_dtype("bf16")
+        if rank == 0:
+            print("note: --use_amp: bf16 matrix operands with fp32 accumulation (libblvm_hip operand dtype bf16)", file=sys.stderr)
     if isinstance(args.batch_len, float):
         args.batch_len = int(16000 * args.batch_len)
     return rank, world, dev

@@ -43,6 +43,15 @@ int blvm_async_errors(unsigned* last_code);
  * BLVM_PCHAIN_MAX_B / BLVM_PCHAIN=0).  `waves` = 8 or 16 waves per workgroup of the persistent kernels (other values: unchanged). */
 int blvm_pchain_configure(int max_batch, int waves);
 int blvm_pchain_max_batch(void); /* the current limit (at most 128) */
+/* Operand type of the matrix products — the reference's `--use_amp True` switch (`experiments/experiment_vrnn_audio.py:198,219-230`:
+ * torch.autocast around forward).  BLVM_DTYPE_F32 (default): fp32 operands, exact fp32 fma chains.  BLVM_DTYPE_BF16: the
+ * persistent recurrent chains (K1-K5 with B <= blvm_pchain_max_batch()) and the K6 GEMMs round their operands to bf16 (nearest
+ * even) and multiply on the bf16 matrix pipe; accumulation, epilogues, reductions, likelihoods and everything stored stay fp32
+ * (autocast keeps bf16 outputs; this mode is at least as precise).  Also settable with env BLVM_DTYPE=bf16 before the first call. */
+#define BLVM_DTYPE_F32 0
+#define BLVM_DTYPE_BF16 1
+int blvm_set_operand_dtype(int dtype);
+int blvm_get_operand_dtype(void);
 /* Diagnostics: while `device_buffer` (64 zero-initialised uint64 in device memory, caller-owned) is installed, the persistent kernels
  * add the 100 MHz wall-clock ticks two of their workgroups spend in every descriptor of the step program (waits included): words
  * [0..31] workgroup 0 (critical path), [32..55] the first workgroup of the deferred range ([64..127]: the same for backward
