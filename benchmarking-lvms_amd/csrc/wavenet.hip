@@ -151,7 +151,37 @@ struct FusedFwdArgs {
 
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <int C, int S>
+// Two interleaved 16x16 products over the 4 k-values a lane holds of each operand (w = weights as the A operand, x = data as the B
+// operand).  fp32: four v_mfma_f32_16x16x4_f32 per product, the two accumulator chains alternating; BF (operand_bf16(), the
+// reference's --use_amp regime, experiments/experiment_wavenet_audio.py): the same 4 k-values rounded to bf16 are exactly one
+// v_mfma_f32_16x16x16_bf16 per product — a quarter of the matrix-pipe time of kernels whose fp32 form is bound by it.
+typedef short wn_s16x4 __attribute__((ext_vector_type(4)));
+typedef float wn_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 wn_b2 __attribute__((ext_vector_type(2)));
+typedef unsigned wn_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ wn_s16x4 pk4(float a, float b, float c, float d) {
+  const wn_u2 q = {__builtin_bit_cast(unsigned, __builtin_convertvector((wn_f2){a, b}, wn_b2)), __builtin_bit_cast(unsigned, __builtin_convertvector((wn_f2){c, d}, wn_b2))};
+  return __builtin_bit_cast(wn_s16x4, q);
+}
+__device__ __forceinline__ wn_s16x4 pk4(const float4& v) { return pk4(v.x, v.y, v.z, v.w); }
+template <bool BF>
+__device__ __forceinline__ void mma4x2(f32x4& a0, const float4& w0, const float4& x0, f32x4& a1, const float4& w1, const float4& x1) {
+  if constexpr (BF) {
+    a0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pk4(w0), pk4(x0), a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pk4(w1), pk4(x1), a1, 0, 0, 0);
+  } else {
+    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.x, x0.x, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.x, x1.x, a1, 0, 0, 0);
+    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.y, x0.y, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.y, x1.y, a1, 0, 0, 0);
+    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.z, x0.z, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.z, x1.z, a1, 0, 0, 0);
+    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0.w, x0.w, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1.w, x1.w, a1, 0, 0, 0);
+  }
+}
+
+template <int C, int S, bool BF>
 __global__ __launch_bounds__(256, 2) void wn_block_fused_fwd_kernel(FusedFwdArgs a) {
   constexpr int LDX = C + 4, KC = C / 16, NT = C / 16, NR = (C + S) / 16;
   constexpr int WAVE_FLOATS = 16 * 3 * LDX;
@@ -249,22 +279,8 @@ __global__ __launch_bounds__(256, 2) void wn_block_fused_fwd_kernel(FusedFwdArgs
     for (int j = 0; j < JH; ++j) {
       const float4 x0 = *reinterpret_cast<const float4*>(ap0 + 16 * (j0 + j));
       const float4 x1 = *reinterpret_cast<const float4*>(ap1 + 16 * (j0 + j));
-      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(F.t0[j].x, x0.x, aT, 0, 0, 0);
-      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(F.s0[j].x, x0.x, aS, 0, 0, 0);
-      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(F.t0[j].y, x0.y, aT, 0, 0, 0);
-      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(F.s0[j].y, x0.y, aS, 0, 0, 0);
-      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(F.t0[j].z, x0.z, aT, 0, 0, 0);
-      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(F.s0[j].z, x0.z, aS, 0, 0, 0);
-      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(F.t0[j].w, x0.w, aT, 0, 0, 0);
-      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(F.s0[j].w, x0.w, aS, 0, 0, 0);
-      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(F.t1[j].x, x1.x, aT, 0, 0, 0);
-      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(F.s1[j].x, x1.x, aS, 0, 0, 0);
-      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(F.t1[j].y, x1.y, aT, 0, 0, 0);
-      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(F.s1[j].y, x1.y, aS, 0, 0, 0);
-      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(F.t1[j].z, x1.z, aT, 0, 0, 0);
-      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(F.s1[j].z, x1.z, aS, 0, 0, 0);
-      aT = __builtin_amdgcn_mfma_f32_16x16x4f32(F.t1[j].w, x1.w, aT, 0, 0, 0);
-      aS = __builtin_amdgcn_mfma_f32_16x16x4f32(F.s1[j].w, x1.w, aS, 0, 0, 0);
+      mma4x2<BF>(aT, F.t0[j], x0, aS, F.s0[j], x0);
+      mma4x2<BF>(aT, F.t1[j], x1, aS, F.s1[j], x1);
     }
     if (j0 + JH < KC) return;
     // weights as the A operand: the accumulator holds data row lane & 15, channels 4 (lane >> 4) + r — 16-byte pieces of a row
@@ -314,14 +330,7 @@ __global__ __launch_bounds__(256, 2) void wn_block_fused_fwd_kernel(FusedFwdArgs
 #pragma unroll
     for (int j = 0; j < KC; ++j) {
       const float4 v = *reinterpret_cast<const float4*>(ap + 16 * j);
-      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(G.f0[j].x, v.x, c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(G.f1[j].x, v.x, c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(G.f0[j].y, v.y, c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(G.f1[j].y, v.y, c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(G.f0[j].z, v.z, c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(G.f1[j].z, v.z, c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(G.f0[j].w, v.w, c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(G.f1[j].w, v.w, c1, 0, 0, 0);
+      mma4x2<BF>(c0, G.f0[j], v, c1, G.f1[j], v);
     }
     if (!live) return;
 #pragma unroll
@@ -359,7 +368,7 @@ template <int C, int S>
 int launch_fused_fwd(const FusedFwdArgs& a, hipStream_t s) {
   constexpr size_t lds = sizeof(float) * 4 * 16 * 3 * (C + 4);
   static_assert(2 * lds <= 160 * 1024, "fused WaveNet block: two workgroups per CU");
-  auto kern = wn_block_fused_fwd_kernel<C, S>;
+  auto kern = operand_bf16() ? wn_block_fused_fwd_kernel<C, S, true> : wn_block_fused_fwd_kernel<C, S, false>;
   if (lds > 64 * 1024) BLVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const size_t tiles = (a.rows + 63) / 64;
   BLVM_REQUIRE(tiles < (1ull << 31), "wavenet_block_fwd: too many rows");
@@ -391,7 +400,7 @@ struct FusedBwdAArgs {
   float inv_std;
 };
 
-template <int C, int S>
+template <int C, int S, bool BF>
 __global__ __launch_bounds__(256, 2) void wn_block_fused_bwd_a_kernel(FusedBwdAArgs a) {
   constexpr int W = C + S, LDR = W + 4, KR = W / 16, NT = C / 16, KH = KR / 2;
   constexpr int NP = (16 * W / 4 + 63) / 64;
@@ -450,14 +459,7 @@ __global__ __launch_bounds__(256, 2) void wn_block_fused_bwd_a_kernel(FusedBwdAA
     for (int j = 0; j < KH; ++j) {
       const float4 u = *reinterpret_cast<const float4*>(ap + 16 * j);
       const float4 v = *reinterpret_cast<const float4*>(ap + 16 * (KH + j));
-      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[j].x, u.x, c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[KH + j].x, v.x, c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[j].y, u.y, c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[KH + j].y, v.y, c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[j].z, u.z, c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[KH + j].z, v.z, c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[j].w, u.w, c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[KH + j].w, v.w, c1, 0, 0, 0);
+      mma4x2<BF>(c0, F.f[j], u, c1, F.f[KH + j], v);
     }
     // accumulators: data row lane & 15, channels 4 (lane >> 4) + r
     const size_t gr = r0 + rr;
@@ -491,7 +493,7 @@ struct FusedBwdBArgs {
   float inv_std;
 };
 
-template <int C>
+template <int C, bool BF>
 __global__ __launch_bounds__(256, 2) void wn_block_fused_bwd_b_kernel(FusedBwdBArgs a) {
   constexpr int K2 = 2 * C, LDA = K2 + 4, KR = K2 / 16, NT = C / 16, KH = KR / 2;
   constexpr int NP = (16 * K2 / 4 + 63) / 64;
@@ -535,14 +537,7 @@ __global__ __launch_bounds__(256, 2) void wn_block_fused_bwd_b_kernel(FusedBwdBA
     for (int j = 0; j < KH; ++j) {
       const float4 u = *reinterpret_cast<const float4*>(ap + 16 * j);
       const float4 v = *reinterpret_cast<const float4*>(ap + 16 * (KH + j));
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[j].x, u.x, c, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[KH + j].x, v.x, c1, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[j].y, u.y, c, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[KH + j].y, v.y, c1, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[j].z, u.z, c, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[KH + j].z, v.z, c1, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[j].w, u.w, c, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.f[KH + j].w, v.w, c1, 0, 0, 0);
+      mma4x2<BF>(c, F.f[j], u, c1, F.f[KH + j], v);
     }
     c += c1;
   };
@@ -584,8 +579,13 @@ int launch_fused_bwd(const FusedBwdAArgs& aa, const FusedBwdBArgs& ab, hipStream
   static_assert(2 * lds_a <= 160 * 1024 && 2 * lds_b <= 160 * 1024, "fused WaveNet block backward: two workgroups per CU");
   const size_t ta = (aa.rows + 63) / 64, tb = (ab.rows + ab.shift + 63) / 64;
   BLVM_REQUIRE(tb < (1ull << 31), "wavenet_block_bwd: too many rows");
-  hipLaunchKernelGGL((wn_block_fused_bwd_a_kernel<C, S>), dim3((unsigned)ta), dim3(256), lds_a, s, aa);
-  hipLaunchKernelGGL((wn_block_fused_bwd_b_kernel<C>), dim3((unsigned)tb), dim3(256), lds_b, s, ab);
+  if (operand_bf16()) {
+    hipLaunchKernelGGL((wn_block_fused_bwd_a_kernel<C, S, true>), dim3((unsigned)ta), dim3(256), lds_a, s, aa);
+    hipLaunchKernelGGL((wn_block_fused_bwd_b_kernel<C, true>), dim3((unsigned)tb), dim3(256), lds_b, s, ab);
+  } else {
+    hipLaunchKernelGGL((wn_block_fused_bwd_a_kernel<C, S, false>), dim3((unsigned)ta), dim3(256), lds_a, s, aa);
+    hipLaunchKernelGGL((wn_block_fused_bwd_b_kernel<C, false>), dim3((unsigned)tb), dim3(256), lds_b, s, ab);
+  }
   return BLVM_OK;
 }
 
@@ -607,7 +607,7 @@ struct TsArgs {
   float* colsum;     // [2C] += column sums of A, or null
 };
 
-template <int C, bool DUAL>
+template <int C, bool DUAL, bool BF>
 __global__ __launch_bounds__(256) void wn_ts_wgrad_kernel(TsArgs a) {
   constexpr int M = 2 * C, N = C, MT = M / 16, NT = N / 16, MW = MT / 4, NB = DUAL ? 2 : 1, KB = 16;
   constexpr int LDA = M + 4, LDB = N + 4;  // a lane's fragment = rows 4 kq .. 4 kq + 3 of one column: stride = 4 mod 8 spreads the 4 kq groups over all banks
@@ -693,14 +693,30 @@ __global__ __launch_bounds__(256) void wn_ts_wgrad_kernel(TsArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) fb[b][j][e] = p[e * LDB];
         }
+      if constexpr (BF) {
+        wn_s16x4 ha[MW], hb[NB][NT];
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+        for (int i = 0; i < MW; ++i) ha[i] = pk4(fa[i][0], fa[i][1], fa[i][2], fa[i][3]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) hb[b][j] = pk4(fb[b][j][0], fb[b][j][1], fb[b][j][2], fb[b][j][3]);
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
           for (int i = 0; i < MW; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[b][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[b][j][e], acc[b][i][j], 0, 0, 0);
+            for (int j = 0; j < NT; ++j) acc[b][i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ha[i], hb[b][j], acc[b][i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < MW; ++i)
+#pragma unroll
+              for (int j = 0; j < NT; ++j) acc[b][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[b][j][e], acc[b][i][j], 0, 0, 0);
+      }
     }
     if (a.colsum != nullptr && tid < M) {
 #pragma unroll
@@ -732,7 +748,8 @@ int launch_ts_wgrad(TsArgs a, hipStream_t s) {
   if (grid > n_chunks) grid = n_chunks;
   a.chunks_per_wg = (n_chunks + grid - 1) / grid;
   grid = (n_chunks + a.chunks_per_wg - 1) / a.chunks_per_wg;
-  hipLaunchKernelGGL((wn_ts_wgrad_kernel<C, DUAL>), dim3((unsigned)grid), dim3(256), 0, s, a);
+  if (operand_bf16()) hipLaunchKernelGGL((wn_ts_wgrad_kernel<C, DUAL, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((wn_ts_wgrad_kernel<C, DUAL, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
   return BLVM_OK;
 }
 

@@ -171,3 +171,25 @@ def test_srnn_bf16_delta_within_budget():
     _hip.set_operand_dtype("bf16")
     d = ((eb - ef).abs() / x_sl.double()).max()
     assert 0.0 < float(d) < NATS_PER_FRAME_BUDGET, float(d)
+
+
+def test_wavenet_c5_dims_bf16_delta_within_budget():
+    """BASELINE configs[4] (the reference runs WaveNet under fp16 autocast): C5 dims on the golden inputs of
+    `test_wavenet_c5_dims_vs_reference_golden` with the block kernels' products on the bf16 matrix pipe (fused forward / backward /
+    weight-gradient kernels of K10 and the K6 GEMMs around them), against the REFERENCE's fp32 values."""
+    from blvm.models import WaveNet
+    from blvm.modules.distributions import DiscretizedLogisticMixtureDense
+
+    g = np.load(os.path.join(GOLDEN, "wavenet.npz"))
+    torch.manual_seed(0)
+    lik = DiscretizedLogisticMixtureDense(96, 1, num_mix=10, num_bins=2**16)
+    m = WaveNet(likelihood=lik, n_layers=10, n_stacks=5, res_channels=96, kernel_size=2, base_dilation=2, n_stack_frames=1).to(DEV)
+    x, x_sl = O.synth_batch(2, 1500, seed=0, ragged=True)
+    loss, metrics, out = m(x.to(DEV), x_sl)
+    loss.backward()
+    d = ((out.log_prob.detach().cpu().double() - T(g["f_log_prob"]).double()).abs() / x_sl.double()).max()
+    assert 0.0 < float(d) < NATS_PER_FRAME_BUDGET, float(d)
+    assert float(loss) == pytest.approx(float(g["f_loss"]), rel=1e-4)
+    grads = dict(m.named_parameters())
+    for name, ref in zip(g["f_grad_names"].tolist(), g["f_grad_norms"].tolist()):
+        assert grads[name].grad.double().norm().item() == pytest.approx(ref, rel=5e-2), name
