@@ -49,6 +49,16 @@ class SrnnWeights(ctypes.Structure):
     ]  # fmt: skip
 
 
+class SrnnDecodeWeights(ctypes.Structure):
+    """struct BlvmSrnnDecodeWeights."""
+
+    _fields_ = [
+        ("enc_w", c_void_p * 3), ("enc_b", c_void_p * 3), ("gru_wih", c_void_p), ("gru_whh", c_void_p), ("gru_bih", c_void_p),
+        ("gru_bhh", c_void_p), ("chain", ctypes.POINTER(SrnnWeights)), ("dec_w", c_void_p * 3), ("dec_b", c_void_p * 3),
+        ("lik_w", c_void_p), ("lik_b", c_void_p),
+    ]  # fmt: skip
+
+
 class RssmWeights(ctypes.Structure):
     """struct BlvmRssmWeights / BlvmRssmGrads."""
 
@@ -88,6 +98,8 @@ _SIGNATURES = {
                             c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "blvm_vrnn_decode_scratch_floats": (c_size_t, [c_int] * 4),
     "blvm_vrnn_decode": (c_int, [ctypes.POINTER(VrnnDecodeWeights)] + [c_void_p] * 5 + [c_int] * 7 + [c_float] * 3 + [c_void_p] * 4),
+    "blvm_srnn_generate_scratch_floats": (c_size_t, [c_int] * 6),
+    "blvm_srnn_generate": (c_int, [ctypes.POINTER(SrnnDecodeWeights)] + [c_void_p] * 6 + [c_int] * 7 + [c_float] * 3 + [c_void_p] * 5),
     "blvm_vrnn_generate_scratch_floats": (c_size_t, [c_int] * 6),
     "blvm_vrnn_generate": (c_int, [ctypes.POINTER(VrnnDecodeWeights)] + [c_void_p] * 5 + [c_int] * 7 + [c_float] * 3 + [c_void_p] * 4),
     "blvm_vrnn_reserve_floats": (c_size_t, [c_int] * 6),

@@ -175,17 +175,28 @@ class SRNN(nn.Module):
 
     @torch.no_grad()
     def generate(self, x, u=None, d_0=None, a_0=None, z_0=None, h_p_0=None, n_samples: int = 1, max_timesteps: int = 100,
-                 stop_value: float = None, use_mode: bool = False, eps=None, uniforms=None):  # fmt: skip
+                 stop_value: float = None, use_mode: bool = False, eps=None, uniforms=None, fused: Optional[bool] = None):  # fmt: skip
         """Unconditional autoregressive sampling (srnn.py:304-403): encode the previous frame stack, one GRU step for d_t, draw
         z_t from the prior given cat[d_t, z_{t-1}] (its mean if use_mode), decode cat[z_t, d_t], SAMPLE the next frame stack and
         feed it back.  x [B,1,S] start frames.  Returns ((x [B,T,S,1], x_sl), ns(h_p)).  `eps` [T,B,z] and `uniforms`
-        (list of the head sampler's draws per step) optionally supply the randomness.  Every step runs K6 / K2 / K3 at T' = 1."""
+        (list of the head sampler's draws per step) optionally supply the randomness.  Every step runs K6 / K2 / K3 at T' = 1;
+        `fused` (DMoL head, no stop value, at most `blvm_pchain_max_batch()` utterances; default: whenever that holds) runs ALL steps
+        in one persistent launch (K3c, `ops.srnn_generate`)."""
         if u is not None or x.size(1) > 1:
             raise NotImplementedError("libblvm_hip: SRNN.generate is built for unconditional generation (x [B,1,S], u=None)")
         S, enc_lin, dec_lin, lik = self._plan()
         dev = x.device
         H, Z, R = self.h_dim, self.z_dim, self.r_dim
         n = n_samples
+        can_fuse = (stop_value is None and isinstance(lik, DiscretizedLogisticMixtureDense) and len(enc_lin) == 3 and len(dec_lin) == 3
+                    and 0 < n <= ops.load().blvm_pchain_max_batch() and all(v % 16 == 0 for v in (S, H, Z, R)))  # fmt: skip
+        if fused is None:
+            fused = can_fuse
+        if fused:
+            if not can_fuse:
+                raise NotImplementedError("libblvm_hip: the one-launch SRNN decoder needs the SRNNAudio(DMoL) structure, no stop value, "
+                                          "dimensions in multiples of 16 and at most blvm_pchain_max_batch() utterances")  # fmt: skip
+            return self._generate_fused(x, d_0, z_0, n, max_timesteps, use_mode, eps, uniforms, S, enc_lin, dec_lin, lik)
         x_sl = torch.zeros(n)
         d_t = torch.zeros(n, R, device=dev) if d_0 is None else d_0.reshape(n, R).contiguous()
         z_t = torch.zeros(n, Z, device=dev) if z_0 is None else z_0.contiguous()
@@ -215,6 +226,30 @@ class SRNN(nn.Module):
             t += 1
             all_ended = bool(torch.all(1 - seq_active))
         return (torch.stack(all_x, dim=1), x_sl), SimpleNamespace(h_p=h_p)
+
+
+    def _generate_fused(self, x, d_0, z_0, n, T, use_mode, eps, uniforms, S, enc_lin, dec_lin, lik):
+        dev = x.device
+        H, Z, R = self.h_dim, self.z_dim, self.r_dim
+        if use_mode:  # the reference's use_mode takes the PRIOR's mean and still samples the observation (srnn.py:366-392)
+            eps = torch.zeros(T, n, Z, device=dev)
+        elif eps is None:
+            eps = torch.randn(T, n, Z, device=dev)
+        else:
+            eps = torch.as_tensor(eps)[:T].reshape(T, n, Z).to(dev)
+        if uniforms is None:
+            u = torch.empty(T, n, S, lik.num_mix, device=dev).uniform_(1e-5, 1.0 - 1e-5)
+            v = torch.empty(T, n, S, device=dev).uniform_(1e-8, 1.0 - 1e-8)
+        else:
+            u = torch.stack([uniforms[t][0].reshape(n, S, lik.num_mix) for t in range(T)]).to(dev)
+            v = torch.stack([uniforms[t][1].reshape(n, S) for t in range(T)]).to(dev)
+        slope = next(m.negative_slope for m in self.encoder if isinstance(m, nn.LeakyReLU))
+        d0 = None if d_0 is None else d_0.reshape(n, R)
+        xs, d_n, zs = ops.srnn_generate(enc_lin, self.d_forward_recurrent, self._chain_params(), dec_lin, lik.params, x.reshape(n, S), d0, z_0,
+                                        eps, u, v, S, H, Z, R, lik.num_mix, self.prior[6].epsilon, slope, lik.log_epsilon)  # fmt: skip
+        z_prev = zs[T - 2] if T > 1 else (torch.zeros(n, Z, device=dev) if z_0 is None else z_0)
+        x_sl = torch.zeros(n) + T
+        return (xs.unsqueeze(-1), x_sl), SimpleNamespace(h_p=torch.cat([d_n, z_prev], -1))
 
 
 class SRNNAudio(BaseModel):

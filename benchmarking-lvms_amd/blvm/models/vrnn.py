@@ -249,13 +249,18 @@ class VRNN(nn.Module):
     @torch.no_grad()
     def generate(self, x: torch.Tensor, h0: Optional[torch.Tensor] = None, n_samples: int = 1, max_timesteps: int = 100,
                  stop_value: float = None, use_mode: bool = False, eps: Optional[torch.Tensor] = None, uniforms=None,
-                 fused: bool = False):  # fmt: skip
+                 fused: Optional[bool] = None):  # fmt: skip
         """Autoregressive sampling (vrnn.py:371-434): the previous frame stack is encoded, the cell draws z from its prior and
         updates h, the decoder (on cat[phi_z, h_new] — the UPDATED state here, unlike `forward`) parameterises the next frame
         stack, which is sampled (or its mode taken) and fed back.  x [B,S,1] initial frame stack; returns ((x [B,1+T,S], x_sl), ns).
         `eps` [T,B,z] optionally supplies the prior noise, `uniforms` = (u [T,B,S,K], v [T,B,S]) the sampler's draws.  Every step
-        runs the K6 / K1 / K7-head kernels at T' = 1; `fused=True` (DMoL head, no stop value) runs ALL steps in one launch (K1c)."""
+        runs the K6 / K1 / K7-head kernels at T' = 1; `fused=True` (DMoL head, no stop value) runs ALL steps in one launch (K1c);
+        the default (None) takes the one-launch path whenever the model has that structure."""
         S, enc_lin, dec_lin, lik = self._plan()
+        if fused is None:
+            c = self.vrnn_cell
+            fused = (stop_value is None and isinstance(lik, DiscretizedLogisticMixtureDense) and len(enc_lin) == 3 and len(dec_lin) == 3
+                     and all(v % 16 == 0 for v in (S, c.h_dim, c.z_dim, c.r_dim)))  # fmt: skip
         if fused:
             return self._generate_fused(x, h0, n_samples, max_timesteps, stop_value, use_mode, eps, uniforms)
         if x.size(0) > 1:
@@ -370,8 +375,8 @@ class VRNNAudio(BaseModel):
         return self.vrnn(x, x_sl, beta, free_nats, h0, eps)
 
     def generate(self, n_samples: int = 1, max_timesteps: int = 100, use_mode: bool = False, x=None, h0=None, eps=None, uniforms=None,
-                 fused: bool = False):  # fmt: skip
-        """Same arguments as the reference (vrnn.py:529-546); `fused=True`: every step in one launch (K1c)."""
+                 fused: Optional[bool] = None):  # fmt: skip
+        """Same arguments as the reference (vrnn.py:529-546); `fused`: every step in one launch (K1c; default: when it applies)."""
         x = torch.zeros(n_samples, self.input_size, 1, device=self.device) if x is None else x
         return self.vrnn.generate(n_samples=n_samples, max_timesteps=max_timesteps, stop_value=None, use_mode=use_mode, x=x, h0=h0,
                                   eps=eps, uniforms=uniforms, fused=fused)  # fmt: skip

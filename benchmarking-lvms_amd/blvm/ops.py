@@ -659,6 +659,40 @@ def _pack_srnn(ts):
     return w
 
 
+def srnn_generate(enc_lin, gru, chain_params, dec_lin, lik_lin, x0, d0, z0, eps, u, v, S, H, Z, R, num_mix, sd_eps, slope, log_eps):
+    """K3c: T = eps.shape[0] steps of ancestral sampling from SRNNAudio for all B <= 128 utterances in one persistent launch.
+    enc_lin / dec_lin: 3 nn.Linear each; gru: the forward nn.GRU (parameter container); chain_params in `_SRNN_PARAM_ORDER`;
+    lik_lin the DMoL head's Linear.  x0 [B,S]; d0 [B,R], z0 [B,Z] or None; eps [T,B,Z]; u [T,B,S,num_mix] / v [T,B,S] (None: the
+    mode).  -> (x [B,T,S], d_T [B,R], z [T,B,Z])."""
+    import ctypes
+
+    lib = load()
+    T, B = eps.shape[0], x0.shape[0]
+    dev = x0.device
+    keep = [_f32c(t) for lin in (*enc_lin, *dec_lin, lik_lin) for t in (lin.weight, lin.bias)]
+    gk = [_f32c(t) for t in (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0)]
+    cp = [_f32c(p) for p in chain_params]
+    cw = _pack_srnn(cp)
+    w = _hip.SrnnDecodeWeights()
+    for i in range(3):
+        w.enc_w[i], w.enc_b[i] = ptr(keep[2 * i]), ptr(keep[2 * i + 1])
+        w.dec_w[i], w.dec_b[i] = ptr(keep[6 + 2 * i]), ptr(keep[6 + 2 * i + 1])
+    w.lik_w, w.lik_b = ptr(keep[12]), ptr(keep[13])
+    w.gru_wih, w.gru_whh, w.gru_bih, w.gru_bhh = (ptr(t) for t in gk)
+    w.chain = ctypes.pointer(cw)
+    x0, eps = _f32c(x0), _f32c(eps)
+    d0 = _f32c(d0) if d0 is not None else None
+    z0 = _f32c(z0) if z0 is not None else None
+    u = _f32c(u) if u is not None else None
+    v = _f32c(v) if v is not None else None
+    f32 = dict(device=dev, dtype=torch.float32)
+    scratch = torch.empty(lib.blvm_srnn_generate_scratch_floats(T, B, S, H, Z, R), **f32)
+    x, dn, zs = torch.empty(B, T, S, **f32), torch.empty(B, R, **f32), torch.empty(T, B, Z, **f32)
+    check(lib.blvm_srnn_generate(ctypes.byref(w), ptr(x0), ptr(d0), ptr(z0), ptr(eps), ptr(u), ptr(v), T, B, S, H, Z, R, num_mix, sd_eps,
+                                 slope, log_eps, ptr(x), ptr(dn), ptr(zs), ptr(scratch), stream_ptr()), "blvm_srnn_generate")  # fmt: skip
+    return x, dn, zs
+
+
 class _SRNNLatentFunction(torch.autograd.Function):
     """(d, a, z0, eps, 16 params) -> zs [T'+1,B,Z], kld [B], kld_fn [B]  (+ non-differentiable mu/sd)."""
 

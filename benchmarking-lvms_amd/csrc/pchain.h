@@ -204,7 +204,8 @@ __device__ __forceinline__ void mgemm_trip(const rsrc_t (&ar)[GA], unsigned aoff
 
 template <int NW, bool BF, int GA, int G, class AMap, class Mid = NoMid>
 __device__ __forceinline__ void mgemm16(const float* const (&A)[GA], const int (&lda)[GA], bool polled, int r0, int nrows,
-                                        const float* const (&W)[G], const int (&c0)[G], int K, f32x4 (&acc)[G], Poll& pl, Mid mid = Mid()) {
+                                        const float* const (&W)[G], const int (&c0)[G], int K, f32x4 (&acc)[G], Poll& pl, Mid mid = Mid(),
+                                        int a_width = 0) {  // a_width: columns of the polled T16 slab when it is wider than K (a concatenation's first part)
   constexpr int STEP = NW * 16;
   // fragment registers of a trip: 4 * CH * (G + GA); trips of 6 / 4 / 2 / 1 chunks (K = 256, 512, 1536 on 8 waves: 2, 4, 6 + 6)
   constexpr int FR = 12 / (G + GA);
@@ -220,7 +221,7 @@ __device__ __forceinline__ void mgemm16(const float* const (&A)[GA], const int (
     ar[g] = make_rsrc(A[g]);
     ap[g] = A[g] + (size_t)(aok ? r0 + rr : r0) * (polled ? 0 : lda[g]) + 4 * q;
   }
-  const unsigned aoff = 4u * ((unsigned)(r0 >> 4) * 16u * (unsigned)K + 4u * (unsigned)lane);  // T16: row tile's slab + this lane's fragment
+  const unsigned aoff = 4u * ((unsigned)(r0 >> 4) * 16u * (unsigned)(a_width > 0 ? a_width : K) + 4u * (unsigned)lane);  // T16: row tile's slab + this lane's fragment
 #pragma unroll
   for (int g = 0; g < G; ++g) wp[g] = reinterpret_cast<const char*>(W[g]) + (BF ? 2 : 4) * ((size_t)c0[g] * K + 4 * lane);
   int nch = (K / 16 - wave + NW - 1) / NW;  // chunks wave, wave + NW, ... below K / 16 (wave-uniform)
@@ -286,10 +287,10 @@ struct TileIter {
 // Cheap wait in front of a polled product for tiles OFF the critical path: one wave polls ONE word of every 1 KB block of the
 // T16 operand A16[r0 .. r0+15][0 .. K) instead of every wave polling its fragments; the barrier then releases the other waves into
 // the validating operand poll, which normally succeeds at once.  Costs a round trip, saves the fabric most of the idle polling.
-__device__ __forceinline__ void canary_wait(const float* A16, int r0, int K, Poll& pl) {
+__device__ __forceinline__ void canary_wait(const float* A16, int r0, int K, Poll& pl, int a_width = 0) {  // a_width: as mgemm16
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x, np = K >> 4;
-    const rsrc_t r = make_rsrc(A16 + (size_t)(r0 >> 4) * 16 * K);  // word 0 of a block = row r0, always written
+    const rsrc_t r = make_rsrc(A16 + (size_t)(r0 >> 4) * 16 * (a_width > 0 ? a_width : K));  // word 0 of a block = row r0, always written
     unsigned spins = 0;
     for (;;) {
       bool bad = false;
@@ -362,7 +363,7 @@ __device__ __forceinline__ void tile_lin(const float* A, int lda, bool a_polled,
     const float* const As[1] = {A};
     const float* const Ws[1] = {W};
     const int la[1] = {lda}, cs[1] = {c0};
-    mgemm16<NW, BF, 1, 1, MapSame>(As, la, a_polled, r0, B, Ws, cs, K, acc, pl, prefetch);
+    mgemm16<NW, BF, 1, 1, MapSame>(As, la, a_polled, r0, B, Ws, cs, K, acc, pl, prefetch, a_polled ? lda : 0);  // polled: lda = slab width (0 = K)
   }
   float v[1];
   reduce_tiles<1, NW>(acc, red, v);
@@ -803,8 +804,9 @@ inline int range_for(int tiles, int avail) { return std::max(8, std::min(avail &
 
 // enqueue the persistent launch of a program (pchain.hip); grid = highest workgroup any descriptor names
 int pchain_launch(const pchain::Program& prog, hipStream_t stream);
-// dst = T16 copy [ceil(B/16)*16, K] of the rows of src [B, K] (row stride ld; null: zeros); rows >= B are left alone (never read)
-int pchain_rows_to_t16(const float* src, int ld, int B, int K, float* dst, hipStream_t stream);
+// dst = T16 copy [ceil(B/16)*16, K] of the rows of src [B, K] (row stride ld; null: zeros); rows >= B are left alone (never read).
+// n16 > 0: dst is a slab of n16 blocks per row tile (a concatenation; dst points at this part's first block)
+int pchain_rows_to_t16(const float* src, int ld, int B, int K, float* dst, hipStream_t stream, int n16 = 0);
 inline int device_cus() {
   static int v = [] {
     int dev = 0, n = 0;

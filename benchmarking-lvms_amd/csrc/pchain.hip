@@ -2,10 +2,10 @@
 // whole recurrent sequence.  Replaces, per model, thousands of dependent launches (VRNN [64,16000]: 4 500 per train step) by one
 // forward and one backward launch.  Pointer roles of a descriptor by tile kind:
 //
-//   K_LIN   p: 0 A (T16 copy, polled | row-major when DF_A_PLAIN, ld[0])  1 W (T16)  2 bias  3 add (ld[1])  4 gate (ld[2])
+//   K_LIN   p: 0 A (T16 copy, polled, ld[0] = its width when wider than K | row-major when DF_A_PLAIN, ld[0])  1 W (T16)  2 bias  3 add (ld[1])  4 gate (ld[2])
 //              5 out row-major (ld[3])  6 out T16 (n16[0])  7 second out T16 (n16[1])            f: 0 slope
 //   K_HEAD  p: 0 P16  1 Q16  2 Wp  3 bp  4 Wq  5 bq  6 eps  7 mu_p  8 sd_p  9 mu_q  10 sd_q  11 raw_p  12 raw_q  13 muq_raw
-//              14 z row-major (ld[3])  15 z T16 (n16[0])               i: 0 Z  1 residual      f: 0 beta  1 1/beta  2 sd_eps
+//              14 z row-major (ld[3])  15 z T16 (n16[0])  16 second z T16 (n16[1])    i: 0 Z  1 residual      f: 0 beta  1 1/beta  2 sd_eps
 //   K_GRU   p: 0 X16  1 Wih (T16)  2 xg  3 gh (polled words)  4 h_prev (polled words, ld[0])  5 h_new row-major (ld[3])
 //              6 h_new T16 (n16[0])  7 rg  8 ug  9 ng  10 b_ih  11 second h_new T16 (n16[1])         i: 0 R
 //   K_DZ    p: 0 D16  1 WT  2 D2_16  3 WT2  4 dz_add (ld[1])  5 mu_q  6 sd_q  7 mu_p  8 sd_p  9 eps  10 raw_q  11 raw_p  12 muq_raw
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
             const float slope = d.f<0>();
             for (int tk = 0; tk < nt; ++tk) {
               const int trc = d.tile(tk), tr0 = trc & 0xffff, tc0 = (trc >> 16) * 16;
-              if ((flags & DF_CANARY) && a_polled) canary_wait(A, tr0, K, pl);
+              if ((flags & DF_CANARY) && a_polled) canary_wait(A, tr0, K, pl, ld0);
 #ifdef PCHAIN_TPROF2
               const unsigned long long tq1 = wall_clock64();
               tq[0] += tq1 - tq0;
@@ -197,7 +197,8 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
           } break;
 #ifndef PCHAIN_ONLY_LIN
           case K_HEAD: {
-            const HeadOut o{d.m<7>(s), d.m<8>(s), d.m<9>(s), d.m<10>(s), d.m<11>(s), d.m<12>(s), d.m<13>(s), Out{d.m<14>(s), ld3, false, d.m<15>(s), n16}};
+            const HeadOut o{d.m<7>(s), d.m<8>(s), d.m<9>(s), d.m<10>(s), d.m<11>(s), d.m<12>(s), d.m<13>(s),
+                            Out{d.m<14>(s), ld3, false, d.m<15>(s), n16, d.m<16>(s), d.w<RD_N16 + 1>()}};
             const int Z = d.w<RD_I + 0>(), residual = d.w<RD_I + 1>();
             for (int tk = 0; tk < nt; ++tk) {
               const int trc = d.tile(tk);
@@ -276,18 +277,18 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
   }
 }
 
-__global__ void rows_to_t16_kernel(const float* src, int ld, int B, int K, float* dst) {
+__global__ void rows_to_t16_kernel(const float* src, int ld, int B, int K, float* dst, int n16) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * K) return;
   const int row = i / K, k = i % K;
-  dst[((size_t)(row >> 4) * (K >> 4) + (k >> 4)) * 256 + ((row & 15) + 16 * ((k & 15) >> 2)) * 4 + (k & 3)] = src ? src[(size_t)row * ld + k] : 0.f;
+  dst[((size_t)(row >> 4) * n16 + (k >> 4)) * 256 + ((row & 15) + 16 * ((k & 15) >> 2)) * 4 + (k & 3)] = src ? src[(size_t)row * ld + k] : 0.f;
 }
 
 }  // namespace
 
-int pchain_rows_to_t16(const float* src, int ld, int B, int K, float* dst, hipStream_t stream) {
-  BLVM_REQUIRE(B > 0 && K > 0 && K % 16 == 0 && dst != nullptr, "pchain_rows_to_t16: bad arguments");
-  hipLaunchKernelGGL(rows_to_t16_kernel, dim3((B * K + 255) / 256), dim3(256), 0, stream, src, ld, B, K, dst);
+int pchain_rows_to_t16(const float* src, int ld, int B, int K, float* dst, hipStream_t stream, int n16) {
+  BLVM_REQUIRE(B > 0 && K > 0 && K % 16 == 0 && dst != nullptr && (n16 == 0 || n16 >= K / 16), "pchain_rows_to_t16: bad arguments");
+  hipLaunchKernelGGL(rows_to_t16_kernel, dim3((B * K + 255) / 256), dim3(256), 0, stream, src, ld, B, K, dst, n16 > 0 ? n16 : K / 16);
   BLVM_CHECK_LAUNCH("pchain_rows_to_t16");
   return BLVM_OK;
 }

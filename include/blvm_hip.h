@@ -319,6 +319,25 @@ int blvm_srnn_latent_bwd(const BlvmSrnnWeights* w, const float* d, const float* 
                          int residual_posterior, float sd_eps, float slope, float* d_d, float* d_a, float* d_z0,
                          const BlvmSrnnGrads* grads, float* workspace, void* stream);
 
+/* K3c  Ancestral sampling from SRNNAudio: every step of every utterance in ONE persistent launch (B <= 128).  Replaces the loop of
+ *   `SRNN.generate` (`blvm/models/srnn.py:304-403`): enc = encoder(x_t) -> d_t = GRU(enc, d_{t-1}) -> prior(cat[d_t, z_{t-1}]) ->
+ *   z_t = mu + sd eps -> decoder(cat[z_t, d_t]) -> DMoL head per sample -> draw -> x_{t+1}; 13 links per step dealt over all CUs
+ *   (csrc/pchain.hip).  Weights in their PyTorch layouts; encoder / decoder are 3 x (Linear + LeakyReLU(slope)) as in
+ *   `srnn.py:456-474`, x_dim = H.  x0 [B,S]; d0 [B,R], z0 [B,Z] or NULL (zeros); eps [T,B,Z]; u [T,B,S,num_mix], v [T,B,S] as in
+ *   blvm_mix_sample (both NULL: the mode).  Outputs: x_out [B,T,S]; d_out [B,R] = d_T and z_out [T,B,Z] (each may be NULL).
+ *   scratch: blvm_srnn_generate_scratch_floats(...) floats (weight copies + one slab per step of every activation). */
+typedef struct BlvmSrnnDecodeWeights {
+  const float *enc_w[3], *enc_b[3];                    /* [H,S], [H,H], [H,H] */
+  const float *gru_wih, *gru_whh, *gru_bih, *gru_bhh;  /* d_forward_recurrent: [3R,H], [3R,R], [3R], [3R] */
+  const BlvmSrnnWeights* chain;                        /* prior_* are read */
+  const float *dec_w[3], *dec_b[3];                    /* [H,Z+R] (input order cat[z, d]), [H,H], [S*3*num_mix,H] */
+  const float *lik_w, *lik_b;                          /* [3*num_mix, 3*num_mix], [3*num_mix] */
+} BlvmSrnnDecodeWeights;
+size_t blvm_srnn_generate_scratch_floats(int T, int B, int S, int H, int Z, int R);
+int blvm_srnn_generate(const BlvmSrnnDecodeWeights* w, const float* x0, const float* d0, const float* z0, const float* eps,
+                       const float* u, const float* v, int T, int B, int S, int H, int Z, int R, int num_mix, float sd_eps,
+                       float slope, float log_eps, float* x_out, float* d_out, float* z_out, float* scratch, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * K10  WaveNet: dilated causal convolution (kernel size 2) and the gated residual block.  Replaces
  *      `CausalConv1d` (`blvm/models/wavenet/wavenet_modules.py:14-50`) and `Conv1dResidualGLU` (`:53-117`).

@@ -573,6 +573,43 @@ def gen_generate():
     save("generate.npz", **arrays)
 
 
+def gen_generate16():
+    """Ancestral sampling at widths the one-launch decoders accept (all of S, H, Z, R multiples of 16): VRNNAudio and SRNNAudio
+    with SAMPLED observations.  Draw order per step (vrnn.py:405-417, srnn.py:366-392, variational.py:337,291): randn(B, z) for the
+    prior sample, then the head sampler's uniform_(1e-5, 1-1e-5) over [B,S,K] and uniform_(1e-8, 1-1e-8) over [B,S,1]."""
+    arrays = {}
+
+    def replay(seed, T, B, Z, S):
+        torch.manual_seed(seed)
+        e, u, u2 = [], [], []
+        for _ in range(T):
+            e.append(torch.randn(B, Z))
+            u.append(torch.empty(B, S, 10).uniform_(1e-5, 1 - 1e-5))
+            u2.append(torch.empty(B, S, 1).uniform_(1e-8, 1 - 1e-8))
+        return torch.stack(e), torch.stack(u), torch.stack(u2)
+
+    S, H, Z, B, T = 16, 32, 16, 5, 7
+    torch.manual_seed(17)
+    v = RM.VRNNAudio(likelihood="DMoL", input_size=S, hidden_size=H, latent_size=Z, residual_posterior=True, num_mix=10, num_bins=2**16)
+    e, u, u2 = replay(31, T, B, Z, S)
+    x0 = (torch.rand(B, S, 1, generator=torch.Generator().manual_seed(5)) * 0.2 - 0.1)
+    torch.manual_seed(31)
+    (xv, xv_sl), _ = v.generate(n_samples=B, max_timesteps=T, x=x0)
+    arrays.update(vr_x=xv, vr_x_sl=xv_sl, vr_x0=x0, vr_eps=e, vr_u=u, vr_u2=u2)
+    for k, p in v.state_dict().items():
+        arrays[f"vr_sd.{k}"] = p
+
+    torch.manual_seed(19)
+    sr = RM.SRNNAudio(likelihood="DMoL", input_size=S, hidden_size=H, latent_size=Z, residual_posterior=True, smoothing=True)
+    e, u, u2 = replay(37, T, B, Z, S)
+    torch.manual_seed(37)
+    (xs_, xs_sl), out = sr.generate(n_samples=B, max_timesteps=T)
+    arrays.update(sr_x=xs_, sr_x_sl=xs_sl, sr_eps=e, sr_u=u, sr_u2=u2, sr_h_p=out.h_p)
+    for k, p in sr.state_dict().items():
+        arrays[f"sr_sd.{k}"] = p
+    save("generate16.npz", **arrays)
+
+
 def gen_data():
     """Host-side data front-end: batches of the reference's length samplers for a seeded `random`, pools, padded collation."""
     import random
@@ -655,6 +692,6 @@ def gen_lstm():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn", "wavenet", "rssm", "cwvae", "stcn", "heads", "generate", "data"]
+    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn", "wavenet", "rssm", "cwvae", "stcn", "heads", "generate", "generate16", "data"]
     for w in which:
         globals()[f"gen_{w}"]()

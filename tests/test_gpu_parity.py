@@ -640,6 +640,66 @@ def test_srnn_generate_matches_reference():
     assert tuple(xs.shape) == (2, 3, 8, 1) and torch.isfinite(xs).all()
 
 
+@pytest.mark.parametrize("whole_chip", [False, True])
+def test_vrnn_one_launch_decoders_match_reference_samples(whole_chip, monkeypatch):
+    """K1c, both forms (16 utterances per CU | every layer dealt over the whole chip), against the REFERENCE's own samples
+    (`tests/golden/generate16.npz`: VRNNAudio.generate with sampled observations, prior noise and sampler draws replayed)."""
+    g = np.load(os.path.join(GOLDEN, "generate16.npz"))
+    m = VRNNAudio(likelihood="DMoL", input_size=16, hidden_size=32, latent_size=16, residual_posterior=True, num_mix=10, num_bins=2**16)
+    m.load_state_dict({k[6:]: T(g[k]) for k in g.files if k.startswith("vr_sd.")})
+    m = m.to(DEV)
+    real = ops.vrnn_decode
+    monkeypatch.setattr(ops, "vrnn_decode", lambda *a, **k: real(*a, whole_chip=whole_chip, **k))
+    uni = (T(g["vr_u"]).to(DEV), T(g["vr_u2"]).to(DEV))
+    for fused in (True, False):  # the step-by-step path on the same fixture
+        (x, x_sl), _ = m.generate(n_samples=5, max_timesteps=7, x=T(g["vr_x0"]).to(DEV), eps=T(g["vr_eps"]).to(DEV), uniforms=uni, fused=fused)
+        assert tuple(x.shape) == tuple(g["vr_x"].shape) and x_sl.tolist() == g["vr_x_sl"].tolist()
+        diff = (x.cpu() - T(g["vr_x"])).abs()
+        assert float((diff > 1e-4).float().mean()) < 0.02, (fused, float((diff > 1e-4).float().mean()))  # Gumbel-max ties may flip a pick
+    _hip.check_async()
+
+
+def test_srnn_one_launch_decoder_matches_reference_samples():
+    """K3c (`blvm_srnn_generate`: all steps in one persistent launch) against the REFERENCE's own samples and final state."""
+    from blvm.models import SRNNAudio
+
+    g = np.load(os.path.join(GOLDEN, "generate16.npz"))
+    m = SRNNAudio(likelihood="DMoL", input_size=16, hidden_size=32, latent_size=16, residual_posterior=True, smoothing=True)
+    m.load_state_dict({k[6:]: T(g[k]) for k in g.files if k.startswith("sr_sd.")})
+    m = m.to(DEV)
+    uni = [(u.to(DEV), u2.to(DEV)) for u, u2 in zip(T(g["sr_u"]), T(g["sr_u2"]))]
+    for fused in (True, False):
+        x = torch.zeros(5, 1, 16, device=DEV)
+        (xs, x_sl), out = m.srnn.generate(x=x, n_samples=5, max_timesteps=7, eps=T(g["sr_eps"]).to(DEV), uniforms=uni, fused=fused)
+        assert tuple(xs.shape) == tuple(g["sr_x"].shape) and x_sl.tolist() == g["sr_x_sl"].tolist()
+        diff = (xs.cpu() - T(g["sr_x"])).abs()
+        assert float((diff > 1e-4).float().mean()) < 0.02, (fused, float((diff > 1e-4).float().mean()))
+        hp = out.h_p.reshape(5, -1).cpu()
+        assert float(((hp - T(g["sr_h_p"]).reshape(5, -1)).abs() > 1e-3).float().mean()) < 0.05, fused
+    _hip.check_async()
+
+
+@pytest.mark.parametrize("B", [3, 64])
+def test_srnn_one_launch_decoder_matches_stepwise_at_full_width(B):
+    """K3c at the C3 widths (S 64, H 256, Z 256, R 512) against the step-by-step path on the same draws."""
+    from blvm.models import SRNNAudio
+
+    torch.manual_seed(B)
+    m = SRNNAudio(likelihood="DMoL", input_size=64, hidden_size=256, latent_size=256, residual_posterior=True, smoothing=True).to(DEV)
+    T_ = 6
+    g = torch.Generator().manual_seed(3)
+    eps = torch.randn(T_, B, 256, generator=g).to(DEV)
+    uni = [(torch.empty(B, 64, 10).uniform_(1e-5, 1 - 1e-5, generator=g).to(DEV), torch.empty(B, 64, 1).uniform_(1e-8, 1 - 1e-8, generator=g).to(DEV))
+           for _ in range(T_)]
+    x0 = (torch.rand(B, 1, 64, generator=g) * 0.2 - 0.1).to(DEV)
+    (a, _), oa = m.srnn.generate(x=x0, n_samples=B, max_timesteps=T_, eps=eps, uniforms=uni, fused=False)
+    (b, _), ob = m.srnn.generate(x=x0, n_samples=B, max_timesteps=T_, eps=eps, uniforms=uni, fused=True)
+    assert tuple(a.shape) == tuple(b.shape) == (B, T_, 64, 1) and torch.isfinite(b).all()
+    assert float(((a - b).abs() > 2e-4).float().mean()) < 0.02, (a - b).abs().max()
+    assert float(((oa.h_p - ob.h_p).abs() > 1e-3).float().mean()) < 0.02
+    _hip.check_async()
+
+
 def test_wavenet_generate_matches_reference():
     """WaveNet.generate (window re-evaluation per frame, skip / variance_scale, sample, FIFO) against the reference's own
     samples for the same uniform draws."""

@@ -21,22 +21,60 @@ def timed(fn, n):
     return (time.perf_counter() - t) / n
 
 
+def gpu_ms(fn, reps=3):
+    fn()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return best
+
+
 def main():
+    from blvm import _hip, ops
+    from blvm.models import CWVAEAudio
+
     torch.manual_seed(0)
+    T = 250  # 1 s of audio at 64 samples per step
     for name, cls in (("VRNN", VRNNAudio), ("SRNN", SRNNAudio)):
         kw = dict(likelihood="DMoL", input_size=64, hidden_size=256, latent_size=256, residual_posterior=True)
         if cls is SRNNAudio:
             kw["smoothing"] = True
         m = cls(**kw).cuda()
-        wbytes = sum(p.numel() for p in m.parameters()) * 4
-        for B in (2, 16, 64, 1024):
-            dt = timed(lambda n: m.generate(n_samples=B, max_timesteps=n), 60)
-            print(f"{name} generate B={B}: {dt * 1e3:.3f} ms per 64-sample stack ({64 * B / dt:.3g} samples/s); parameters {wbytes / 1e6:.1f} MB "
-                  f"-> {wbytes / dt / 1e9:.0f} GB/s of weights per step", flush=True)
-            if cls is VRNNAudio:  # K1c: every step in one launch; 12.5 MB of weights are read per step and 16-utterance group
-                df = timed(lambda n: m.generate(n_samples=B, max_timesteps=n, fused=True), 400)
-                print(f"{name} generate B={B}, one launch (K1c): {df * 1e3:.3f} ms per stack ({64 * B / df:.3g} samples/s) "
-                      f"-> {12.5e6 * ((B + 15) // 16) / df / 1e9:.0f} GB/s of weights", flush=True)
+        # what one step multiplies: encoder, recurrent cell without its posterior, decoder, head
+        if cls is VRNNAudio:
+            used = [m.vrnn.encoder, m.vrnn.vrnn_cell.prior, m.vrnn.vrnn_cell.phi_z, m.vrnn.vrnn_cell.gru_cell, m.vrnn.decoder, m.vrnn.likelihood]
+        else:
+            used = [m.srnn.encoder, m.srnn.prior, m.srnn.d_forward_recurrent, m.srnn.decoder, m.srnn.likelihood]
+        wbytes = sum(p.numel() for mod in used for p in mod.parameters()) * 4
+        for B in (2, 16, 64, 128):
+            gen = (lambda fused: m.generate(n_samples=B, max_timesteps=T, fused=fused)) if cls is VRNNAudio else (
+                lambda fused: m.srnn.generate(x=torch.zeros(B, 1, 64, device="cuda"), n_samples=B, max_timesteps=T, fused=fused))
+            step = timed(lambda n: (m.generate(n_samples=B, max_timesteps=n, fused=False) if cls is VRNNAudio else
+                                    m.srnn.generate(x=torch.zeros(B, 1, 64, device="cuda"), n_samples=B, max_timesteps=n, fused=False)), 40) * 1e3
+            one = gpu_ms(lambda: gen(True)) / T
+            _hip.check_async()
+            print(f"{name} generate B={B}: step by step {step:.3f} ms per 64-sample stack | one persistent launch {one:.4f} ms per stack "
+                  f"({64 * B / one * 1e3:.3g} samples/s); weights read per step {wbytes / 1e6:.1f} MB -> {wbytes / one / 1e6:.0f} GB/s from the L2s", flush=True)
+            if cls is VRNNAudio:
+                real = ops.vrnn_decode
+                ops.vrnn_decode = lambda *a, **k: real(*a, whole_chip=False, **k)
+                k1c = gpu_ms(lambda: gen(True)) / T
+                ops.vrnn_decode = real
+                print(f"     one launch, 16 utterances per CU (K1c, round 1): {k1c:.4f} ms per stack", flush=True)
+    # CW-VAE: one persistent launch per level (top-down), then the K11 context decoders and the head
+    m = CWVAEAudio(z_size=[128, 64, 32], h_size=192, strides=[64, 16, 16], num_level_layers=8, stride_per_layer=2, likelihood="DMoL",
+                   num_bins=2**16, precision_posterior=True).cuda()
+    for B in (2, 8):
+        n = 49152
+        ms = gpu_ms(lambda: m.generate(n_samples=B, max_timesteps=n))
+        _hip.check_async()
+        print(f"CW-VAE generate B={B}, {n} samples: {ms:.1f} ms = {ms / (n // 64) * 1e3:.1f} us per bottom-level step ({B * n / ms * 1e3:.3g} samples/s)", flush=True)
     m = WaveNet(likelihood=DiscretizedLogisticMixtureDense(64, 1, num_mix=10, num_bins=2**16), n_layers=10, n_stacks=5, res_channels=64).cuda()
     wbytes = sum(p.numel() for p in m.parameters()) * 4
     for B in (1, 16, 64):
