@@ -646,6 +646,210 @@ __device__ __forceinline__ void tile_grub(const GrubIn& a, int K, int R, int r0,
   st_sc1(make_rsrc(a.ga), 4u * ((unsigned)row * (unsigned)R + (unsigned)col), g * u + dd);
 }
 
+// ---- whole GRU / LSTM sequences (rnn.hip: nn.GRU forward / per-row time-reversed, packed nn.LSTM) as one link per step ------------
+// time index processed by `row` at recurrence step j: forward j; reversed: len-1-j inside the row's length, j in the right padding
+__device__ __forceinline__ int seq_time_index(int j, int reverse, const int32_t* lens, int row) {
+  if (!reverse) return j;
+  const int n = lens[row];
+  return j < n ? n - 1 - j : j;
+}
+struct GruSeqIn {
+  const float *H16, *Whh, *bhh;  // state entering the step (T16 slab, polled), [3R,R] rows [r|z|n] in T16, [3R]
+  const float* xg;               // [T,B,3R] input projection incl. b_ih, TIME indexed
+  const int32_t* lens;           // [B] (reverse map) or null
+  const float* hprev;            // [B,R] row-major: written by THIS thread one step earlier (plain)
+  float* out;                    // element (idx,row,col) at out + idx*out_ts + row*out_ld + col
+  float *rg, *ug, *ng, *ghn;     // [B,R] saves of this step
+  long out_ts;
+  int out_ld, j, reverse;
+};
+template <int NW, bool BF = false>
+__device__ __forceinline__ void tile_gru_seq(const GruSeqIn& a, const Out& hnext, int R, int r0, int c0, int B, float* red, Poll& pl) {
+  const int t = threadIdx.x & 255;
+  const int row = r0 + (t >> 4), col = c0 + (t & 15);
+  const bool own = threadIdx.x < 256 && row < B;
+  const int rowc = row < B ? row : r0;
+  const size_t o = (size_t)rowc * R + col;
+  int idx = 0;
+  float x0 = 0.f, x1 = 0.f, x2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, hp = 0.f;
+  auto prefetch = [&]() {
+    idx = seq_time_index(a.j, a.reverse, a.lens, rowc);
+    const size_t ox = ((size_t)idx * B + rowc) * 3 * R + col;
+    x0 = a.xg[ox]; x1 = a.xg[ox + R]; x2 = a.xg[ox + 2 * R];
+    b0 = a.bhh[col]; b1 = a.bhh[R + col]; b2 = a.bhh[2 * R + col];
+    hp = a.hprev[o];
+  };
+  f32x4 acc[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  {
+    const float* const As[1] = {a.H16};
+    const float* const Ws[3] = {a.Whh, a.Whh, a.Whh};
+    const int la[1] = {0}, cs[3] = {c0, R + c0, 2 * R + c0};
+    mgemm16<NW, BF, 1, 3, MapSame>(As, la, true, r0, B, Ws, cs, R, acc, pl, prefetch);
+  }
+  float v[3];
+  reduce_tiles<3, NW>(acc, red, v);
+  if (!own) return;
+  const float hn = v[2] + b2;
+  const float r = sigmoidf_(x0 + v[0] + b0);
+  const float u = sigmoidf_(x1 + v[1] + b1);
+  const float n = tanhf(x2 + r * hn);
+  const float h2 = (1.f - u) * n + u * hp;
+  put(hnext, r0, c0, row, col, h2);
+  a.out[(size_t)idx * a.out_ts + (size_t)row * a.out_ld + col] = h2;
+  a.rg[o] = r; a.ug[o] = u; a.ng[o] = n; a.ghn[o] = hn;
+}
+
+struct GruSeqBwdIn {
+  const float *DGHn16, *WhhT;           // hidden-projection grads of recurrence step j+1 (T16 slab, polled; K = 3R), [R,3R] in T16
+  const float* dout;                    // time-indexed grad wrt the outputs (GruSeqIn::out addressing)
+  const float *rg, *ug, *ng, *ghn, *hprev;  // saves of step j
+  const int32_t* lens;
+  float* G;                             // [B,R] running grad through the u-gate path: read and written by THIS thread only
+  float* DGI;                           // [T,B,3R] TIME indexed
+  float* dh0;                           // [B,R]: written when has_gates == 0
+  long out_ts;
+  int out_ld, j, reverse;
+  bool has_gemm, has_gates;
+};
+template <int NW, bool BF = false>
+__device__ __forceinline__ void tile_gru_seq_bwd(const GruSeqBwdIn& a, const Out& dgh, int R, int r0, int c0, int B, float* red, Poll& pl) {
+  const int t = threadIdx.x & 255;
+  const int row = r0 + (t >> 4), col = c0 + (t & 15);
+  const bool own = threadIdx.x < 256 && row < B;
+  const int rowc = row < B ? row : r0;
+  const size_t o = (size_t)rowc * R + col;
+  float g = 0.f, dout = 0.f, r = 0.f, u = 0.f, n = 0.f, hn = 0.f, hp = 0.f;
+  int idx = 0;
+  auto prefetch = [&]() {
+    g = a.G[o];
+    if (a.has_gates) {  // uniform
+      idx = seq_time_index(a.j, a.reverse, a.lens, rowc);
+      dout = a.dout[(size_t)idx * a.out_ts + (size_t)rowc * a.out_ld + col];
+      r = a.rg[o]; u = a.ug[o]; n = a.ng[o]; hn = a.ghn[o]; hp = a.hprev[o];
+    }
+  };
+  float v[1] = {0.f};
+  if (a.has_gemm) {  // uniform
+    f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+    const float* const As[1] = {a.DGHn16};
+    const float* const Ws[1] = {a.WhhT};
+    const int la[1] = {0}, cs[1] = {c0};
+    mgemm16<NW, BF, 1, 1, MapSame>(As, la, true, r0, B, Ws, cs, 3 * R, acc, pl, prefetch);
+    reduce_tiles<1, NW>(acc, red, v);
+  } else {
+    prefetch();
+    __syncthreads();  // (every tile has exactly one workgroup barrier)
+  }
+  if (!own) return;
+  g += dout + v[0];
+  if (!a.has_gates) { a.dh0[o] = g; return; }
+  const float dn_pre = g * (1.f - u) * (1.f - n * n);
+  const float du_pre = g * (hp - n) * u * (1.f - u);
+  const float dr_pre = dn_pre * hn * r * (1.f - r);
+  const size_t oi = ((size_t)idx * B + row) * 3 * R + col;
+  a.DGI[oi] = dr_pre; a.DGI[oi + R] = du_pre; a.DGI[oi + 2 * R] = dn_pre;
+  put(dgh, r0, c0, row, col, dr_pre);
+  put(dgh, r0, R + c0, row, R + col, du_pre);
+  put(dgh, r0, 2 * R + c0, row, 2 * R + col, dn_pre * r);
+  a.G[o] = g * u;
+}
+
+struct LstmSeqIn {
+  const float *H16, *Whh, *bhh;  // state entering the step (T16 slab, polled), [4H,H] rows [i|f|g|o] in T16, [4H]
+  const float* xg;               // [B,4H] input projection of this step incl. b_ih
+  const int32_t* lens;           // [B] valid steps per row (packed-sequence semantics) or null
+  const float *hprev, *cprev;    // [B,H] row-major: written by THIS thread one step earlier (plain)
+  float *cnext, *out, *gates;    // [B,H], [B,H] (zero past the row's length), [B,4H] saved i,f,g,o (zero where masked)
+  int t;
+};
+template <int NW, bool BF = false>
+__device__ __forceinline__ void tile_lstm_seq(const LstmSeqIn& a, const Out& hnext, int H, int r0, int c0, int B, float* red, Poll& pl) {
+  const int tt = threadIdx.x & 255;
+  const int row = r0 + (tt >> 4), col = c0 + (tt & 15);
+  const bool own = threadIdx.x < 256 && row < B;
+  const int rowc = row < B ? row : r0;
+  const size_t o = (size_t)rowc * H + col, o4 = (size_t)rowc * 4 * H + col;
+  float x0 = 0.f, x1 = 0.f, x2 = 0.f, x3 = 0.f, hp = 0.f, cp = 0.f;
+  bool live = true;
+  auto prefetch = [&]() {
+    x0 = a.xg[o4] + a.bhh[col]; x1 = a.xg[o4 + H] + a.bhh[H + col];
+    x2 = a.xg[o4 + 2 * H] + a.bhh[2 * H + col]; x3 = a.xg[o4 + 3 * H] + a.bhh[3 * H + col];
+    hp = a.hprev[o]; cp = a.cprev[o];
+    live = a.lens == nullptr || a.t < a.lens[rowc];
+  };
+  f32x4 acc[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  {
+    const float* const As[1] = {a.H16};
+    const float* const Ws[4] = {a.Whh, a.Whh, a.Whh, a.Whh};
+    const int la[1] = {0}, cs[4] = {c0, H + c0, 2 * H + c0, 3 * H + c0};
+    mgemm16<NW, BF, 1, 4, MapSame>(As, la, true, r0, B, Ws, cs, H, acc, pl, prefetch);
+  }
+  float v[4];
+  reduce_tiles<4, NW>(acc, red, v);
+  if (!own) return;
+  const float i = sigmoidf_(v[0] + x0), f = sigmoidf_(v[1] + x1), g = tanhf(v[2] + x2), og = sigmoidf_(v[3] + x3);
+  const float c2 = f * cp + i * g;
+  const float h2 = og * tanhf(c2);
+  a.cnext[o] = live ? c2 : cp;
+  put(hnext, r0, c0, row, col, live ? h2 : hp);
+  a.out[o] = live ? h2 : 0.f;
+  a.gates[o4] = live ? i : 0.f;
+  a.gates[o4 + H] = live ? f : 0.f;
+  a.gates[o4 + 2 * H] = live ? g : 0.f;
+  a.gates[o4 + 3 * H] = live ? og : 0.f;
+}
+
+struct LstmSeqBwdIn {
+  const float *DGn16, *WhhT;  // gate pre-activation grads of step s+1 (T16 slab, polled; K = 4H), [H,4H] in T16
+  const float *dout, *gates, *c_s, *c_s1;  // [B,H] grad wrt out_s, [B,4H] saved gates, cell state entering / leaving step s
+  float* DC;                  // [B,H] running grad wrt the cell state: read and written by THIS thread only
+  float* dh0;                 // [B,H]: written when has_gates == 0
+  bool has_gemm, has_gates;
+};
+template <int NW, bool BF = false>
+__device__ __forceinline__ void tile_lstm_seq_bwd(const LstmSeqBwdIn& a, const Out& dg, int H, int r0, int c0, int B, float* red, Poll& pl) {
+  const int tt = threadIdx.x & 255;
+  const int row = r0 + (tt >> 4), col = c0 + (tt & 15);
+  const bool own = threadIdx.x < 256 && row < B;
+  const int rowc = row < B ? row : r0;
+  const size_t o = (size_t)rowc * H + col, o4 = (size_t)rowc * 4 * H + col;
+  float dh = 0.f, ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cs = 0.f, cs1 = 0.f, dc = 0.f;
+  auto prefetch = [&]() {
+    if (a.has_gates) {  // uniform
+      dh = a.dout[o];
+      ig = a.gates[o4]; fg = a.gates[o4 + H]; gg = a.gates[o4 + 2 * H]; og = a.gates[o4 + 3 * H];
+      cs = a.c_s[o]; cs1 = a.c_s1[o]; dc = a.DC[o];
+    }
+  };
+  float v[1] = {0.f};
+  if (a.has_gemm) {  // uniform
+    f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
+    const float* const As[1] = {a.DGn16};
+    const float* const Ws[1] = {a.WhhT};
+    const int la[1] = {0}, cs_[1] = {c0};
+    mgemm16<NW, BF, 1, 1, MapSame>(As, la, true, r0, B, Ws, cs_, 4 * H, acc, pl, prefetch);
+    reduce_tiles<1, NW>(acc, red, v);
+  } else {
+    prefetch();
+    __syncthreads();
+  }
+  if (!own) return;
+  dh += v[0];
+  if (!a.has_gates) { a.dh0[o] = dh; return; }
+  const float tc = tanhf(cs1);
+  const float d_o = dh * tc;
+  const float dct = dc + dh * og * (1.f - tc * tc);
+  put(dg, r0, c0, row, col, dct * gg * ig * (1.f - ig));
+  put(dg, r0, H + c0, row, H + col, dct * cs * fg * (1.f - fg));
+  put(dg, r0, 2 * H + c0, row, 2 * H + col, dct * ig * (1.f - gg * gg));
+  put(dg, r0, 3 * H + c0, row, 3 * H + col, d_o * og * (1.f - og));
+  a.DC[o] = dct * fg;
+}
+
 // Sampling from a DMoL head during generation (`VRNN.generate`, blvm/models/vrnn.py:371-434: likelihood(dec) -> sample): a tile =
 // 16 utterances x 4 samples of one frame stack.  dec [B, S*F] (F = 3 * num_mix = 30 head inputs per sample, row-major, polled words:
 // the last decoder layer of this step) -> per sample the head's Linear(F -> F) -> Gumbel-max component pick with u, clamped
@@ -739,7 +943,7 @@ __device__ __forceinline__ void tile_dmol_sample(const float* dec, int ldd, cons
 // are its own (TileIter over [wg0, wg0 + nwg)).  A pointer of a descriptor is `p[k] + s * stride[sidx[k]]` (stride table of the
 // program, entry 0 = 0: constants and null pointers); a backward sequence passes its last step's slabs and negative strides.
 // =================================================================================================================================
-enum Kind : int { K_LIN = 0, K_HEAD = 1, K_GRU = 2, K_DZ = 3, K_GRUB = 4, K_DMOLS = 5 };
+enum Kind : int { K_LIN = 0, K_HEAD = 1, K_GRU = 2, K_DZ = 3, K_GRUB = 4, K_DMOLS = 5, K_GRUS = 6, K_GRUSB = 7, K_LSTMS = 8, K_LSTMSB = 9 };
 enum DescFlag : int {
   DF_RELU = 1,         // K_LIN: leaky ReLU (f[0] = slope) on the result
   DF_A_PLAIN = 2,      // K_LIN: A is a row-major buffer written before the launch (ld[0]), not a polled T16 copy
@@ -760,6 +964,7 @@ struct Desc {
 };
 struct Program {
   int bf16 = 0;  // weights are bf16 T16 packs, products on the bf16 matrix pipe (see mgemm_trip)
+  int s_first = 0;  // the launch walks steps [s_first, S): a sequence may be cut into several launches (everything a later one needs is in the slabs)
   int ndesc, S, B, xcd;
   long stride[16];
   Ctl ctl;

@@ -16,6 +16,16 @@
 //              i: 0 R  1 first step with the products  2 first step WITHOUT gates  3 first step with g_in
 //   K_DMOLS p: 0 dec (row-major, polled words, ld[0])  1 head W [F,F]  2 head b  3 u  4 v  5 x row-major (ld[3])  6 x T16 (n16[0])
 //              i: 0 S  1 F  2 num_mix      f: 0 log_eps        (ct counts tiles of 4 samples)
+//   K_GRUS  p: 0 H16 (state entering the step)  1 Whh (T16)  2 b_hh  3 xg [T,B,3R] (time indexed)  4 lens  5 h_prev row-major
+//              6 h_next row-major (ld[3])  7 h_next T16 (n16[0])  8 out (time indexed)  9 rg  10 ug  11 ng  12 ghn
+//              i: 0 R  1 reverse  2 out_ts  3 out_ld                                   (recurrence step j = s)
+//   K_GRUSB p: 0 DGH16 of step j+1  1 WhhT (T16)  2 dout (time indexed)  3 rg  4 ug  5 ng  6 ghn  7 h_prev  8 lens  9 G (in place)
+//              10 DGI [T,B,3R] (time indexed)  11 DGH row-major (ld[3] = 3R)  12 DGH T16 (n16[0])  13 dh0
+//              i: 0 R  1 reverse  2 out_ts  3 out_ld    n16[1]: T   (j = T-1-s; s = 0: no product; s = T: only dh0)
+//   K_LSTMS p: 0 H16  1 Whh (T16)  2 b_hh  3 xg of the step [B,4H]  4 lens  5 h_prev  6 h_next row-major (ld[3])  7 h_next T16
+//              8 c_prev  9 c_next  10 out  11 gates [B,4H]        i: 0 H                (t = s)
+//   K_LSTMSB p: 0 DG16 of step t+1  1 WhhT (T16)  2 dout  3 gates  4 c_s (c_{s+1} = one [B,H] slab further)  5 DC (in place)
+//              6 DG row-major (ld[3] = 4H)  7 DG T16 (n16[0])  8 dh0       i: 0 H       n16[1]: T   (t = T-1-s)
 #include <algorithm>
 #include <mutex>
 
@@ -41,7 +51,7 @@ enum { RD_KIND = 0, RD_CT, RD_WG0, RD_NWG, RD_FLAGS, RD_K, RD_SBEGIN, RD_SEND, R
        RD_NT = 84, RD_TILE = 85 };
 constexpr int kMaxTilesPerWg = kDescWords - RD_TILE;
 struct Hdr {
-  int ndesc, S, B, xcd, prof_wg, lds_products;
+  int ndesc, s0, S, B, xcd, prof_wg, lds_products;  // steps [s0, S)
   Ctl ctl;
   unsigned long long* prof;
 };
@@ -157,8 +167,8 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
   unsigned long long tq[3] = {0ull, 0ull, 0ull}, tq_end = 0ull;
 #endif
   DescRegs d, nx;
-  d.fetch(ltab, __builtin_ctz(mine), 0);
-  for (int s = 0; s < a.S; ++s) {
+  d.fetch(ltab, __builtin_ctz(mine), a.s0);
+  for (int s = a.s0; s < a.S; ++s) {
     for (unsigned m = mine; m != 0; m &= m - 1) {
       const int i = __builtin_ctz(m);
 #ifdef PCHAIN_TPROF2
@@ -243,6 +253,55 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
             for (int tk = 0; tk < nt; ++tk) {
               const int trc = d.tile(tk);
               tile_grub<NW, BF>(g, K, R, trc & 0xffff, (trc >> 16) * 16, B, red(), pl);
+            }
+          } break;
+          case K_GRUS: {
+            const int R = d.w<RD_I + 0>();
+            GruSeqIn g;
+            g.H16 = d.p<0>(s); g.Whh = d.base<1>(); g.bhh = d.base<2>(); g.xg = d.base<3>(); g.lens = reinterpret_cast<const int32_t*>(d.base<4>());
+            g.hprev = d.p<5>(s); g.out = const_cast<float*>(d.base<8>()); g.rg = d.m<9>(s); g.ug = d.m<10>(s); g.ng = d.m<11>(s); g.ghn = d.m<12>(s);
+            g.out_ts = d.w<RD_I + 2>(); g.out_ld = d.w<RD_I + 3>(); g.j = s; g.reverse = d.w<RD_I + 1>();
+            const Out o{d.m<6>(s), ld3, false, d.m<7>(s), n16};
+            for (int tk = 0; tk < nt; ++tk) {
+              const int trc = d.tile(tk);
+              tile_gru_seq<NW, BF>(g, o, R, trc & 0xffff, (trc >> 16) * 16, B, red(), pl);
+            }
+          } break;
+          case K_GRUSB: {
+            const int R = d.w<RD_I + 0>(), T = d.w<RD_N16 + 1>();
+            GruSeqBwdIn g;
+            g.DGHn16 = d.p<0>(s); g.WhhT = d.base<1>(); g.dout = d.base<2>(); g.rg = d.p<3>(s); g.ug = d.p<4>(s); g.ng = d.p<5>(s); g.ghn = d.p<6>(s);
+            g.hprev = d.p<7>(s); g.lens = reinterpret_cast<const int32_t*>(d.base<8>()); g.G = const_cast<float*>(d.base<9>());
+            g.DGI = const_cast<float*>(d.base<10>()); g.dh0 = const_cast<float*>(d.base<13>());
+            g.out_ts = d.w<RD_I + 2>(); g.out_ld = d.w<RD_I + 3>(); g.j = T - 1 - s; g.reverse = d.w<RD_I + 1>();
+            g.has_gemm = s >= 1; g.has_gates = s < T;
+            const Out o{d.m<11>(s), ld3, false, d.m<12>(s), n16};
+            for (int tk = 0; tk < nt; ++tk) {
+              const int trc = d.tile(tk);
+              tile_gru_seq_bwd<NW, BF>(g, o, R, trc & 0xffff, (trc >> 16) * 16, B, red(), pl);
+            }
+          } break;
+          case K_LSTMS: {
+            const int H = d.w<RD_I + 0>();
+            LstmSeqIn g;
+            g.H16 = d.p<0>(s); g.Whh = d.base<1>(); g.bhh = d.base<2>(); g.xg = d.p<3>(s); g.lens = reinterpret_cast<const int32_t*>(d.base<4>());
+            g.hprev = d.p<5>(s); g.cprev = d.p<8>(s); g.cnext = d.m<9>(s); g.out = d.m<10>(s); g.gates = d.m<11>(s); g.t = s;
+            const Out o{d.m<6>(s), ld3, false, d.m<7>(s), n16};
+            for (int tk = 0; tk < nt; ++tk) {
+              const int trc = d.tile(tk);
+              tile_lstm_seq<NW, BF>(g, o, H, trc & 0xffff, (trc >> 16) * 16, B, red(), pl);
+            }
+          } break;
+          case K_LSTMSB: {
+            const int H = d.w<RD_I + 0>(), T = d.w<RD_N16 + 1>();
+            LstmSeqBwdIn g;
+            g.DGn16 = d.p<0>(s); g.WhhT = d.base<1>(); g.dout = d.p<2>(s); g.gates = d.p<3>(s); g.c_s = d.p<4>(s); g.c_s1 = g.c_s + (size_t)B * H;
+            g.DC = const_cast<float*>(d.base<5>()); g.dh0 = const_cast<float*>(d.base<8>());
+            g.has_gemm = s >= 1; g.has_gates = s < T;
+            const Out o{d.m<6>(s), ld3, false, d.m<7>(s), n16};
+            for (int tk = 0; tk < nt; ++tk) {
+              const int trc = d.tile(tk);
+              tile_lstm_seq_bwd<NW, BF>(g, o, H, trc & 0xffff, (trc >> 16) * 16, B, red(), pl);
             }
           } break;
           case K_DMOLS: {
@@ -333,7 +392,8 @@ int pchain_launch(const pchain::Program& prog, hipStream_t stream) {
     for (int k = 0; k < part.ndesc; ++k) part.d[k] = prog.d[first + k];
     hipLaunchKernelGGL(pchain_resolve_kernel, dim3(1), dim3(256), 0, stream, part, tab);
   }
-  Hdr h{prog.ndesc, prog.S, prog.B, prog.xcd, prog.prof_wg, prog.lds_products, prog.ctl, prog.prof};
+  BLVM_REQUIRE(prog.s_first >= 0 && prog.s_first < prog.S, "pchain: empty step range [%d, %d)", prog.s_first, prog.S);
+  Hdr h{prog.ndesc, prog.s_first, prog.S, prog.B, prog.xcd, prog.prof_wg, prog.lds_products, prog.ctl, prog.prof};
   const int nw = pchain_waves();
   const size_t lds_fixed = sizeof(int) * kDescWords * pchain::kMaxDesc + 32 * sizeof(unsigned long long);
   const size_t lds = lds_fixed + sizeof(float) * 2 * (size_t)prog.lds_products * nw * 256;

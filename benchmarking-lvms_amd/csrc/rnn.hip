@@ -9,6 +9,7 @@
 // derivatives (backward, fused into the dgrad that completes dL/dh of the step) lives in the epilogue.  The input
 // projection and every weight gradient are hoisted out of the loop into the big MFMA GEMM (gemm.hip).
 #include "common.h"
+#include "pchain.h"
 
 namespace blvm {
 namespace {
@@ -146,7 +147,11 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(const float* DGn, con
   DC[o] = dct * fg;
 }
 
-struct LstmReserve { float *XG, *Hs, *Cs, *GATES, *WhhP; };  // WhhP: T16 copy of Whh
+// sequences of at most this many rows may run as ONE persistent launch (pchain.h): their buffers get the T16 operand copies
+inline size_t t16_rows(int B) { return (size_t)((B + 15) / 16) * 16; }
+inline bool seq_persistent(int T, int B) { return pchain_applies(B) && device_cus() >= 32 && T >= 4; }
+
+struct LstmReserve { float *XG, *Hs, *Cs, *GATES, *WhhP, *H16; };  // WhhP: T16 copy of Whh; H16: (T+1) T16 slabs of the state
 size_t carve_lstm(float* base, int T, int B, int H, LstmReserve* r) {
   size_t off = 0;
   auto take = [&](size_t cnt) { float* p = base ? base + off : nullptr; off += (cnt + 3) & ~(size_t)3; return p; };
@@ -156,10 +161,11 @@ size_t carve_lstm(float* base, int T, int B, int H, LstmReserve* r) {
   t.Cs = take((size_t)(T + 1) * B * H);
   t.GATES = take((size_t)T * B * 4 * H);
   t.WhhP = take((size_t)4 * H * H);
+  t.H16 = B <= kPchainCarveMaxB ? take((size_t)(T + 1) * t16_rows(B) * H) : nullptr;
   if (r) *r = t;
   return off;
 }
-struct LstmWs { float *WhhT, *DG, *DC; };
+struct LstmWs { float *WhhT, *DG, *DC, *DG16; };
 size_t carve_lstm_ws(float* base, int T, int B, int H, LstmWs* w) {
   size_t off = 0;
   auto take = [&](size_t cnt) { float* p = base ? base + off : nullptr; off += (cnt + 3) & ~(size_t)3; return p; };
@@ -167,6 +173,7 @@ size_t carve_lstm_ws(float* base, int T, int B, int H, LstmWs* w) {
   t.WhhT = take((size_t)H * 4 * H);
   t.DG = take((size_t)T * B * 4 * H);
   t.DC = take((size_t)B * H);
+  t.DG16 = B <= kPchainCarveMaxB ? take((size_t)(T + 1) * t16_rows(B) * 4 * H) : nullptr;
   if (w) *w = t;
   return off;
 }
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(NW * 64) void gru_bwd_kernel(const float* DGHn, con
   G[o] = g * u;
 }
 
-struct GruReserve { float *XG, *Hs, *RG, *UG, *NG, *GHN, *WhhP; };  // WhhP: T16 copy of Whh
+struct GruReserve { float *XG, *Hs, *RG, *UG, *NG, *GHN, *WhhP, *H16; };  // WhhP: T16 copy of Whh; H16: (T+1) T16 slabs of the state
 size_t carve_gru(float* base, int T, int B, int R, GruReserve* r) {
   size_t off = 0;
   auto take = [&](size_t cnt) { float* p = base ? base + off : nullptr; off += (cnt + 3) & ~(size_t)3; return p; };
@@ -298,10 +305,11 @@ size_t carve_gru(float* base, int T, int B, int R, GruReserve* r) {
   t.Hs = take((size_t)(T + 1) * B * R);
   t.RG = take(n * R); t.UG = take(n * R); t.NG = take(n * R); t.GHN = take(n * R);
   t.WhhP = take((size_t)3 * R * R);
+  t.H16 = B <= kPchainCarveMaxB ? take((size_t)(T + 1) * t16_rows(B) * R) : nullptr;
   if (r) *r = t;
   return off;
 }
-struct GruWs { float *WhhT, *DGI, *DGH, *G; };
+struct GruWs { float *WhhT, *DGI, *DGH, *G, *DGH16; };
 size_t carve_gru_ws(float* base, int T, int B, int R, GruWs* w) {
   size_t off = 0;
   auto take = [&](size_t cnt) { float* p = base ? base + off : nullptr; off += (cnt + 3) & ~(size_t)3; return p; };
@@ -311,6 +319,7 @@ size_t carve_gru_ws(float* base, int T, int B, int R, GruWs* w) {
   t.DGI = take(n * 3 * R);
   t.DGH = take(n * 3 * R);
   t.G = take((size_t)B * R);
+  t.DGH16 = B <= kPchainCarveMaxB ? take((size_t)(T + 1) * t16_rows(B) * 3 * R) : nullptr;
   if (w) *w = t;
   return off;
 }
@@ -349,8 +358,34 @@ extern "C" int blvm_lstm_seq_fwd(const float* Wih, const float* Whh, const float
   else BLVM_HIP(hipMemsetAsync(rs.Hs, 0, sizeof(float) * bh, s));
   if (c0) BLVM_HIP(hipMemcpyAsync(rs.Cs, c0, sizeof(float) * bh, hipMemcpyDeviceToDevice, s));
   else BLVM_HIP(hipMemsetAsync(rs.Cs, 0, sizeof(float) * bh, s));
+  const bool bf16_seq = pchain_bf16(B) && seq_persistent(T, B);  // bf16-operand mode of the persistent path
+  const T16PackScope pack_scope(bf16_seq);
   rc = t16_pack_rows(Whh, H, 4 * H, H, rs.WhhP, s);  // operand layout of the chain (once per sequence)
   if (rc) return rc;
+  if (seq_persistent(T, B)) {
+    // one persistent launch for the whole sequence (pchain.hip): one link per step — the hidden projection with the gate math
+    using namespace pchain;
+    const int rt = (B + 15) / 16, ctH = H / 16;
+    const long sH = (long)bh, s4H = 4 * sH, xH = (long)rt * 16 * H;
+    Builder bld;
+    bld.p.bf16 = bf16_seq; bld.p.S = T; bld.p.B = B; bld.p.xcd = (pchain_tune() & 4) ? 1 : 0; bld.p.lds_products = 4;
+    bld.p.prof = pchain_profile_buffer(); bld.p.prof_wg = 1;
+    Desc& d = bld.add(K_LSTMS, ctH, 0, range_for(ctH * rt, device_cus() & ~7), H, 0, 0, T);
+    bld.ptr(d, 0, rs.H16, xH); bld.ptr(d, 1, rs.WhhP); bld.ptr(d, 2, bhh); bld.ptr(d, 3, rs.XG, s4H); bld.ptr(d, 4, lens);
+    bld.ptr(d, 5, rs.Hs, sH); bld.ptr(d, 6, rs.Hs + sH, sH); bld.ptr(d, 7, rs.H16 + xH, xH); bld.ptr(d, 8, rs.Cs, sH); bld.ptr(d, 9, rs.Cs + sH, sH);
+    bld.ptr(d, 10, out, sH); bld.ptr(d, 11, rs.GATES, s4H);
+    d.ld[3] = H; d.n16[0] = ctH; d.i[0] = H;
+    rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
+    if (rc) return rc;
+    BLVM_HIP(hipMemsetAsync(rs.H16 + xH, 0xFF, sizeof(float) * (size_t)T * xH, s));
+    rc = pchain_rows_to_t16(rs.Hs, H, B, H, rs.H16, s);
+    if (rc) return rc;
+    rc = pchain_launch(bld.p, s);
+    if (rc) return rc;
+    if (hn) BLVM_HIP(hipMemcpyAsync(hn, rs.Hs + T * bh, sizeof(float) * bh, hipMemcpyDeviceToDevice, s));
+    if (cn) BLVM_HIP(hipMemcpyAsync(cn, rs.Cs + T * bh, sizeof(float) * bh, hipMemcpyDeviceToDevice, s));
+    return BLVM_OK;
+  }
   const int nw = pick_nw(H, 4);
   const dim3 grid(H / 16, (B + 15) / 16);
   for (int t = 0; t < T; ++t) {
@@ -381,9 +416,30 @@ extern "C" int blvm_lstm_seq_bwd(const float* Wih, const float* Whh, const float
   LstmWs ws;
   carve_lstm_ws(workspace, T, B, H, &ws);
   const size_t n = (size_t)T * B, bh = (size_t)B * H;
+  const bool bf16_seq = pchain_bf16(B) && seq_persistent(T, B);  // bf16-operand mode of the persistent path
+  const T16PackScope pack_scope(bf16_seq);
   rc = t16_pack_transposed(Whh, H, 4 * H, H, ws.WhhT, s);
   if (rc) return rc;
   BLVM_HIP(hipMemsetAsync(ws.DC, 0, sizeof(float) * bh, s));
+  if (seq_persistent(T, B)) {
+    using namespace pchain;
+    const int rt = (B + 15) / 16, ctH = H / 16;
+    const long sH = (long)bh, s4H = 4 * sH, x4H = (long)rt * 16 * 4 * H;
+    Builder bld;
+    bld.p.bf16 = bf16_seq; bld.p.S = d_h0 ? T + 1 : T; bld.p.B = B; bld.p.xcd = (pchain_tune() & 4) ? 1 : 0; bld.p.lds_products = 1;
+    bld.p.prof = pchain_profile_buffer() ? pchain_profile_buffer() + 64 : nullptr; bld.p.prof_wg = 1;
+    Desc& d = bld.add(K_LSTMSB, ctH, 0, range_for(ctH * rt, device_cus() & ~7), 4 * H, 0, 0, T + 1);
+    // step s handles t = T-1-s: time-indexed slabs start at the last step and walk backwards; the T16 slabs are indexed by s
+    bld.ptr(d, 0, ws.DG16 - x4H, x4H); bld.ptr(d, 1, ws.WhhT); bld.ptr(d, 2, d_out + (long)(T - 1) * sH, -sH);
+    bld.ptr(d, 3, rs.GATES + (long)(T - 1) * s4H, -s4H); bld.ptr(d, 4, rs.Cs + (long)(T - 1) * sH, -sH); bld.ptr(d, 5, ws.DC);
+    bld.ptr(d, 6, ws.DG + (long)(T - 1) * s4H, -s4H); bld.ptr(d, 7, ws.DG16, x4H); bld.ptr(d, 8, d_h0 ? d_h0 : ws.DC);
+    d.ld[3] = 4 * H; d.n16[0] = 4 * ctH; d.n16[1] = T; d.i[0] = H;
+    rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
+    if (rc) return rc;
+    BLVM_HIP(hipMemsetAsync(ws.DG16, 0xFF, sizeof(float) * (size_t)T * x4H, s));
+    rc = pchain_launch(bld.p, s);
+    if (rc) return rc;
+  } else {
   const int nw = pick_nw(4 * H, 1);
   const dim3 grid(H / 16, (B + 15) / 16);
   // scratch for dh0 when the caller does not want it
@@ -398,6 +454,7 @@ extern "C" int blvm_lstm_seq_bwd(const float* Wih, const float* Whh, const float
     if (nw == 16) hipLaunchKernelGGL((lstm_bwd_kernel<16>), grid, dim3(1024), 0, s, DGn, (const float*)ws.WhhT, dout_s, gates_s, c_s, ws.DC, b_h, has, DG_s, d_h0);
     else if (nw == 8) hipLaunchKernelGGL((lstm_bwd_kernel<8>), grid, dim3(512), 0, s, DGn, (const float*)ws.WhhT, dout_s, gates_s, c_s, ws.DC, b_h, has, DG_s, d_h0);
     else hipLaunchKernelGGL((lstm_bwd_kernel<4>), grid, dim3(256), 0, s, DGn, (const float*)ws.WhhT, dout_s, gates_s, c_s, ws.DC, b_h, has, DG_s, d_h0);
+  }
   }
   BLVM_CHECK_LAUNCH("lstm_seq_bwd");
   if (d_c0) BLVM_HIP(hipMemcpyAsync(d_c0, ws.DC, sizeof(float) * bh, hipMemcpyDeviceToDevice, s));
@@ -433,8 +490,33 @@ extern "C" int blvm_gru_seq_fwd(const float* Wih, const float* Whh, const float*
   if (rc) return rc;
   if (h0) BLVM_HIP(hipMemcpyAsync(rs.Hs, h0, sizeof(float) * br, hipMemcpyDeviceToDevice, s));
   else BLVM_HIP(hipMemsetAsync(rs.Hs, 0, sizeof(float) * br, s));
+  const bool bf16_seq = pchain_bf16(B) && seq_persistent(T, B);  // bf16-operand mode of the persistent path
+  const T16PackScope pack_scope(bf16_seq);
   rc = t16_pack_rows(Whh, R, 3 * R, R, rs.WhhP, s);  // operand layout of the chain (once per sequence)
   if (rc) return rc;
+  if (seq_persistent(T, B)) {
+    using namespace pchain;
+    BLVM_REQUIRE(out_ts >= 0 && out_ts < (1ll << 31), "gru_fwd: output step stride out of range");
+    const int rt = (B + 15) / 16, ctR = R / 16;
+    const long sR = (long)br, xR = (long)rt * 16 * R;
+    Builder bld;
+    bld.p.bf16 = bf16_seq; bld.p.S = T; bld.p.B = B; bld.p.xcd = (pchain_tune() & 4) ? 1 : 0; bld.p.lds_products = 3;
+    bld.p.prof = pchain_profile_buffer(); bld.p.prof_wg = 1;
+    Desc& d = bld.add(K_GRUS, ctR, 0, range_for(ctR * rt, device_cus() & ~7), R, 0, 0, T);
+    bld.ptr(d, 0, rs.H16, xR); bld.ptr(d, 1, rs.WhhP); bld.ptr(d, 2, bhh); bld.ptr(d, 3, rs.XG); bld.ptr(d, 4, lens); bld.ptr(d, 5, rs.Hs, sR);
+    bld.ptr(d, 6, rs.Hs + sR, sR); bld.ptr(d, 7, rs.H16 + xR, xR); bld.ptr(d, 8, out); bld.ptr(d, 9, rs.RG, sR); bld.ptr(d, 10, rs.UG, sR);
+    bld.ptr(d, 11, rs.NG, sR); bld.ptr(d, 12, rs.GHN, sR);
+    d.ld[3] = R; d.n16[0] = ctR; d.i[0] = R; d.i[1] = reverse ? 1 : 0; d.i[2] = (int)out_ts; d.i[3] = out_ld;
+    rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
+    if (rc) return rc;
+    BLVM_HIP(hipMemsetAsync(rs.H16 + xR, 0xFF, sizeof(float) * (size_t)T * xR, s));
+    rc = pchain_rows_to_t16(rs.Hs, R, B, R, rs.H16, s);
+    if (rc) return rc;
+    rc = pchain_launch(bld.p, s);
+    if (rc) return rc;
+    if (hn) BLVM_HIP(hipMemcpyAsync(hn, rs.Hs + T * br, sizeof(float) * br, hipMemcpyDeviceToDevice, s));
+    return BLVM_OK;
+  }
   const int nw = pick_nw(R, 3);
   const dim3 grid(R / 16, (B + 15) / 16);
   for (int j = 0; j < T; ++j) {
@@ -466,9 +548,32 @@ extern "C" int blvm_gru_seq_bwd(const float* Wih, const float* Whh, const float*
   GruWs ws;
   carve_gru_ws(workspace, T, B, R, &ws);
   const size_t n = (size_t)T * B, br = (size_t)B * R;
+  const bool bf16_seq = pchain_bf16(B) && seq_persistent(T, B);  // bf16-operand mode of the persistent path
+  const T16PackScope pack_scope(bf16_seq);
   rc = t16_pack_transposed(Whh, R, 3 * R, R, ws.WhhT, s);
   if (rc) return rc;
   BLVM_HIP(hipMemsetAsync(ws.G, 0, sizeof(float) * br, s));
+  if (seq_persistent(T, B)) {
+    using namespace pchain;
+    BLVM_REQUIRE(out_ts >= 0 && out_ts < (1ll << 31), "gru_bwd: output step stride out of range");
+    const int rt = (B + 15) / 16, ctR = R / 16;
+    const long sR = (long)br, s3R = 3 * sR, x3R = (long)rt * 16 * 3 * R;
+    Builder bld;
+    bld.p.bf16 = bf16_seq; bld.p.S = d_h0 ? T + 1 : T; bld.p.B = B; bld.p.xcd = (pchain_tune() & 4) ? 1 : 0; bld.p.lds_products = 1;
+    bld.p.prof = pchain_profile_buffer() ? pchain_profile_buffer() + 64 : nullptr; bld.p.prof_wg = 1;
+    Desc& d = bld.add(K_GRUSB, ctR, 0, range_for(ctR * rt, device_cus() & ~7), 3 * R, 0, 0, T + 1);
+    // step s handles recurrence step j = T-1-s: the saves walk backwards from their last slab; the T16 slabs are indexed by s
+    bld.ptr(d, 0, ws.DGH16 - x3R, x3R); bld.ptr(d, 1, ws.WhhT); bld.ptr(d, 2, d_out);
+    bld.ptr(d, 3, rs.RG + (long)(T - 1) * sR, -sR); bld.ptr(d, 4, rs.UG + (long)(T - 1) * sR, -sR); bld.ptr(d, 5, rs.NG + (long)(T - 1) * sR, -sR);
+    bld.ptr(d, 6, rs.GHN + (long)(T - 1) * sR, -sR); bld.ptr(d, 7, rs.Hs + (long)(T - 1) * sR, -sR); bld.ptr(d, 8, lens); bld.ptr(d, 9, ws.G);
+    bld.ptr(d, 10, ws.DGI); bld.ptr(d, 11, ws.DGH + (long)(T - 1) * s3R, -s3R); bld.ptr(d, 12, ws.DGH16, x3R); bld.ptr(d, 13, d_h0 ? d_h0 : ws.G);
+    d.ld[3] = 3 * R; d.n16[0] = 3 * ctR; d.n16[1] = T; d.i[0] = R; d.i[1] = reverse ? 1 : 0; d.i[2] = (int)out_ts; d.i[3] = out_ld;
+    rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
+    if (rc) return rc;
+    BLVM_HIP(hipMemsetAsync(ws.DGH16, 0xFF, sizeof(float) * (size_t)T * x3R, s));
+    rc = pchain_launch(bld.p, s);
+    if (rc) return rc;
+  } else {
   const int nw = pick_nw(3 * R, 1);
   const dim3 grid(R / 16, (B + 15) / 16);
   for (int j = T - 1; j >= -1; --j) {
@@ -488,6 +593,7 @@ extern "C" int blvm_gru_seq_bwd(const float* Wih, const float* Whh, const float*
       else if (nw == 8) hipLaunchKernelGGL((gru_bwd_kernel<8>), grid, dim3(512), 0, s, a.DGHn, a.WhhT, a.G, b_r, has, a);
       else hipLaunchKernelGGL((gru_bwd_kernel<4>), grid, dim3(256), 0, s, a.DGHn, a.WhhT, a.G, b_r, has, a);
     }
+  }
   }
   BLVM_CHECK_LAUNCH("gru_seq_bwd");
   if (d_in) {

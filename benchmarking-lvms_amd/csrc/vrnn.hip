@@ -251,6 +251,15 @@ inline int overlap_chunk_steps() {
 }
 
 
+// parts the persistent backward sequence is cut into so that finished rows' batched GEMMs overlap the rest (1 = no overlap)
+inline int pchain_wgrad_parts() {
+  static int v = [] {
+    const char* e = getenv("BLVM_PCHAIN_WGRAD_PARTS");
+    return e ? atoi(e) : 1;
+  }();
+  return v;
+}
+
 int check_dims(int Tp, int B, int X, int H, int Z, int R) {
   BLVM_REQUIRE(Tp > 0 && B > 0, "vrnn: bad Tp=%d B=%d", Tp, B);
   BLVM_REQUIRE(X > 0 && H > 0 && Z > 0 && R > 0 && X % 16 == 0 && H % 16 == 0 && Z % 16 == 0 && R % 16 == 0,
@@ -612,9 +621,38 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     if (rc) return rc;
     // sentinel-fill what the launch polls: GA, GB (single words) and the T16 copies
     BLVM_HIP(hipMemsetAsync(ws.GA, 0xFF, (size_t)(reinterpret_cast<char*>(ws.x16_end) - reinterpret_cast<char*>(ws.GA)), s));
-    rc = pchain_launch(bld.p, s);
+    // The batched GEMMs of the steps the chain has passed can run UNDER the rest of the chain (which keeps a quarter of the chip
+    // busy): the sequence is cut into `parts` launches, after each the finished rows go to a low-priority side stream.
+    const int parts = std::max(1, std::min(pchain_wgrad_parts(), T / 8));
+    if (parts == 1) {
+      rc = pchain_launch(bld.p, s);
+      if (rc) return rc;
+      return batched(0, n, s);
+    }
+    SideStream& sd = side_stream();
+    rc = sd.ensure();
     if (rc) return rc;
-    return batched(0, n, s);
+    int done_steps = 0;  // steps s < done_steps are finished: rows of t in [T - done_steps, T)
+    for (int k = 0; k < parts; ++k) {
+      const int s_end = k + 1 == parts ? T + 1 : (int)((long)T * (k + 1) / parts);
+      bld.p.s_first = done_steps; bld.p.S = s_end;
+      if (k > 0) {  // a fresh abort epoch per launch
+        rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
+        if (rc) return rc;
+      }
+      rc = pchain_launch(bld.p, s);
+      if (rc) return rc;
+      const int fin = std::min(s_end, T);
+      // (all ranges on the ONE side stream: two of them accumulating into the same gradient must not run concurrently)
+      BLVM_HIP(hipEventRecord(sd.ready, s));
+      BLVM_HIP(hipStreamWaitEvent(sd.stream, sd.ready, 0));
+      rc = batched((size_t)(T - fin) * B, (size_t)(fin - done_steps) * B, sd.stream);
+      if (rc) return rc;
+      done_steps = fin;
+    }
+    BLVM_HIP(hipEventRecord(sd.done, sd.stream));
+    BLVM_HIP(hipStreamWaitEvent(s, sd.done, 0));
+    return BLVM_OK;
   }
   const int chunk = overlap_chunk_steps();
   const bool overlap = chunk > 0 && Tp >= 2 * chunk;

@@ -317,15 +317,26 @@ def test_full_size_properties():
 # ----------------------------------------------------------------------------------------------------------------------
 
 
+@pytest.fixture(params=[True, False], ids=["one_launch", "launch_per_step"])
+def sequence_path(request):
+    """Both execution paths of K1-K5: the whole sequence as one persistent launch | one launch per step."""
+    lib = _hip.load()
+    before = lib.blvm_pchain_max_batch()
+    lib.blvm_pchain_configure(128 if request.param else 0, 0)
+    yield request.param
+    lib.blvm_pchain_configure(before, 0)
+    _hip.check_async()
+
+
 @pytest.mark.parametrize("reverse", [False, True])
-def test_gru_sequence_vs_torch(reverse):
+@pytest.mark.parametrize("T_,B,I,R", [(11, 5, 24, 32), (37, 35, 48, 128)])
+def test_gru_sequence_vs_torch(reverse, T_, B, I, R, sequence_path):
     """nn.GRU (and reverse_sequences -> nn.GRU -> reverse_sequences) on the CPU vs the HIP sequence kernels."""
     torch.manual_seed(7)
-    T_, B, I, R = 11, 5, 24, 32
     gru = torch.nn.GRU(I, R)
     x = torch.randn(T_, B, I)
     h0 = torch.randn(B, R) * 0.5
-    lens = torch.tensor([11, 9, 6, 2, 1])
+    lens = torch.tensor([11, 9, 6, 2, 1]) if B == 5 else torch.tensor([max(1, T_ - (k * T_) // B) for k in range(B)])
     w = torch.randn(T_, B, R)
     xr = x.clone().requires_grad_(True)
     h0r = h0.clone().requires_grad_(True)
@@ -348,12 +359,12 @@ def test_gru_sequence_vs_torch(reverse):
         assert rel_l2(a, b) < 2e-5
 
 
-def test_lstm_sequence_packed_vs_torch():
+@pytest.mark.parametrize("T_,B,I,H", [(9, 6, 16, 32), (41, 37, 64, 128)])
+def test_lstm_sequence_packed_vs_torch(T_, B, I, H, sequence_path):
     torch.manual_seed(8)
-    T_, B, I, H = 9, 6, 16, 32
     lstm = torch.nn.LSTM(I, H, batch_first=True)
     x = torch.randn(B, T_, I)
-    lens = torch.tensor([9, 9, 7, 4, 2, 1])
+    lens = torch.tensor([9, 9, 7, 4, 2, 1]) if B == 6 else torch.tensor([max(1, T_ - (k * T_) // B) for k in range(B)])
     w = torch.randn(B, T_, H)
     xr = x.clone().requires_grad_(True)
     ps = torch.nn.utils.rnn.pack_padded_sequence(xr, lens, batch_first=True)
