@@ -129,14 +129,13 @@ class _MLPFunction(torch.autograd.Function):
             inp = acts[l]
             M, K = inp.shape
             N = W.shape[0]
-            if ctx.needs_input_grad[3 + 2 * l]:
-                dW = torch.zeros_like(W, dtype=torch.float32)
-                gemm(1, 1, N, K, M, dz, N, inp, inp.stride(0), dW, K, accumulate=True, split_k=_pick_split(N, K, M))
-                grads[2 * l] = dW
-            if b is not None and ctx.needs_input_grad[4 + 2 * l]:
-                db = torch.empty(N, device=dz.device, dtype=torch.float32)
-                colsum(dz, db)
-                grads[2 * l + 1] = db
+            # weight and bias gradient in one launch (the GEMM's first column block also sums the dz tiles it stages)
+            dW = torch.zeros_like(W, dtype=torch.float32) if ctx.needs_input_grad[3 + 2 * l] else None
+            db = torch.zeros(N, device=dz.device, dtype=torch.float32) if (b is not None and ctx.needs_input_grad[4 + 2 * l]) else None
+            if dW is not None or db is not None:
+                check(load().blvm_wgrad_f32(N, K, M, ptr(dz), N, ptr(inp), inp.stride(0), ptr(dW), K, ptr(db), _pick_split(N, K, M), stream_ptr()),
+                      "blvm_wgrad_f32")  # fmt: skip
+            grads[2 * l], grads[2 * l + 1] = dW, db
             if l > 0 or ctx.needs_input_grad[0]:
                 dx = torch.empty(M, K, device=dz.device, dtype=torch.float32)
                 # dgrad with the derivative of the PREVIOUS layer's activation fused into the epilogue

@@ -346,7 +346,7 @@ unsigned long long* pchain_profile_buffer();  // diagnostics: null unless blvm_p
 // internal launchers shared between translation units (defined in gemm.hip)
 int gemm_f32(int op_a, int op_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
              int ldc, const float* bias, int act, float slope, const float* gate, int ldg, int accumulate,
-             int split_k, hipStream_t stream);
+             int split_k, hipStream_t stream, float* colsum = nullptr);  // colsum (op_a == 1): [M] += sum over k of A[k][:]
 int colsum_f32(int M, int N, const float* X, int ldx, float* out, int accumulate, hipStream_t stream);
 int transpose_f32(int M, int N, const float* X, int ldx, float* out, int ldo, hipStream_t stream);
 // Operand type of the matrix products (core.hip; blvm_set_operand_dtype / env BLVM_DTYPE=bf16): false = fp32 (the default), true =

@@ -36,6 +36,7 @@ struct GemmArgs {
   int accumulate;
   int k_per_split;  // multiple of BK
   int a_vec, b_vec;  // 16-byte vector loads allowed for A / B
+  float* colsum;     // op_a == 1 only: [M] += column sums of A over k (the bias gradient of a weight-gradient GEMM), or null
 };
 
 // Load 4 consecutive elements p[0..3] with element-wise validity n_valid (0..4).
@@ -143,11 +144,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
   if (kbeg < kend) load_tiles(kbeg);
   const int li = lane & 31, lh = lane >> 5;
+  // bias gradient riding on a weight-gradient GEMM: the workgroups of the first column block also sum their A tiles over k
+  // (A = the pre-activation gradients [rows, M]; the staged tile is k-major, so thread m reads a conflict-free column)
+  const bool do_csum = OPA == 1 && g.colsum != nullptr && blockIdx.x == 0;
+  constexpr int CS = BM <= 64 ? 4 : (BM <= 128 ? 2 : 1);
+  float csum = 0.f;
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     __syncthreads();  // previous tile fully consumed
     store_tiles();
     __syncthreads();
     if (k0 + BK < kend) load_tiles(k0 + BK);  // prefetch next tile into registers
+    if (do_csum && tid / BM < CS) {  // CS threads share a column: every wave carries the same few extra LDS reads
+#pragma unroll
+      for (int kk = 0; kk < BK / CS; ++kk) csum += As[(kk * CS + tid / BM) * LDA_S + tid % BM];
+    }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       float a[TM], b[TN];
@@ -163,6 +173,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
   }
 
+  if (do_csum && tid / BM < CS && m0 + tid % BM < g.M) atomicAdd(g.colsum + m0 + tid % BM, csum);
   // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const bool atomic = gridDim.z > 1;
 #pragma unroll
@@ -414,7 +425,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(int M, int N, const floa
 
 int gemm_f32(int op_a, int op_b, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
              int ldc, const float* bias, int act, float slope, const float* gate, int ldg, int accumulate,
-             int split_k, hipStream_t stream) {
+             int split_k, hipStream_t stream, float* colsum) {
   BLVM_REQUIRE(M >= 0 && N >= 0 && K >= 0, "gemm: negative dimension");
   if (M == 0 || N == 0) return BLVM_OK;
   BLVM_REQUIRE(A && B && C, "gemm: null operand");
@@ -443,6 +454,12 @@ int gemm_f32(int op_a, int op_b, int M, int N, int K, const float* A, int lda, c
   const int bn = big ? (n192 ? 192 : 128) : 64;
   const bool bf16 = operand_bf16();
   const int bk = bf16 ? BKB : BK;
+  if (colsum != nullptr && (bf16 || op_a != 1 || K == 0)) {  // (the bf16 kernel stages ROUNDED operands: the bias gradient stays an fp32 sum)
+    const int rc = op_a == 1 ? colsum_f32(K, M, A, lda, colsum, 1, stream) : BLVM_EINVAL;
+    if (rc) return rc;
+    colsum = nullptr;
+  }
+  g.colsum = colsum;
   int ksteps = (K + bk - 1) / bk;
   if (split_k > ksteps) split_k = ksteps > 0 ? ksteps : 1;
   g.k_per_split = ((ksteps + split_k - 1) / split_k) * bk;
@@ -566,6 +583,16 @@ extern "C" int blvm_gemm_f32(int op_a, int op_b, int M, int N, int K, const floa
                              const float* gate, int ldg, int accumulate, int split_k, void* stream) {
   return blvm::gemm_f32(op_a, op_b, M, N, K, A, lda, B, ldb, C, ldc, bias, act, slope, gate, ldg, accumulate,
                         split_k, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int blvm_wgrad_f32(int N_out, int K_in, int rows, const float* D, int ldd, const float* X, int ldx, float* dW, int lddw, float* db,
+                              int split_k, void* stream) {
+  using namespace blvm;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  BLVM_REQUIRE(N_out >= 0 && K_in >= 0 && rows >= 0, "wgrad: negative dimension");
+  if (dW == nullptr) return db ? colsum_f32(rows, N_out, D, ldd, db, 1, s) : BLVM_OK;
+  if (split_k < 1) split_k = gemm_pick_split(N_out, K_in, rows);
+  return gemm_f32(1, 1, N_out, K_in, rows, D, ldd, X, ldx, dW, lddw, nullptr, 0, 0.f, nullptr, 0, 1, split_k, s, db);
 }
 
 extern "C" int blvm_act_bwd_f32(const float* dy, const float* y, float slope, float* dz, size_t n, void* stream) {

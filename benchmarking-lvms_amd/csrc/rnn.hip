@@ -462,10 +462,11 @@ extern "C" int blvm_lstm_seq_bwd(const float* Wih, const float* Whh, const float
     rc = gemm_f32(0, 1, (int)n, I, 4 * H, ws.DG, 4 * H, Wih, I, d_in, I, nullptr, 0, 0.f, nullptr, 0, 0, 1, s);
     if (rc) return rc;
   }
-  if (dWih) { rc = gemm_f32(1, 1, 4 * H, I, (int)n, ws.DG, 4 * H, in, I, dWih, I, nullptr, 0, 0.f, nullptr, 0, 1, pick_split(4 * H, I, (int)n), s); if (rc) return rc; }
-  if (dWhh) { rc = gemm_f32(1, 1, 4 * H, H, (int)n, ws.DG, 4 * H, rs.Hs, H, dWhh, H, nullptr, 0, 0.f, nullptr, 0, 1, pick_split(4 * H, H, (int)n), s); if (rc) return rc; }
-  if (dbih) { rc = colsum_f32((int)n, 4 * H, ws.DG, 4 * H, dbih, 1, s); if (rc) return rc; }
-  if (dbhh) { rc = colsum_f32((int)n, 4 * H, ws.DG, 4 * H, dbhh, 1, s); if (rc) return rc; }
+  // weight + bias gradients: the bias sums ride on the weight-gradient GEMMs (gemm.hip: column sums of the staged D tiles)
+  if (dWih) { rc = gemm_f32(1, 1, 4 * H, I, (int)n, ws.DG, 4 * H, in, I, dWih, I, nullptr, 0, 0.f, nullptr, 0, 1, pick_split(4 * H, I, (int)n), s, dbih); if (rc) return rc; }
+  else if (dbih) { rc = colsum_f32((int)n, 4 * H, ws.DG, 4 * H, dbih, 1, s); if (rc) return rc; }
+  if (dWhh) { rc = gemm_f32(1, 1, 4 * H, H, (int)n, ws.DG, 4 * H, rs.Hs, H, dWhh, H, nullptr, 0, 0.f, nullptr, 0, 1, pick_split(4 * H, H, (int)n), s, dbhh); if (rc) return rc; }
+  else if (dbhh) { rc = colsum_f32((int)n, 4 * H, ws.DG, 4 * H, dbhh, 1, s); if (rc) return rc; }
   return BLVM_OK;
 }
 
@@ -600,9 +601,9 @@ extern "C" int blvm_gru_seq_bwd(const float* Wih, const float* Whh, const float*
     rc = gemm_f32(0, 1, (int)n, I, 3 * R, ws.DGI, 3 * R, Wih, I, d_in, ld_din, nullptr, 0, 0.f, nullptr, 0, accumulate_din, 1, s);
     if (rc) return rc;
   }
-  if (dWih) { rc = gemm_f32(1, 1, 3 * R, I, (int)n, ws.DGI, 3 * R, in, ld_in, dWih, I, nullptr, 0, 0.f, nullptr, 0, 1, pick_split(3 * R, I, (int)n), s); if (rc) return rc; }
-  if (dWhh) { rc = gemm_f32(1, 1, 3 * R, R, (int)n, ws.DGH, 3 * R, rs.Hs, R, dWhh, R, nullptr, 0, 0.f, nullptr, 0, 1, pick_split(3 * R, R, (int)n), s); if (rc) return rc; }
-  if (dbih) { rc = colsum_f32((int)n, 3 * R, ws.DGI, 3 * R, dbih, 1, s); if (rc) return rc; }
-  if (dbhh) { rc = colsum_f32((int)n, 3 * R, ws.DGH, 3 * R, dbhh, 1, s); if (rc) return rc; }
+  if (dWih) { rc = gemm_f32(1, 1, 3 * R, I, (int)n, ws.DGI, 3 * R, in, ld_in, dWih, I, nullptr, 0, 0.f, nullptr, 0, 1, pick_split(3 * R, I, (int)n), s, dbih); if (rc) return rc; }
+  else if (dbih) { rc = colsum_f32((int)n, 3 * R, ws.DGI, 3 * R, dbih, 1, s); if (rc) return rc; }
+  if (dWhh) { rc = gemm_f32(1, 1, 3 * R, R, (int)n, ws.DGH, 3 * R, rs.Hs, R, dWhh, R, nullptr, 0, 0.f, nullptr, 0, 1, pick_split(3 * R, R, (int)n), s, dbhh); if (rc) return rc; }
+  else if (dbhh) { rc = colsum_f32((int)n, 3 * R, ws.DGH, 3 * R, dbhh, 1, s); if (rc) return rc; }
   return BLVM_OK;
 }

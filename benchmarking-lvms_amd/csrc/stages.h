@@ -589,12 +589,13 @@ inline void launch_lin(const LinLaunch& l, hipStream_t s) {
 
 inline int pick_split(int M, int N, int K) { return gemm_pick_split(M, N, K); }
 
-// dW (+)= D^T Act over all rows
+// dW (+)= D^T Act over all rows; db (+)= column sums of D in the same launch (null: none)
+inline int bgrad(const float* D, int ldd, int n_out, float* db, size_t rows, hipStream_t s);
 inline int wgrad(const float* D, int ldd, int n_out, const float* Act, int lda, int k_in, float* dW, int ldw, size_t rows,
-          hipStream_t s) {
-  if (!dW) return BLVM_OK;
+          hipStream_t s, float* db = nullptr) {
+  if (!dW) return bgrad(D, ldd, n_out, db, rows, s);
   return gemm_f32(1, 1, n_out, k_in, (int)rows, D, ldd, Act, lda, dW, ldw, nullptr, 0, 0.f, nullptr, 0, 1,
-                  pick_split(n_out, k_in, (int)rows), s);
+                  pick_split(n_out, k_in, (int)rows), s, db);
 }
 
 inline int bgrad(const float* D, int ldd, int n_out, float* db, size_t rows, hipStream_t s) {

@@ -91,6 +91,14 @@ int blvm_gemm_f32(int op_a, int op_b, int M, int N, int K, const float* A, int l
  * (used where no producing GEMM exists to fuse it into, e.g. behind the DMoL head).  dz may alias dy. */
 int blvm_act_bwd_f32(const float* dy, const float* y, float slope, float* dz, size_t n, void* stream);
 
+/* Weight + bias gradient of y = x W^T + b in ONE launch (autograd's `grad_weight = dy^T x`, `grad_bias = dy.sum(0)`):
+ *   dW[n*lddw + k] += sum_r D[r*ldd + n] X[r*ldx + k]   ;   db[n] += sum_r D[r*ldd + n]     (both ACCUMULATE; caller zeroes)
+ * D [rows, N_out] pre-activation gradients, X [rows, K_in] the layer's input; dW or db may be NULL; split_k < 1: chosen here.
+ * The workgroups of the GEMM's first column block sum the D tiles they stage anyway (fp32 operands; in the bf16-operand mode the
+ * bias gradient stays an fp32 sum in its own launch). */
+int blvm_wgrad_f32(int N_out, int K_in, int rows, const float* D, int ldd, const float* X, int ldx, float* dW, int lddw, float* db,
+                   int split_k, void* stream);
+
 /* out[n] (=|+=) sum_m X[m*ldx + n]   (bias gradients). */
 int blvm_colsum_f32(int M, int N, const float* X, int ldx, float* out, int accumulate, void* stream);
 

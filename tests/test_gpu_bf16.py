@@ -83,6 +83,17 @@ def test_gemm_bf16_split_k_wide_tiles_accumulate(op_a, op_b, M, N, K, split):
     assert torch.all(C[:, N:] == 2)
 
 
+def test_wgrad_bias_gradient_stays_fp32_in_bf16_mode():
+    g = torch.Generator().manual_seed(4)
+    N, K, rows = 256, 192, 9000
+    D, X = torch.randn(rows, N, generator=g), torch.randn(rows, K, generator=g)
+    dW, db = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+    Dd, Xd = D.to(DEV), X.to(DEV)
+    _hip.check(_hip.load().blvm_wgrad_f32(N, K, rows, _hip.ptr(Dd), N, _hip.ptr(Xd), K, _hip.ptr(dW), K, _hip.ptr(db), 0, _hip.stream_ptr()), "wgrad")
+    assert rel_l2(dW, rb(D).t() @ rb(X)) < 3e-6
+    assert rel_l2(db, D.double().sum(0)) < 3e-6  # NOT the sum of the rounded operands
+
+
 def _run(model, x, x_sl, eps, beta, fn):
     model.zero_grad()
     loss, metrics, out = model(x.to(DEV), x_sl, beta=beta, free_nats=fn, eps=eps.to(DEV))

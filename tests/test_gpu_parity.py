@@ -87,6 +87,22 @@ def test_gemm_192_wide_tiles(op_a, op_b, M, N, K, split):
     assert rel_l2(C, ref + 2) < 3e-6
 
 
+@pytest.mark.parametrize("N,K,rows,split", [(256, 256, 16000, 0), (96, 80, 4099, 16), (1920, 256, 3000, 1), (30, 30, 1000, 0), (384, 200, 20001, 24)])
+def test_wgrad_with_bias_gradient_in_one_launch(N, K, rows, split):
+    """blvm_wgrad_f32: dW += D^T X and db += column sums of D from the same launch (first column block of the GEMM), both accumulating."""
+    g = torch.Generator().manual_seed(N + K + rows)
+    D, X = torch.randn(rows, N + 4, generator=g), torch.randn(rows, K, generator=g)
+    dW, db = torch.ones(N, K, device=DEV), torch.full((N,), 2.0, device=DEV)
+    Dd, Xd = D.to(DEV), X.to(DEV)
+    lib = _hip.load()
+    _hip.check(lib.blvm_wgrad_f32(N, K, rows, _hip.ptr(Dd), N + 4, _hip.ptr(Xd), K, _hip.ptr(dW), K, _hip.ptr(db), split, _hip.stream_ptr()), "wgrad")
+    assert rel_l2(dW, D[:, :N].double().t() @ X.double() + 1) < 3e-6
+    assert rel_l2(db, D[:, :N].double().sum(0) + 2) < 3e-6
+    db2 = torch.zeros(N, device=DEV)  # bias gradient alone
+    _hip.check(lib.blvm_wgrad_f32(N, K, rows, _hip.ptr(Dd), N + 4, _hip.ptr(Xd), K, None, K, _hip.ptr(db2), split, _hip.stream_ptr()), "wgrad")
+    assert rel_l2(db2, D[:, :N].double().sum(0)) < 3e-6
+
+
 def test_mlp_function_forward_backward_vs_torch():
     torch.manual_seed(3)
     lins = [torch.nn.Linear(24, 64), torch.nn.Linear(64, 64), torch.nn.Linear(64, 48)]
