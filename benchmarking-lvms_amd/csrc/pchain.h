@@ -39,7 +39,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 constexpr int AUX_SC1 = 16;
 __device__ __forceinline__ rsrc_t make_rsrc(const void* base) {  // base must be wave-uniform
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xFFFFFFFFu, 0x00020000);
+  // (said to the compiler, too: a pointer that reached here through a struct assigned under control flow counts as divergent, and
+  // every buffer access through it became a waterfall loop over the "different" resources)
+  const unsigned long long u = reinterpret_cast<unsigned long long>(base);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, 0xFFFFFFFFu, 0x00020000);
 }
 __device__ __forceinline__ f32x4 ld_sc1_x4(rsrc_t r, unsigned byte_off) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, AUX_SC1));
@@ -340,10 +344,18 @@ __device__ __forceinline__ void put(const Out& o, int r0, int c0, int row, int c
 
 // out = gate(act(A W^T + bias + add)):  bias [ncols] or null; add [B, ldadd] or null (add_polled: produced inside this launch);
 // relu: act = leaky ReLU with `slope`; gate [B, ldgate] or null: result *= (gate > 0 ? 1 : slope) — the backward of that activation.
-template <int NW, bool BF = false>
-__device__ __forceinline__ void tile_lin(const float* A, int lda, bool a_polled, const float* W, int K, const float* bias,
-                                         const float* add, int ldadd, bool add_polled, const float* gate, int ldgate, bool relu,
-                                         float slope, const Out& out, int r0, int c0, int B, float* red, Poll& pl) {
+// What a linear tile needs only AFTER its operand loads are in flight (epilogue operands, output targets): produced by a functor
+// the tile calls behind the first trip's loads, so that extracting them from a descriptor runs in the shadow of the operand wait.
+struct LinLate {
+  const float *bias, *add, *gate;
+  int ldadd, ldgate;
+  bool add_polled, relu;
+  float slope;
+  Out out;
+};
+template <int NW, bool BF, class Late>
+__device__ __forceinline__ void tile_lin_late(const float* A, int lda, bool a_polled, const float* W, int K, Late& late, int r0, int c0, int B,
+                                              float* red, Poll& pl) {
   const int t = threadIdx.x & 255;
   const int row = r0 + (t >> 4), col = c0 + (t & 15);
   const bool own = threadIdx.x < 256 && row < B;
@@ -353,10 +365,12 @@ __device__ __forceinline__ void tile_lin(const float* A, int lda, bool a_polled,
   pl.t_first = 0; pl.polls = 0;
 #endif
   float e_bias = 0.f, e_gate = 1.f, e_add = 0.f;
+  LinLate L;
   auto prefetch = [&]() {  // the epilogue's operands, requested behind the product's operand loads
-    if (bias) e_bias = bias[col];
-    if (gate) e_gate = gate[(size_t)rowc * ldgate + col];
-    if (add && !add_polled) e_add = add[(size_t)rowc * ldadd + col];
+    L = late();
+    if (L.bias) e_bias = L.bias[col];
+    if (L.gate) e_gate = L.gate[(size_t)rowc * L.ldgate + col];
+    if (L.add && !L.add_polled) e_add = L.add[(size_t)rowc * L.ldadd + col];
   };
   f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
   {
@@ -375,21 +389,28 @@ __device__ __forceinline__ void tile_lin(const float* A, int lda, bool a_polled,
   }
 #endif
   if (threadIdx.x >= 256) return;
-  if (add && add_polled) {
-    const rsrc_t rs[1] = {make_rsrc(add)};
-    const unsigned os[1] = {4u * ((unsigned)rowc * (unsigned)ldadd + (unsigned)col)};
+  if (L.add && L.add_polled) {
+    const rsrc_t rs[1] = {make_rsrc(L.add)};
+    const unsigned os[1] = {4u * ((unsigned)rowc * (unsigned)L.ldadd + (unsigned)col)};
     float ws[1];
     poll_words<1>(rs, os, ws, own, pl);
     e_add = ws[0];
   }
   if (!own) return;
   float x = v[0] + e_bias + e_add;
-  if (relu) x = x > 0.f ? x : x * slope;
-  if (gate) x = e_gate > 0.f ? x : x * slope;
-  put(out, r0, c0, row, col, x);
+  if (L.relu) x = x > 0.f ? x : x * L.slope;
+  if (L.gate) x = e_gate > 0.f ? x : x * L.slope;
+  put(L.out, r0, c0, row, col, x);
 #ifdef PCHAIN_TPROF
   if (a_polled && pl.nap == 1) { pl.t_end = wall_clock64(); }
 #endif
+}
+template <int NW, bool BF = false>
+__device__ __forceinline__ void tile_lin(const float* A, int lda, bool a_polled, const float* W, int K, const float* bias,
+                                         const float* add, int ldadd, bool add_polled, const float* gate, int ldgate, bool relu,
+                                         float slope, const Out& out, int r0, int c0, int B, float* red, Poll& pl) {
+  auto late = [&]() { return LinLate{bias, add, gate, ldadd, ldgate, add_polled, relu, slope, out}; };
+  tile_lin_late<NW, BF>(A, lda, a_polled, W, K, late, r0, c0, B, red, pl);
 }
 
 // Both Gaussian heads + posterior combination + reparameterised sample (stages.h head_stage_kernel): P, Q [B,H] are the last

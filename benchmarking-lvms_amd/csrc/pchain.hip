@@ -164,7 +164,7 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
   const bool profiled = a.prof != nullptr && (w == 0 || w == a.prof_wg) && threadIdx.x == 0;
   unsigned long long tprev = profiled ? wall_clock64() : 0ull;
 #ifdef PCHAIN_TPROF2
-  unsigned long long tq[3] = {0ull, 0ull, 0ull}, tq_end = 0ull;
+  unsigned long long tq[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull}, tq_end = 0ull;
 #endif
   DescRegs d, nx;
   d.fetch(ltab, __builtin_ctz(mine), a.s0);
@@ -177,19 +177,37 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
 #endif
       // request the next descriptor of this workgroup's walk now; it lands while this tile runs
       const unsigned rest = m & (m - 1);
-      nx.fetch(ltab, __builtin_ctz(rest != 0 ? rest : mine), rest != 0 ? s : s + 1);
+      const int nx_i = __builtin_ctz(rest != 0 ? rest : mine), nx_s = rest != 0 ? s : s + 1;
       const int kind = d.w<RD_KIND>(), flags = d.w<RD_FLAGS>(), K = d.w<RD_K>();
-      if (s >= d.w<RD_SBEGIN>() && s < d.w<RD_SEND>()) {
+      const bool active = s >= d.w<RD_SBEGIN>() && s < d.w<RD_SEND>();
+#ifdef PCHAIN_TPROF2
+      const unsigned long long tqa = wall_clock64();
+      tq[3] += tqa - tq0;
+#endif
+      // (a linear tile fetches the next descriptor itself, in the shadow of its operand wait)
+      if (!active || kind != K_LIN) nx.fetch(ltab, nx_i, nx_s);
+      if (active) {
         const int nt = d.w<RD_NT>();
         pl.nap = (flags & DF_GENTLE) ? 16 : 1;
         pl.code = ((unsigned)s << 4) | (unsigned)i;
-        const int ld0 = d.w<RD_LD + 0>(), ld1 = d.w<RD_LD + 1>(), ld2 = d.w<RD_LD + 2>(), ld3 = d.w<RD_LD + 3>(), n16 = d.w<RD_N16>();
         switch (kind) {
           case K_LIN: {
+            // Only what the operand loads need is taken out of the descriptor here; everything the epilogue needs (and the next
+            // descriptor's fetch) is done by `late`, which the tile calls once its first loads are in flight.
             const bool a_polled = !(flags & DF_A_PLAIN);
-            const float *A = d.p<0>(s), *W = d.base<1>(), *bias = d.base<2>(), *add = d.p<3>(s), *gate = d.p<4>(s);
-            const Out o{d.m<5>(s), ld3, (flags & DF_RM_SC1) != 0, d.m<6>(s), n16, d.m<7>(s), d.w<RD_N16 + 1>()};
-            const float slope = d.f<0>();
+            const float *A = d.p<0>(s), *W = d.base<1>();
+            const int ld0 = d.w<RD_LD + 0>();
+#ifdef PCHAIN_TPROF2
+            const unsigned long long tqb = wall_clock64();
+            tq[4] += tqb - tqa;
+#endif
+            bool nx_done = false;
+            auto late = [&]() {
+              __builtin_amdgcn_sched_barrier(0);
+              if (!nx_done) { nx.fetch(ltab, nx_i, nx_s); nx_done = true; }
+              return LinLate{d.base<2>(), d.p<3>(s), d.p<4>(s), d.w<RD_LD + 1>(), d.w<RD_LD + 2>(), (flags & DF_ADD_POLLED) != 0, (flags & DF_RELU) != 0, d.f<0>(),
+                             Out{d.m<5>(s), d.w<RD_LD + 3>(), (flags & DF_RM_SC1) != 0, d.m<6>(s), d.w<RD_N16>(), d.m<7>(s), d.w<RD_N16 + 1>()}};
+            };
             for (int tk = 0; tk < nt; ++tk) {
               const int trc = d.tile(tk), tr0 = trc & 0xffff, tc0 = (trc >> 16) * 16;
               if ((flags & DF_CANARY) && a_polled) canary_wait(A, tr0, K, pl, ld0);
@@ -197,16 +215,18 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
               const unsigned long long tq1 = wall_clock64();
               tq[0] += tq1 - tq0;
 #endif
-              tile_lin<NW, BF>(A, ld0, a_polled, W, K, bias, add, ld1, (flags & DF_ADD_POLLED) != 0, gate, ld2, (flags & DF_RELU) != 0, slope, o, tr0, tc0, B,
-                           red(), pl);
+              tile_lin_late<NW, BF>(A, ld0, a_polled, W, K, late, tr0, tc0, B, red(), pl);
 #ifdef PCHAIN_TPROF2
               tq_end = wall_clock64();
               tq[1] += tq_end - tq1;
 #endif
             }
+            if (!nx_done) nx.fetch(ltab, nx_i, nx_s);  // (a visit without tiles)
           } break;
 #ifndef PCHAIN_ONLY_LIN
           case K_HEAD: {
+            const int ld0 = d.w<RD_LD + 0>(), ld1 = d.w<RD_LD + 1>(), ld2 = d.w<RD_LD + 2>(), ld3 = d.w<RD_LD + 3>(), n16 = d.w<RD_N16>();
+            (void)ld0; (void)ld1; (void)ld2; (void)ld3; (void)n16;
             const HeadOut o{d.m<7>(s), d.m<8>(s), d.m<9>(s), d.m<10>(s), d.m<11>(s), d.m<12>(s), d.m<13>(s),
                             Out{d.m<14>(s), ld3, false, d.m<15>(s), n16, d.m<16>(s), d.w<RD_N16 + 1>()}};
             const int Z = d.w<RD_I + 0>(), residual = d.w<RD_I + 1>();
@@ -217,6 +237,8 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
             }
           } break;
           case K_GRU: {
+            const int ld0 = d.w<RD_LD + 0>(), ld1 = d.w<RD_LD + 1>(), ld2 = d.w<RD_LD + 2>(), ld3 = d.w<RD_LD + 3>(), n16 = d.w<RD_N16>();
+            (void)ld0; (void)ld1; (void)ld2; (void)ld3; (void)n16;
             const Out o{d.m<5>(s), ld3, true, d.m<6>(s), n16, d.m<11>(s), d.w<RD_N16 + 1>()};
             const int R = d.w<RD_I + 0>();
             for (int tk = 0; tk < nt; ++tk) {
@@ -226,6 +248,8 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
             }
           } break;
           case K_DZ: {
+            const int ld0 = d.w<RD_LD + 0>(), ld1 = d.w<RD_LD + 1>(), ld2 = d.w<RD_LD + 2>(), ld3 = d.w<RD_LD + 3>(), n16 = d.w<RD_N16>();
+            (void)ld0; (void)ld1; (void)ld2; (void)ld3; (void)n16;
             DzIn z;
             z.mu_q = d.p<5>(s); z.sd_q = d.p<6>(s); z.mu_p = d.p<7>(s); z.sd_p = d.p<8>(s); z.eps = d.p<9>(s); z.raw_q = d.p<10>(s); z.raw_p = d.p<11>(s);
             z.muq_raw = d.p<12>(s);
@@ -242,6 +266,8 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
             }
           } break;
           case K_GRUB: {
+            const int ld0 = d.w<RD_LD + 0>(), ld1 = d.w<RD_LD + 1>(), ld2 = d.w<RD_LD + 2>(), ld3 = d.w<RD_LD + 3>(), n16 = d.w<RD_N16>();
+            (void)ld0; (void)ld1; (void)ld2; (void)ld3; (void)n16;
             GrubIn g;
             g.D0 = d.p<0>(s); g.D1 = d.p<1>(s); g.W0 = d.base<2>(); g.W1 = d.base<3>(); g.g_in = d.p<4>(s); g.g_add = d.p<17>(s); g.ld_gadd = ld1;
             g.rg = d.p<5>(s); g.ug = d.p<6>(s); g.ng = d.p<7>(s); g.gh = d.p<8>(s); g.hprev = d.p<9>(s); g.dd = d.p<10>(s); g.ldh = ld0;
@@ -256,6 +282,8 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
             }
           } break;
           case K_GRUS: {
+            const int ld0 = d.w<RD_LD + 0>(), ld1 = d.w<RD_LD + 1>(), ld2 = d.w<RD_LD + 2>(), ld3 = d.w<RD_LD + 3>(), n16 = d.w<RD_N16>();
+            (void)ld0; (void)ld1; (void)ld2; (void)ld3; (void)n16;
             const int R = d.w<RD_I + 0>();
             GruSeqIn g;
             g.H16 = d.p<0>(s); g.Whh = d.base<1>(); g.bhh = d.base<2>(); g.xg = d.base<3>(); g.lens = reinterpret_cast<const int32_t*>(d.base<4>());
@@ -268,6 +296,8 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
             }
           } break;
           case K_GRUSB: {
+            const int ld0 = d.w<RD_LD + 0>(), ld1 = d.w<RD_LD + 1>(), ld2 = d.w<RD_LD + 2>(), ld3 = d.w<RD_LD + 3>(), n16 = d.w<RD_N16>();
+            (void)ld0; (void)ld1; (void)ld2; (void)ld3; (void)n16;
             const int R = d.w<RD_I + 0>(), T = d.w<RD_N16 + 1>();
             GruSeqBwdIn g;
             g.DGHn16 = d.p<0>(s); g.WhhT = d.base<1>(); g.dout = d.base<2>(); g.rg = d.p<3>(s); g.ug = d.p<4>(s); g.ng = d.p<5>(s); g.ghn = d.p<6>(s);
@@ -282,6 +312,8 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
             }
           } break;
           case K_LSTMS: {
+            const int ld0 = d.w<RD_LD + 0>(), ld1 = d.w<RD_LD + 1>(), ld2 = d.w<RD_LD + 2>(), ld3 = d.w<RD_LD + 3>(), n16 = d.w<RD_N16>();
+            (void)ld0; (void)ld1; (void)ld2; (void)ld3; (void)n16;
             const int H = d.w<RD_I + 0>();
             LstmSeqIn g;
             g.H16 = d.p<0>(s); g.Whh = d.base<1>(); g.bhh = d.base<2>(); g.xg = d.p<3>(s); g.lens = reinterpret_cast<const int32_t*>(d.base<4>());
@@ -293,6 +325,8 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
             }
           } break;
           case K_LSTMSB: {
+            const int ld0 = d.w<RD_LD + 0>(), ld1 = d.w<RD_LD + 1>(), ld2 = d.w<RD_LD + 2>(), ld3 = d.w<RD_LD + 3>(), n16 = d.w<RD_N16>();
+            (void)ld0; (void)ld1; (void)ld2; (void)ld3; (void)n16;
             const int H = d.w<RD_I + 0>(), T = d.w<RD_N16 + 1>();
             LstmSeqBwdIn g;
             g.DGn16 = d.p<0>(s); g.WhhT = d.base<1>(); g.dout = d.p<2>(s); g.gates = d.p<3>(s); g.c_s = d.p<4>(s); g.c_s1 = g.c_s + (size_t)B * H;
@@ -305,6 +339,8 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
             }
           } break;
           case K_DMOLS: {
+            const int ld0 = d.w<RD_LD + 0>(), ld1 = d.w<RD_LD + 1>(), ld2 = d.w<RD_LD + 2>(), ld3 = d.w<RD_LD + 3>(), n16 = d.w<RD_N16>();
+            (void)ld0; (void)ld1; (void)ld2; (void)ld3; (void)n16;
             const Out o{d.m<5>(s), ld3, false, d.m<6>(s), n16};
             const int S = d.w<RD_I + 0>(), F = d.w<RD_I + 1>(), nmix = d.w<RD_I + 2>();
             for (int tk = 0; tk < nt; ++tk) {
@@ -332,6 +368,7 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
 #endif
 #ifdef PCHAIN_TPROF2
     if (w == 0) for (int l = 0; l < 3; ++l) a.prof[60 + l] += tq[l];
+    if (w == 0) for (int l = 3; l < 6; ++l) a.prof[70 + l] += tq[l];
 #endif
   }
 }
