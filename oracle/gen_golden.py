@@ -573,6 +573,33 @@ def gen_generate():
     save("generate.npz", **arrays)
 
 
+def gen_wavenet_stacked():
+    """WaveNet on frame stacks (the s=64 / s=256 lines of experiments/benchmarks.txt:7-8): n_stack_frames = 4 at reduced size, a
+    length that is not a multiple of the stack, full tensors and every gradient."""
+    arrays = {}
+    torch.manual_seed(43)
+    lik = DiscretizedLogisticMixtureDense(16, 1, num_mix=10, num_bins=2**16)
+    m = RM.WaveNet(likelihood=lik, n_layers=3, n_stacks=2, res_channels=16, kernel_size=2, base_dilation=2, n_stack_frames=4)
+    x, _ = O.synth_batch(3, 203, seed=9)
+    x_sl = torch.tensor([203, 150, 81])
+    x = x * (torch.arange(203).unsqueeze(0) < x_sl.unsqueeze(1))
+    for tag, pad_rf in (("s", True), ("n", False)):
+        m.zero_grad()
+        xr = x.clone().requires_grad_(True)
+        torch.manual_seed(1)
+        loss, metrics, o = m(xr, x_sl, pad_receptive_field=pad_rf)
+        loss.backward()
+        arrays.update({f"{tag}_loss": loss, f"{tag}_log_prob": o.log_prob, f"{tag}_dx": xr.grad})
+        arrays[f"{tag}_metric_names"] = np.array([mm.name for mm in metrics])
+        arrays[f"{tag}_metric_values"] = np.array([mm.value for mm in metrics], dtype=np.float64)
+        for k, p in m.named_parameters():
+            arrays[f"{tag}_grad.{k}"] = p.grad
+    arrays.update(x=x, x_sl=x_sl, rf=np.int64(m.receptive_field))
+    for k, v in m.state_dict().items():
+        arrays[f"sd.{k}"] = v
+    save("wavenet_stacked.npz", **arrays)
+
+
 def gen_generate16():
     """Ancestral sampling at widths the one-launch decoders accept (all of S, H, Z, R multiples of 16): VRNNAudio and SRNNAudio
     with SAMPLED observations.  Draw order per step (vrnn.py:405-417, srnn.py:366-392, variational.py:337,291): randn(B, z) for the
@@ -692,6 +719,6 @@ def gen_lstm():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn", "wavenet", "rssm", "cwvae", "stcn", "heads", "generate", "generate16", "data"]
+    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn", "wavenet", "rssm", "cwvae", "stcn", "heads", "generate", "generate16", "wavenet_stacked", "data"]
     for w in which:
         globals()[f"gen_{w}"]()

@@ -557,6 +557,32 @@ def test_wavenet_small_vs_reference_golden(tag, pad_rf):
     assert out.predictions.shape == out.predictions_mode.shape == (3, 50 if pad_rf else 50 - m.receptive_field, 1)
 
 
+@pytest.mark.parametrize("tag,pad_rf", [("s", True), ("n", False)])
+def test_wavenet_on_frame_stacks_vs_reference_golden(tag, pad_rf):
+    """n_stack_frames = 4 (the s=64 / s=256 lines of the reference's benchmarks.txt run this path), ragged lengths that are not
+    multiples of the stack: loss, per-utterance log-prob, metrics, input gradient and every parameter gradient vs the reference."""
+    from blvm.models import WaveNet
+    from blvm.modules.distributions import DiscretizedLogisticMixtureDense
+
+    g = np.load(os.path.join(GOLDEN, "wavenet_stacked.npz"))
+    lik = DiscretizedLogisticMixtureDense(16, 1, num_mix=10, num_bins=2**16)
+    m = WaveNet(likelihood=lik, n_layers=3, n_stacks=2, res_channels=16, kernel_size=2, base_dilation=2, n_stack_frames=4)
+    m.load_state_dict({k[3:]: T(g[k]) for k in g.files if k.startswith("sd.")})
+    m = m.to(DEV)
+    assert m.receptive_field == int(g["rf"])
+    x = T(g["x"]).to(DEV).requires_grad_(True)
+    loss, metrics, out = m(x, T(g["x_sl"]), pad_receptive_field=pad_rf)
+    loss.backward()
+    assert float(loss) == pytest.approx(float(g[f"{tag}_loss"]), rel=1e-5)
+    torch.testing.assert_close(out.log_prob.cpu(), T(g[f"{tag}_log_prob"]), rtol=1e-5, atol=1e-3)
+    vals = {mm.name: mm.value for mm in metrics}
+    for name, val in zip(g[f"{tag}_metric_names"].tolist(), g[f"{tag}_metric_values"].tolist()):
+        assert vals[name] == pytest.approx(val, rel=1e-5), name
+    assert rel_l2(x.grad, T(g[f"{tag}_dx"])) < 1e-3
+    for k, p in m.named_parameters():
+        assert rel_l2(p.grad, T(g[f"{tag}_grad.{k}"])) < 1e-3, k
+
+
 def test_wavenet_causality_by_input_gradient_and_short_input():
     """The reference's test strategy for the stack (tests/models/wavenet/test_wavenet.py:65-102): the loss on frames
     < s must not depend on inputs >= s - 1 ... checked through d(loss)/d(x); too-short inputs raise InputSizeError."""
