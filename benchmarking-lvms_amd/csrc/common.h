@@ -353,14 +353,16 @@ int transpose_f32(int M, int N, const float* X, int ldx, float* out, int ldo, hi
 // bf16 operands with fp32 accumulation for the persistent chains and K6 — the reference's `--use_amp True` regime
 // (experiments/experiment_vrnn_audio.py:219-230).  Everything stored, every epilogue and every reduction stays fp32.
 bool operand_bf16();
-// while one is alive on this thread with bf16 = true, t16_pack writes bf16 elements (the first half of dst)
+// While one is alive on this thread, t16_pack() calls on `stream` are collected and launched TOGETHER by flush() (or at the scope's
+// end); bf16 = true: the packs are written as bf16 elements (the first half of each dst).
 struct T16PackScope {
-  explicit T16PackScope(bool bf16);
+  T16PackScope(bool bf16, hipStream_t stream);
   ~T16PackScope();
+  int flush();
   T16PackScope(const T16PackScope&) = delete;
   T16PackScope& operator=(const T16PackScope&) = delete;
  private:
-  bool prev_;
+  bool prev_, prev_active_;
 };
 // dst = T16 operand layout (see wave_gemm16) of the [R,K] matrix M[r][k] = src[r * rs + k * cs]; R, K multiples of 16.
 int t16_pack(const float* src, long rs, long cs, int R, int K, float* dst, hipStream_t stream);

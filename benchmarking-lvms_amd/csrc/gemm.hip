@@ -9,6 +9,7 @@
 // done by the global->LDS stage.  Next tile is prefetched into registers while the current one is multiplied.
 // f32-in MFMA is an exact fp32 fma chain (guide §3 'FP32-input MFMA'), so results are bit-reproducible except
 // for split-K (atomic) accumulation order.
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -549,16 +550,73 @@ __global__ __launch_bounds__(256) void t16_pack_bf16_kernel(const float* __restr
   dst[w] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2));
 }
 
-namespace {
-thread_local bool g_pack_bf16 = false;
+// Several packs in ONE launch (a recurrent sequence packs 13-15 weight matrices per call, ~4 us of launch each): while a
+// T16PackScope is alive on this thread, t16_pack() only records its job; flush() (or the scope's end) launches them together.
+constexpr int kPackJobs = 40;
+struct PackJob { const float* src; float* dst; long rs, cs; int KB; unsigned n; };  // n: output words of the job
+struct PackJobs { PackJob j[kPackJobs]; };
+static_assert(sizeof(PackJobs) <= 4000, "kernel argument size");
+
+__global__ __launch_bounds__(256) void t16_pack_jobs_kernel(PackJobs a, int bf16) {
+  const PackJob q = a.j[blockIdx.y];
+  for (size_t w = (size_t)blockIdx.x * 256 + threadIdx.x; w < q.n; w += (size_t)gridDim.x * 256) {
+    const size_t i = bf16 ? 2 * w : w;
+    const int e = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    const size_t blk = i >> 8;
+    const int j = (int)(blk % q.KB);
+    const size_t t = blk / q.KB;
+    const size_t r = 16 * t + (lane & 15);
+    const int k = 16 * j + 4 * (lane >> 4) + e;
+    if (bf16) {
+      typedef float f2 __attribute__((ext_vector_type(2)));
+      typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+      const f2 v = {q.src[r * q.rs + (size_t)k * q.cs], q.src[r * q.rs + (size_t)(k + 1) * q.cs]};
+      reinterpret_cast<unsigned*>(q.dst)[w] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2));
+    } else {
+      q.dst[w] = q.src[r * q.rs + (size_t)k * q.cs];
+    }
+  }
 }
-T16PackScope::T16PackScope(bool bf16) : prev_(g_pack_bf16) { g_pack_bf16 = bf16; }
-T16PackScope::~T16PackScope() { g_pack_bf16 = prev_; }
+
+namespace {
+struct PackState {
+  bool active = false, bf16 = false;
+  int n = 0;
+  hipStream_t stream = nullptr;
+  PackJobs jobs;
+};
+thread_local PackState g_pack;
+int pack_flush() {
+  PackState& p = g_pack;
+  if (p.n == 0) return BLVM_OK;
+  unsigned most = 0;
+  for (int i = 0; i < p.n; ++i) most = std::max(most, p.jobs.j[i].n);
+  const unsigned bx = std::min<unsigned>((most + 255) / 256, 512);
+  hipLaunchKernelGGL(t16_pack_jobs_kernel, dim3(bx, (unsigned)p.n), dim3(256), 0, p.stream, p.jobs, p.bf16 ? 1 : 0);
+  p.n = 0;
+  BLVM_CHECK_LAUNCH("t16_pack_jobs");
+  return BLVM_OK;
+}
+}  // namespace
+T16PackScope::T16PackScope(bool bf16, hipStream_t stream) : prev_(g_pack.bf16), prev_active_(g_pack.active) {
+  g_pack.bf16 = bf16; g_pack.active = true; g_pack.stream = stream;
+}
+int T16PackScope::flush() { return pack_flush(); }
+T16PackScope::~T16PackScope() {
+  (void)pack_flush();  // (a caller that returned early; an error here resurfaces at the next checked launch)
+  g_pack.bf16 = prev_; g_pack.active = prev_active_;
+}
 
 int t16_pack(const float* src, long rs, long cs, int R, int K, float* dst, hipStream_t stream) {
   BLVM_REQUIRE(src && dst && R > 0 && K > 0 && R % 16 == 0 && K % 16 == 0 && aligned16(dst), "t16_pack: R=%d, K=%d must be multiples of 16", R, K);
   const size_t n = (size_t)R * K;
-  if (g_pack_bf16) {
+  BLVM_REQUIRE(n < (1ull << 31), "t16_pack: matrix too large");
+  if (g_pack.active && g_pack.stream == stream) {  // deferred: one launch for all packs of the scope
+    if (g_pack.n == kPackJobs) { const int rc = pack_flush(); if (rc) return rc; }
+    g_pack.jobs.j[g_pack.n++] = PackJob{src, dst, rs, cs, K / 16, (unsigned)(g_pack.bf16 ? n / 2 : n)};
+    return BLVM_OK;
+  }
+  if (g_pack.bf16) {
     hipLaunchKernelGGL(t16_pack_bf16_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, stream, src, rs, cs, K / 16, n / 2, reinterpret_cast<unsigned*>(dst));
     BLVM_CHECK_LAUNCH("t16_pack_bf16");
     return BLVM_OK;

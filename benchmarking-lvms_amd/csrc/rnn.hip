@@ -359,8 +359,10 @@ extern "C" int blvm_lstm_seq_fwd(const float* Wih, const float* Whh, const float
   if (c0) BLVM_HIP(hipMemcpyAsync(rs.Cs, c0, sizeof(float) * bh, hipMemcpyDeviceToDevice, s));
   else BLVM_HIP(hipMemsetAsync(rs.Cs, 0, sizeof(float) * bh, s));
   const bool bf16_seq = pchain_bf16(B) && seq_persistent(T, B);  // bf16-operand mode of the persistent path
-  const T16PackScope pack_scope(bf16_seq);
+  T16PackScope pack_scope(bf16_seq, s);
   rc = t16_pack_rows(Whh, H, 4 * H, H, rs.WhhP, s);  // operand layout of the chain (once per sequence)
+  if (rc) return rc;
+  rc = pack_scope.flush();
   if (rc) return rc;
   if (seq_persistent(T, B)) {
     // one persistent launch for the whole sequence (pchain.hip): one link per step — the hidden projection with the gate math
@@ -417,8 +419,10 @@ extern "C" int blvm_lstm_seq_bwd(const float* Wih, const float* Whh, const float
   carve_lstm_ws(workspace, T, B, H, &ws);
   const size_t n = (size_t)T * B, bh = (size_t)B * H;
   const bool bf16_seq = pchain_bf16(B) && seq_persistent(T, B);  // bf16-operand mode of the persistent path
-  const T16PackScope pack_scope(bf16_seq);
+  T16PackScope pack_scope(bf16_seq, s);
   rc = t16_pack_transposed(Whh, H, 4 * H, H, ws.WhhT, s);
+  if (rc) return rc;
+  rc = pack_scope.flush();
   if (rc) return rc;
   BLVM_HIP(hipMemsetAsync(ws.DC, 0, sizeof(float) * bh, s));
   if (seq_persistent(T, B)) {
@@ -492,8 +496,10 @@ extern "C" int blvm_gru_seq_fwd(const float* Wih, const float* Whh, const float*
   if (h0) BLVM_HIP(hipMemcpyAsync(rs.Hs, h0, sizeof(float) * br, hipMemcpyDeviceToDevice, s));
   else BLVM_HIP(hipMemsetAsync(rs.Hs, 0, sizeof(float) * br, s));
   const bool bf16_seq = pchain_bf16(B) && seq_persistent(T, B);  // bf16-operand mode of the persistent path
-  const T16PackScope pack_scope(bf16_seq);
+  T16PackScope pack_scope(bf16_seq, s);
   rc = t16_pack_rows(Whh, R, 3 * R, R, rs.WhhP, s);  // operand layout of the chain (once per sequence)
+  if (rc) return rc;
+  rc = pack_scope.flush();
   if (rc) return rc;
   if (seq_persistent(T, B)) {
     using namespace pchain;
@@ -550,8 +556,10 @@ extern "C" int blvm_gru_seq_bwd(const float* Wih, const float* Whh, const float*
   carve_gru_ws(workspace, T, B, R, &ws);
   const size_t n = (size_t)T * B, br = (size_t)B * R;
   const bool bf16_seq = pchain_bf16(B) && seq_persistent(T, B);  // bf16-operand mode of the persistent path
-  const T16PackScope pack_scope(bf16_seq);
+  T16PackScope pack_scope(bf16_seq, s);
   rc = t16_pack_transposed(Whh, R, 3 * R, R, ws.WhhT, s);
+  if (rc) return rc;
+  rc = pack_scope.flush();
   if (rc) return rc;
   BLVM_HIP(hipMemsetAsync(ws.G, 0, sizeof(float) * br, s));
   if (seq_persistent(T, B)) {

@@ -219,7 +219,7 @@ extern "C" int blvm_rssm_seq_fwd(const BlvmRssmWeights* w, const float* enc, con
   rc = gemm_f32(0, 0, (int)n, H, E, enc, E, w->post_w[0] + H, ldq, rs.XQ, H, w->post_b[0], 0, 0.f, nullptr, 0, 0, 1, s);
   if (rc) return rc;
   // T16 operand copies of the chain's weights (once per sequence): z columns of the GRU input layer, h columns of post_w0
-  const T16PackScope pack_scope(pchain_bf16(B));  // bf16-operand mode: the persistent launch multiplies bf16 weight packs
+  T16PackScope pack_scope(pchain_bf16(B), s);  // bf16-operand mode: the persistent launch multiplies bf16 weight packs
   rc = t16_pack_rows(w->gin_w, ldg, H, Z, rs.Wgz, s); if (rc) return rc;
   rc = t16_pack_rows(w->gru_wih, H, 3 * H, H, rs.Wih, s); if (rc) return rc;
   rc = t16_pack_rows(w->gru_whh, H, 3 * H, H, rs.Whh, s); if (rc) return rc;
@@ -231,6 +231,8 @@ extern "C" int blvm_rssm_seq_fwd(const BlvmRssmWeights* w, const float* enc, con
   }
   rc = t16_pack_rows(w->post_hw, H, 2 * Z, H, rs.Wqh, s); if (rc) return rc;
   rc = t16_pack_rows(w->prior_hw, H, 2 * Z, H, rs.Wph, s); if (rc) return rc;
+  rc = pack_scope.flush();  // all packs above in one launch
+  if (rc) return rc;
   if (z0) BLVM_HIP(hipMemcpyAsync(zs, z0, sizeof(float) * (size_t)B * Z, hipMemcpyDeviceToDevice, s));
   else BLVM_HIP(hipMemsetAsync(zs, 0, sizeof(float) * (size_t)B * Z, s));
   if (h0) BLVM_HIP(hipMemcpyAsync(hs, h0, sizeof(float) * (size_t)B * H, hipMemcpyDeviceToDevice, s));
@@ -359,7 +361,7 @@ extern "C" int blvm_rssm_seq_bwd(const BlvmRssmWeights* w, const float* enc, con
   const int ldg = Z + C, ldq = H + E;
   const float beta = (float)(0.6931471805599453 / (1.0 - (double)sd_eps));
 #define TRY(x) do { rc = (x); if (rc) return rc; } while (0)
-  const T16PackScope pack_scope(pchain_bf16(B));  // bf16-operand mode: the persistent launch multiplies bf16 weight packs
+  T16PackScope pack_scope(pchain_bf16(B), s);  // bf16-operand mode: the persistent launch multiplies bf16 weight packs
   TRY(t16_pack_transposed(w->gin_w, ldg, H, Z, ws.gzT, s));
   TRY(t16_pack_transposed(w->gru_wih, H, 3 * H, H, ws.wihT, s));
   TRY(t16_pack_transposed(w->gru_whh, H, 3 * H, H, ws.whhT, s));
@@ -371,6 +373,7 @@ extern "C" int blvm_rssm_seq_bwd(const BlvmRssmWeights* w, const float* enc, con
   }
   TRY(t16_pack_transposed(w->post_hw, H, 2 * Z, H, ws.qhT, s));
   TRY(t16_pack_transposed(w->prior_hw, H, 2 * Z, H, ws.phT, s));
+  TRY(pack_scope.flush());
   BLVM_HIP(hipMemsetAsync(ws.G, 0, sizeof(float) * bh, s));
   const int rt = (B + 15) / 16;
   const bool persistent = pchain_applies(B) && device_cus() >= 32;

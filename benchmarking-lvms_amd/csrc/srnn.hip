@@ -111,7 +111,7 @@ extern "C" int blvm_srnn_latent_fwd(const BlvmSrnnWeights* w, const float* d, co
   rc = gemm_f32(0, 0, (int)n, H, R, a, R, w->post_w[0], ldw0, rs.XQ, H, w->post_b[0], 0, 0.f, nullptr, 0, 0, 1, s);
   if (rc) return rc;
   // T16 operand copies of the chain's weights (once per sequence); layer 0: the z columns
-  const T16PackScope pack_scope(pchain_bf16(B));  // bf16-operand mode: the persistent launch multiplies bf16 weight packs
+  T16PackScope pack_scope(pchain_bf16(B), s);  // bf16-operand mode: the persistent launch multiplies bf16 weight packs
   rc = t16_pack_rows(w->prior_w[0] + R, ldw0, H, Z, rs.Wp[0], s); if (rc) return rc;
   rc = t16_pack_rows(w->post_w[0] + R, ldw0, H, Z, rs.Wq[0], s); if (rc) return rc;
   for (int k = 1; k < 3; ++k) {
@@ -120,6 +120,8 @@ extern "C" int blvm_srnn_latent_fwd(const BlvmSrnnWeights* w, const float* d, co
   }
   rc = t16_pack_rows(w->prior_hw, H, 2 * Z, H, rs.Wph, s); if (rc) return rc;
   rc = t16_pack_rows(w->post_hw, H, 2 * Z, H, rs.Wqh, s); if (rc) return rc;
+  rc = pack_scope.flush();  // all packs above in one launch
+  if (rc) return rc;
   if (z0) BLVM_HIP(hipMemcpyAsync(zs, z0, sizeof(float) * (size_t)B * Z, hipMemcpyDeviceToDevice, s));
   else BLVM_HIP(hipMemsetAsync(zs, 0, sizeof(float) * (size_t)B * Z, s));
   const int rt = (B + 15) / 16;
@@ -208,7 +210,7 @@ extern "C" int blvm_srnn_latent_bwd(const BlvmSrnnWeights* w, const float* d, co
   const int ldw0 = R + Z;
   const float beta = (float)(0.6931471805599453 / (1.0 - (double)sd_eps));
 #define TRY(x) do { rc = (x); if (rc) return rc; } while (0)
-  const T16PackScope pack_scope(pchain_bf16(B));  // bf16-operand mode: the persistent launch multiplies bf16 weight packs
+  T16PackScope pack_scope(pchain_bf16(B), s);  // bf16-operand mode: the persistent launch multiplies bf16 weight packs
   TRY(t16_pack_transposed(w->prior_w[0] + R, ldw0, H, Z, ws.pzT, s));
   TRY(t16_pack_transposed(w->post_w[0] + R, ldw0, H, Z, ws.qzT, s));
   for (int k = 1; k < 3; ++k) {
@@ -217,6 +219,7 @@ extern "C" int blvm_srnn_latent_bwd(const BlvmSrnnWeights* w, const float* d, co
   }
   TRY(t16_pack_transposed(w->prior_hw, H, 2 * Z, H, ws.phT, s));
   TRY(t16_pack_transposed(w->post_hw, H, 2 * Z, H, ws.qhT, s));
+  TRY(pack_scope.flush());
   const int rt = (B + 15) / 16;
   const bool persistent = pchain_applies(B) && device_cus() >= 32;
   if (persistent) {

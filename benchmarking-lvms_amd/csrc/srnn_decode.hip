@@ -75,7 +75,7 @@ extern "C" int blvm_srnn_generate(const BlvmSrnnDecodeWeights* w, const float* x
   const BlvmSrnnWeights* c = w->chain;
   const SdPack p = sd_pack_layout(S, H, Z, R);
   const SdBufs b = sd_layout(p.total, T, B, S, H, Z, R);
-  const T16PackScope pack_scope(pchain_bf16(B));
+  T16PackScope pack_scope(pchain_bf16(B), s);
   int rc;
 #define PACK(dst, src, ld, rows, k)                               \
   do {                                                            \
@@ -88,6 +88,8 @@ extern "C" int blvm_srnn_generate(const BlvmSrnnDecodeWeights* w, const float* x
   PACK(p.prior_h, c->prior_hw, H, 2 * Z, H);
   PACK(p.dec[0], w->dec_w[0], Z + R, H, Z + R); PACK(p.dec[1], w->dec_w[1], H, H, H); PACK(p.dec[2], w->dec_w[2], H, S * SD_F, H);
 #undef PACK
+  rc = pack_scope.flush();  // all packs above in one launch
+  if (rc) return rc;
   const int rt = (B + 15) / 16, ctS = S / 16, ctH = H / 16, ctZ = Z / 16, ctR = R / 16, cus = device_cus() & ~7;
   const int nCP = (R + Z) / 16, nDC = (Z + R) / 16;
   const long rows = (long)rt * 16, xS = rows * S, xH = rows * H, xCP = rows * (R + Z), xDC = rows * (Z + R);

@@ -304,7 +304,7 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
   if (rc) return rc;
 
   // T16 operand copies of the chain's weights (once per sequence)
-  const T16PackScope pack_scope(pchain_bf16(B));  // bf16-operand mode: the persistent launch multiplies bf16 weight packs
+  T16PackScope pack_scope(pchain_bf16(B), s);  // bf16-operand mode: the persistent launch multiplies bf16 weight packs
   rc = t16_pack_rows(w->prior_w[0], R, H, R, rs.Wp[0], s); if (rc) return rc;
   rc = t16_pack_rows(w->post_w[0], R + X, H, R, rs.Wq[0], s); if (rc) return rc;  // the h columns
   for (int l = 1; l < 3; ++l) {
@@ -317,6 +317,8 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
   for (int l = 1; l < 4; ++l) { rc = t16_pack_rows(w->phi_w[l], H, H, H, rs.Wf[l], s); if (rc) return rc; }
   rc = t16_pack_rows(w->gru_wih + X, X + H, 3 * R, H, rs.Wih, s); if (rc) return rc;  // the phi columns
   rc = t16_pack_rows(w->gru_whh, R, 3 * R, R, rs.Whh, s); if (rc) return rc;
+  rc = pack_scope.flush();  // all packs above in one launch
+  if (rc) return rc;
 
   // initial state -> h-part of decin row 0
   if (h0) BLVM_HIP(hipMemcpy2DAsync(decin + H, sizeof(float) * ldd, h0, sizeof(float) * R, sizeof(float) * R, B, hipMemcpyDeviceToDevice, s));
@@ -477,7 +479,7 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
   const float beta = (float)(0.6931471805599453 / (1.0 - (double)sd_eps));
 
   // transposed T16 operand copies of every weight the chain multiplies from the right
-  const T16PackScope pack_scope(pchain_bf16(B));  // bf16-operand mode: the persistent launch multiplies bf16 weight packs
+  T16PackScope pack_scope(pchain_bf16(B), s);  // bf16-operand mode: the persistent launch multiplies bf16 weight packs
   rc = t16_pack_transposed(w->prior_w[0], R, H, R, ws.pT[0], s); if (rc) return rc;
   rc = t16_pack_transposed(w->prior_w[1], H, H, H, ws.pT[1], s); if (rc) return rc;
   rc = t16_pack_transposed(w->prior_w[2], H, H, H, ws.pT[2], s); if (rc) return rc;
@@ -490,6 +492,8 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
   for (int i = 1; i < 4; ++i) { rc = t16_pack_transposed(w->phi_w[i], H, H, H, ws.fT[i], s); if (rc) return rc; }
   rc = t16_pack_transposed(w->gru_wih + X, X + H, 3 * R, H, ws.wihT, s); if (rc) return rc;
   rc = t16_pack_transposed(w->gru_whh, R, 3 * R, R, ws.whhT, s); if (rc) return rc;
+  rc = pack_scope.flush();  // all packs above in one launch
+  if (rc) return rc;
 
   BLVM_HIP(hipMemsetAsync(ws.G, 0, sizeof(float) * (size_t)B * R, s));
   const int rt = (B + 15) / 16;

@@ -557,7 +557,7 @@ extern "C" int blvm_vrnn_generate(const BlvmVrnnDecodeWeights* w, const float* x
   const VdPack p = vd_pack_layout(S, H, Z, R);
   const VgBufs b = vg_layout(p.total, T, B, S, H, Z, R);
   int rc;
-  const T16PackScope pack_scope(pchain_bf16(B));
+  T16PackScope pack_scope(pchain_bf16(B), s);
 #define PACK(dst, src, ld, rows, k)                               \
   do {                                                            \
     rc = t16_pack_rows(src, ld, rows, k, scratch + (dst), s);     \
@@ -571,6 +571,8 @@ extern "C" int blvm_vrnn_generate(const BlvmVrnnDecodeWeights* w, const float* x
   PACK(p.wih, c->gru_wih, 2 * H, 3 * R, 2 * H); PACK(p.whh, c->gru_whh, R, 3 * R, R);
   PACK(p.dec[0], w->dec_w[0], H + R, H, H + R); PACK(p.dec[1], w->dec_w[1], H, H, H); PACK(p.dec[2], w->dec_w[2], H, S * VD_F, H);
 #undef PACK
+  rc = pack_scope.flush();  // all packs above in one launch
+  if (rc) return rc;
   const int rt = (B + 15) / 16, ctS = S / 16, ctH = H / 16, ctZ = Z / 16, ctR = R / 16, X = H, cus = device_cus() & ~7;
   const long rows = (long)rt * 16, xS = rows * S, xH = rows * H, xZ = rows * Z, xR = rows * R, xC = rows * (X + H), xD = rows * (H + R);
   const long sR = (long)B * R, s3R = 3 * sR, sZ = (long)B * Z, sF = (long)B * S * VD_F;
