@@ -104,9 +104,12 @@ struct Poll {
 };
 
 // which activation operand product g multiplies
-struct MapSame { static constexpr int of(int) { return 0; } };        // every product reads A[0]           (GRU / LSTM gates)
-struct MapId { static constexpr int of(int g) { return g; } };        // product g reads A[g]               (dh: DP0 | DQ0)
-struct MapPairs { static constexpr int of(int g) { return g >> 1; } };  // products 2a, 2a+1 read A[a]       (both Gaussian heads)
+struct MapSame { static constexpr int of(int) { return 0; } static constexpr bool sum = false; };        // every product reads A[0]     (GRU / LSTM gates)
+struct MapId { static constexpr int of(int g) { return g; } static constexpr bool sum = false; };        // product g reads A[g]         (dh: DP0 | DQ0)
+struct MapPairs { static constexpr int of(int g) { return g >> 1; } static constexpr bool sum = false; };  // products 2a, 2a+1 read A[a] (both Gaussian heads)
+// every product reads the SUM of all GA operands: the operand was produced in GA parts by links that split a long K among
+// themselves (each part a full [rows, K] slab of partial sums) and is added up in the consumer's registers
+struct MapSum { static constexpr int of(int) { return 0; } static constexpr bool sum = true; };
 
 // ---- polled 16x16xK products ------------------------------------------------------------------------------------------------
 // acc[g] += A[AMap(g)][r0+i][k] W[g][c0[g]+j][k] over the k-chunks owned by `wave` (chunk = 16 k, waves interleave chunks), W in
@@ -183,6 +186,12 @@ __device__ __forceinline__ void mgemm_trip(const rsrc_t (&ar)[GA], unsigned aoff
     pl.t_ok = wall_clock64();
 #endif
   }
+  if constexpr (AMap::sum) {
+#pragma unroll
+    for (int u = 0; u < CH; ++u)
+#pragma unroll
+      for (int ga = 1; ga < GA; ++ga) a[0][u] += a[ga][u];
+  }
   if constexpr (BF) {
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
@@ -209,7 +218,7 @@ __device__ __forceinline__ void mgemm_trip(const rsrc_t (&ar)[GA], unsigned aoff
 template <int NW, bool BF, int GA, int G, class AMap, class Mid = NoMid>
 __device__ __forceinline__ void mgemm16(const float* const (&A)[GA], const int (&lda)[GA], bool polled, int r0, int nrows,
                                         const float* const (&W)[G], const int (&c0)[G], int K, f32x4 (&acc)[G], Poll& pl, Mid mid = Mid(),
-                                        int a_width = 0) {  // a_width: columns of the polled T16 slab when it is wider than K (a concatenation's first part)
+                                        int a_width = 0, int w_width = 0) {  // a_width / w_width: columns of the polled T16 slab / of the packed weight rows when wider than K (the product covers a K-range of them; the pointers start at the range)
   constexpr int STEP = NW * 16;
   // fragment registers of a trip: 4 * CH * (G + GA); trips of 6 / 4 / 2 / 1 chunks (K = 256, 512, 1536 on 8 waves: 2, 4, 6 + 6)
   constexpr int FR = 12 / (G + GA);
@@ -227,7 +236,7 @@ __device__ __forceinline__ void mgemm16(const float* const (&A)[GA], const int (
   }
   const unsigned aoff = 4u * ((unsigned)(r0 >> 4) * 16u * (unsigned)(a_width > 0 ? a_width : K) + 4u * (unsigned)lane);  // T16: row tile's slab + this lane's fragment
 #pragma unroll
-  for (int g = 0; g < G; ++g) wp[g] = reinterpret_cast<const char*>(W[g]) + (BF ? 2 : 4) * ((size_t)c0[g] * K + 4 * lane);
+  for (int g = 0; g < G; ++g) wp[g] = reinterpret_cast<const char*>(W[g]) + (BF ? 2 : 4) * ((size_t)c0[g] * (w_width > 0 ? w_width : K) + 4 * lane);
   int nch = (K / 16 - wave + NW - 1) / NW;  // chunks wave, wave + NW, ... below K / 16 (wave-uniform)
   int kc = wave * 16;
   bool mid_pending = true;
@@ -355,7 +364,7 @@ struct LinLate {
 };
 template <int NW, bool BF, class Late>
 __device__ __forceinline__ void tile_lin_late(const float* A, int lda, bool a_polled, const float* W, int K, Late& late, int r0, int c0, int B,
-                                              float* red, Poll& pl) {
+                                              float* red, Poll& pl, const float* A2 = nullptr, const float* A3 = nullptr, int w_width = 0) {
   const int t = threadIdx.x & 255;
   const int row = r0 + (t >> 4), col = c0 + (t & 15);
   const bool own = threadIdx.x < 256 && row < B;
@@ -373,11 +382,16 @@ __device__ __forceinline__ void tile_lin_late(const float* A, int lda, bool a_po
     if (L.add && !L.add_polled) e_add = L.add[(size_t)rowc * L.ldadd + col];
   };
   f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-  {
+  if (A2 != nullptr) {  // (uniform) the operand arrives as three partial-sum slabs
+    const float* const As[3] = {A, A2, A3};
+    const float* const Ws[1] = {W};
+    const int la[3] = {0, 0, 0}, cs[1] = {c0};
+    mgemm16<NW, BF, 3, 1, MapSum>(As, la, true, r0, B, Ws, cs, K, acc, pl, prefetch, lda, w_width);
+  } else {
     const float* const As[1] = {A};
     const float* const Ws[1] = {W};
     const int la[1] = {lda}, cs[1] = {c0};
-    mgemm16<NW, BF, 1, 1, MapSame>(As, la, a_polled, r0, B, Ws, cs, K, acc, pl, prefetch, a_polled ? lda : 0);  // polled: lda = slab width (0 = K)
+    mgemm16<NW, BF, 1, 1, MapSame>(As, la, a_polled, r0, B, Ws, cs, K, acc, pl, prefetch, a_polled ? lda : 0, w_width);  // polled: lda = slab width (0 = K)
   }
   float v[1];
   reduce_tiles<1, NW>(acc, red, v);
@@ -972,6 +986,7 @@ enum DescFlag : int {
   DF_RM_SC1 = 8,       // the row-major output is polled word-wise by other workgroups
   DF_GENTLE = 16,      // off the critical path: nap between polls
   DF_CANARY = 32,      // one-word canary wait in front of the operand poll
+  DF_A_SUM3 = 64,      // K_LIN: the polled operand is the sum of three slabs (p[0], p[8], p[9]) of partial sums
 };
 constexpr int kMaxDesc = 24, kMaxPtr = 20;
 struct Desc {

@@ -3,7 +3,8 @@
 // forward and one backward launch.  Pointer roles of a descriptor by tile kind:
 //
 //   K_LIN   p: 0 A (T16 copy, polled, ld[0] = its width when wider than K | row-major when DF_A_PLAIN, ld[0])  1 W (T16)  2 bias  3 add (ld[1])  4 gate (ld[2])
-//              5 out row-major (ld[3])  6 out T16 (n16[0])  7 second out T16 (n16[1])            f: 0 slope
+//              5 out row-major (ld[3])  6 out T16 (n16[0])  7 second out T16 (n16[1])  8, 9 (DF_A_SUM3) two more slabs of A: the
+//              operand is the sum of the three            i: 0 width of W's packed rows when the product covers a K-range of them            f: 0 slope
 //   K_HEAD  p: 0 P16  1 Q16  2 Wp  3 bp  4 Wq  5 bq  6 eps  7 mu_p  8 sd_p  9 mu_q  10 sd_q  11 raw_p  12 raw_q  13 muq_raw
 //              14 z row-major (ld[3])  15 z T16 (n16[0])  16 second z T16 (n16[1])    i: 0 Z  1 residual      f: 0 beta  1 1/beta  2 sd_eps
 //   K_GRU   p: 0 X16  1 Wih (T16)  2 xg  3 gh (polled words)  4 h_prev (polled words, ld[0])  5 h_new row-major (ld[3])
@@ -196,7 +197,8 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
             // descriptor's fetch) is done by `late`, which the tile calls once its first loads are in flight.
             const bool a_polled = !(flags & DF_A_PLAIN);
             const float *A = d.p<0>(s), *W = d.base<1>();
-            const int ld0 = d.w<RD_LD + 0>();
+            const float *A2 = (flags & DF_A_SUM3) ? d.p<8>(s) : nullptr, *A3 = (flags & DF_A_SUM3) ? d.p<9>(s) : nullptr;
+            const int ld0 = d.w<RD_LD + 0>(), w_width = d.w<RD_I + 0>();
 #ifdef PCHAIN_TPROF2
             const unsigned long long tqb = wall_clock64();
             tq[4] += tqb - tqa;
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
               const unsigned long long tq1 = wall_clock64();
               tq[0] += tq1 - tq0;
 #endif
-              tile_lin_late<NW, BF>(A, ld0, a_polled, W, K, late, tr0, tc0, B, red(), pl);
+              tile_lin_late<NW, BF>(A, ld0, a_polled, W, K, late, tr0, tc0, B, red(), pl, A2, A3, w_width);
 #ifdef PCHAIN_TPROF2
               tq_end = wall_clock64();
               tq[1] += tq_end - tq1;

@@ -183,7 +183,8 @@ struct BwdWs {
   float *DGI, *DGH, *DPHI[4], *DQH, *DPH, *DP[3], *DQ[3], *G;
   // persistent backward (B <= kPchainCarveMaxB): the running state gradient as per-step slabs (written once each), [T',B,R], and
   // T16 copies of every gradient a link multiplies, per step [rt*16, width]
-  float *GA, *GB, *DP16[3], *DQ16[3], *DGI16, *DGH16, *DPHI16[4], *DPH16, *DQH16, *x16_end;
+  float *GA, *GB, *DP16[3], *DQ16[3], *DGI16, *DGH16, *DPHI16[4], *DPH16, *DQH16, *DPHI16b, *DPHI16c, *x16_end;
+  float *DPHI3b, *DPHI3c;  // row-major partial sums of DPHI[3] when its K = 3R product is split over three links (added up after the launch)
 };
 
 size_t carve_ws(float* base, int Tp, int B, int X, int H, int Z, int R, BwdWs* w) {
@@ -214,7 +215,9 @@ size_t carve_ws(float* base, int Tp, int B, int X, int H, int Z, int R, BwdWs* w
     t.DGI16 = take(m * 3 * R); t.DGH16 = take(m * 3 * R);
     for (int i = 0; i < 4; ++i) t.DPHI16[i] = take(m * H);
     t.DPH16 = take(m * 2 * Z); t.DQH16 = take(m * 2 * Z);
+    t.DPHI16b = take(m * H); t.DPHI16c = take(m * H);
     t.x16_end = take(0);
+    t.DPHI3b = take(n * H); t.DPHI3c = take(n * H);
   }
   if (w) *w = t;
   return off;
@@ -251,6 +254,16 @@ inline int overlap_chunk_steps() {
 }
 
 
+// a += b + c over n4 float4 (the three partial sums of DPHI[3])
+__global__ __launch_bounds__(256) void add3_kernel(float4* __restrict__ a, const float4* __restrict__ b, const float4* __restrict__ c, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 x = a[i];
+    const float4 y = b[i], z = c[i];
+    x.x += y.x + z.x; x.y += y.y + z.y; x.z += y.z + z.z; x.w += y.w + z.w;
+    a[i] = x;
+  }
+}
+
 // parts the persistent backward sequence is cut into so that finished rows' batched GEMMs overlap the rest (1 = no overlap)
 inline int pchain_wgrad_parts() {
   static int v = [] {
@@ -258,6 +271,15 @@ inline int pchain_wgrad_parts() {
     return e ? atoi(e) : 1;
   }();
   return v;
+}
+
+// the K = 3R link of the persistent backward as three K = R links (env BLVM_PCHAIN_SPLIT3=0: one link)
+inline bool pchain_split3() {
+  static int v = [] {
+    const char* e = getenv("BLVM_PCHAIN_SPLIT3");
+    return e ? atoi(e) : 1;
+  }();
+  return v != 0;
 }
 
 int check_dims(int Tp, int B, int X, int H, int Z, int R) {
@@ -586,12 +608,37 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
       d.ld[1] = ldadd; d.ld[2] = ldgate; d.ld[3] = ldo; d.n16[0] = n16; d.f[0] = 0.f;
     };
     // Bb: dphi through the GRU input projection (+ the decoder's gradient, through phi's ReLU) | GB[t] = GA[t] + DGH[t] W_hh
-    lin(ws.DGI16, x3R, ws.wihT, 3 * R, d_decin, sD, ldd, decin, sD, ldd, ws.DPHI[3], sH, H, ws.DPHI16[3], xH, ctH, ctH, 0, range_for(ctH * rt, g), 0);
+    // The K = 3R product is the fattest link of the step (96 KB of operands per tile): when a third range of workgroups is free it
+    // runs as three K = R links side by side (the r | u | n thirds of DGI and of W_ih^T), each writing a full slab of partial sums
+    // (the derivative mask distributes over the sum; the decoder's gradient joins the first), and B3 adds the three slabs up as it
+    // loads them.
+    const int spare = cus - g - def_n;
+    const bool split3 = spare >= 8 && half >= 8 && pchain_split3();
+    if (split3) {
+      const size_t wthird = (size_t)ctR * 256 / (bld.p.bf16 ? 2 : 1);  // the packed weight's k-chunks [ctR * part, ...) (bf16 packs: half the floats)
+      float* const orm[3] = {ws.DPHI[3], ws.DPHI3b, ws.DPHI3c};
+      float* const o16[3] = {ws.DPHI16[3], ws.DPHI16b, ws.DPHI16c};
+      const int wg0s[3] = {0, half, g + def_n}, nwgs[3] = {range_for(ctH * rt, half), range_for(ctH * rt, half), range_for(ctH * rt, spare)};
+      for (int part = 0; part < 3; ++part) {
+        lin(ws.DGI16 + (size_t)part * ctR * 256, x3R, ws.wihT + part * wthird, R, part == 0 ? d_decin : nullptr, sD, ldd, decin, sD, ldd, orm[part], sH, H, o16[part], xH,
+            ctH, ctH, wg0s[part], nwgs[part], 0);
+        Desc& d = bld.p.d[bld.p.ndesc - 1];
+        d.ld[0] = 3 * R; d.i[0] = 3 * R;  // widths of the slab / of the packed rows the K-range is taken from
+      }
+    } else {
+      lin(ws.DGI16, x3R, ws.wihT, 3 * R, d_decin, sD, ldd, decin, sD, ldd, ws.DPHI[3], sH, H, ws.DPHI16[3], xH, ctH, ctH, 0, range_for(ctH * rt, g), 0);
+    }
     lin(ws.DGH16, x3R, ws.whhT, 3 * R, ws.GA, sR, R, nullptr, 0, 0, ws.GB, sR, R, nullptr, 0, 0, ctR, g, def_n,
         DF_ADD_POLLED | DF_RM_SC1 | DF_GENTLE | ((pchain_tune() & 16) ? DF_CANARY : 0));
     // B3..B5: back through phi_z layers 3, 2, 1
-    for (int l = 3; l >= 1; --l)
-      lin(ws.DPHI16[l], xH, ws.fT[l], H, nullptr, 0, 0, rs.FZ[l - 1], sH, H, ws.DPHI[l - 1], sH, H, ws.DPHI16[l - 1], xH, ctH, ctH, 0, range_for(ctH * rt, g), 0);
+    for (int l = 3; l >= 1; --l) {
+      lin(ws.DPHI16[l], xH, ws.fT[l], H, nullptr, 0, 0, rs.FZ[l - 1], sH, H, ws.DPHI[l - 1], sH, H, ws.DPHI16[l - 1], xH, ctH, ctH, 0, range_for(ctH * rt, g),
+          l == 3 && split3 ? DF_A_SUM3 : 0);
+      if (l == 3 && split3) {
+        Desc& d = bld.p.d[bld.p.ndesc - 1];
+        bld.ptr(d, 8, ws.DPHI16b + (long)(T - 1) * xH, -xH); bld.ptr(d, 9, ws.DPHI16c + (long)(T - 1) * xH, -xH);
+      }
+    }
     {  // B6: dz and the heads
       Desc& d = bld.add(K_DZ, ctZ, 0, range_for(ctZ * rt, g), H, 0, 0, T);
       bld.ptr(d, 0, last(ws.DPHI16[0], xH), -xH); bld.ptr(d, 1, ws.fT[0]); bld.ptr(d, 2, nullptr); bld.ptr(d, 3, nullptr); bld.ptr(d, 4, nullptr);
@@ -618,9 +665,16 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     // The batched GEMMs of the steps the chain has passed can run UNDER the rest of the chain (which keeps a quarter of the chip
     // busy): the sequence is cut into `parts` launches, after each the finished rows go to a low-priority side stream.
     const int parts = std::max(1, std::min(pchain_wgrad_parts(), T / 8));
+    auto add_partials = [&](size_t r0, size_t nr) {  // DPHI[3] rows [r0, r0 + nr) += the two other partial sums
+      if (!split3 || nr == 0) return;
+      const size_t n4 = nr * H / 4;
+      hipLaunchKernelGGL(add3_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 2048)), dim3(256), 0, s, reinterpret_cast<float4*>(ws.DPHI[3] + r0 * H),
+                         reinterpret_cast<const float4*>(ws.DPHI3b + r0 * H), reinterpret_cast<const float4*>(ws.DPHI3c + r0 * H), n4);
+    };
     if (parts == 1) {
       rc = pchain_launch(bld.p, s);
       if (rc) return rc;
+      add_partials(0, n);
       return batched(0, n, s);
     }
     SideStream& sd = side_stream();
@@ -637,6 +691,7 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
       rc = pchain_launch(bld.p, s);
       if (rc) return rc;
       const int fin = std::min(s_end, T);
+      add_partials((size_t)(T - fin) * B, (size_t)(fin - done_steps) * B);
       // (all ranges on the ONE side stream: two of them accumulating into the same gradient must not run concurrently)
       BLVM_HIP(hipEventRecord(sd.ready, s));
       BLVM_HIP(hipStreamWaitEvent(sd.stream, sd.ready, 0));
