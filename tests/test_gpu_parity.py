@@ -333,6 +333,28 @@ def test_full_size_properties():
 # ----------------------------------------------------------------------------------------------------------------------
 
 
+@pytest.mark.parametrize("B,N,L", [(8, 256, 300), (64, 192, 200), (37, 512, 120)])
+def test_persistent_engine_chain_of_links_vs_torch(B, N, L):
+    """The engine itself (`blvm_pchain_chain_probe`): a chain of L dependent links x <- relu(x W^T + b) as a one-descriptor program
+    (sentinel-polled T16 hand-offs, ragged last row tile) against float64 torch, every link's output."""
+    lib = _hip.load()
+    torch.manual_seed(B + N)
+    W = ((torch.rand(N, N) * 2 - 1) * 2.45 / N**0.5).to(DEV)
+    b = ((torch.rand(N) * 2 - 1) * 0.1).to(DEV)
+    x0 = (torch.rand(B, N) * 2 - 1).to(DEV)
+    rows = (B + 15) // 16 * 16
+    W16, x16, xs = torch.empty(N * N, device=DEV), torch.empty((L + 1) * rows * N, device=DEV), torch.empty(L, B, N, device=DEV)
+    _hip.check(lib.blvm_pchain_rows_to_t16(_hip.ptr(W), N, N, N, _hip.ptr(W16), _hip.stream_ptr()), "t16 W")
+    _hip.check(lib.blvm_pchain_rows_to_t16(_hip.ptr(x0), N, B, N, _hip.ptr(x16), _hip.stream_ptr()), "t16 x")
+    _hip.check(lib.blvm_pchain_chain_probe(_hip.ptr(W16), _hip.ptr(b), _hip.ptr(x16), _hip.ptr(xs), B, N, L, 0, _hip.stream_ptr()), "chain probe")
+    torch.cuda.synchronize()
+    _hip.check_async()
+    x, Wd, bd = x0.double(), W.double(), b.double()
+    for s in range(L):
+        x = torch.relu(x @ Wd.t() + bd)
+        assert rel_l2(xs[s], x) < 1e-5 * (1 + s / 20), s  # fp32 round-off accumulates along the chain
+
+
 @pytest.fixture(params=[True, False], ids=["one_launch", "launch_per_step"])
 def sequence_path(request):
     """Both execution paths of K1-K5: the whole sequence as one persistent launch | one launch per step."""
