@@ -204,3 +204,22 @@ def test_wavenet_c5_dims_bf16_delta_within_budget():
     grads = dict(m.named_parameters())
     for name, ref in zip(g["f_grad_names"].tolist(), g["f_grad_norms"].tolist()):
         assert grads[name].grad.double().norm().item() == pytest.approx(ref, rel=5e-2), name
+
+
+def test_one_launch_decoders_in_bf16_mode():
+    """The sampling programs with bf16 weight packs: finite, in range, and — where no mixture pick flips — close to the fp32 roll-out."""
+    B, T_ = 8, 6
+    g = torch.Generator().manual_seed(13)
+    torch.manual_seed(23)
+    v = VRNNAudio(likelihood="DMoL", input_size=16, hidden_size=32, latent_size=16, residual_posterior=True).to(DEV)
+    eps = torch.randn(T_, B, 16, generator=g).to(DEV)
+    uni = (torch.empty(T_, B, 16, 10).uniform_(1e-5, 1 - 1e-5, generator=g).to(DEV), torch.empty(T_, B, 16).uniform_(1e-8, 1 - 1e-8, generator=g).to(DEV))
+    x0 = (torch.rand(B, 16, 1, generator=g) * 0.2 - 0.1).to(DEV)
+    (b, _), _ = v.generate(n_samples=B, max_timesteps=T_, x=x0, eps=eps, uniforms=uni, fused=True)
+    _hip.set_operand_dtype("f32")
+    (a, _), _ = v.generate(n_samples=B, max_timesteps=T_, x=x0, eps=eps, uniforms=uni, fused=True)
+    _hip.set_operand_dtype("bf16")
+    assert torch.isfinite(b).all() and float(b.abs().max()) <= 1.0
+    assert float(((a[:, :2] - b[:, :2]).abs() > 2e-2).float().mean()) < 0.1  # the first generated stack: one step of bf16 products
+    assert not torch.equal(a, b)
+    _hip.check_async()
