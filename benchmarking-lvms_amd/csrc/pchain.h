@@ -221,7 +221,8 @@ __device__ __forceinline__ void mgemm16(const float* const (&A)[GA], const int (
                                         int a_width = 0, int w_width = 0) {  // a_width / w_width: columns of the polled T16 slab / of the packed weight rows when wider than K (the product covers a K-range of them; the pointers start at the range)
   constexpr int STEP = NW * 16;
   // fragment registers of a trip: 4 * CH * (G + GA); trips of 6 / 4 / 2 / 1 chunks (K = 256, 512, 1536 on 8 waves: 2, 4, 6 + 6)
-  constexpr int FR = 12 / (G + GA);
+  // (16 waves share the K of a tile two ways finer and have half the registers each: trips of at most 3 -> 2 / 1 chunks)
+  constexpr int FR = (NW >= 16 ? 6 : 12) / (G + GA);
   constexpr int MAXCH = FR >= 6 ? 6 : (FR >= 4 ? 4 : (FR >= 2 ? 2 : 1));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rr = lane & 15, q = lane >> 4;
