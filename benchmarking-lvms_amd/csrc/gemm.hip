@@ -601,7 +601,11 @@ int pack_flush() {
 T16PackScope::T16PackScope(bool bf16, hipStream_t stream) : prev_(g_pack.bf16), prev_active_(g_pack.active) {
   g_pack.bf16 = bf16; g_pack.active = true; g_pack.stream = stream;
 }
-int T16PackScope::flush() { return pack_flush(); }
+int T16PackScope::flush() {
+  const int rc = pack_flush();
+  g_pack.active = false;  // packs requested after the flush run at once again (their consumers may follow immediately)
+  return rc;
+}
 T16PackScope::~T16PackScope() {
   (void)pack_flush();  // (a caller that returned early; an error here resurfaces at the next checked launch)
   g_pack.bf16 = prev_; g_pack.active = prev_active_;
