@@ -10,6 +10,7 @@
 // projection and every weight gradient are hoisted out of the loop into the big MFMA GEMM (gemm.hip).
 #include "common.h"
 #include "pchain.h"
+#include "seqchain.h"
 
 namespace blvm {
 namespace {
@@ -149,6 +150,10 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(const float* DGn, con
 
 // sequences of at most this many rows may run as ONE persistent launch (pchain.h): their buffers get the T16 operand copies
 inline size_t t16_rows(int B) { return (size_t)((B + 15) / 16) * 16; }
+// Backward sequences take the register-resident kernel up to this K (= 3R | 4H): beyond it a step is bound by every tile pulling the
+// whole [B, K] gradient slab through the fabric, which the engine's two-trip tile hides better (GRU R = 512: 5.8 vs 6.2 us per step;
+// LSTM H = 256, K = 1024: 4.23 vs 4.49 ms per train step in favour of the registers)
+constexpr int kSeqRegsMaxKBwd = 1024;
 inline bool seq_persistent(int T, int B) { return pchain_applies(B) && device_cus() >= 32 && T >= 4; }
 
 struct LstmReserve { float *XG, *Hs, *Cs, *GATES, *WhhP, *H16; };  // WhhP: T16 copy of Whh; H16: (T+1) T16 slabs of the state
@@ -364,6 +369,21 @@ extern "C" int blvm_lstm_seq_fwd(const float* Wih, const float* Whh, const float
   if (rc) return rc;
   rc = pack_scope.flush();
   if (rc) return rc;
+  if (seq_persistent(T, B) && (seq_regs_mask() & 1) && seq_regs_applies(H, 4 * H, H, B, 4)) {
+    // one persistent launch with the workgroup's weight slice in registers (seqchain.hip)
+    const long xH = (long)((B + 15) / 16) * 16 * H;
+    SeqLstmFwd q{rs.H16, rs.WhhP, bhh, rs.XG, lens, rs.Hs, rs.Cs, out, rs.GATES, T, B, H, bf16_seq ? 1 : 0, {}};
+    rc = pchain_ctl(&q.ctl.dev, &q.ctl.host, &q.ctl.epoch);
+    if (rc) return rc;
+    BLVM_HIP(hipMemsetAsync(rs.H16 + xH, 0xFF, sizeof(float) * (size_t)T * xH, s));
+    rc = pchain_rows_to_t16(rs.Hs, H, B, H, rs.H16, s);
+    if (rc) return rc;
+    rc = seq_lstm_fwd(q, s);
+    if (rc) return rc;
+    if (hn) BLVM_HIP(hipMemcpyAsync(hn, rs.Hs + T * bh, sizeof(float) * bh, hipMemcpyDeviceToDevice, s));
+    if (cn) BLVM_HIP(hipMemcpyAsync(cn, rs.Cs + T * bh, sizeof(float) * bh, hipMemcpyDeviceToDevice, s));
+    return BLVM_OK;
+  }
   if (seq_persistent(T, B)) {
     // one persistent launch for the whole sequence (pchain.hip): one link per step — the hidden projection with the gate math
     using namespace pchain;
@@ -425,7 +445,15 @@ extern "C" int blvm_lstm_seq_bwd(const float* Wih, const float* Whh, const float
   rc = pack_scope.flush();
   if (rc) return rc;
   BLVM_HIP(hipMemsetAsync(ws.DC, 0, sizeof(float) * bh, s));
-  if (seq_persistent(T, B)) {
+  if (seq_persistent(T, B) && (seq_regs_mask() & 2) && 4 * H <= kSeqRegsMaxKBwd && seq_regs_applies(H, 4 * H, H, B, 4)) {
+    const long x4H = (long)((B + 15) / 16) * 16 * 4 * H;
+    SeqLstmBwd q{ws.DG16, ws.WhhT, d_out, rs.GATES, rs.Cs, ws.DC, ws.DG, d_h0 ? d_h0 : ws.DC, T, B, H, d_h0 ? T + 1 : T, bf16_seq ? 1 : 0, {}};
+    rc = pchain_ctl(&q.ctl.dev, &q.ctl.host, &q.ctl.epoch);
+    if (rc) return rc;
+    BLVM_HIP(hipMemsetAsync(ws.DG16, 0xFF, sizeof(float) * (size_t)T * x4H, s));
+    rc = seq_lstm_bwd(q, s);
+    if (rc) return rc;
+  } else if (seq_persistent(T, B)) {
     using namespace pchain;
     const int rt = (B + 15) / 16, ctH = H / 16;
     const long sH = (long)bh, s4H = 4 * sH, x4H = (long)rt * 16 * 4 * H;
@@ -501,6 +529,19 @@ extern "C" int blvm_gru_seq_fwd(const float* Wih, const float* Whh, const float*
   if (rc) return rc;
   rc = pack_scope.flush();
   if (rc) return rc;
+  if (seq_persistent(T, B) && (seq_regs_mask() & 1) && seq_regs_applies(R, 3 * R, R, B, 3)) {
+    const long xR = (long)((B + 15) / 16) * 16 * R;
+    SeqGruFwd q{rs.H16, rs.WhhP, bhh, rs.XG, lens, rs.Hs, out, rs.RG, rs.UG, rs.NG, rs.GHN, (long)out_ts, out_ld, T, B, R, reverse ? 1 : 0, bf16_seq ? 1 : 0, {}};
+    rc = pchain_ctl(&q.ctl.dev, &q.ctl.host, &q.ctl.epoch);
+    if (rc) return rc;
+    BLVM_HIP(hipMemsetAsync(rs.H16 + xR, 0xFF, sizeof(float) * (size_t)T * xR, s));
+    rc = pchain_rows_to_t16(rs.Hs, R, B, R, rs.H16, s);
+    if (rc) return rc;
+    rc = seq_gru_fwd(q, s);
+    if (rc) return rc;
+    if (hn) BLVM_HIP(hipMemcpyAsync(hn, rs.Hs + T * br, sizeof(float) * br, hipMemcpyDeviceToDevice, s));
+    return BLVM_OK;
+  }
   if (seq_persistent(T, B)) {
     using namespace pchain;
     BLVM_REQUIRE(out_ts >= 0 && out_ts < (1ll << 31), "gru_fwd: output step stride out of range");
@@ -562,7 +603,16 @@ extern "C" int blvm_gru_seq_bwd(const float* Wih, const float* Whh, const float*
   rc = pack_scope.flush();
   if (rc) return rc;
   BLVM_HIP(hipMemsetAsync(ws.G, 0, sizeof(float) * br, s));
-  if (seq_persistent(T, B)) {
+  if (seq_persistent(T, B) && (seq_regs_mask() & 2) && 3 * R <= kSeqRegsMaxKBwd && seq_regs_applies(R, 3 * R, R, B, 3)) {
+    const long x3R = (long)((B + 15) / 16) * 16 * 3 * R;
+    SeqGruBwd q{ws.DGH16, ws.WhhT, d_out, rs.RG, rs.UG, rs.NG, rs.GHN, rs.Hs, lens, ws.G, ws.DGI, ws.DGH, d_h0 ? d_h0 : ws.G, (long)out_ts, out_ld, T, B, R,
+                reverse ? 1 : 0, d_h0 ? T + 1 : T, bf16_seq ? 1 : 0, {}};
+    rc = pchain_ctl(&q.ctl.dev, &q.ctl.host, &q.ctl.epoch);
+    if (rc) return rc;
+    BLVM_HIP(hipMemsetAsync(ws.DGH16, 0xFF, sizeof(float) * (size_t)T * x3R, s));
+    rc = seq_gru_bwd(q, s);
+    if (rc) return rc;
+  } else if (seq_persistent(T, B)) {
     using namespace pchain;
     BLVM_REQUIRE(out_ts >= 0 && out_ts < (1ll << 31), "gru_bwd: output step stride out of range");
     const int rt = (B + 15) / 16, ctR = R / 16;
