@@ -150,10 +150,10 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_kernel(const float* DGn, con
 
 // sequences of at most this many rows may run as ONE persistent launch (pchain.h): their buffers get the T16 operand copies
 inline size_t t16_rows(int B) { return (size_t)((B + 15) / 16) * 16; }
-// Backward sequences take the register-resident kernel up to this K (= 3R | 4H): beyond it a step is bound by every tile pulling the
-// whole [B, K] gradient slab through the fabric, which the engine's two-trip tile hides better (GRU R = 512: 5.8 vs 6.2 us per step;
-// LSTM H = 256, K = 1024: 4.23 vs 4.49 ms per train step in favour of the registers)
-constexpr int kSeqRegsMaxKBwd = 1024;
+// Backward sequences take the register-resident kernel up to this K (= 3R | 4H).  At K >= 1536 a step is bound by every tile pulling
+// the whole [B, K] gradient slab through the fabric (GRU R = 512: 12 MB per step); there the kernel reads the slab once per XCD
+// (seqchain.hip, SHARED): GRU R = 512 backward 5.8 (engine tile) / 6.2 (every tile its own sc1 reads) -> ~5.5 us per step
+constexpr int kSeqRegsMaxKBwd = 1536;
 inline bool seq_persistent(int T, int B) { return pchain_applies(B) && device_cus() >= 32 && T >= 4; }
 
 struct LstmReserve { float *XG, *Hs, *Cs, *GATES, *WhhP, *H16; };  // WhhP: T16 copy of Whh; H16: (T+1) T16 slabs of the state

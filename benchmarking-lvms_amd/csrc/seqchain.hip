@@ -20,7 +20,13 @@ __device__ __forceinline__ void load_w(typename WFrag<BF>::type (&w)[G][NCH], co
     for (int u = 0; u < NCH; ++u) w[g][u] = *reinterpret_cast<const wfrag*>(base + (size_t)ES * 256 * (size_t)(wave + u * NW));
   }
 }
-template <bool BF, int G, int NCH, class Mid>
+// SHARED (wide operands, K >= 1024): every tile of a row tile reads the same [16, K] slab, and the workgroups of one XCD all belong
+// to the same row tile (blockIdx % 8 fixes blockIdx % rt for rt = 1, 2, 4, 8) — so once one wave has seen the slab's canary words
+// arrive (sc1 polls of word 0 of every 1 KB block), the fragments are read with ORDINARY loads: the first workgroup of the XCD
+// brings a line into the XCD's L2, the others hit it, and the fabric carries the slab once per XCD instead of once per tile.  Every
+// word is still validated: a fragment that holds a sentinel (a line cached before its last store landed) is re-read with sc1 loads,
+// which bypass the stale line.
+template <bool BF, int G, int NCH, bool SHARED, class Mid>
 __device__ __forceinline__ void product(const float* A16, int r0, int nrows, int K, const typename WFrag<BF>::type (&w)[G][NCH], f32x4 (&acc)[G], Poll& pl,
                                         Mid mid) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -30,6 +36,18 @@ __device__ __forceinline__ void product(const float* A16, int r0, int nrows, int
   f32x4 a[NCH];
   unsigned spins = 0;
   bool mid_pending = true;
+  if constexpr (SHARED) {
+    canary_wait(A16, r0, K, pl);  // (one wave polls; ends in a workgroup barrier)
+    const float* ap = A16 + (size_t)(r0 >> 4) * 16 * K + 4 * lane + 256 * wave;
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) a[u] = *reinterpret_cast<const f32x4*>(ap + 256 * (size_t)(u * NW));
+    mid();
+    mid_pending = false;
+    bool bad = false;
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) bad |= any_sentinel(a[u]);
+    if (!__any(bad && aok)) goto multiply;
+  }
   for (;;) {
 #pragma unroll
     for (int u = 0; u < NCH; ++u) a[u] = ld_sc1_x4(ar, aoff + 1024u * (unsigned)(u * NW));
@@ -41,6 +59,7 @@ __device__ __forceinline__ void product(const float* A16, int r0, int nrows, int
     if (spin_tick(spins, pl.ctl, pl.code, pl.dead)) break;
     pl.sleep();
   }
+multiply:
   if constexpr (BF) {
 #pragma unroll
     for (int u = 0; u < NCH; ++u) {
@@ -93,7 +112,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gru_fwd_kernel(SeqGruFwd a) {
       hp = a.Hs[(size_t)j * sR + o];
     };
     f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    product<BF, 3, NCH>(a.H16 + (size_t)j * xR, r0, B, R, w, acc, pl, prefetch);
+    product<BF, 3, NCH, false>(a.H16 + (size_t)j * xR, r0, B, R, w, acc, pl, prefetch);
     float v[3];
     reduce_tiles<3, NW>(acc, red[j & 1], v);
     if (!own) continue;
@@ -144,7 +163,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gru_bwd_kernel(SeqGruBwd a) {
     float v[1] = {0.f};
     if (has_gemm) {  // uniform
       f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-      product<BF, 1, NCH>(a.DGH16 + (size_t)(s - 1) * x3R, r0, B, 3 * R, w, acc, pl, prefetch);
+      product<BF, 1, NCH, (NCH >= 12)>(a.DGH16 + (size_t)(s - 1) * x3R, r0, B, 3 * R, w, acc, pl, prefetch);
       reduce_tiles<1, NW>(acc, red[s & 1], v);
     } else {
       prefetch();
@@ -193,7 +212,7 @@ __global__ __launch_bounds__(NW * 64, 1) void lstm_fwd_kernel(SeqLstmFwd a) {
       hp = a.Hs[(size_t)t * sH + o];
     };
     f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    product<BF, 4, NCH>(a.H16 + (size_t)t * xH, r0, B, H, w, acc, pl, prefetch);
+    product<BF, 4, NCH, false>(a.H16 + (size_t)t * xH, r0, B, H, w, acc, pl, prefetch);
     float v[4];
     reduce_tiles<4, NW>(acc, red[t & 1], v);
     if (!own) continue;
@@ -243,7 +262,7 @@ __global__ __launch_bounds__(NW * 64, 1) void lstm_bwd_kernel(SeqLstmBwd a) {
     float v[1] = {0.f};
     if (has_gemm) {  // uniform
       f32x4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
-      product<BF, 1, NCH>(a.DG16 + (size_t)(s - 1) * x4H, r0, B, 4 * H, w, acc, pl, prefetch);
+      product<BF, 1, NCH, (NCH >= 12)>(a.DG16 + (size_t)(s - 1) * x4H, r0, B, 4 * H, w, acc, pl, prefetch);
       reduce_tiles<1, NW>(acc, red[s & 1], v);
     } else {
       prefetch();

@@ -367,7 +367,7 @@ def sequence_path(request):
 
 
 @pytest.mark.parametrize("reverse", [False, True])
-@pytest.mark.parametrize("T_,B,I,R", [(11, 5, 24, 32), (37, 35, 48, 128), (9, 70, 16, 256)])
+@pytest.mark.parametrize("T_,B,I,R", [(11, 5, 24, 32), (37, 35, 48, 128), (9, 70, 16, 256), (6, 40, 16, 512)])
 def test_gru_sequence_vs_torch(reverse, T_, B, I, R, sequence_path):
     """nn.GRU (and reverse_sequences -> nn.GRU -> reverse_sequences) on the CPU vs the HIP sequence kernels."""
     torch.manual_seed(7)
@@ -375,7 +375,8 @@ def test_gru_sequence_vs_torch(reverse, T_, B, I, R, sequence_path):
     x = torch.randn(T_, B, I)
     h0 = torch.randn(B, R) * 0.5
     lens = torch.tensor([11, 9, 6, 2, 1]) if B == 5 else torch.tensor([max(1, T_ - (k * T_) // B) for k in range(B)])
-    # (R = 32: a program of the persistent-chain engine; R = 128, 256: the register-resident sequence kernels, seqchain.hip)
+    # (R = 32: a program of the persistent-chain engine; R = 128, 256, 512: the register-resident sequence kernels, seqchain.hip —
+    # at R = 512 the backward reads its K = 1536 operand once per XCD)
     w = torch.randn(T_, B, R)
     xr = x.clone().requires_grad_(True)
     h0r = h0.clone().requires_grad_(True)
