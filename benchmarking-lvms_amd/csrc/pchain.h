@@ -979,7 +979,7 @@ __device__ __forceinline__ void tile_dmol_sample(const float* dec, int ldd, cons
 // are its own (TileIter over [wg0, wg0 + nwg)).  A pointer of a descriptor is `p[k] + s * stride[sidx[k]]` (stride table of the
 // program, entry 0 = 0: constants and null pointers); a backward sequence passes its last step's slabs and negative strides.
 // =================================================================================================================================
-enum Kind : int { K_LIN = 0, K_HEAD = 1, K_GRU = 2, K_DZ = 3, K_GRUB = 4, K_DMOLS = 5, K_GRUS = 6, K_GRUSB = 7, K_LSTMS = 8, K_LSTMSB = 9 };
+enum Kind : int { K_LIN = 0, K_HEAD = 1, K_GRU = 2, K_DZ = 3, K_GRUB = 4, K_DMOLS = 5, K_GRUS = 6, K_GRUSB = 7, K_LSTMS = 8, K_LSTMSB = 9, K_LINSEQ = 10 };
 enum DescFlag : int {
   DF_RELU = 1,         // K_LIN: leaky ReLU (f[0] = slope) on the result
   DF_A_PLAIN = 2,      // K_LIN: A is a row-major buffer written before the launch (ld[0]), not a polled T16 copy
@@ -988,6 +988,7 @@ enum DescFlag : int {
   DF_GENTLE = 16,      // off the critical path: nap between polls
   DF_CANARY = 32,      // one-word canary wait in front of the operand poll
   DF_A_SUM3 = 64,      // K_LIN: the polled operand is the sum of three slabs (p[0], p[8], p[9]) of partial sums
+  DF_SEQ_GATE = 128,   // K_LINSEQ: the per-link auxiliary pointer is the derivative gate (backward chains), not the bias
 };
 constexpr int kMaxDesc = 24, kMaxPtr = 20;
 struct Desc {

@@ -17,6 +17,11 @@
 //              i: 0 R  1 first step with the products  2 first step WITHOUT gates  3 first step with g_in
 //   K_DMOLS p: 0 dec (row-major, polled words, ld[0])  1 head W [F,F]  2 head b  3 u  4 v  5 x row-major (ld[3])  6 x T16 (n16[0])
 //              i: 0 S  1 F  2 num_mix      f: 0 log_eps        (ct counts tiles of 4 samples)
+//   K_LINSEQ  n = i[1] <= 4 CONSECUTIVE links of one shape (K, ct, range) walked inside one visit — out_i = act(A_i W_i^T + bias_i) with
+//              A_0 = p[0] and A_i = the T16 output of link i-1: between them only the pointers change, so the walk of the program
+//              (descriptor fetch, decode, tile list) is paid once per visit instead of once per link
+//              p: 0 A_0  1+i W_i  5+i bias_i | gate_i (DF_SEQ_GATE, ld = i[2])  9+i out_i row-major (ld[i])  13+i out_i T16 (n16[0])
+//                 17, 18 (DF_A_SUM3) two more slabs of A_0      i: 0 width of W's rows (0 = K)  1 n  2 ldgate      f: 0 slope
 //   K_GRUS  p: 0 H16 (state entering the step)  1 Whh (T16)  2 b_hh  3 xg [T,B,3R] (time indexed)  4 lens  5 h_prev row-major
 //              6 h_next row-major (ld[3])  7 h_next T16 (n16[0])  8 out (time indexed)  9 rg  10 ug  11 ng  12 ghn
 //              i: 0 R  1 reverse  2 out_ts  3 out_ld                                   (recurrence step j = s)
@@ -132,6 +137,16 @@ struct DescRegs {
   }
   template <int K>
   __device__ __forceinline__ float* m(int s) const { return const_cast<float*>(p<K>(s)); }
+  // the same with a wave-uniform RUN-TIME pointer index (v_readlane takes the lane from an SGPR)
+  __device__ __forceinline__ const float* pdyn(int k) const {
+    const unsigned long long lo = (unsigned)__builtin_amdgcn_readlane((int)plo, k), hi = (unsigned)__builtin_amdgcn_readlane((int)phi, k);
+    return reinterpret_cast<const float*>((hi << 32) | lo);
+  }
+  __device__ __forceinline__ const float* basedyn(int k) const {  // (RD_P + 2k < 64: pointers live in v0)
+    const unsigned long long lo = (unsigned)__builtin_amdgcn_readlane(v0, RD_P + 2 * k), hi = (unsigned)__builtin_amdgcn_readlane(v0, RD_P + 2 * k + 1);
+    return reinterpret_cast<const float*>((hi << 32) | lo);
+  }
+  __device__ __forceinline__ int wdyn(int idx) const { return __builtin_amdgcn_readlane(v0, idx); }  // idx < 64
 };
 
 template <int NW, bool BF>
@@ -186,7 +201,7 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
       tq[3] += tqa - tq0;
 #endif
       // (a linear tile fetches the next descriptor itself, in the shadow of its operand wait)
-      if (!active || kind != K_LIN) nx.fetch(ltab, nx_i, nx_s);
+      if (!active || (kind != K_LIN && kind != K_LINSEQ)) nx.fetch(ltab, nx_i, nx_s);
       if (active) {
         const int nt = d.w<RD_NT>();
         pl.nap = (flags & DF_GENTLE) ? 16 : 1;
@@ -224,6 +239,30 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
 #endif
             }
             if (!nx_done) nx.fetch(ltab, nx_i, nx_s);  // (a visit without tiles)
+          } break;
+          case K_LINSEQ: {
+            const int n = d.w<RD_I + 1>(), w_width = d.w<RD_I + 0>();
+            const bool gated = (flags & DF_SEQ_GATE) != 0;
+            bool nx_done = false;
+            const float* A = d.p<0>(s);
+            for (int li = 0; li < n; ++li) {  // (links outside, tiles inside: link li+1 of any tile needs link li of ALL tiles of its row tile)
+              pl.code = ((unsigned)s << 4) | (unsigned)i | ((unsigned)li << 28);
+              const float* W = d.basedyn(1 + li);
+              auto late = [&]() {
+                __builtin_amdgcn_sched_barrier(0);
+                if (!nx_done) { nx.fetch(ltab, nx_i, nx_s); nx_done = true; }
+                const float* aux = gated ? d.pdyn(5 + li) : d.basedyn(5 + li);
+                return LinLate{gated ? nullptr : aux, nullptr, gated ? aux : nullptr, 0, d.w<RD_I + 2>(), false, (flags & DF_RELU) != 0, d.f<0>(),
+                               Out{const_cast<float*>(d.pdyn(9 + li)), d.wdyn(RD_LD + li), false, const_cast<float*>(d.pdyn(13 + li)), d.w<RD_N16>()}};
+              };
+              const bool sum3 = li == 0 && (flags & DF_A_SUM3);
+              for (int tk = 0; tk < nt; ++tk) {
+                const int trc = d.tile(tk), tr0 = trc & 0xffff, tc0 = (trc >> 16) * 16;
+                tile_lin_late<NW, BF>(A, 0, true, W, K, late, tr0, tc0, B, red(), pl, sum3 ? d.p<17>(s) : nullptr, sum3 ? d.p<18>(s) : nullptr, w_width);
+              }
+              A = d.pdyn(13 + li);  // the next link multiplies what this one stored
+            }
+            if (!nx_done) nx.fetch(ltab, nx_i, nx_s);
           } break;
 #ifndef PCHAIN_ONLY_LIN
           case K_HEAD: {
