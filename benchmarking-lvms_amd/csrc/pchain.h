@@ -21,6 +21,7 @@
 // raises the launch's abort word, every other spin sees it and the grid drains (the host reports BLVM_ELAUNCH).
 #pragma once
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -1039,6 +1040,35 @@ struct Builder {
     d.sidx[k] = (unsigned char)(q ? stride_index(stride) : 0);
   }
 };
+
+// A run of n <= 4 consecutive links of one shape as ONE K_LINSEQ descriptor (pchain.hip): out_i = act(A_i W_i^T + bias_i) or, with
+// `gated` (backward chains), (A_i W_i^T) masked by the derivative of the activation whose output is gate_i; A_0 = A16, A_i = o16 of
+// link i-1.  Steps of the stepped pointers: a_step (A_0), aux_step (gates), rm_step[i] (row-major outputs), o16_step (T16 outputs).
+struct SeqLink {
+  const float* W;
+  const float* aux;  // bias (not stepped) | gate (stepped by aux_step)
+  float* orm;
+  long rm_step;
+  int ldo;
+  float* o16;
+};
+inline Desc& add_linseq(Builder& b, int ct, int wg0, int nwg, int K, bool relu, bool gated, int s_begin, int s_end, const float* A16, long a_step, int n,
+                        const SeqLink* L, long aux_step, long o16_step, int n16, float slope, int ldgate) {
+  Desc& d = b.add(K_LINSEQ, ct, wg0, nwg, K, (relu ? DF_RELU : 0) | (gated ? DF_SEQ_GATE : 0), s_begin, s_end);
+  b.ptr(d, 0, A16, a_step);
+  for (int i = 0; i < n && i < 4; ++i) {
+    b.ptr(d, 1 + i, L[i].W); b.ptr(d, 5 + i, L[i].aux, gated ? aux_step : 0); b.ptr(d, 9 + i, L[i].orm, L[i].rm_step); b.ptr(d, 13 + i, L[i].o16, o16_step);
+    d.ld[i] = L[i].ldo;
+  }
+  if (n > 4) b.overflow = true;
+  d.n16[0] = n16; d.i[1] = n; d.i[2] = ldgate; d.f[0] = slope;
+  return d;
+}
+// env BLVM_PCHAIN_LINSEQ=0: one descriptor per link (A/B switch)
+inline bool linseq_enabled() {
+  static const int v = [] { const char* e = getenv("BLVM_PCHAIN_LINSEQ"); return e ? atoi(e) : 1; }();
+  return v != 0;
+}
 
 // workgroups for `tiles` tiles out of `avail` (a multiple of 8, at least 8): XCD-aware placement deals ranges in eights
 inline int range_for(int tiles, int avail) { return std::max(8, std::min(avail & ~7, (tiles + 7) & ~7)); }

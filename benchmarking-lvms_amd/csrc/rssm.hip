@@ -269,9 +269,16 @@ extern "C" int blvm_rssm_seq_fwd(const BlvmRssmWeights* w, const float* enc, con
     // L3..L5: posterior | prior MLPs on h_t
     lin(rs.H16 + xH, xH, rs.Wq[0], H, nullptr, rs.XQ, sH, rs.Q[0], sH, H, false, rs.Q16[0], xH, ctH, 0, r_h, DF_RELU);
     lin(rs.H16 + xH, xH, rs.Wp[0], H, w->prior_b[0], nullptr, 0, rs.P[0], sH, H, false, rs.P16[0], xH, ctH, r_h, r_h, DF_RELU);
-    for (int k = 1; k < 3; ++k) {
-      lin(rs.Q16[k - 1], xH, rs.Wq[k], H, w->post_b[k], nullptr, 0, rs.Q[k], sH, H, false, rs.Q16[k], xH, ctH, 0, r_h, DF_RELU);
-      lin(rs.P16[k - 1], xH, rs.Wp[k], H, w->prior_b[k], nullptr, 0, rs.P[k], sH, H, false, rs.P16[k], xH, ctH, r_h, r_h, DF_RELU);
+    if (linseq_enabled()) {  // layers 2, 3 of the posterior | prior MLP: one visit each (K_LINSEQ)
+      const SeqLink lq[2] = {{rs.Wq[1], w->post_b[1], rs.Q[1], sH, H, rs.Q16[1]}, {rs.Wq[2], w->post_b[2], rs.Q[2], sH, H, rs.Q16[2]}};
+      const SeqLink lp[2] = {{rs.Wp[1], w->prior_b[1], rs.P[1], sH, H, rs.P16[1]}, {rs.Wp[2], w->prior_b[2], rs.P[2], sH, H, rs.P16[2]}};
+      add_linseq(bld, ctH, 0, r_h, H, true, false, 0, T, rs.Q16[0], xH, 2, lq, 0, xH, ctH, 0.f, 0);
+      add_linseq(bld, ctH, r_h, r_h, H, true, false, 0, T, rs.P16[0], xH, 2, lp, 0, xH, ctH, 0.f, 0);
+    } else {
+      for (int k = 1; k < 3; ++k) {
+        lin(rs.Q16[k - 1], xH, rs.Wq[k], H, w->post_b[k], nullptr, 0, rs.Q[k], sH, H, false, rs.Q16[k], xH, ctH, 0, r_h, DF_RELU);
+        lin(rs.P16[k - 1], xH, rs.Wp[k], H, w->prior_b[k], nullptr, 0, rs.P[k], sH, H, false, rs.P16[k], xH, ctH, r_h, r_h, DF_RELU);
+      }
     }
     {  // L6: heads, combination, sample
       Desc& d = bld.add(K_HEAD, ctZ, 0, range_for(ctZ * rt, 2 * r_h), H, 0, 0, T);
@@ -417,9 +424,19 @@ extern "C" int blvm_rssm_seq_bwd(const BlvmRssmWeights* w, const float* enc, con
     lin(ws.DPH16, x2Z, T - 1, ws.phT, 2 * Z, nullptr, 0, 0, 0, false, rs.P[2], sH, ws.DP[2], sH, H, false, ws.DP16[2], xH, ctH, ctH, r_h, r_h, 0, 0, T);
     lin(ws.DGH16, x3H, T, ws.whhT, 3 * H, ws.GA, sH, T, H, true, nullptr, 0, ws.GB, sH, H, true, nullptr, 0, 0, ctH, 2 * r_h, r_gb, DF_GENTLE, 1, T);
     // B3, B4
-    for (int k = 2; k >= 1; --k) {
-      lin(ws.DQ16[k], xH, T - 1, ws.qT[k], H, nullptr, 0, 0, 0, false, rs.Q[k - 1], sH, ws.DQ[k - 1], sH, H, false, ws.DQ16[k - 1], xH, ctH, ctH, 0, r_h, 0, 0, T);
-      lin(ws.DP16[k], xH, T - 1, ws.pT[k], H, nullptr, 0, 0, 0, false, rs.P[k - 1], sH, ws.DP[k - 1], sH, H, false, ws.DP16[k - 1], xH, ctH, ctH, r_h, r_h, 0, 0, T);
+    if (linseq_enabled()) {  // one visit per branch (K_LINSEQ)
+      auto atm = [&](float* base, long step, int t0) { return base ? base + (long)t0 * step : nullptr; };
+      const SeqLink lq[2] = {{ws.qT[2], at(rs.Q[1], sH, T - 1), atm(ws.DQ[1], sH, T - 1), -sH, H, atm(ws.DQ16[1], xH, T - 1)},
+                             {ws.qT[1], at(rs.Q[0], sH, T - 1), atm(ws.DQ[0], sH, T - 1), -sH, H, atm(ws.DQ16[0], xH, T - 1)}};
+      const SeqLink lp[2] = {{ws.pT[2], at(rs.P[1], sH, T - 1), atm(ws.DP[1], sH, T - 1), -sH, H, atm(ws.DP16[1], xH, T - 1)},
+                             {ws.pT[1], at(rs.P[0], sH, T - 1), atm(ws.DP[0], sH, T - 1), -sH, H, atm(ws.DP16[0], xH, T - 1)}};
+      add_linseq(bld, ctH, 0, r_h, H, false, true, 0, T, at(ws.DQ16[2], xH, T - 1), -xH, 2, lq, -sH, -xH, ctH, 0.f, H);
+      add_linseq(bld, ctH, r_h, r_h, H, false, true, 0, T, at(ws.DP16[2], xH, T - 1), -xH, 2, lp, -sH, -xH, ctH, 0.f, H);
+    } else {
+      for (int k = 2; k >= 1; --k) {
+        lin(ws.DQ16[k], xH, T - 1, ws.qT[k], H, nullptr, 0, 0, 0, false, rs.Q[k - 1], sH, ws.DQ[k - 1], sH, H, false, ws.DQ16[k - 1], xH, ctH, ctH, 0, r_h, 0, 0, T);
+        lin(ws.DP16[k], xH, T - 1, ws.pT[k], H, nullptr, 0, 0, 0, false, rs.P[k - 1], sH, ws.DP[k - 1], sH, H, false, ws.DP16[k - 1], xH, ctH, ctH, r_h, r_h, 0, 0, T);
+      }
     }
     {  // B5: complete dL/dh_t, gate derivatives of step t
       Desc& d = bld.add(K_GRUB, ctH, 0, r_h, H, 0, 0, T);

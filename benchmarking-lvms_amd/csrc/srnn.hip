@@ -142,9 +142,16 @@ extern "C" int blvm_srnn_latent_fwd(const BlvmSrnnWeights* w, const float* d, co
     };
     lin(rs.Z16, xZ, rs.Wp[0], Z, nullptr, rs.XP, rs.P[0], rs.P16[0], 0);
     lin(rs.Z16, xZ, rs.Wq[0], Z, nullptr, rs.XQ, rs.Q[0], rs.Q16[0], half);
-    for (int k = 1; k < 3; ++k) {
-      lin(rs.P16[k - 1], xH, rs.Wp[k], H, w->prior_b[k], nullptr, rs.P[k], rs.P16[k], 0);
-      lin(rs.Q16[k - 1], xH, rs.Wq[k], H, w->post_b[k], nullptr, rs.Q[k], rs.Q16[k], half);
+    if (linseq_enabled()) {  // layers 2, 3 of the prior | posterior MLP: one visit each
+      const SeqLink lp[2] = {{rs.Wp[1], w->prior_b[1], rs.P[1], sH, H, rs.P16[1]}, {rs.Wp[2], w->prior_b[2], rs.P[2], sH, H, rs.P16[2]}};
+      const SeqLink lq[2] = {{rs.Wq[1], w->post_b[1], rs.Q[1], sH, H, rs.Q16[1]}, {rs.Wq[2], w->post_b[2], rs.Q[2], sH, H, rs.Q16[2]}};
+      add_linseq(bld, ctH, 0, half, H, true, false, 0, Tp, rs.P16[0], xH, 2, lp, 0, xH, ctH, slope, 0);
+      add_linseq(bld, ctH, half, half, H, true, false, 0, Tp, rs.Q16[0], xH, 2, lq, 0, xH, ctH, slope, 0);
+    } else {
+      for (int k = 1; k < 3; ++k) {
+        lin(rs.P16[k - 1], xH, rs.Wp[k], H, w->prior_b[k], nullptr, rs.P[k], rs.P16[k], 0);
+        lin(rs.Q16[k - 1], xH, rs.Wq[k], H, w->post_b[k], nullptr, rs.Q[k], rs.Q16[k], half);
+      }
     }
     {
       Desc& d = bld.add(K_HEAD, ctZ, 0, range_for(ctZ * rt, 2 * half), H, 0, 0, Tp);
@@ -254,9 +261,19 @@ extern "C" int blvm_srnn_latent_bwd(const BlvmSrnnWeights* w, const float* d, co
     // B2: heads -> third layers;  B3, B4: down to the first layers (LeakyReLU derivatives fused)
     lin(ws.DPH16, x2Z, ws.phT, 2 * Z, rs.P[2], ws.DP[2], ws.DP16[2], 0);
     lin(ws.DQH16, x2Z, ws.qhT, 2 * Z, rs.Q[2], ws.DQ[2], ws.DQ16[2], half);
-    for (int k = 2; k >= 1; --k) {
-      lin(ws.DP16[k], xH, ws.pT[k], H, rs.P[k - 1], ws.DP[k - 1], ws.DP16[k - 1], 0);
-      lin(ws.DQ16[k], xH, ws.qT[k], H, rs.Q[k - 1], ws.DQ[k - 1], ws.DQ16[k - 1], half);
+    if (linseq_enabled()) {  // B3, B4 of the prior | posterior: one visit each
+      auto atm = [&](float* base, long step, int t0) { return base ? base + (long)t0 * step : nullptr; };
+      const SeqLink lp[2] = {{ws.pT[2], at(rs.P[1], sH, T - 1), atm(ws.DP[1], sH, T - 1), -sH, H, atm(ws.DP16[1], xH, T - 1)},
+                             {ws.pT[1], at(rs.P[0], sH, T - 1), atm(ws.DP[0], sH, T - 1), -sH, H, atm(ws.DP16[0], xH, T - 1)}};
+      const SeqLink lq[2] = {{ws.qT[2], at(rs.Q[1], sH, T - 1), atm(ws.DQ[1], sH, T - 1), -sH, H, atm(ws.DQ16[1], xH, T - 1)},
+                             {ws.qT[1], at(rs.Q[0], sH, T - 1), atm(ws.DQ[0], sH, T - 1), -sH, H, atm(ws.DQ16[0], xH, T - 1)}};
+      add_linseq(bld, ctH, 0, half, H, false, true, 0, T, at(ws.DP16[2], xH, T - 1), -xH, 2, lp, -sH, -xH, ctH, slope, H);
+      add_linseq(bld, ctH, half, half, H, false, true, 0, T, at(ws.DQ16[2], xH, T - 1), -xH, 2, lq, -sH, -xH, ctH, slope, H);
+    } else {
+      for (int k = 2; k >= 1; --k) {
+        lin(ws.DP16[k], xH, ws.pT[k], H, rs.P[k - 1], ws.DP[k - 1], ws.DP16[k - 1], 0);
+        lin(ws.DQ16[k], xH, ws.qT[k], H, rs.Q[k - 1], ws.DQ[k - 1], ws.DQ16[k - 1], half);
+      }
     }
     if (d_z0) {  // s = T': gradient wrt the initial latent through both first layers of step 0 (two links: every word written once)
       const int r_z = range_for(ctZ * rt, half);
