@@ -113,8 +113,14 @@ extern "C" int blvm_srnn_generate(const BlvmSrnnDecodeWeights* w, const float* x
   const int rH = range_for(ctH * rt, r_main);
   // CP slab index: slab 0 = [d_0 | -], slab s + 1 = cat[d_s | z_{s-1}] of step s
   lin(b.X16, xS, ctS, p.enc[0], S, w->enc_b[0], ctH, DF_RELU, nullptr, 0, 0, b.E16[0], xH, ctH, 0, rH);
-  lin(b.E16[0], xH, ctH, p.enc[1], H, w->enc_b[1], ctH, DF_RELU, nullptr, 0, 0, b.E16[1], xH, ctH, 0, rH);
-  lin(b.E16[1], xH, ctH, p.enc[2], H, w->enc_b[2], ctH, DF_RELU, nullptr, 0, 0, b.ENC16, xH, ctH, 0, rH);
+  const bool seq = linseq_enabled();  // runs of links of one shape as one descriptor (K_LINSEQ)
+  if (seq) {
+    const SeqLink le[2] = {{sc + p.enc[1], w->enc_b[1], nullptr, 0, 0, sc + b.E16[1]}, {sc + p.enc[2], w->enc_b[2], nullptr, 0, 0, sc + b.ENC16}};
+    add_linseq(bld, ctH, 0, rH, H, true, false, 0, T, sc + b.E16[0], xH, 2, le, 0, xH, ctH, slope, 0);
+  } else {
+    lin(b.E16[0], xH, ctH, p.enc[1], H, w->enc_b[1], ctH, DF_RELU, nullptr, 0, 0, b.E16[1], xH, ctH, 0, rH);
+    lin(b.E16[1], xH, ctH, p.enc[2], H, w->enc_b[2], ctH, DF_RELU, nullptr, 0, 0, b.ENC16, xH, ctH, 0, rH);
+  }
   // gh_s = d_{s-1} Whh^T + b_hh: reads the d-part of slab s, first needed by the GRU link's epilogue
   lin(b.CP16, xCP, nCP, p.whh, R, w->gru_bhh, 3 * ctR, DF_RM_SC1 | DF_GENTLE | ((pchain_tune() & 16) ? DF_CANARY : 0), sc + b.GHb, s3R, 3 * R, 0, 0, 0, r_main,
       r_side);
@@ -127,8 +133,13 @@ extern "C" int blvm_srnn_generate(const BlvmSrnnDecodeWeights* w, const float* x
   }
   // prior(cat[d_s, z_{s-1}])
   lin(b.CP16 + xCP, xCP, nCP, p.prior[0], R + Z, c->prior_b[0], ctH, DF_RELU, nullptr, 0, 0, b.P16[0], xH, ctH, 0, rH);
-  lin(b.P16[0], xH, ctH, p.prior[1], H, c->prior_b[1], ctH, DF_RELU, nullptr, 0, 0, b.P16[1], xH, ctH, 0, rH);
-  lin(b.P16[1], xH, ctH, p.prior[2], H, c->prior_b[2], ctH, DF_RELU, nullptr, 0, 0, b.P16[2], xH, ctH, 0, rH);
+  if (seq) {
+    const SeqLink lp[2] = {{sc + p.prior[1], c->prior_b[1], nullptr, 0, 0, sc + b.P16[1]}, {sc + p.prior[2], c->prior_b[2], nullptr, 0, 0, sc + b.P16[2]}};
+    add_linseq(bld, ctH, 0, rH, H, true, false, 0, T, sc + b.P16[0], xH, 2, lp, 0, xH, ctH, slope, 0);
+  } else {
+    lin(b.P16[0], xH, ctH, p.prior[1], H, c->prior_b[1], ctH, DF_RELU, nullptr, 0, 0, b.P16[1], xH, ctH, 0, rH);
+    lin(b.P16[1], xH, ctH, p.prior[2], H, c->prior_b[2], ctH, DF_RELU, nullptr, 0, 0, b.P16[2], xH, ctH, 0, rH);
+  }
   {  // z_s ~ prior: into the decoder input and into the NEXT step's prior input
     Desc& d = bld.add(K_HEAD, ctZ, 0, range_for(ctZ * rt, r_main), H, 0, 0, T);
     bld.ptr(d, 0, sc + b.P16[2], xH); bld.ptr(d, 1, sc + b.P16[2], xH); bld.ptr(d, 2, sc + p.prior_h); bld.ptr(d, 3, c->prior_hb);

@@ -602,8 +602,14 @@ extern "C" int blvm_vrnn_generate(const BlvmVrnnDecodeWeights* w, const float* x
   lin(b.H16, xR, p.prior[0], R, c->prior_b[0], ctH, DF_RELU, 0.f, nullptr, 0, 0, b.P16[0], xH, ctH, 0, 0, 0, 0, rH);
   lin(b.H16, xR, p.whh, R, c->gru_bhh, 3 * ctR, DF_RM_SC1 | DF_GENTLE | ((pchain_tune() & 16) ? DF_CANARY : 0), 0.f, sc + b.GHb, s3R, 3 * R, 0, 0, 0, 0, 0, 0,
       r_main, r_side);
-  lin(b.P16[0], xH, p.prior[1], H, c->prior_b[1], ctH, DF_RELU, 0.f, nullptr, 0, 0, b.P16[1], xH, ctH, 0, 0, 0, 0, rH);
-  lin(b.P16[1], xH, p.prior[2], H, c->prior_b[2], ctH, DF_RELU, 0.f, nullptr, 0, 0, b.P16[2], xH, ctH, 0, 0, 0, 0, rH);
+  const bool seq = linseq_enabled();  // runs of links of one shape as one descriptor (K_LINSEQ)
+  if (seq) {
+    const SeqLink lp[2] = {{sc + p.prior[1], c->prior_b[1], nullptr, 0, 0, sc + b.P16[1]}, {sc + p.prior[2], c->prior_b[2], nullptr, 0, 0, sc + b.P16[2]}};
+    add_linseq(bld, ctH, 0, rH, H, true, false, 0, T, sc + b.P16[0], xH, 2, lp, 0, xH, ctH, 0.f, 0);
+  } else {
+    lin(b.P16[0], xH, p.prior[1], H, c->prior_b[1], ctH, DF_RELU, 0.f, nullptr, 0, 0, b.P16[1], xH, ctH, 0, 0, 0, 0, rH);
+    lin(b.P16[1], xH, p.prior[2], H, c->prior_b[2], ctH, DF_RELU, 0.f, nullptr, 0, 0, b.P16[2], xH, ctH, 0, 0, 0, 0, rH);
+  }
   {  // z ~ prior (head in generation mode: the posterior operands are the prior's)
     Desc& d = bld.add(K_HEAD, ctZ, 0, range_for(ctZ * rt, r_main), H, 0, 0, T);
     bld.ptr(d, 0, sc + b.P16[2], xH); bld.ptr(d, 1, sc + b.P16[2], xH); bld.ptr(d, 2, sc + p.prior_h); bld.ptr(d, 3, c->prior_hb);
@@ -613,9 +619,17 @@ extern "C" int blvm_vrnn_generate(const BlvmVrnnDecodeWeights* w, const float* x
     d.ld[3] = Z; d.n16[0] = ctZ; d.i[0] = Z; d.i[1] = 3; d.f[0] = beta; d.f[1] = 1.f / beta; d.f[2] = sd_eps;
   }
   // phi_z(z): the last layer feeds the GRU input cat[enc, phi] and the decoder input cat[phi, h_new]
-  lin(b.Z16, xZ, p.phi[0], Z, c->phi_b[0], ctH, DF_RELU, 0.f, nullptr, 0, 0, b.F16[0], xH, ctH, 0, 0, 0, 0, rH);
-  lin(b.F16[0], xH, p.phi[1], H, c->phi_b[1], ctH, DF_RELU, 0.f, nullptr, 0, 0, b.F16[1], xH, ctH, 0, 0, 0, 0, rH);
-  lin(b.F16[1], xH, p.phi[2], H, c->phi_b[2], ctH, DF_RELU, 0.f, nullptr, 0, 0, b.F16[2], xH, ctH, 0, 0, 0, 0, rH);
+  if (seq) {
+    const int f0 = Z == H ? 0 : 1;  // (the first layer's K is Z)
+    if (f0) lin(b.Z16, xZ, p.phi[0], Z, c->phi_b[0], ctH, DF_RELU, 0.f, nullptr, 0, 0, b.F16[0], xH, ctH, 0, 0, 0, 0, rH);
+    SeqLink lf[3];
+    for (int l = f0; l < 3; ++l) lf[l - f0] = SeqLink{sc + p.phi[l], c->phi_b[l], nullptr, 0, 0, sc + b.F16[l]};
+    add_linseq(bld, ctH, 0, rH, H, true, false, 0, T, f0 ? sc + b.F16[0] : sc + b.Z16, f0 ? xH : xZ, 3 - f0, lf, 0, xH, ctH, 0.f, 0);
+  } else {
+    lin(b.Z16, xZ, p.phi[0], Z, c->phi_b[0], ctH, DF_RELU, 0.f, nullptr, 0, 0, b.F16[0], xH, ctH, 0, 0, 0, 0, rH);
+    lin(b.F16[0], xH, p.phi[1], H, c->phi_b[1], ctH, DF_RELU, 0.f, nullptr, 0, 0, b.F16[1], xH, ctH, 0, 0, 0, 0, rH);
+    lin(b.F16[1], xH, p.phi[2], H, c->phi_b[2], ctH, DF_RELU, 0.f, nullptr, 0, 0, b.F16[2], xH, ctH, 0, 0, 0, 0, rH);
+  }
   lin(b.F16[2], xH, p.phi[3], H, c->phi_b[3], ctH, DF_RELU, 0.f, nullptr, 0, 0, b.CAT16 + (size_t)(X / 16) * 256, xC, (X + H) / 16, b.DC16, xD,
       (H + R) / 16, 0, rH);
   {  // GRU(cat[enc, phi], h_{t-1}) -> h_t: row-major (polled words of the next step), T16 for the next step, T16 into cat[phi, h_t]
