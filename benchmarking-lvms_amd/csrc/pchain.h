@@ -1086,6 +1086,10 @@ inline int device_cus() {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (const char* e = getenv("BLVM_PCHAIN_CUS")) {  // experiments: programs dealt over fewer workgroups than the chip has CUs
+      const int m = atoi(e) & ~7;
+      if (m >= 32 && m < n) n = m;
+    }
     return n;
   }();
   return v;
