@@ -607,16 +607,29 @@ struct TsArgs {
   float* colsum;     // [2C] += column sums of A, or null
 };
 
-template <int C, bool DUAL, bool BF>
+// NPW < C/16 (few rows: the reference's own batch of 4 utterances): a workgroup owns NPW column tiles of ONE tap instead of the whole
+// output — NSPLIT = taps * (C/16) / NPW workgroups share a slice of rows (all on one XCD, so the slice's A rows come from HBM once)
+// and there are NSPLIT times fewer row slices for the same number of workgroups, i.e. NSPLIT times fewer atomic adds on the same
+// [2C, C(, 2)] words: with 512 slices of 8 chunks each the kernel spent 171 us in 18.9 M contended atomics for 30 us of MFMA.
+template <int C, bool DUAL, bool BF, int NPW>
 __global__ __launch_bounds__(256) void wn_ts_wgrad_kernel(TsArgs a) {
-  constexpr int M = 2 * C, N = C, MT = M / 16, NT = N / 16, MW = MT / 4, NB = DUAL ? 2 : 1, KB = 16;
-  constexpr int LDA = M + 4, LDB = N + 4;  // a lane's fragment = rows 4 kq .. 4 kq + 3 of one column: stride = 4 mod 8 spreads the 4 kq groups over all banks
-  constexpr int NA4 = KB * M / 4, NB4 = KB * N / 4;           // 16-byte pieces per chunk
+  constexpr bool SPLIT = NPW < C / 16;
+  constexpr int M = 2 * C, N = C, MT = M / 16, MW = MT / 4, KB = 16;
+  constexpr int NT = SPLIT ? NPW : N / 16, NB = SPLIT ? 1 : (DUAL ? 2 : 1), NW_ = NT * 16;  // column tiles, taps and B columns of this workgroup
+  constexpr int NSPLIT = SPLIT ? (DUAL ? 2 : 1) * (N / 16) / NPW : 1;
+  static_assert(!SPLIT || (N / 16) % NPW == 0, "column tiles per workgroup must divide C/16");
+  constexpr int LDA = M + 4, LDB = NW_ + 4;  // a lane's fragment = rows 4 kq .. 4 kq + 3 of one column: stride = 4 mod 8 spreads the 4 kq groups over all banks
+  constexpr int NA4 = KB * M / 4, NB4 = KB * NW_ / 4;           // 16-byte pieces per chunk
   constexpr int PA = (NA4 + 255) / 256, PB = (NB4 + 255) / 256;
   __shared__ __align__(16) float sA[2][KB * LDA];
   __shared__ __align__(16) float sB[2][NB][KB * LDB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
-  const size_t c_begin = (size_t)blockIdx.x * a.chunks_per_wg;
+  // workgroup -> (row slice, part): ids are dealt round-robin over the 8 XCDs; the NSPLIT parts of a slice stay on one XCD
+  const int q_ = blockIdx.x >> 3, part = SPLIT ? q_ % NSPLIT : 0;
+  const size_t slice = SPLIT ? (size_t)(q_ / NSPLIT) * 8 + (blockIdx.x & 7) : blockIdx.x;
+  const int tap = SPLIT ? part / ((N / 16) / NPW) : 0, j0 = SPLIT ? (part % ((N / 16) / NPW)) * NPW : 0;
+  const float* Bsrc[2] = {SPLIT ? (tap ? a.B1 : a.B0) + j0 * 16 : a.B0, a.B1};
+  const size_t c_begin = slice * a.chunks_per_wg;
   const size_t n_chunks = (a.rows + KB - 1) / KB;
   size_t c_end = c_begin + a.chunks_per_wg;
   if (c_end > n_chunks) c_end = n_chunks;
@@ -630,6 +643,7 @@ __global__ __launch_bounds__(256) void wn_ts_wgrad_kernel(TsArgs a) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[b][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float csum = 0.f;
+  const bool do_csum = a.colsum != nullptr && part == 0 && tid < M;
 
   float4 ra[PA], rb[NB][PB];
   auto fetch = [&](size_t chunk) {
@@ -644,11 +658,11 @@ __global__ __launch_bounds__(256) void wn_ts_wgrad_kernel(TsArgs a) {
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
       const int i = tid + 256 * p;
-      const int row = (i * 4) / N, col = (i * 4) - row * N;
+      const int row = (i * 4) / NW_, col = (i * 4) - row * NW_;
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         rb[b][p] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < NB4 && row0 + row < a.rows) rb[b][p] = *reinterpret_cast<const float4*>((b ? a.B1 : a.B0) + (row0 + row) * N + col);
+        if (i < NB4 && row0 + row < a.rows) rb[b][p] = *reinterpret_cast<const float4*>(Bsrc[b] + (row0 + row) * N + col);
       }
     }
   };
@@ -662,7 +676,7 @@ __global__ __launch_bounds__(256) void wn_ts_wgrad_kernel(TsArgs a) {
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
       const int i = tid + 256 * p;
-      const int row = (i * 4) / N, col = (i * 4) - row * N;
+      const int row = (i * 4) / NW_, col = (i * 4) - row * NW_;
 #pragma unroll
       for (int b = 0; b < NB; ++b)
         if (i < NB4) *reinterpret_cast<float4*>(&sB[buf][b][row * LDB + col]) = rb[b][p];
@@ -718,7 +732,7 @@ __global__ __launch_bounds__(256) void wn_ts_wgrad_kernel(TsArgs a) {
               for (int j = 0; j < NT; ++j) acc[b][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[b][j][e], acc[b][i][j], 0, 0, 0);
       }
     }
-    if (a.colsum != nullptr && tid < M) {
+    if (do_csum) {
 #pragma unroll
       for (int r = 0; r < KB; ++r) csum += A_[r * LDA + tid];
     }
@@ -735,21 +749,36 @@ __global__ __launch_bounds__(256) void wn_ts_wgrad_kernel(TsArgs a) {
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int m = (wave * MW + i) * 16 + 4 * kq + r, n = j * 16 + li;
-          atomicAdd(a.out + ((size_t)m * N + n) * a.ostride + b, acc[b][i][j][r]);
+          const int m = (wave * MW + i) * 16 + 4 * kq + r, n = (j0 + j) * 16 + li;
+          atomicAdd(a.out + ((size_t)m * N + n) * a.ostride + (SPLIT ? tap : b), acc[b][i][j][r]);
         }
-  if (a.colsum != nullptr && tid < M) atomicAdd(a.colsum + tid, csum);
+  if (do_csum) atomicAdd(a.colsum + tid, csum);
 }
 
+template <int C, bool DUAL, int NPW>
+void launch_ts_wgrad_npw(TsArgs a, size_t n_chunks, hipStream_t s) {
+  constexpr int NSPLIT = NPW < C / 16 ? (DUAL ? 2 : 1) * (C / 16) / NPW : 1;
+  size_t slices = NSPLIT == 1 ? 512 : (512 / NSPLIT + 7) / 8 * 8;  // ~two workgroups per CU in all
+  if (slices > n_chunks) slices = n_chunks;
+  a.chunks_per_wg = (n_chunks + slices - 1) / slices;
+  slices = (n_chunks + a.chunks_per_wg - 1) / a.chunks_per_wg;
+  const size_t grid = NSPLIT == 1 ? slices : 8 * NSPLIT * ((slices + 7) / 8);  // (slices past the last chunk return at once)
+  if (operand_bf16()) hipLaunchKernelGGL((wn_ts_wgrad_kernel<C, DUAL, true, NPW>), dim3((unsigned)grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((wn_ts_wgrad_kernel<C, DUAL, false, NPW>), dim3((unsigned)grid), dim3(256), 0, s, a);
+}
+
+// column tiles per workgroup: all of them (operands stream exactly once) while every workgroup has >= 64 chunks of 16 rows to
+// amortise its [2C, C(, 2)] atomic adds over; half or one of them for fewer rows.  env BLVM_WN_WGRAD_NPW forces a value (experiments)
 template <int C, bool DUAL>
 int launch_ts_wgrad(TsArgs a, hipStream_t s) {
+  constexpr int NT = C / 16;
   const size_t n_chunks = (a.rows + 15) / 16;
-  size_t grid = 512;  // two workgroups per CU
-  if (grid > n_chunks) grid = n_chunks;
-  a.chunks_per_wg = (n_chunks + grid - 1) / grid;
-  grid = (n_chunks + a.chunks_per_wg - 1) / a.chunks_per_wg;
-  if (operand_bf16()) hipLaunchKernelGGL((wn_ts_wgrad_kernel<C, DUAL, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((wn_ts_wgrad_kernel<C, DUAL, false>), dim3((unsigned)grid), dim3(256), 0, s, a);
+  static const int forced = [] { const char* e = getenv("BLVM_WN_WGRAD_NPW"); return e ? atoi(e) : 0; }();
+  int npw = n_chunks >= 512 * 64 ? NT : (NT >= 2 ? NT / 2 : 1);
+  if (forced > 0) npw = forced >= NT ? NT : (forced > 1 && NT >= 2 ? NT / 2 : 1);
+  if (npw >= NT) launch_ts_wgrad_npw<C, DUAL, NT>(a, n_chunks, s);
+  else if (npw > 1) launch_ts_wgrad_npw<C, DUAL, (NT >= 2 ? NT / 2 : 1)>(a, n_chunks, s);
+  else launch_ts_wgrad_npw<C, DUAL, 1>(a, n_chunks, s);
   return BLVM_OK;
 }
 
@@ -849,9 +878,11 @@ extern "C" int blvm_wavenet_block_fwd(const float* x, const float* conv_w, const
   if (fused_fwd_enabled() && S == C && (C == 32 || C == 64 || C == 96) && aligned16(skip) && (o == nullptr || aligned16(o))) {
     // operand-layout copies: the two taps straight out of the interleaved Conv1d weight, the 1x1 weight behind them
     float* Wrs = W1 + nk;
+    T16PackScope pack_scope(false, s);  // the three packs in one launch (the block kernels round fp32 packs themselves in the bf16 mode)
     int rc = t16_pack(conv_w, 2 * C, 2, 2 * C, C, W0, s); if (rc) return rc;
     rc = t16_pack(conv_w + 1, 2 * C, 2, 2 * C, C, W1, s); if (rc) return rc;
     rc = t16_pack_rows(rs_w, C, C + S, C, Wrs, s); if (rc) return rc;
+    rc = pack_scope.flush(); if (rc) return rc;
     FusedFwdArgs a;
     a.x = x; a.W0 = W0; a.W1 = W1; a.Wrs = Wrs; a.conv_b = conv_b; a.rs_b = rs_b;
     a.pre = pre; a.act = act; a.o = o; a.skip = skip;
@@ -897,9 +928,11 @@ extern "C" int blvm_wavenet_block_bwd(const float* x, const float* conv_w, const
     float* WrsT = W0;
     float* W0T = W1;
     float* W1T = dW0;
+    T16PackScope pack_scope(false, s);
     rc = t16_pack_transposed(rs_w, C, C + S, C, WrsT, s); if (rc) return rc;
     rc = t16_pack(conv_w, 2, 2 * C, C, 2 * C, W0T, s); if (rc) return rc;
     rc = t16_pack(conv_w + 1, 2, 2 * C, C, 2 * C, W1T, s); if (rc) return rc;
+    rc = pack_scope.flush(); if (rc) return rc;
     FusedBwdAArgs aa;
     aa.d_o = d_o; aa.d_skip = d_skip; aa.pre = pre; aa.WrsT = WrsT; aa.d_rs = d_rs; aa.d_pre = d_pre;
     aa.rows = rows; aa.off = rows - (size_t)T_skip * B; aa.inv_std = inv_std;

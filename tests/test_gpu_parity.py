@@ -945,11 +945,13 @@ def test_wavenet_decode_kernel_matches_window_generation(B, C, layers, stacks):
     assert tuple(free.shape) == (B, 5, 1) and torch.isfinite(free).all() and float(free.abs().max()) <= 1.0
 
 
-@pytest.mark.parametrize("C,B,L,dil,T_skip", [(32, 3, 77, (1, 2, 4), 50), (64, 5, 203, (1, 8), 120), (96, 2, 131, (4, 1, 2), 100)])
+@pytest.mark.parametrize("C,B,L,dil,T_skip", [(32, 3, 77, (1, 2, 4), 50), (64, 5, 203, (1, 8), 120), (96, 2, 131, (4, 1, 2), 100),
+                                              (32, 64, 8300, (2, 1), 8000)])  # fmt: skip
 def test_wavenet_fused_block_kernels_match_torch(C, B, L, dil, T_skip):
     """The fused block kernels (C in {32, 64, 96}: forward; backward A / B) against a float64 torch restatement of the residual
     stack (`wavenet_modules.py:53-117,178-215`): row counts that are not multiples of the 64-row tile, a skip window that starts
-    inside a tile, a last block without residual output."""
+    inside a tile, a last block without residual output.  The last case has > 524 288 rows per block: the weight-gradient kernel's
+    whole-output form (every workgroup owns all column tiles); the others run its column-split form (few rows)."""
     from blvm import ops
 
     g = torch.Generator().manual_seed(C + L)

@@ -8,9 +8,11 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows]
 # step boundary: the clip / Adam multi_tensor_apply burst; take the last two occurrences of the first kernel after a pchain pair
 marks = [i for i, e in enumerate(ev) if "pchain_kernel" in e[2]]
-# forward pchain launches are every other one
-fw = marks[0::2]
-a, b = fw[-2], fw[-1]
+if len(sys.argv) > 2 or len(marks) < 4:  # no persistent launches to cut steps at (or "tail" asked for): the last third of the trace
+    a, b = len(ev) * 2 // 3, len(ev) - 1
+else:
+    fw = marks[0::2]  # forward launches are every other one (VRNN: one forward + one backward per step)
+    a, b = fw[-2], fw[-1]
 seg = ev[a:b]
 busy = 0
 cur_end = seg[0][0]
