@@ -136,6 +136,9 @@ _SIGNATURES = {
     "blvm_wavenet_block_workspace_floats": (c_size_t, [c_int] * 5),
     "blvm_wavenet_block_fwd": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_float] + [c_void_p] * 5),
     "blvm_wavenet_block_bwd": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_float] + [c_void_p] * 7),
+    "blvm_wavenet_stack_floats": (c_int, [c_int] * 3 + [c_void_p, c_int, c_void_p, c_void_p]),
+    "blvm_wavenet_stack_fwd": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_float] + [c_void_p] * 5),
+    "blvm_wavenet_stack_bwd": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_float] + [c_void_p] * 8),
     "blvm_wavenet_decode_pack_floats": (c_size_t, [c_int] * 4),
     "blvm_wavenet_decode_scratch_floats": (c_size_t, [c_void_p] + [c_int] * 4),
     "blvm_wavenet_decode": (c_int, [c_void_p] * 2 + [c_int] * 7 + [c_float] * 3 + [c_void_p] * 5),

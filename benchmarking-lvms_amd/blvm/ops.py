@@ -849,6 +849,8 @@ class _WaveNetStackFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, dilations, groups, T_skip, inv_std, S, *params):
+        import ctypes
+
         x = _f32c(x)
         params = tuple(_f32c(p) for p in params)
         L, B, C = x.shape
@@ -856,51 +858,42 @@ class _WaveNetStackFunction(torch.autograd.Function):
         f32 = dict(device=x.device, dtype=torch.float32)
         n_out = max(groups) + 1
         skips = [torch.zeros(T_skip, B, S, **f32) for _ in range(n_out)]
+        n = max(i for i in range(len(dilations)) if groups[i] >= 0) + 1  # blocks after the last used skip cannot influence any output
+        dil = (ctypes.c_int * n)(*dilations[:n])
+        grp = (ctypes.c_int * n)(*groups[:n])
+        na, nr = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        check(lib.blvm_wavenet_stack_floats(L, B, C, dil, n, ctypes.byref(na), ctypes.byref(nr)), "blvm_wavenet_stack_floats")
+        acts = torch.empty(max(na.value, 1), **f32)  # residual outputs of blocks 0 .. n-2, back to back
+        reserve = torch.empty(nr.value, **f32)
         ws = torch.empty(lib.blvm_wavenet_block_workspace_floats(L, B, C, S, 1), **f32)
-        acts, reserves = [x], []
-        n = len(dilations)
-        last_used = max(i for i in range(n) if groups[i] >= 0)
-        for i, d in enumerate(dilations[: last_used + 1]):  # blocks after the last used skip cannot influence any output
-            cw, cb, rw, rb = params[4 * i : 4 * i + 4]
-            xi = acts[-1]
-            Li = xi.shape[0]
-            res = torch.empty(lib.blvm_wavenet_block_reserve_floats(Li, B, C, d), **f32)
-            o = torch.empty(Li - d, B, C, **f32) if i < last_used else None  # the last block's residual output is never used
-            Si = S if groups[i] >= 0 else 0
-            check(lib.blvm_wavenet_block_fwd(ptr(xi), ptr(cw), ptr(cb), ptr(rw), ptr(rb), Li, B, C, Si, d, T_skip, inv_std, ptr(o),
-                                             ptr(skips[groups[i]]) if Si else None, ptr(res), ptr(ws), stream_ptr()),
-                  "blvm_wavenet_block_fwd")  # fmt: skip
-            reserves.append(res)
-            if o is not None:
-                acts.append(o)
-        ctx.cfg = (tuple(dilations), tuple(groups), T_skip, inv_std, S, L, B, C, last_used)
-        ctx.n_acts = len(acts)
-        ctx.save_for_backward(*acts, *reserves, *params)
+        pp = (ctypes.c_void_p * (4 * n))(*[p.data_ptr() for p in params[: 4 * n]])
+        sk = (ctypes.c_void_p * n_out)(*[t.data_ptr() for t in skips])
+        check(lib.blvm_wavenet_stack_fwd(ptr(x), pp, dil, grp, n, L, B, C, S, T_skip, inv_std, ptr(acts), sk, ptr(reserve), ptr(ws),
+                                         stream_ptr()), "blvm_wavenet_stack_fwd")  # fmt: skip
+        ctx.cfg = (tuple(dilations), tuple(groups), T_skip, inv_std, S, L, B, C, n)
+        ctx.save_for_backward(x, acts, reserve, *params)
         return tuple(skips)
 
     @staticmethod
     def backward(ctx, *d_skips):
-        dilations, groups, T_skip, inv_std, S, L, B, C, last_used = ctx.cfg
-        n = last_used + 1
-        saved = ctx.saved_tensors
-        acts, reserves, params = saved[: ctx.n_acts], saved[ctx.n_acts : ctx.n_acts + n], saved[ctx.n_acts + n :]
+        import ctypes
+
+        dilations, groups, T_skip, inv_std, S, L, B, C, n = ctx.cfg
+        x, acts, reserve, *params = ctx.saved_tensors
         lib = load()
-        f32 = dict(device=acts[0].device, dtype=torch.float32)
+        f32 = dict(device=x.device, dtype=torch.float32)
         d_skips = [_f32c(g) if g is not None else torch.zeros(T_skip, B, S, **f32) for g in d_skips]
         ws = torch.empty(lib.blvm_wavenet_block_workspace_floats(L, B, C, S, 1), **f32)
         grads = _zeros_like_many(params)
-        d_o = None
-        for i in range(n - 1, -1, -1):
-            cw, _, rw, _ = params[4 * i : 4 * i + 4]
-            xi = acts[i]
-            d_x = torch.empty_like(xi)
-            Si = S if groups[i] >= 0 else 0
-            check(lib.blvm_wavenet_block_bwd(ptr(xi), ptr(cw), ptr(rw), ptr(reserves[i]), ptr(d_o),
-                                             ptr(d_skips[groups[i]]) if Si else None, xi.shape[0], B, C, Si, dilations[i], T_skip,
-                                             inv_std, ptr(d_x), ptr(grads[4 * i]), ptr(grads[4 * i + 1]), ptr(grads[4 * i + 2]),
-                                             ptr(grads[4 * i + 3]), ptr(ws), stream_ptr()), "blvm_wavenet_block_bwd")  # fmt: skip
-            d_o = d_x
-        return (d_o, None, None, None, None, None, *grads)
+        d_x, d_scratch = torch.empty_like(x), torch.empty_like(x)
+        dil = (ctypes.c_int * n)(*dilations[:n])
+        grp = (ctypes.c_int * n)(*groups[:n])
+        pp = (ctypes.c_void_p * (4 * n))(*[p.data_ptr() for p in params[: 4 * n]])
+        gp = (ctypes.c_void_p * (4 * n))(*[g.data_ptr() for g in grads[: 4 * n]])
+        ds = (ctypes.c_void_p * len(d_skips))(*[t.data_ptr() for t in d_skips])
+        check(lib.blvm_wavenet_stack_bwd(ptr(x), pp, dil, grp, n, L, B, C, S, T_skip, inv_std, ptr(acts), ptr(reserve), ds, ptr(d_x),
+                                         ptr(d_scratch), gp, ptr(ws), stream_ptr()), "blvm_wavenet_stack_bwd")  # fmt: skip
+        return (d_x, None, None, None, None, None, *grads)
 
 
 @torch.no_grad()

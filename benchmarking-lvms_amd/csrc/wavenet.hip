@@ -9,6 +9,8 @@
 // accumulating), the 1x1 convolution is one GEMM.  The element-wise pieces (gate, residual/skip, their derivatives)
 // are 16-byte-vectorised streaming kernels.  Nothing is padded inside the stack: like the reference, block i
 // consumes d_i frames on the left.
+#include <vector>
+
 #include "common.h"
 
 namespace blvm {
@@ -614,7 +616,8 @@ struct TsArgs {
 template <int C, bool DUAL, bool BF, int NPW>
 __global__ __launch_bounds__(256) void wn_ts_wgrad_kernel(TsArgs a) {
   constexpr bool SPLIT = NPW < C / 16;
-  constexpr int M = 2 * C, N = C, MT = M / 16, MW = MT / 4, KB = 16;
+  constexpr int M = 2 * C, N = C, MT = M / 16, MW = MT / 4;
+  constexpr int KB = SPLIT ? 32 : 16;  // rows per staged chunk (few rows: the single prefetched chunk must cover an HBM round trip)
   constexpr int NT = SPLIT ? NPW : N / 16, NB = SPLIT ? 1 : (DUAL ? 2 : 1), NW_ = NT * 16;  // column tiles, taps and B columns of this workgroup
   constexpr int NSPLIT = SPLIT ? (DUAL ? 2 : 1) * (N / 16) / NPW : 1;
   static_assert(!SPLIT || (N / 16) % NPW == 0, "column tiles per workgroup must divide C/16");
@@ -690,12 +693,13 @@ __global__ __launch_bounds__(256) void wn_ts_wgrad_kernel(TsArgs a) {
     const bool more = c + 1 < c_end;
     if (more) fetch(c + 1);  // in flight under this chunk's MFMAs
     const float* A_ = sA[buf];
-    {
-      // fragments: k = rows 4 kq + e of the chunk, e = 0..3 (the same assignment for both operands), one MFMA per e
+#pragma unroll
+    for (int ks = 0; ks < KB / 16; ++ks) {
+      // fragments: k = rows 16 ks + 4 kq + e of the chunk, e = 0..3 (the same assignment for both operands), one MFMA per e
       float fa[MW][4], fb[NB][NT][4];
 #pragma unroll
       for (int i = 0; i < MW; ++i) {
-        const float* p = A_ + (4 * kq) * LDA + (wave * MW + i) * 16 + li;
+        const float* p = A_ + (16 * ks + 4 * kq) * LDA + (wave * MW + i) * 16 + li;
 #pragma unroll
         for (int e = 0; e < 4; ++e) fa[i][e] = p[e * LDA];
       }
@@ -703,7 +707,7 @@ __global__ __launch_bounds__(256) void wn_ts_wgrad_kernel(TsArgs a) {
       for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          const float* p = sB[buf][b] + (4 * kq) * LDB + j * 16 + li;
+          const float* p = sB[buf][b] + (16 * ks + 4 * kq) * LDB + j * 16 + li;
 #pragma unroll
           for (int e = 0; e < 4; ++e) fb[b][j][e] = p[e * LDB];
         }
@@ -750,14 +754,20 @@ __global__ __launch_bounds__(256) void wn_ts_wgrad_kernel(TsArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int m = (wave * MW + i) * 16 + 4 * kq + r, n = (j0 + j) * 16 + li;
+#ifdef WN_TS_NOATOMIC  // timing experiment only: wrong results
+          if (a.rows == 1) a.out[((size_t)m * N + n) * a.ostride + (SPLIT ? tap : b)] = acc[b][i][j][r];
+#else
           atomicAdd(a.out + ((size_t)m * N + n) * a.ostride + (SPLIT ? tap : b), acc[b][i][j][r]);
+#endif
         }
   if (do_csum) atomicAdd(a.colsum + tid, csum);
 }
 
 template <int C, bool DUAL, int NPW>
-void launch_ts_wgrad_npw(TsArgs a, size_t n_chunks, hipStream_t s) {
+void launch_ts_wgrad_npw(TsArgs a, hipStream_t s) {
   constexpr int NSPLIT = NPW < C / 16 ? (DUAL ? 2 : 1) * (C / 16) / NPW : 1;
+  constexpr int KB = NSPLIT > 1 ? 32 : 16;  // (the kernel's chunk)
+  const size_t n_chunks = (a.rows + KB - 1) / KB;
   size_t slices = NSPLIT == 1 ? 512 : (512 / NSPLIT + 7) / 8 * 8;  // ~two workgroups per CU in all
   if (slices > n_chunks) slices = n_chunks;
   a.chunks_per_wg = (n_chunks + slices - 1) / slices;
@@ -776,9 +786,9 @@ int launch_ts_wgrad(TsArgs a, hipStream_t s) {
   static const int forced = [] { const char* e = getenv("BLVM_WN_WGRAD_NPW"); return e ? atoi(e) : 0; }();
   int npw = n_chunks >= 512 * 64 ? NT : (NT >= 2 ? NT / 2 : 1);
   if (forced > 0) npw = forced >= NT ? NT : (forced > 1 && NT >= 2 ? NT / 2 : 1);
-  if (npw >= NT) launch_ts_wgrad_npw<C, DUAL, NT>(a, n_chunks, s);
-  else if (npw > 1) launch_ts_wgrad_npw<C, DUAL, (NT >= 2 ? NT / 2 : 1)>(a, n_chunks, s);
-  else launch_ts_wgrad_npw<C, DUAL, 1>(a, n_chunks, s);
+  if (npw >= NT) launch_ts_wgrad_npw<C, DUAL, NT>(a, s);
+  else if (npw > 1) launch_ts_wgrad_npw<C, DUAL, (NT >= 2 ? NT / 2 : 1)>(a, s);
+  else launch_ts_wgrad_npw<C, DUAL, 1>(a, s);
   return BLVM_OK;
 }
 
@@ -991,5 +1001,83 @@ extern "C" int blvm_wavenet_block_bwd(const float* x, const float* conv_w, const
     if (rc) return rc;
   }
   BLVM_CHECK_LAUNCH("wavenet_block_bwd");
+  return BLVM_OK;
+}
+
+// ---- the whole residual stack in one call (`ResidualStack.forward`, wavenet_modules.py:178-215) ---------------------------------
+// At the reference's own batch (4 utterances) a block's kernels take 0.1-0.2 ms while the Python loop around blvm_wavenet_block_*
+// (two allocations and seventeen converted arguments per block) takes as long: the host, not the GPU, set the step time.  Here the
+// host loop is in the library; block outputs and reserves are slices of two caller-allocated buffers.
+namespace {
+// block i (input length Li): output rows and reserve floats, in floats from the start of the concatenated buffers
+struct StackLayout {
+  std::vector<size_t> act_off, res_off;  // [n + 1]
+  std::vector<int> L_in;                 // [n]
+};
+int stack_layout(int L, int B, int C, const int* dilations, int n, StackLayout& lay) {
+  BLVM_REQUIRE(n > 0 && n <= 4096 && dilations != nullptr && L > 0 && B > 0 && C > 0 && C % 4 == 0, "wavenet_stack: bad shape (%d blocks)", n);
+  lay.act_off.assign(n + 1, 0); lay.res_off.assign(n + 1, 0); lay.L_in.assign(n, 0);
+  int Li = L;
+  for (int i = 0; i < n; ++i) {
+    BLVM_REQUIRE(dilations[i] > 0 && Li > dilations[i], "wavenet_stack: block %d: input length %d, dilation %d", i, Li, dilations[i]);
+    lay.L_in[i] = Li;
+    lay.res_off[i + 1] = lay.res_off[i] + blvm_wavenet_block_reserve_floats(Li, B, C, dilations[i]);
+    lay.act_off[i + 1] = lay.act_off[i] + (i + 1 < n ? (size_t)(Li - dilations[i]) * B * C : 0);  // the last block has no residual output
+    Li -= dilations[i];
+  }
+  return BLVM_OK;
+}
+}  // namespace
+
+extern "C" int blvm_wavenet_stack_floats(int L, int B, int C, const int* dilations, int n_blocks, size_t* acts_floats, size_t* reserve_floats) {
+  StackLayout lay;
+  const int rc = stack_layout(L, B, C, dilations, n_blocks, lay);
+  if (rc) return rc;
+  if (acts_floats) *acts_floats = lay.act_off[n_blocks];
+  if (reserve_floats) *reserve_floats = lay.res_off[n_blocks];
+  return BLVM_OK;
+}
+
+extern "C" int blvm_wavenet_stack_fwd(const float* x, const float* const* params, const int* dilations, const int* groups, int n_blocks, int L,
+                                      int B, int C, int S, int T_skip, float inv_std, float* acts, float* const* skips, float* reserve,
+                                      float* workspace, void* stream) {
+  BLVM_REQUIRE(x && params && groups && reserve && workspace && (acts || n_blocks == 1), "wavenet_stack_fwd: null pointer");
+  StackLayout lay;
+  int rc = stack_layout(L, B, C, dilations, n_blocks, lay);
+  if (rc) return rc;
+  for (int i = 0; i < n_blocks; ++i) {
+    const float* xi = i == 0 ? x : acts + lay.act_off[i - 1];
+    float* o = i + 1 < n_blocks ? acts + lay.act_off[i] : nullptr;
+    const int Si = groups[i] >= 0 ? S : 0;
+    BLVM_REQUIRE(Si == 0 || (skips && skips[groups[i]]), "wavenet_stack_fwd: block %d: no skip tensor %d", i, groups[i]);
+    rc = blvm_wavenet_block_fwd(xi, params[4 * i], params[4 * i + 1], params[4 * i + 2], params[4 * i + 3], lay.L_in[i], B, C, Si, dilations[i],
+                                T_skip, inv_std, o, Si ? skips[groups[i]] : nullptr, reserve + lay.res_off[i], workspace, stream);
+    if (rc) return rc;
+  }
+  return BLVM_OK;
+}
+
+extern "C" int blvm_wavenet_stack_bwd(const float* x, const float* const* params, const int* dilations, const int* groups, int n_blocks, int L,
+                                      int B, int C, int S, int T_skip, float inv_std, const float* acts, const float* reserve,
+                                      const float* const* d_skips, float* d_x, float* d_scratch, float* const* grads, float* workspace,
+                                      void* stream) {
+  BLVM_REQUIRE(x && params && groups && reserve && workspace && d_x && grads && (acts || n_blocks == 1) && (d_scratch || n_blocks == 1),
+               "wavenet_stack_bwd: null pointer");
+  StackLayout lay;
+  int rc = stack_layout(L, B, C, dilations, n_blocks, lay);
+  if (rc) return rc;
+  // input gradients ping-pong between d_x (even blocks; block 0's is the result) and d_scratch (odd blocks), both [L,B,C]
+  const float* d_o = nullptr;
+  for (int i = n_blocks - 1; i >= 0; --i) {
+    const float* xi = i == 0 ? x : acts + lay.act_off[i - 1];
+    float* d_xi = (i & 1) ? d_scratch : d_x;
+    const int Si = groups[i] >= 0 ? S : 0;
+    BLVM_REQUIRE(Si == 0 || (d_skips && d_skips[groups[i]]), "wavenet_stack_bwd: block %d: no skip gradient %d", i, groups[i]);
+    rc = blvm_wavenet_block_bwd(xi, params[4 * i], params[4 * i + 2], reserve + lay.res_off[i], d_o, Si ? d_skips[groups[i]] : nullptr, lay.L_in[i],
+                                B, C, Si, dilations[i], T_skip, inv_std, d_xi, grads[4 * i], grads[4 * i + 1], grads[4 * i + 2], grads[4 * i + 3],
+                                workspace, stream);
+    if (rc) return rc;
+    d_o = d_xi;
+  }
   return BLVM_OK;
 }

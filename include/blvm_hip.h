@@ -376,6 +376,22 @@ int blvm_wavenet_block_bwd(const float* x, const float* conv_w, const float* rs_
                            int T_skip, float inv_std, float* d_x, float* dconv_w, float* dconv_b, float* drs_w,
                            float* drs_b, float* workspace, void* stream);
 
+/*   The whole residual stack in one call (`ResidualStack.forward`, `blvm/models/wavenet/wavenet_modules.py:178-215`: the loop over
+ *   `Conv1dResidualGLU` blocks and the sum of their skip outputs): the host loop over blvm_wavenet_block_fwd / _bwd inside the library.
+ *   params: HOST array of 4 n_blocks device pointers (conv_w, conv_b, rs_w, rs_b per block); dilations, groups: HOST arrays
+ *   [n_blocks]; groups[i] = index into skips / d_skips of the tensor block i's skip branch is accumulated into, -1 = unused
+ *   (that block runs with S = 0).  acts: the residual outputs of blocks 0 .. n-2 back to back, reserve: the blocks' reserves back
+ *   to back (sizes from blvm_wavenet_stack_floats).  Backward: d_x [L,B,C] (=), d_scratch [L,B,C] (overwritten), grads: HOST array
+ *   of 4 n_blocks device pointers (+=, each may be NULL). */
+int blvm_wavenet_stack_floats(int L, int B, int C, const int* dilations, int n_blocks, size_t* acts_floats, size_t* reserve_floats);
+int blvm_wavenet_stack_fwd(const float* x, const float* const* params, const int* dilations, const int* groups, int n_blocks, int L,
+                           int B, int C, int S, int T_skip, float inv_std, float* acts, float* const* skips, float* reserve,
+                           float* workspace, void* stream);
+int blvm_wavenet_stack_bwd(const float* x, const float* const* params, const int* dilations, const int* groups, int n_blocks, int L,
+                           int B, int C, int S, int T_skip, float inv_std, const float* acts, const float* reserve,
+                           const float* const* d_skips, float* d_x, float* d_scratch, float* const* grads, float* workspace,
+                           void* stream);
+
 /* K10c  Autoregressive WaveNet sampling: all frames of all utterances in ONE launch, from an all-zero start.  Replaces the
  *   per-frame loop of `WaveNet.generate` (`blvm/models/wavenet/wavenet.py:254-293`) with the cached formulation its TODO
  *   names: block i keeps a ring buffer of its input over the last dilation_i frames.  in_channels = n_stack_frames = 1.

@@ -1,5 +1,6 @@
-"""Host enqueue time of each phase of a VRNN [64,16000] train step, with the queue drained before every step (a phase that
-waits for the GPU shows up as long as the GPU work before it).  Run on the GPU box."""
+"""Host enqueue time of each phase of a train step (default VRNN [64,16000]; `probe_host_phases.py wavenet 4` = bench.py's model of
+that name at batch 4), with the queue drained before every step (a phase that waits for the GPU shows up as long as the GPU work
+before it).  Run on the GPU box."""
 import math
 import os
 import sys
@@ -8,17 +9,22 @@ import time
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "benchmarking-lvms_amd"))
-from blvm.models import VRNNAudio  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench  # noqa: E402
 
+name = sys.argv[1] if len(sys.argv) > 1 else "vrnn"
+Bn = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 torch.manual_seed(0)
 dev = torch.device("cuda", 0)
-m = VRNNAudio(likelihood="DMoL", input_size=64, hidden_size=256, latent_size=256, residual_posterior=True).to(dev)
+m = bench.build_model(name, dev)
+free_nats = {"vrnn": 2.0, "srnn": 2.0, "cwvae": 4.0, "stcn": 4.0}.get(name)
 params = list(m.parameters())
 opt = torch.optim.Adam(params, lr=3e-4)
 g = torch.Generator().manual_seed(0)
-u = (torch.rand(64, 16000, generator=g) * 2 - 1) * 0.5
+Tn = 49152 if name == "cwvae" else 16000
+u = (torch.rand(Bn, Tn, generator=g) * 2 - 1) * 0.5
 x = (u.sign() * torch.log1p(65535 * u.abs()) / math.log(65536)).to(dev)
-x_sl = torch.full((64,), 16000, dtype=torch.int64)
+x_sl = torch.full((Bn,), Tn, dtype=torch.int64)
 acc = {}
 
 
@@ -32,7 +38,7 @@ def step():
     t0 = t = time.perf_counter()
     opt.zero_grad(set_to_none=True)
     t = mark("zero_grad", t)
-    loss, _, _ = m(x, x_sl, beta=1.0, free_nats=2.0)
+    loss, _, _ = m(x, x_sl, beta=1.0, free_nats=free_nats) if free_nats is not None else m(x, x_sl)
     t = mark("forward", t)
     loss.backward()
     t = mark("backward", t)
