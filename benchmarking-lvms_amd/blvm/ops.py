@@ -181,6 +181,21 @@ def _dmol_check_shapes(dec, W, y, B, T, Tp, S, num_mix):
         raise _hip.BlvmHipError(f"DMoL: targets must be [B={B}, T={T}] with T <= T'*S={Tp * S}, got {tuple(y.shape)}")
 
 
+def _head_linear_grads(d_par, dec, W, b, F, n_frames, need_w, need_b):
+    """Gradients of a likelihood head's per-frame Linear(F, F): dW = d_par^T dec and db = column sums of d_par over all frames, in one
+    launch when both are wanted (the bias gradient rides in the weight-gradient GEMM)."""
+    dW = db = None
+    if need_w:
+        dW = torch.zeros_like(W)
+        db = torch.zeros_like(b) if need_b else None
+        check(load().blvm_wgrad_f32(F, F, n_frames, ptr(d_par), F, ptr(dec), F, ptr(dW), F, ptr(db), max(256, min(1024, n_frames // 1024)),
+                                    stream_ptr()), "blvm_wgrad_f32")  # fmt: skip
+    elif need_b:
+        db = torch.empty_like(b)
+        colsum(d_par.view(n_frames, F), db)
+    return dW, db
+
+
 class _DMoLFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dec, W, b, y, x_sl_dev, layout, B, T, Tp, S, num_mix, num_bins, log_eps):
@@ -213,13 +228,7 @@ class _DMoLFunction(torch.autograd.Function):
             "blvm_dmol_bwd",
         )  # fmt: skip
         n_frames = dec.numel() // F
-        dW = db = None
-        if ctx.has_linear and ctx.needs_input_grad[1]:
-            dW = torch.zeros_like(W)
-            gemm(1, 1, F, F, n_frames, d_par, F, dec, F, dW, F, accumulate=True, split_k=max(256, min(1024, n_frames // 1024)))
-        if ctx.has_linear and ctx.needs_input_grad[2]:
-            db = torch.empty_like(b)
-            colsum(d_par.view(n_frames, F), db)
+        dW, db = _head_linear_grads(d_par, dec, W, b, F, n_frames, ctx.has_linear and ctx.needs_input_grad[1], ctx.has_linear and ctx.needs_input_grad[2])
         return (d_dec if ctx.needs_input_grad[0] else None, dW, db) + (None,) * 10
 
 
@@ -275,13 +284,7 @@ class _GaussHeadFunction(torch.autograd.Function):
                                          sd_eps, ptr(d_dec), ptr(d_par), stream_ptr())  # fmt: skip
         check(rc, "blvm_gmm_bwd" if kind == 1 else "blvm_gauss_head_bwd")
         n_frames = dec.numel() // F
-        dW = db = None
-        if ctx.has_linear and ctx.needs_input_grad[1]:
-            dW = torch.zeros_like(W)
-            gemm(1, 1, F, F, n_frames, d_par, F, dec, F, dW, F, accumulate=True, split_k=max(256, min(1024, n_frames // 1024)))
-        if ctx.has_linear and ctx.needs_input_grad[2]:
-            db = torch.empty_like(b)
-            colsum(d_par.view(n_frames, F), db)
+        dW, db = _head_linear_grads(d_par, dec, W, b, F, n_frames, ctx.has_linear and ctx.needs_input_grad[1], ctx.has_linear and ctx.needs_input_grad[2])
         return (d_dec if ctx.needs_input_grad[0] else None, dW, db) + (None,) * 11
 
 

@@ -851,13 +851,13 @@ extern "C" int blvm_conv1d_k2_bwd(const float* x, const float* W, const float* d
   if (dW) {
     BLVM_HIP(hipMemsetAsync(dW0, 0, sizeof(float) * 2 * nk4, s));
     const int sp = pick_split(Cout, Cin, (int)rows);
-    rc = gemm_f32(1, 1, Cout, Cin, (int)rows, d_out, Cout, x, Cin, dW0, Cin, nullptr, 0, 0.f, nullptr, 0, 1, sp, s);
+    rc = gemm_f32(1, 1, Cout, Cin, (int)rows, d_out, Cout, x, Cin, dW0, Cin, nullptr, 0, 0.f, nullptr, 0, 1, sp, s, db);  // (+ db)
     if (rc) return rc;
     rc = gemm_f32(1, 1, Cout, Cin, (int)rows, d_out, Cout, x + shift * Cin, Cin, dW1, Cin, nullptr, 0, 0.f, nullptr, 0, 1, sp, s);
     if (rc) return rc;
     hipLaunchKernelGGL(merge_taps_kernel, ew_grid(nk), dim3(256), 0, s, dW0, dW1, dW, nk);
   }
-  if (db) { rc = colsum_f32((int)rows, Cout, d_out, Cout, db, 1, s); if (rc) return rc; }
+  if (db && !dW) { rc = colsum_f32((int)rows, Cout, d_out, Cout, db, 1, s); if (rc) return rc; }
   BLVM_CHECK_LAUNCH("conv1d_k2_bwd");
   return BLVM_OK;
 }
@@ -979,21 +979,22 @@ extern "C" int blvm_wavenet_block_bwd(const float* x, const float* conv_w, const
     BLVM_CHECK_LAUNCH("wavenet_block_bwd (fused)");
     return BLVM_OK;
   }
-  if (drs_w) { rc = gemm_f32(1, 1, C + S, C, (int)rows, d_rs, C + S, act, C, drs_w, C, nullptr, 0, 0.f, nullptr, 0, 1, pick_split(C + S, C, (int)rows), s); if (rc) return rc; }
-  if (drs_b) { rc = colsum_f32((int)rows, C + S, d_rs, C + S, drs_b, 1, s); if (rc) return rc; }
+  // (bias gradients = column sums of the GEMM's A operand: they ride in its first column block, gemm.hip)
+  if (drs_w) { rc = gemm_f32(1, 1, C + S, C, (int)rows, d_rs, C + S, act, C, drs_w, C, nullptr, 0, 0.f, nullptr, 0, 1, pick_split(C + S, C, (int)rows), s, drs_b); if (rc) return rc; }
+  else if (drs_b) { rc = colsum_f32((int)rows, C + S, d_rs, C + S, drs_b, 1, s); if (rc) return rc; }
   // gate
   if (!fused) hipLaunchKernelGGL(gate_bwd_kernel, ew_grid(rows * (C / 4)), dim3(256), 0, s, pre, d_act, d_pre, rows, C);
   // dilated convolution: weight gradients of both taps, then the two shifted input gradients
   if (dconv_w) {
     BLVM_HIP(hipMemsetAsync(dW0, 0, sizeof(float) * 2 * nk, s));
     const int sp = pick_split(2 * C, C, (int)rows);
-    rc = gemm_f32(1, 1, 2 * C, C, (int)rows, d_pre, 2 * C, x, C, dW0, C, nullptr, 0, 0.f, nullptr, 0, 1, sp, s);
+    rc = gemm_f32(1, 1, 2 * C, C, (int)rows, d_pre, 2 * C, x, C, dW0, C, nullptr, 0, 0.f, nullptr, 0, 1, sp, s, dconv_b);
     if (rc) return rc;
     rc = gemm_f32(1, 1, 2 * C, C, (int)rows, d_pre, 2 * C, x + shift * C, C, dW1, C, nullptr, 0, 0.f, nullptr, 0, 1, sp, s);
     if (rc) return rc;
     hipLaunchKernelGGL(merge_taps_kernel, ew_grid(nk), dim3(256), 0, s, dW0, dW1, dconv_w, nk);
   }
-  if (dconv_b) { rc = colsum_f32((int)rows, 2 * C, d_pre, 2 * C, dconv_b, 1, s); if (rc) return rc; }
+  if (dconv_b && !dconv_w) { rc = colsum_f32((int)rows, 2 * C, d_pre, 2 * C, dconv_b, 1, s); if (rc) return rc; }
   if (!fused) {
     rc = gemm_f32(0, 1, (int)rows, C, 2 * C, d_pre, 2 * C, W0, C, d_x, C, nullptr, 0, 0.f, nullptr, 0, 1, 1, s);
     if (rc) return rc;
