@@ -21,7 +21,7 @@ free_nats = {"vrnn": 2.0, "srnn": 2.0, "cwvae": 4.0, "stcn": 4.0}.get(name)
 params = list(m.parameters())
 opt = torch.optim.Adam(params, lr=3e-4)
 g = torch.Generator().manual_seed(0)
-Tn = 49152 if name == "cwvae" else 16000
+Tn = int(sys.argv[3]) if len(sys.argv) > 3 else (49152 if name == "cwvae" else 16000)
 u = (torch.rand(Bn, Tn, generator=g) * 2 - 1) * 0.5
 x = (u.sign() * torch.log1p(65535 * u.abs()) / math.log(65536)).to(dev)
 x_sl = torch.full((Bn,), Tn, dtype=torch.int64)
