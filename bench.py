@@ -388,7 +388,7 @@ def main():
             # the large-batch regime of the same kernels (the chain's cost per link does not depend on B until B ~ 256): same
             # model, same step, fewer timed steps.  Not the headline: `value` above stays the B = 64 configuration.
             sweep = [dict(batch_per_gpu=B, ms_per_step=m["ms_median"], frames_per_s=B * T / (m["ms_median"] * 1e-3), roofline_frac=achieved / peak)]
-            for Bs in (256, 1024):
+            for Bs in (128, 256, 1024):  # 128: still the persistent launches; 256 and up: a launch per link on 32x32 tiles
                 ms_ = measure(args.model, model, Bs, T, 5, 2, rank, dev, False, FlatGradAllReduce)
                 mc, _ = model_macs(args.model, model, Bs, T)
                 tf = 6 * mc / ((ms_["fwd_ms"] + ms_["bwd_ms"]) * 1e-3) / 1e12
