@@ -152,7 +152,12 @@ __device__ __forceinline__ void mgemm_trip(const rsrc_t (&ar)[GA], unsigned aoff
 #pragma unroll
   for (int u = 0; u < CH; ++u)
 #pragma unroll
+#ifdef PCHAIN_W_HOT  // timing experiment (garbage results): every weight fragment from the tile's first, cache-resident block —
+                     // an upper bound on what weights kept next to the matrix pipe (LDS / registers) could save
+    for (int g = 0; g < G; ++g) w[g][u] = *reinterpret_cast<const wfrag*>(wp[g] + (size_t)ES * 16 * (size_t)(u & 1));
+#else
     for (int g = 0; g < G; ++g) w[g][u] = *reinterpret_cast<const wfrag*>(wp[g] + (size_t)ES * 16 * (size_t)(kc + u * STEP));
+#endif
   if (!polled) {
 #pragma unroll
     for (int u = 0; u < CH; ++u)
