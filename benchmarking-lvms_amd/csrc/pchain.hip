@@ -514,9 +514,18 @@ extern "C" int blvm_pchain_chain_probe(const float* W16, const float* bias, floa
   Builder bld;
   bld.p.S = L; bld.p.B = B; bld.p.xcd = (pchain_tune() & 4) ? 1 : 0; bld.p.lds_products = 1;
   bld.p.prof = pchain_profile_buffer(); bld.p.prof_wg = 1;
-  Desc& d = bld.add(K_LIN, N / 16, 0, nwg > 0 ? nwg : range_for((N / 16) * rt, device_cus() & ~7), N, DF_RELU, 0, L);
-  bld.ptr(d, 0, x16, x); bld.ptr(d, 1, W16); bld.ptr(d, 2, bias); bld.ptr(d, 5, xs, sN); bld.ptr(d, 6, x16 + x, x);
-  d.ld[3] = N; d.n16[0] = N / 16; d.f[0] = 0.f;
+  static const int run = [] { const char* e = getenv("BLVM_PCHAIN_PROBE_RUN"); return e ? atoi(e) : 1; }();  // links per K_LINSEQ visit
+  const int nw = nwg > 0 ? nwg : range_for((N / 16) * rt, device_cus() & ~7);
+  if (run >= 2 && run <= 4 && L % run == 0) {  // the same chain as runs of `run` links in one descriptor visit
+    bld.p.S = L / run;
+    SeqLink lk[4];
+    for (int i = 0; i < run; ++i) lk[i] = SeqLink{W16, bias, xs + (long)i * sN, run * sN, N, x16 + (long)(i + 1) * x};
+    add_linseq(bld, N / 16, 0, nw, N, true, false, 0, L / run, x16, run * x, run, lk, 0, run * x, N / 16, 0.f, 0);
+  } else {
+    Desc& d = bld.add(K_LIN, N / 16, 0, nw, N, DF_RELU, 0, L);
+    bld.ptr(d, 0, x16, x); bld.ptr(d, 1, W16); bld.ptr(d, 2, bias); bld.ptr(d, 5, xs, sN); bld.ptr(d, 6, x16 + x, x);
+    d.ld[3] = N; d.n16[0] = N / 16; d.f[0] = 0.f;
+  }
   int rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
   if (rc) return rc;
   BLVM_HIP(hipMemsetAsync(x16 + x, 0xFF, sizeof(float) * (size_t)x * L, s));

@@ -34,8 +34,12 @@ def run(B, N, L, nwg=0, check_out=True):
             x = torch.relu(x @ W.double().t() + b.double())
             err = max(err, float((xs[s].double() - x).abs().max() / (x.abs().max() + 1e-30)))
     print(f"engine chain B={B} N=K={N} L={L} nwg={nwg}: {best * 1e3 / L:.3f} us/link (incl. resolve + memset), max rel err over 50 links {err:.1e}", flush=True)
-for B in (8, 64):
-    for N in (256, 512, 192):
-        run(B, N, 2000)
-run(64, 256, 2000, nwg=256)
-run(8, 256, 2000, nwg=256)
+if os.environ.get("QUICK"):  # (BLVM_PCHAIN_PROBE_RUN=n: the chain as runs of n links per K_LINSEQ visit)
+    run(64, 256, 2000)
+    run(8, 256, 2000)
+else:
+    for B in (8, 64):
+        for N in (256, 512, 192):
+            run(B, N, 2000)
+    run(64, 256, 2000, nwg=256)
+    run(8, 256, 2000, nwg=256)
