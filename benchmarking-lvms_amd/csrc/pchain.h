@@ -995,7 +995,6 @@ enum DescFlag : int {
   DF_CANARY = 32,      // one-word canary wait in front of the operand poll
   DF_A_SUM3 = 64,      // K_LIN: the polled operand is the sum of three slabs (p[0], p[8], p[9]) of partial sums
   DF_SEQ_GATE = 128,   // K_LINSEQ: the per-link auxiliary pointer is the derivative gate (backward chains), not the bias
-  DF_SEQ_ADD0 = 256,   // K_LINSEQ: link 0 adds p[19] (a row-major addend computed before the launch)
 };
 constexpr int kMaxDesc = 24, kMaxPtr = 20;
 struct Desc {

@@ -378,6 +378,11 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
       bld.ptr(d, 5, orm, rm_step); bld.ptr(d, 6, o16, o16_step);
       d.ld[1] = ldadd; d.ld[3] = ldo; d.n16[0] = n16; d.f[0] = 0.f;
     };
+    // F1: first prior layer | h-half of the first posterior layer | hidden projection
+    lin(rs.H16, xR, rs.Wp[0], R, w->prior_b[0], nullptr, 0, 0, rs.P[0], sH, H, rs.P16[0], xH, ctH, ctH, 0, half, DF_RELU);
+    lin(rs.H16, xR, rs.Wq[0], R, nullptr, rs.XQ, sH, H, rs.Q[0], sH, H, rs.Q16[0], xH, ctH, ctH, half, half, DF_RELU);
+    lin(rs.H16, xR, rs.Whh, R, w->gru_bhh, nullptr, 0, 0, rs.GHb, s3R, 3 * R, nullptr, 0, 0, 3 * ctR, g, def_n,
+        DF_RM_SC1 | DF_GENTLE | ((pchain_tune() & 16) ? DF_CANARY : 0));
     // a run of consecutive links of one shape as one descriptor: out_i = relu(A_i W_i^T + b_i), A_{i+1} = out_i
     struct SeqLink { const float* W; const float* bias; float* orm; long rm_step; int ldo; float* o16; };
     auto linseq = [&](const float* A16, long a_step, int K, int n, const SeqLink* L, int wg0, int nwg) {
@@ -390,27 +395,13 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
       d.n16[0] = ctH; d.i[1] = n; d.f[0] = 0.f;
     };
     const bool seq = pchain_linseq();
-    // F1: first prior layer | h-half of the first posterior layer | hidden projection
-    if (!seq) {
-      lin(rs.H16, xR, rs.Wp[0], R, w->prior_b[0], nullptr, 0, 0, rs.P[0], sH, H, rs.P16[0], xH, ctH, ctH, 0, half, DF_RELU);
-      lin(rs.H16, xR, rs.Wq[0], R, nullptr, rs.XQ, sH, H, rs.Q[0], sH, H, rs.Q16[0], xH, ctH, ctH, half, half, DF_RELU);
-    }
-    // F1..F3 as one run per branch (the first layer has its own K = R and, for the posterior, the hoisted enc half as addend)
+    // F2, F3
     if (seq) {
-      const SeqLink lp[3] = {{rs.Wp[0], w->prior_b[0], rs.P[0], sH, H, rs.P16[0]}, {rs.Wp[1], w->prior_b[1], rs.P[1], sH, H, rs.P16[1]},
-                             {rs.Wp[2], w->prior_b[2], rs.P[2], sH, H, rs.P16[2]}};
-      const SeqLink lq[3] = {{rs.Wq[0], nullptr, rs.Q[0], sH, H, rs.Q16[0]}, {rs.Wq[1], w->post_b[1], rs.Q[1], sH, H, rs.Q16[1]},
-                             {rs.Wq[2], w->post_b[2], rs.Q[2], sH, H, rs.Q16[2]}};
-      linseq(rs.H16, xR, H, 3, lp, 0, half);
-      bld.p.d[bld.p.ndesc - 1].i[3] = R;
-      linseq(rs.H16, xR, H, 3, lq, half, half);
-      Desc& dq = bld.p.d[bld.p.ndesc - 1];
-      dq.i[3] = R; dq.i[2] = H; dq.flags |= DF_SEQ_ADD0;
-      bld.ptr(dq, 19, rs.XQ, sH);
-    }
-    lin(rs.H16, xR, rs.Whh, R, w->gru_bhh, nullptr, 0, 0, rs.GHb, s3R, 3 * R, nullptr, 0, 0, 3 * ctR, g, def_n,
-        DF_RM_SC1 | DF_GENTLE | ((pchain_tune() & 16) ? DF_CANARY : 0));
-    if (!seq) {  // F2, F3
+      const SeqLink lp[2] = {{rs.Wp[1], w->prior_b[1], rs.P[1], sH, H, rs.P16[1]}, {rs.Wp[2], w->prior_b[2], rs.P[2], sH, H, rs.P16[2]}};
+      const SeqLink lq[2] = {{rs.Wq[1], w->post_b[1], rs.Q[1], sH, H, rs.Q16[1]}, {rs.Wq[2], w->post_b[2], rs.Q[2], sH, H, rs.Q16[2]}};
+      linseq(rs.P16[0], xH, H, 2, lp, 0, half);
+      linseq(rs.Q16[0], xH, H, 2, lq, half, half);
+    } else {
       for (int l = 1; l < 3; ++l) {
         lin(rs.P16[l - 1], xH, rs.Wp[l], H, w->prior_b[l], nullptr, 0, 0, rs.P[l], sH, H, rs.P16[l], xH, ctH, ctH, 0, half, DF_RELU);
         lin(rs.Q16[l - 1], xH, rs.Wq[l], H, w->post_b[l], nullptr, 0, 0, rs.Q[l], sH, H, rs.Q16[l], xH, ctH, ctH, half, half, DF_RELU);
@@ -425,7 +416,7 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
       d.ld[3] = Z; d.n16[0] = ctZ; d.i[0] = Z; d.i[1] = residual_posterior; d.f[0] = beta; d.f[1] = 1.f / beta; d.f[2] = sd_eps;
     }
     // F5..F8: phi_z MLP (the last layer writes phi into decin row t)
-    const int first_seq = !seq ? 4 : 0;  // (the first layer's K is Z: i[3] of the run)
+    const int first_seq = !seq ? 4 : (Z == H ? 0 : 1);  // (the first layer's K is Z: part of the run only when Z == H)
     for (int l = 0; l < first_seq; ++l) {
       const float* A = l == 0 ? rs.Z16 : rs.FZ16[l - 1];
       lin(A, l == 0 ? xZ : xH, rs.Wf[l], l == 0 ? Z : H, w->phi_b[l], nullptr, 0, 0, l == 3 ? decin : rs.FZ[l], l == 3 ? sD : sH, l == 3 ? ldd : H,
@@ -436,7 +427,6 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
       for (int l = first_seq; l < 4; ++l)
         lf[l - first_seq] = SeqLink{rs.Wf[l], w->phi_b[l], l == 3 ? decin : rs.FZ[l], l == 3 ? sD : sH, l == 3 ? ldd : H, l == 3 ? rs.PHI16 : rs.FZ16[l]};
       linseq(first_seq == 0 ? rs.Z16 : rs.FZ16[first_seq - 1], first_seq == 0 ? xZ : xH, H, 4 - first_seq, lf, 0, range_for(ctH * rt, g));
-      if (first_seq == 0) bld.p.d[bld.p.ndesc - 1].i[3] = Z;
     }
     {  // F9: GRU
       Desc& d = bld.add(K_GRU, ctR, 0, range_for(ctR * rt, g), H, 0, 0, Tp);
@@ -678,10 +668,9 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     // B3..B5: back through phi_z layers 3, 2, 1
     // a run of consecutive backward links of one shape as one descriptor (K_LINSEQ): D_{i+1} = (D_i W_i) masked by the saved activation
     struct SeqLinkB { const float* WT; const float* gate; float* orm; float* o16; };
-    auto linseq_b = [&](const float* A16, long a_x, int K0, int n, const SeqLinkB* L, int wg0, int nwg, int flags) -> Desc& {
+    auto linseq_b = [&](const float* A16, int n, const SeqLinkB* L, int wg0, int nwg, int flags) -> Desc& {
       Desc& d = bld.add(K_LINSEQ, ctH, wg0, nwg, H, flags | DF_SEQ_GATE, 0, T);
-      d.i[3] = K0;  // (the first link's own reduction length; 0 = H)
-      bld.ptr(d, 0, last(A16, a_x), -a_x);
+      bld.ptr(d, 0, last(A16, xH), -xH);
       for (int i = 0; i < n; ++i) {
         bld.ptr(d, 1 + i, L[i].WT); bld.ptr(d, 5 + i, last(L[i].gate, sH), -sH); bld.ptr(d, 9 + i, last(L[i].orm, sH), -sH);
         bld.ptr(d, 13 + i, last(L[i].o16, xH), -xH);
@@ -693,7 +682,7 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     const bool seq = pchain_linseq();
     if (seq) {
       const SeqLinkB lf[3] = {{ws.fT[3], rs.FZ[2], ws.DPHI[2], ws.DPHI16[2]}, {ws.fT[2], rs.FZ[1], ws.DPHI[1], ws.DPHI16[1]}, {ws.fT[1], rs.FZ[0], ws.DPHI[0], ws.DPHI16[0]}};
-      Desc& d = linseq_b(ws.DPHI16[3], xH, 0, 3, lf, 0, range_for(ctH * rt, g), split3 ? DF_A_SUM3 : 0);
+      Desc& d = linseq_b(ws.DPHI16[3], 3, lf, 0, range_for(ctH * rt, g), split3 ? DF_A_SUM3 : 0);
       if (split3) { bld.ptr(d, 17, ws.DPHI16b + (long)(T - 1) * xH, -xH); bld.ptr(d, 18, ws.DPHI16c + (long)(T - 1) * xH, -xH); }
     } else {
       for (int l = 3; l >= 1; --l) {
@@ -716,19 +705,18 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
       d.ld[3] = 2 * Z; d.n16[0] = 2 * ctZ; d.i[0] = Z; d.i[1] = residual_posterior; d.i[2] = stride; d.i[3] = T - 1;
       d.f[0] = fn_floor; d.f[1] = beta; d.f[2] = sd_eps;
     }
-    // B7: heads -> last hidden layers (K = 2Z);  B8, B9: hidden layers 2, 1  (prior | posterior): one run per branch
-    if (seq) {
-      const SeqLinkB lp[3] = {{ws.phT, rs.P[2], ws.DP[2], ws.DP16[2]}, {ws.pT[2], rs.P[1], ws.DP[1], ws.DP16[1]}, {ws.pT[1], rs.P[0], ws.DP[0], ws.DP16[0]}};
-      const SeqLinkB lq[3] = {{ws.qhT, rs.Q[2], ws.DQ[2], ws.DQ16[2]}, {ws.qT[2], rs.Q[1], ws.DQ[1], ws.DQ16[1]}, {ws.qT[1], rs.Q[0], ws.DQ[0], ws.DQ16[0]}};
-      linseq_b(ws.DPH16, x2Z, 2 * Z, 3, lp, 0, half, 0);
-      linseq_b(ws.DQH16, x2Z, 2 * Z, 3, lq, half, half, 0);
-    } else {
-      for (int l = 3; l >= 1; --l) {
-        lin(l == 3 ? ws.DPH16 : ws.DP16[l], l == 3 ? x2Z : xH, l == 3 ? ws.phT : ws.pT[l], l == 3 ? 2 * Z : H, nullptr, 0, 0, rs.P[l - 1], sH, H, ws.DP[l - 1], sH, H,
-            ws.DP16[l - 1], xH, ctH, ctH, 0, half, 0);
-        lin(l == 3 ? ws.DQH16 : ws.DQ16[l], l == 3 ? x2Z : xH, l == 3 ? ws.qhT : ws.qT[l], l == 3 ? 2 * Z : H, nullptr, 0, 0, rs.Q[l - 1], sH, H, ws.DQ[l - 1], sH, H,
-            ws.DQ16[l - 1], xH, ctH, ctH, half, half, 0);
-      }
+    // B7: heads -> last hidden layers;  B8, B9: hidden layers 2, 1  (prior | posterior)
+    for (int l = 3; l >= (seq ? 3 : 1); --l) {
+      lin(l == 3 ? ws.DPH16 : ws.DP16[l], l == 3 ? x2Z : xH, l == 3 ? ws.phT : ws.pT[l], l == 3 ? 2 * Z : H, nullptr, 0, 0, rs.P[l - 1], sH, H, ws.DP[l - 1], sH, H,
+          ws.DP16[l - 1], xH, ctH, ctH, 0, half, 0);
+      lin(l == 3 ? ws.DQH16 : ws.DQ16[l], l == 3 ? x2Z : xH, l == 3 ? ws.qhT : ws.qT[l], l == 3 ? 2 * Z : H, nullptr, 0, 0, rs.Q[l - 1], sH, H, ws.DQ[l - 1], sH, H,
+          ws.DQ16[l - 1], xH, ctH, ctH, half, half, 0);
+    }
+    if (seq) {  // B8, B9 of the prior | of the posterior: one visit each
+      const SeqLinkB lp[2] = {{ws.pT[2], rs.P[1], ws.DP[1], ws.DP16[1]}, {ws.pT[1], rs.P[0], ws.DP[0], ws.DP16[0]}};
+      const SeqLinkB lq[2] = {{ws.qT[2], rs.Q[1], ws.DQ[1], ws.DQ16[1]}, {ws.qT[1], rs.Q[0], ws.DQ[0], ws.DQ16[0]}};
+      linseq_b(ws.DP16[2], 2, lp, 0, half, 0);
+      linseq_b(ws.DQ16[2], 2, lq, half, half, 0);
     }
     BLVM_REQUIRE(!bld.overflow, "vrnn_bwd: persistent program overflow");
     rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
