@@ -245,7 +245,9 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
             const bool gated = (flags & DF_SEQ_GATE) != 0;
             bool nx_done = false;
             const float* A = d.p<0>(s);
-            for (int li = 0; li < n; ++li) {  // (links outside, tiles inside: link li+1 of any tile needs link li of ALL tiles of its row tile)
+            for (int lq = 0; lq < n; ++lq) {  // (links outside, tiles inside: link li+1 of any tile needs link li of ALL tiles of its row tile)
+              int li = lq;
+              asm volatile("" : "+s"(li));  // opaque: the five lane indices below are li + constant where they are used, not five more loop counters in SGPRs
               pl.code = ((unsigned)s << 4) | (unsigned)i | ((unsigned)li << 28);
               const float* W = d.basedyn(1 + li);
               auto late = [&]() {
