@@ -255,6 +255,27 @@ def test_persistent_chain_tile_iterator_covers_every_tile_once(tmp_path):
     assert out.returncode == 0 and "0 errors" in out.stdout, out.stdout + out.stderr
 
 
+def test_wavenet_stack_buffer_layout_is_host_arithmetic():
+    """`blvm_wavenet_stack_floats` (the sizes of the two buffers `blvm_wavenet_stack_fwd / _bwd` slice block outputs and reserves
+    from) against the per-block sizes it is defined by; a dilation that leaves no output frames is refused.  No GPU call."""
+    lib = _hip.load()
+    L, B, C = 900, 3, 32
+    dil = [1, 2, 4, 8, 1, 2, 4, 8]
+    arr = (ctypes.c_int * len(dil))(*dil)
+    na, nr = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    assert lib.blvm_wavenet_stack_floats(L, B, C, arr, len(dil), ctypes.byref(na), ctypes.byref(nr)) == 0
+    Li, acts, res = L, 0, 0
+    for i, d in enumerate(dil):
+        res += lib.blvm_wavenet_block_reserve_floats(Li, B, C, d)
+        if i + 1 < len(dil):
+            acts += (Li - d) * B * C
+        Li -= d
+    assert (na.value, nr.value) == (acts, res)
+    assert na.value % 4 == 0 and nr.value % 4 == 0  # every slice starts 16-byte aligned
+    bad = (ctypes.c_int * 2)(5, 900)
+    assert lib.blvm_wavenet_stack_floats(L, B, C, bad, 2, ctypes.byref(na), ctypes.byref(nr)) != 0
+
+
 def test_save_run_load_run_round_trip_with_the_weights_only_loader(tmp_path):
     """checkpoints are read back with loaders that execute nothing from the file."""
     from blvm.training.restore import load_run, save_run
