@@ -35,8 +35,6 @@ class CWVAE(nn.Module):
         as whole-sequence HIP launches, there is nothing to script."""
         super().__init__()
         assert isinstance(strides, list)
-        if with_resets:
-            raise NotImplementedError("libblvm_hip: with_resets=True (state reset on the parent's tick) is not built yet")
         if not (isinstance(encoder, ConvCoder1d) and isinstance(decoder, ConvCoder1d) and decoder.transposed and not encoder.transposed):
             raise NotImplementedError("libblvm_hip: CWVAE needs ConvCoder1d coders (encoder plain, decoder transposed)")
         if not isinstance(likelihood, (DiscretizedLogisticMixtureDense, DiagonalGaussianMixtureDense, DiagonalGaussianDense)):
@@ -71,6 +69,30 @@ class CWVAE(nn.Module):
         length = get_modulo_length(length, self.overall_stride, self.overall_receptive_field)
         overlap = self.overall_receptive_field - self.overall_stride
         return split_sequence(x, x_sl, length=length, overlap=overlap, drop_inactive=drop_inactive)
+
+    # ---- with_resets (clockwork_vae.py:273-275, 369-371) -----------------------------------------------------------------
+    # Below the top level the state is reset to zeros at every step t with t % strides[l + 1] == 0 (t = 0 included, so a carried
+    # state0 is never used there): the level's sequence is T_l / k INDEPENDENT segments of k = strides[l + 1] steps from a zero
+    # state.  Independent sequences are what the batch axis of the cell kernels is for: the segments run as (segment, utterance)
+    # rows of ONE k-step sequence launch — more rows, fewer dependent steps — and are laid back along time afterwards.
+    @staticmethod
+    def _fold(t: Optional[torch.Tensor], k: int, nseg: int):
+        """[T_l, B, F] -> [k, nseg * B, F] (row = segment * B + utterance), zero-padded to nseg * k steps."""
+        if t is None:
+            return None
+        T_l, B, F = t.shape
+        if nseg * k != T_l:
+            t = torch.cat([t, t.new_zeros(nseg * k - T_l, B, F)], 0)
+        return t.view(nseg, k, B, F).transpose(0, 1).reshape(k, nseg * B, F).contiguous()
+
+    @staticmethod
+    def _unfold(t: torch.Tensor, k: int, nseg: int, T_l: int):
+        """[k, nseg * B, F] -> [T_l, B, F]."""
+        B = t.shape[1] // nseg
+        return t.view(k, nseg, B, -1).transpose(0, 1).reshape(nseg * k, B, -1)[:T_l]
+
+    def _resets(self, l: int) -> int:
+        return int(self.strides[l + 1]) if (self.with_resets and l < self.num_levels - 1) else 0
 
     def forward_split(self, x, x_sl, is_last_split: bool, state0=None, beta: float = 1, free_nats: float = 0, y=None,
                       use_mode_global: bool = False):  # fmt: skip
@@ -132,8 +154,23 @@ class CWVAE(nn.Module):
             else:
                 eps_l = torch.randn(T_l, B, Z, device=dev)
             fn_l = free_nats * os_[l] / os_[0]  # free nats scale with the level's stride (clockwork_vae.py:151)
-            zs, hs, kld, kld_fn, mu_q, _, mu_p, _ = self.cells[l].sequence(
-                enc_l[:T_l], None if context is None else context[:T_l], states0[l], eps_l, x_sl_dev, os_[l], fn_l)  # fmt: skip
+            k = self._resets(l)
+            if k:
+                nseg = -(-T_l // k)
+                # valid steps of (segment, utterance): the level's step count of the utterance that falls into the segment
+                steps = (level_sl[l].unsqueeze(0) - k * torch.arange(nseg).unsqueeze(1)).clamp(0, k)  # [nseg, B]
+                seg_sl = ops.upload_i32((steps * os_[l]).reshape(-1), dev)
+                f = lambda t: self._fold(t, k, nseg)  # noqa: E731
+                u = lambda t: self._unfold(t, k, nseg, T_l)  # noqa: E731
+                zs_f, hs_f, kld_f, kld_fn_f, mu_q, _, mu_p, _ = self.cells[l].sequence(
+                    f(enc_l[:T_l]), f(None if context is None else context[:T_l]), None, f(eps_l), seg_sl, os_[l], fn_l)  # fmt: skip
+                zs = torch.cat([zs_f.new_zeros(1, B, Z), u(zs_f[1:])], 0)
+                hs = torch.cat([hs_f.new_zeros(1, B, hs_f.shape[-1]), u(hs_f[1:])], 0)
+                kld, kld_fn = kld_f.view(nseg, B).sum(0), kld_fn_f.view(nseg, B).sum(0)
+                mu_q, mu_p = u(mu_q), u(mu_p)
+            else:
+                zs, hs, kld, kld_fn, mu_q, _, mu_p, _ = self.cells[l].sequence(
+                    enc_l[:T_l], None if context is None else context[:T_l], states0[l], eps_l, x_sl_dev, os_[l], fn_l)  # fmt: skip
             kld_l[l], kld_fn_l[l] = kld, kld_fn
             latents[l], enc_mus[l], prior_mus[l] = zs[1:].transpose(0, 1), mu_q.transpose(0, 1), mu_p.transpose(0, 1)
 
@@ -216,7 +253,14 @@ class CWVAE(nn.Module):
                 raise IndexError(f"generate: level {l} has no steps for {max_timesteps=}")
             Z = self.z_size[l]
             eps_l = eps[l].to(device=dev, dtype=torch.float32).contiguous() if eps is not None else torch.randn(T_l, n_samples, Z, device=dev)
-            zs, hs = self.cells[l].generate_sequence(context, states0[l], eps_l, T_l, n_samples)
+            k = self._resets(l)
+            if k:
+                nseg = -(-T_l // k)
+                zs_f, hs_f = self.cells[l].generate_sequence(self._fold(context[:T_l], k, nseg), None, self._fold(eps_l, k, nseg), k, nseg * n_samples)
+                zs = torch.cat([zs_f.new_zeros(1, n_samples, Z), self._unfold(zs_f[1:], k, nseg, T_l)], 0)
+                hs = torch.cat([hs_f.new_zeros(1, n_samples, hs_f.shape[-1]), self._unfold(hs_f[1:], k, nseg, T_l)], 0)
+            else:
+                zs, hs = self.cells[l].generate_sequence(context, states0[l], eps_l, T_l, n_samples)
             _, context = self.decoder.forward_level_tm(torch.cat([zs[1:], hs[1:]], dim=-1), l, pad_right=same_paddings[l])
         parameters = self.likelihood(context.transpose(0, 1).contiguous())
         x = self.likelihood.mode(parameters) if use_mode_observations else self.likelihood.sample(parameters)

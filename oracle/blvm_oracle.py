@@ -617,7 +617,7 @@ def coder_level(sd, p, hidden, level, block_strides, transposed, pad_right=0):
 
 
 def cwvae_audio_forward(sd, x, x_sl, eps, strides, num_level_layers, stride_per_layer, beta=1.0, free_nats=0.0, state0=None,
-                        residual_posterior=False, precision_posterior=False, num_mix=10, num_bins=256, prefix="cwvae"):
+                        residual_posterior=False, precision_posterior=False, num_mix=10, num_bins=256, prefix="cwvae", with_resets=False):
     """CWVAE.forward with pad_same=True (clockwork_vae.py:200-338) for CWVAEAudio (:396-529).  x [B,T] float, x_sl [B];
     eps[l] [T_l,B,z_l].  Levels run top-down; level l's context is the decoded cat(z, h) of level l+1; the KL of level l
     is masked by ceil(x_sl / overall_stride_l) with free nats scaled by overall_stride_l / overall_stride_0 (:147-153);
@@ -647,8 +647,18 @@ def cwvae_audio_forward(sd, x, x_sl, eps, strides, num_level_layers, stride_per_
         cell_sd = {k[len(f"{prefix}.cells.{l}."):]: v for k, v in sd.items() if k.startswith(f"{prefix}.cells.{l}.")}
         Z, H = cell_sd["prior.6.params.weight"].size(0) // 2, cell_sd["gru_cell.weight_hh"].size(1)
         st0 = (torch.zeros(B, Z, dtype=x.dtype), torch.zeros(B, H, dtype=x.dtype)) if state0 is None else state0[l]
-        zs, hs, d = rssm_sequence(cell_sd, enc, c, st0, eps[l], residual_posterior=residual_posterior,
-                                  precision_posterior=precision_posterior)
+        k_reset = int(strides[l + 1]) if (with_resets and l < NL - 1) else 0
+        if k_reset:  # clockwork_vae.py:273-275: a zero state whenever the level above ticks (t % strides[l + 1] == 0, t = 0 included)
+            parts = []
+            for t0 in range(0, T_l, k_reset):
+                zero = (torch.zeros(B, Z, dtype=x.dtype), torch.zeros(B, H, dtype=x.dtype))
+                parts.append(rssm_sequence(cell_sd, enc[t0:t0 + k_reset], c[t0:t0 + k_reset], zero, eps[l][t0:t0 + k_reset],
+                                           residual_posterior=residual_posterior, precision_posterior=precision_posterior))
+            zs, hs = torch.cat([q[0] for q in parts], 0), torch.cat([q[1] for q in parts], 0)
+            d = {key: torch.cat([q[2][key] for q in parts], 0) for key in parts[0][2]}
+        else:
+            zs, hs, d = rssm_sequence(cell_sd, enc, c, st0, eps[l], residual_posterior=residual_posterior,
+                                      precision_posterior=precision_posterior)
         kl = kl_gaussian(d["enc_mu"], d["enc_sd"], d["prior_mu"], d["prior_sd"])  # [T_l,B,Z]
         sl = torch.ceil(x_sl / os_[l]).to(torch.int64)
         mask = sequence_mask(sl, max_len=T_l).t().unsqueeze(-1)  # [T_l,B,1]

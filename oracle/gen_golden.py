@@ -717,8 +717,58 @@ def gen_lstm():
     save("lstm.npz", **arrays)
 
 
+def gen_cwvae_resets():
+    """CWVAE(with_resets=True) (clockwork_vae.py:273-275: the state of every level below the top is reset to zeros whenever the
+    level above ticks, including t = 0): the reduced CWVAEAudio of gen_cwvae (same seed and configuration, so the same weights)
+    with the flag set on its CWVAE; ragged lengths, free nats, a level whose length is not a multiple of its parent's stride."""
+    cfg = dict(z_size=[32, 16, 16], h_size=16, strides=[4, 2, 2], num_level_layers=2, stride_per_layer=2, likelihood="DMoL",
+               num_mix=10, num_bins=2**16)
+    B, T = 3, 150
+    x, _ = O.synth_batch(B, T, seed=17)
+    x_sl = torch.tensor([150, 97, 41])
+    x = x * (torch.arange(T).unsqueeze(0) < x_sl.unsqueeze(1))
+    torch.manual_seed(51)
+    m = RM.CWVAEAudio(**cfg, precision_posterior=True)
+    m.cwvae.with_resets = True
+    T_l, n = [], T
+    for s_ in cfg["strides"]:
+        n = math.ceil(n / s_)
+        T_l.append(n)
+    eps = replay_eps_levels(77, T_l, B, cfg["z_size"])
+    torch.manual_seed(77)
+    loss, metrics, o = m(x, x_sl, beta=1.0, free_nats=0.5)
+    loss.backward()
+    arrays = dict(x=x, x_sl=x_sl, loss=loss, elbo=o.elbo, log_prob=o.log_prob, kld=o.kld, T_l=np.array(T_l))
+    for l in range(3):
+        arrays.update({f"eps{l}": eps[l], f"z{l}": o.z[l], f"state_z{l}": o.state_n[l][0], f"state_h{l}": o.state_n[l][1]})
+    for k, v in m.state_dict().items():
+        arrays[f"sd.{k}"] = v
+    for k, p in m.named_parameters():
+        arrays[f"grad.{k}"] = p.grad
+    # generation with resets (clockwork_vae.py:369-371): replayed prior noise, the mode of the observation model
+    from blvm.utils.padding import get_same_padding
+
+    Tg, Bg = 64, 2
+    torch.manual_seed(9)
+    with torch.no_grad():
+        (xg, _), _ = m.generate(n_samples=Bg, max_timesteps=Tg, use_mode_observations=True)
+    geps, ctx_len, os_ = [None] * 3, None, [4, 8, 16]  # the prior draws of that call, replayed: top level first, one randn per step
+    torch.manual_seed(9)
+    with torch.no_grad():
+        for l in (2, 1, 0):
+            Tg_l = Tg // os_[l] if l == 2 else ctx_len
+            geps[l] = torch.stack([torch.randn(Bg, cfg["z_size"][l]) for _ in range(Tg_l)], 0)
+            length = math.ceil(Tg / cfg["strides"][l - 1]) if l > 0 else Tg
+            pad = get_same_padding(length, m.cwvae.receptive_fields[l], cfg["strides"][l])
+            ctx_len = m.cwvae.decoder[l](torch.zeros(Bg, cfg["z_size"][l] + cfg["h_size"], Tg_l), pad_right=pad)[1].shape[-1]
+    arrays.update(gen_x=xg, gen_T=np.array([Tg]))
+    for l in range(3):
+        arrays[f"gen_eps{l}"] = geps[l]
+    save("cwvae_resets.npz", **arrays)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn", "wavenet", "rssm", "cwvae", "stcn", "heads", "generate", "generate16", "wavenet_stacked", "data"]
+    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn", "wavenet", "rssm", "cwvae", "stcn", "heads", "generate", "generate16", "wavenet_stacked", "cwvae_resets", "data"]
     for w in which:
         globals()[f"gen_{w}"]()

@@ -105,6 +105,44 @@ def test_cwvae_carried_state(g):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
 
 
+def test_cwvae_with_resets_matches_reference():
+    """CWVAE(with_resets=True) (`clockwork_vae.py:273-275`: every level below the top restarts from a zero state whenever its
+    parent ticks) against the reference's own outputs (tests/golden/cwvae_resets.npz): the HIP path runs the segments between two
+    resets as rows of one short sequence launch.  Level 1 has 19 steps for a parent stride of 2 (a padded last segment); ragged
+    lengths, free nats 0.5; loss / ELBO / KL, latents, the carried states and every parameter gradient; then generation."""
+    g = np.load(os.path.join(GOLDEN, "cwvae_resets.npz"))
+    m = CWVAEAudio(**CW_SMALL, precision_posterior=True)
+    m.load_state_dict({k[3:]: T(g[k]) for k in g.files if k.startswith("sd.")})
+    m.cwvae.with_resets = True
+    m = m.to(DEV)
+    eps = [T(g[f"eps{l}"]).to(DEV) for l in range(3)]
+    loss, _, o = m(T(g["x"]).to(DEV), T(g["x_sl"]), beta=1.0, free_nats=0.5, eps=eps)
+    loss.backward()
+    assert float(loss.detach()) == pytest.approx(float(g["loss"]), rel=1e-5)
+    close(o.elbo, g["elbo"], 1e-5, 1e-3)
+    close(o.log_prob, g["log_prob"], 1e-5, 1e-3)
+    close(o.kld, g["kld"], 1e-4, 1e-3)
+    for l in range(3):
+        close(o.z[l], g[f"z{l}"], 1e-4, 1e-5)
+        close(o.state_n[l][0], g[f"state_z{l}"], 1e-4, 1e-5)
+        close(o.state_n[l][1], g[f"state_h{l}"], 1e-4, 1e-5)
+    # gradients against the float64 oracle, with the reference's own fp32 gradients as the yardstick (as in the test above)
+    sd64 = {k[3:]: T(g[k]).double().requires_grad_(True) for k in g.files if k.startswith("sd.")}
+    out64 = O.cwvae_audio_forward(sd64, T(g["x"]).double(), T(g["x_sl"]), [e.double().cpu() for e in eps], beta=1.0, free_nats=0.5,
+                                  strides=CW_SMALL["strides"], num_level_layers=2, stride_per_layer=2, num_bins=2**16,
+                                  precision_posterior=True, with_resets=True)  # fmt: skip
+    out64["loss"].backward()
+    for k, p in m.named_parameters():
+        truth = sd64[k].grad
+        assert p.grad is not None, k
+        ref_err = rel(T(g[f"grad.{k}"]), truth)
+        assert rel(p.grad, truth) <= max(2 * ref_err, 1e-3), (k, rel(p.grad, truth), ref_err)
+    geps = [T(g[f"gen_eps{l}"]).to(DEV) for l in range(3)]
+    (x, _), _ = m.generate(n_samples=2, max_timesteps=int(g["gen_T"][0]), use_mode_observations=True, eps=geps)
+    assert tuple(x.shape) == tuple(g["gen_x"].shape)
+    close(x, g["gen_x"], 1e-4, 1e-5)
+
+
 def _full_model():
     torch.manual_seed(0)
     return CWVAEAudio(**CW_FULL)

@@ -200,6 +200,34 @@ def test_rssm_cell_sequence(tag, kw, c_dim):
 CW_SMALL = dict(strides=[4, 2, 2], num_level_layers=2, stride_per_layer=2, num_bins=2**16)
 
 
+def test_cwvae_with_resets_forward_backward():
+    """The oracle's with_resets branch (clockwork_vae.py:273-275) pinned by the reference's outputs (cwvae_resets.npz): latents,
+    carried states, loss / ELBO / KL in fp32, and in float64 the gradients within the reference's own fp32 noise."""
+    g = np.load(os.path.join(GOLDEN, "cwvae_resets.npz"))
+    sd = {k[3:]: T(g[k]).clone() for k in g.files if k.startswith("sd.")}
+    x, x_sl = T(g["x"]), T(g["x_sl"])
+    eps = [T(g[f"eps{l}"]) for l in range(3)]
+    kw = dict(beta=1.0, free_nats=0.5, precision_posterior=True, with_resets=True, **CW_SMALL)
+    out = O.cwvae_audio_forward(sd, x, x_sl, eps, **kw)
+    for l in range(3):
+        close(out["z"][l].transpose(0, 1), g[f"z{l}"], 1e-5, 1e-6)
+        close(out["state_n"][l][0], g[f"state_z{l}"], 1e-5, 1e-6)
+        close(out["state_n"][l][1], g[f"state_h{l}"], 1e-5, 1e-6)
+    close(out["loss"], g["loss"], 2e-5, 0)
+    close(out["elbo"], g["elbo"], 2e-5, 0)
+    close(out["kld"], g["kld"], 1e-5, 1e-6)
+    plain = O.cwvae_audio_forward(sd, x, x_sl, eps, **{**kw, "with_resets": False})
+    assert abs(float(plain["loss"]) - float(g["loss"])) > 1e-3  # the flag changes the result
+    sd64 = {k: v.detach().double().requires_grad_(True) for k, v in sd.items()}
+    out64 = O.cwvae_audio_forward(sd64, x.double(), x_sl, [e.double() for e in eps], **kw)
+    out64["loss"].backward()
+    for k in sd:
+        if k.startswith("cwvae.likelihood."):
+            continue
+        ref, truth = T(g[f"grad.{k}"]).double(), sd64[k].grad
+        assert (ref - truth).norm() / (truth.norm() + 1e-12) < 1e-2, k
+
+
 @pytest.mark.parametrize("tag,kw,beta,fn_", [("pw", dict(precision_posterior=True), 1.0, 0.5), ("rs", dict(residual_posterior=True), 0.7, 0.0)])
 def test_cwvae_small_forward_backward(tag, kw, beta, fn_):
     g = np.load(os.path.join(GOLDEN, "cwvae.npz"))
