@@ -147,9 +147,9 @@ class WaveNet(BaseModel):
         `cached=True` (the reference's TODO, arXiv:1611.09482): the same samples from per-block queues of past activations —
         one new frame per block per step instead of the whole window; with the DMoL head and widths the decode kernel takes
         (K10c: every frame in one launch) through `ops.wavenet_decode`, otherwise block by block (`_generate_cached`)."""
-        lik, C = self.likelihood, self.res_channels
-        if self.n_stack_frames != 1:
-            raise NotImplementedError("libblvm_hip: WaveNet.generate is built for n_stack_frames=1")
+        lik, C, nsf = self.likelihood, self.res_channels, self.n_stack_frames
+        if nsf != 1 and (cached or self.in_channels != 1):
+            raise NotImplementedError("libblvm_hip: WaveNet.generate on frame stacks is the window path with in_channels=1 (cached=False)")
         if cached:
             if x is not None:
                 raise NotImplementedError("libblvm_hip: cached generation starts from the all-zero window")
@@ -157,16 +157,17 @@ class WaveNet(BaseModel):
                 return self._generate_decode_kernel(n_samples, n_frames, uniforms)
             return self._generate_cached(n_samples, n_frames, uniforms)
         dev = self.causal.conv.weight.device
-        win = torch.zeros(self.receptive_field, n_samples, self.in_channels, device=dev) if x is None else x.transpose(0, 1).contiguous()
+        win = torch.zeros(self.receptive_field, n_samples, self.in_channels * nsf, device=dev) if x is None else x.transpose(0, 1).contiguous()
         x_hat = []
         for t in range(n_frames):
             out = self.causal.forward_tm(win, pad_causal=False)
             skip = self.res_stack.forward_tm(out, 1)  # [1,B,C]
-            logits = self.out_transform.forward_rows(skip.view(n_samples, C), 1.0 / self.variance_scale)
-            parameters = lik(logits.view(n_samples, 1, C))
-            pred = lik.sample(parameters) if uniforms is None else lik.sample(parameters, uniforms=uniforms[t])  # [B,1,1]
+            logits = self.out_transform.forward_rows(skip.view(n_samples, C), 1.0 / self.variance_scale)  # [B, C * nsf]
+            parameters = lik(logits.view(n_samples, nsf, C))  # unstack_tensor(logits, nsf) (wavenet.py:277-278): one head evaluation per stacked sample
+            pred = lik.sample(parameters) if uniforms is None else lik.sample(parameters, uniforms=uniforms[t])  # [B,nsf,1]
             x_hat.append(pred)
-            win = torch.cat([win[1:], pred.transpose(0, 1).to(torch.float32)], 0)
+            # the nsf new samples are the channels of the next input frame (wavenet.py:290; nsf = 1: one sample, one channel)
+            win = torch.cat([win[1:], pred.reshape(1, n_samples, nsf).to(torch.float32)], 0)
         return torch.hstack(x_hat)
 
     def _decode_kernel_applies(self):

@@ -597,6 +597,17 @@ def gen_wavenet_stacked():
     arrays.update(x=x, x_sl=x_sl, rf=np.int64(m.receptive_field))
     for k, v in m.state_dict().items():
         arrays[f"sd.{k}"] = v
+    # generation on frame stacks (wavenet.py:254-293 with n_stack_frames > 1: the head is evaluated once per stacked sample and the
+    # new samples become the channels of the next input frame); per frame the sampler draws uniforms over [B,4,K] and [B,4,1]
+    torch.manual_seed(47)
+    gu, gu2 = [], []
+    for _ in range(5):
+        gu.append(torch.empty(2, 4, 10).uniform_(1e-5, 1 - 1e-5))
+        gu2.append(torch.empty(2, 4, 1).uniform_(1e-8, 1 - 1e-8))
+    torch.manual_seed(47)
+    with torch.no_grad():
+        xg = m.generate(n_samples=2, n_frames=5)
+    arrays.update(gen_x=xg, gen_u=torch.stack(gu), gen_u2=torch.stack(gu2))
     save("wavenet_stacked.npz", **arrays)
 
 

@@ -607,6 +607,29 @@ def test_wavenet_on_frame_stacks_vs_reference_golden(tag, pad_rf):
         assert rel_l2(p.grad, T(g[f"{tag}_grad.{k}"])) < 1e-3, k
 
 
+def test_wavenet_generation_on_frame_stacks_matches_reference():
+    """WaveNet.generate with n_stack_frames = 4 (`wavenet.py:254-293`: the output transform yields 4 stacked samples per frame, the
+    head is evaluated once per stacked sample, and the 4 new samples are the channels of the next input frame) against the
+    reference's own samples for the same uniform draws (tests/golden/wavenet_stacked.npz)."""
+    from blvm.models import WaveNet
+    from blvm.modules.distributions import DiscretizedLogisticMixtureDense
+
+    g = np.load(os.path.join(GOLDEN, "wavenet_stacked.npz"))
+    lik = DiscretizedLogisticMixtureDense(16, 1, num_mix=10, num_bins=2**16)
+    m = WaveNet(likelihood=lik, n_layers=3, n_stacks=2, res_channels=16, kernel_size=2, base_dilation=2, n_stack_frames=4)
+    m.load_state_dict({k[3:]: T(g[k]) for k in g.files if k.startswith("sd.")})
+    m = m.to(DEV)
+    uni = [(u.to(DEV), u2.to(DEV)) for u, u2 in zip(T(g["gen_u"]), T(g["gen_u2"]))]
+    x = m.generate(n_samples=2, n_frames=5, uniforms=uni)
+    assert tuple(x.shape) == tuple(g["gen_x"].shape) == (2, 20, 1)
+    diff = (x.cpu() - T(g["gen_x"])).abs()
+    assert float((diff > 1e-4).float().mean()) < 0.1, diff  # a Gumbel-max tie may flip one component pick
+    xs = m.generate(n_samples=3, n_frames=2)  # device RNG
+    assert tuple(xs.shape) == (3, 8, 1) and torch.isfinite(xs).all() and float(xs.abs().max()) <= 1.0
+    with pytest.raises(NotImplementedError):
+        m.generate(n_samples=2, n_frames=2, cached=True)
+
+
 def test_wavenet_causality_by_input_gradient_and_short_input():
     """The reference's test strategy for the stack (tests/models/wavenet/test_wavenet.py:65-102): the loss on frames
     < s must not depend on inputs >= s - 1 ... checked through d(loss)/d(x); too-short inputs raise InputSizeError."""
