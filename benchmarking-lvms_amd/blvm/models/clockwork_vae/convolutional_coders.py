@@ -69,8 +69,29 @@ class BlockSeparable(nn.Module):
 
 
 class BlockSimple(nn.Module):
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError("BlockSimple (dense k-tap conv blocks) has no HIP kernel yet; CWVAEAudio uses BlockSeparable")
+    """Dense k-tap (transposed) convolution -> channel norm -> ReLU, plus the nearest-resampled input
+    (convolutional_coders.py:69-91): `ops.dense_conv` (all taps in one K6 GEMM), K11 channel norm, the ReLU pass, K11 resample-add."""
+
+    def __init__(self, channels, kernel_size, stride, dilation, activation_cls: nn.Module, transposed, bias: bool = False):
+        super().__init__()
+        conv_obj = nn.ConvTranspose1d if transposed else nn.Conv1d
+        conv = conv_obj(channels, channels, kernel_size, stride=stride, dilation=dilation, bias=bias)
+        norm = nn.GroupNorm(num_channels=channels, num_groups=channels)  # channel-wise normalisation
+        nonl = activation_cls()
+        require_relu(nonl, "BlockSimple")
+        require_channel_norm(norm, channels, "BlockSimple")
+        self.block = TemporalResidual(nn.Sequential(conv, norm, nonl))
+        self.stride, self.dilation, self.transposed, self.kernel_size = stride, dilation, transposed, kernel_size
+
+    def forward_tm(self, x: torch.Tensor) -> torch.Tensor:
+        conv, norm, _ = self.block.module
+        h = ops.dense_conv(x, conv.weight, conv.bias, self.stride, self.dilation, self.transposed)
+        h = ops.scale_act(ops.chan_norm(h.contiguous(), norm.weight, norm.bias, norm.eps), 1.0, 0.0)
+        return ops.resample_add(h, x)
+
+    def forward(self, x):
+        """Reference layout [B,C,T] (convolutional_coders.py:90-91)."""
+        return self.forward_tm(_to_tm(x)).permute(1, 2, 0)
 
 
 class _Levels(nn.Sequential):

@@ -1190,6 +1190,32 @@ def resample_add(y, x):
     return _ResampleAddFunction.apply(y, x)
 
 
+def dense_conv(x, weight, bias, stride: int = 1, dilation: int = 1, transposed: bool = False):
+    """Dense k-tap Conv1d / ConvTranspose1d (groups = 1, no padding) on time-major x [L,B,Cin] -> [L_out,B,Cout]: the products of
+    ALL taps are one K6 GEMM over every input row ([L*B, Cin] x [Cin, k*Cout], its weight and input gradients from the same node);
+    the taps are then strided slices of that product, summed (convolution) or added into their strided output positions
+    (transposed convolution) by autograd-tracked slicing.  weight: Conv1d [Cout,Cin,k], ConvTranspose1d [Cin,Cout,k].
+    (`BlockSimple`, convolutional_coders.py:69-91 — not a BASELINE configuration: the stride-s convolution multiplies s times the
+    rows it keeps.)"""
+    L, B, Cin = x.shape
+    k = weight.shape[-1]
+    Cout = weight.shape[1] if transposed else weight.shape[0]
+    wcat = (weight.permute(2, 1, 0) if transposed else weight.permute(2, 0, 1)).reshape(k * Cout, Cin)  # row j * Cout + co
+    y = linear(x.reshape(L * B, Cin), wcat, None).view(L, B, k, Cout)
+    if transposed:
+        L_out = (L - 1) * stride + dilation * (k - 1) + 1
+        out = x.new_zeros(L_out, B, Cout)
+        for j in range(k):
+            sl = slice(j * dilation, j * dilation + (L - 1) * stride + 1, stride)
+            out[sl] = out[sl] + y[:, :, j]
+    else:
+        L_out = (L - dilation * (k - 1) - 1) // stride + 1
+        if L_out < 1:
+            raise ValueError(f"dense_conv: input of {L} frames is shorter than the kernel's extent {dilation * (k - 1) + 1}")
+        out = sum(y[j * dilation : j * dilation + (L_out - 1) * stride + 1 : stride, :, j] for j in range(k))
+    return out + bias if bias is not None else out
+
+
 class _SepBlockFunction(torch.autograd.Function):
     """One `BlockSeparable` (convolutional_coders.py:29-66) as a single autograd node on [L,B,C]:
     1x1 conv C->4C + ReLU (K6 epilogue) -> channel norm -> depthwise (transposed) conv k, stride s + ReLU -> channel norm

@@ -9,7 +9,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from blvm import _hip, ops
-from blvm.models.clockwork_vae.convolutional_coders import BlockSeparable, ConvCoder1d
+from blvm.models.clockwork_vae.convolutional_coders import BlockSeparable, BlockSimple, ConvCoder1d
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -146,6 +146,73 @@ def test_separable_block_matches_torch(transposed, stride, C, B, L):
     for n, p in block.named_parameters():
         assert p.grad is not None, n
         assert rel_l2(p.grad, pr[n].grad) < 3e-4, n  # fp32 GEMM weight gradients over L*B rows vs float64
+
+
+def _torch_simple_block(block: BlockSimple, x):
+    """`BlockSimple.forward` (convolutional_coders.py:69-91) from the parameter-holding torch modules, in float64 on the CPU."""
+    h = block.block.module(x)  # conv -> GroupNorm(groups = channels) -> ReLU
+    return h + (x if h.shape[-1] == x.shape[-1] else F.interpolate(x, size=h.shape[-1], mode="nearest"))
+
+
+@pytest.mark.parametrize("transposed", [False, True])
+@pytest.mark.parametrize("stride,dilation,C,B,L,k", [(1, 1, 16, 3, 61, 5), (2, 1, 16, 3, 61, 5), (4, 1, 24, 2, 203, 5), (2, 2, 8, 2, 50, 3), (3, 1, 8, 1, 40, 4)])
+def test_simple_block_matches_torch(transposed, stride, dilation, C, B, L, k):
+    """`BlockSimple` (dense k-tap Conv1d / ConvTranspose1d -> channel norm -> ReLU, + resampled input): all taps as one GEMM and
+    strided tap sums, against the torch operators in float64 — output, input gradient and every parameter gradient."""
+    torch.manual_seed(stride + 10 * transposed + dilation)
+    g = torch.Generator().manual_seed(7)
+    block = BlockSimple(C, k, stride, dilation, nn.ReLU, transposed, bias=True)
+    _randomise_norms(block, g)
+    ref = BlockSimple(C, k, stride, dilation, nn.ReLU, transposed, bias=True).double()
+    ref.load_state_dict(block.state_dict())
+    x = torch.randn(B, C, L, generator=g)
+    xr = x.double().requires_grad_()
+    yr = _torch_simple_block(ref, xr)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+
+    block = block.to(DEV)
+    xd = x.to(DEV).requires_grad_()
+    yd = block(xd)  # reference layout entry point [B,C,T]
+    assert yd.shape == yr.shape
+    yd.backward(dy.to(DEV))
+    assert rel_l2(yd, yr) < TOL
+    assert rel_l2(xd.grad, xr.grad) < 5 * TOL
+    pr = dict(ref.named_parameters())
+    for n, p in block.named_parameters():
+        assert p.grad is not None, n
+        if n == "block.module.0.bias":  # a bias in front of a per-channel norm over time: its gradient is exactly zero (rounding noise on both sides)
+            assert float(p.grad.abs().max()) < 1e-4 and float(pr[n].grad.abs().max()) < 1e-10
+        else:
+            assert rel_l2(p.grad, pr[n].grad) < 3e-4, n
+
+
+def test_conv_coder_of_simple_blocks_runs_and_keeps_the_reference_layout():
+    """ConvCoder1d(block_type="BlockSimple"): same state_dict keys as the module tree the reference builds (block.module.{0,1}),
+    levels strided as planned, encodings against the torch modules."""
+    torch.manual_seed(5)
+    g = torch.Generator().manual_seed(3)
+    kw = dict(strides=[4, 2], channels=8, kernel_size=5, num_blocks=2, stride_per_block=2, transposed=False, activation=nn.ReLU,
+              block_type="BlockSimple", channels_in=3)
+    coder = ConvCoder1d(**kw)
+    _randomise_norms(coder, g)
+    keys = [k for k in coder.state_dict() if k.startswith("levels.0.0.")]
+    assert keys == [f"levels.0.0.block.module.{i}.{p}" for i in (0, 1) for p in ("weight", "bias")]
+    ref = ConvCoder1d(**kw).double()
+    ref.load_state_dict(coder.state_dict())
+    x = torch.randn(2, 3, 203, generator=g)
+    pads = [7, 3]
+    h, encs_r = x.double(), []
+    for l in range(2):
+        if str(l) in ref.in_projs:
+            h = ref.in_projs[str(l)](h)
+        h = F.pad(h, [0, pads[l]])
+        for blk in ref.levels[l]:
+            h = _torch_simple_block(blk, h)
+        encs_r.append(ref.out_projs[str(l)](h) if str(l) in ref.out_projs else h)
+    encs = coder.to(DEV)(x.to(DEV), pad_right=pads)
+    for e, er in zip(encs, encs_r):
+        assert e.shape == er.shape and rel_l2(e, er) < TOL
 
 
 @pytest.mark.parametrize("transposed", [False, True])
