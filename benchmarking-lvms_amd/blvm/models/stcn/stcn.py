@@ -64,8 +64,6 @@ class STCN(BaseModel):
         super().__init__()
         n_latents = len(latent_size)
         n_stacks = len(latent_size) if n_stacks is None else n_stacks
-        if not top_down:
-            raise NotImplementedError("libblvm_hip: bottom-up STCN inference (Monte-Carlo KL) is not built")
         if n_stacks != n_latents:
             raise NotImplementedError("libblvm_hip: STCN is built for n_stacks == number of latent variables")
         self.likelihood, self.n_layers, self.n_stacks, self.n_latents = likelihood, n_layers, n_stacks, n_latents
@@ -81,8 +79,8 @@ class STCN(BaseModel):
         self.receptive_field = self.receptive_fields[-1]
 
         prior, posterior = [None] * n_latents, [None] * n_latents
-        for i, l in enumerate(reversed(range(n_latents))):
-            c_in = res_channels if i == 0 else res_channels + latent_size[l + 1]
+        for i, l in enumerate(reversed(range(n_latents)) if top_down else range(n_latents)):  # (also the creation = RNG order)
+            c_in = res_channels if i == 0 else res_channels + latent_size[l + 1 if top_down else l - 1]
             prior[l] = DiagonalGaussianDenseSTCN(c_in, latent_size[l], res_channels, init_sd_mean=0.5)
             posterior[l] = DiagonalGaussianDenseSTCN(c_in, latent_size[l], res_channels, init_sd_mean=0.1)
         self.prior, self.posterior = nn.ModuleList(prior), nn.ModuleList(posterior)
@@ -111,10 +109,12 @@ class STCN(BaseModel):
         n, S = self.n_latents, self.n_stack_frames
         mu_p, sd_p, mu_q, sd_q, z = ([None] * n for _ in range(5))
         klds, klds_fn = [None] * n, [None] * n
-        for l in reversed(range(n)):
+        order = list(reversed(range(n))) if self.top_down else list(range(n))  # bottom-up: each latent conditions on the one below
+        for i, l in enumerate(order):
             d_p, d_q = skips[l][:-1], skips[l][1:]  # prior sees frame t-1's features, the posterior frame t's (stcn.py:300-302)
-            if l < n - 1:
-                d_p, d_q = torch.cat([d_p, z[l + 1]], -1), torch.cat([d_q, z[l + 1]], -1)
+            if i > 0:
+                zc = z[l + 1 if self.top_down else l - 1]
+                d_p, d_q = torch.cat([d_p, zc], -1), torch.cat([d_q, zc], -1)
             Z = self.latent_size[l]
             mp, sp_raw = self.prior[l].raw(d_p.reshape(T * B, -1))
             mq, sq_raw = self.posterior[l].raw(d_q.reshape(T * B, -1))
@@ -122,7 +122,18 @@ class STCN(BaseModel):
             sp, mq_c, sq_c, z_l = ops.gauss_latent(mp, sp_raw, mq, sq_raw, e, self.prior[l].softplus_beta,
                                                    self.posterior[l].softplus_beta, self.prior[l].epsilon,
                                                    ops.RSSM_PRECISION if self.precision_posterior else ops.RSSM_PLAIN)  # fmt: skip
-            klds[l], klds_fn[l] = ops.gaussian_kl_sums(mq_c, sq_c, mp, sp, x_sl_dev, ops.LAYOUT_TIME_MAJOR, B, T, Z, S, free_nats)
+            if self.top_down:
+                klds[l], klds_fn[l] = ops.gaussian_kl_sums(mq_c, sq_c, mp, sp, x_sl_dev, ops.LAYOUT_TIME_MAJOR, B, T, Z, S, free_nats)
+            else:
+                # Monte-Carlo KL at the drawn z (stcn.py:286-287, variational.py:73-83): log q(z) - log p(z) per element, masked to the
+                # frame stacks that start inside the utterance, free nats shared over the level's Z dimensions; per-utterance sums.
+                # (elementwise torch on [T*B, Z]: this mode is not on a BASELINE configuration and has no fused kernel)
+                ll = lambda v, mu, sd: -((v - mu) ** 2) / (2 * sd**2) - sd.log() - 0.5 * math.log(2 * math.pi)  # noqa: E731
+                kl = (ll(z_l, mq_c, sq_c) - ll(z_l, mp, sp)).view(T, B, Z)
+                mask = (torch.arange(T, device=kl.device).unsqueeze(1) * S < x_sl_dev.unsqueeze(0)).unsqueeze(-1)
+                kl_fn = torch.clamp(kl, min=free_nats / Z) if free_nats else kl
+                klds[l] = (kl * mask).double().sum((0, 2))
+                klds_fn[l] = (kl_fn * mask).double().sum((0, 2))
             mu_p[l], sd_p[l], mu_q[l], sd_q[l], z[l] = (t.view(T, B, Z) for t in (mp, sp, mq_c, sq_c, z_l))
         return mu_p, sd_p, mu_q, sd_q, z, klds, klds_fn
 
@@ -178,7 +189,7 @@ class STCN(BaseModel):
 
         if eps is None:
             eps = [None] * n
-            for l in reversed(range(n)):
+            for l in (reversed(range(n)) if self.top_down else range(n)):  # the reference's draw order
                 eps[l] = torch.randn(T, B, self.latent_size[l], device=dev)
         mu_p, sd_p, mu_q, sd_q, z, klds, klds_fn = self.infer(skips, [e.to(device=dev, dtype=torch.float32).contiguous() for e in eps],
                                                               mask_len, B, T, free_nats)  # fmt: skip

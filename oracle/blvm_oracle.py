@@ -716,9 +716,11 @@ def stcn_gaussian(sd, p, x, init_sd_mean, epsilon=1e-3):
 
 
 def stcn_forward(sd, x, x_sl, eps, n_layers, latent_size, n_stack_frames=1, base_dilation=2, beta=1.0, free_nats=0.0,
-                 precision_posterior=True, dense=True, num_mix=10, num_bins=2**16):
-    """STCN.forward, top-down inference, pad_receptive_field=True, DMoL head (stcn.py:346-431).  x [B,T]; eps[l] [B,T',z_l]
-    (one draw per level, top level first, stcn.py:325).  fp32 reductions with bool masks as the reference."""
+                 precision_posterior=True, dense=True, num_mix=10, num_bins=2**16, top_down=True):
+    """STCN.forward, pad_receptive_field=True, DMoL head (stcn.py:346-431).  x [B,T]; eps[l] [B,T',z_l] (one draw per level in
+    the order the levels are visited, stcn.py:325).  top_down=False (stcn.py:165-170, 284-287, 310-316): the levels are visited
+    bottom first, each conditions on the latent BELOW it, and the KL is the Monte-Carlo estimate log q(z) - log p(z).
+    fp32 reductions with bool masks as the reference."""
     n = len(latent_size)
     S = n_stack_frames
     dil = wavenet_dilations(n_layers, n, base_dilation)
@@ -736,8 +738,9 @@ def stcn_forward(sd, x, x_sl, eps, n_layers, latent_size, n_stack_frames=1, base
     d_p = [t[..., :-1].permute(0, 2, 1) for t in d]
     d_q = [t[..., 1:].permute(0, 2, 1) for t in d]
     mu_p, sd_p, mu_q, sd_q, z = ([None] * n for _ in range(5))
-    for l in reversed(range(n)):
-        in_p, in_q = (d_p[l], d_q[l]) if l == n - 1 else (torch.cat([d_p[l], z[l + 1]], -1), torch.cat([d_q[l], z[l + 1]], -1))
+    for i, l in enumerate(reversed(range(n)) if top_down else range(n)):
+        lc = l + 1 if top_down else l - 1
+        in_p, in_q = (d_p[l], d_q[l]) if i == 0 else (torch.cat([d_p[l], z[lc]], -1), torch.cat([d_q[l], z[lc]], -1))
         mu_p[l], sd_p[l] = stcn_gaussian(sd, f"prior.{l}", in_p, 0.5)
         mu_q[l], sd_q[l] = stcn_gaussian(sd, f"posterior.{l}", in_q, 0.1)
         if precision_posterior:
@@ -754,7 +757,10 @@ def stcn_forward(sd, x, x_sl, eps, n_layers, latent_size, n_stack_frames=1, base
     seq_mask = sequence_mask(x_sl, max_len=y.size(1))
     log_prob = (dmol_ll(y, lg, locs, log_scales, num_bins) * seq_mask).sum(1)
     z_mask = seq_mask[:, ::S].unsqueeze(-1)
-    kl = [kl_gaussian(mu_q[l], sd_q[l], mu_p[l], sd_p[l]) * z_mask for l in range(n)]
+    if top_down:
+        kl = [kl_gaussian(mu_q[l], sd_q[l], mu_p[l], sd_p[l]) * z_mask for l in range(n)]
+    else:  # kl_divergence_gaussian_mc (variational.py:73-83)
+        kl = [(gaussian_ll(z[l], mu_q[l], sd_q[l], 0) - gaussian_ll(z[l], mu_p[l], sd_p[l], 0)) * z_mask for l in range(n)]
     kl_fn = [discount_free_nats(kl[l], free_nats) * z_mask for l in range(n)]
     kld, kld_fn = torch.cat(kl, -1).sum((1, 2)), torch.cat(kl_fn, -1).sum((1, 2))
     elbo = log_prob - kld

@@ -728,6 +728,43 @@ def gen_lstm():
     save("lstm.npz", **arrays)
 
 
+def gen_stcn_bottom_up():
+    """STCN(top_down=False) (stcn.py:165-170, 284-287, 310-316): each latent conditions on the one BELOW it, levels are visited
+    bottom level first, and the KL is the Monte-Carlo estimate log q(z) - log p(z) at the drawn z.  Reduced size, frame stacks,
+    ragged lengths, free nats; full tensors and every gradient."""
+    from blvm.models import STCN
+
+    arrays = {}
+    S, T, beta, fn = 8, 203, 0.8, 1.5
+    cfg = dict(likelihood="DMoL", n_layers=3, latent_size=[16, 16, 32], res_channels=16, n_stack_frames=S, top_down=False)
+    torch.manual_seed(61)
+    m = STCN(**cfg)
+    B = 3
+    x, _ = O.synth_batch(B, T, seed=19)
+    x_sl = torch.tensor([T, int(T * 0.7), int(T * 0.3)])
+    x = x * (torch.arange(T).unsqueeze(0) < x_sl.unsqueeze(1))
+    Tp = math.ceil(T / S)
+    torch.manual_seed(88)  # one randn_like(mu) per level, BOTTOM level first
+    eps = [None] * 3
+    for l in (0, 1, 2):
+        eps[l] = torch.randn(B, Tp, cfg["latent_size"][l])
+    torch.manual_seed(88)
+    loss, metrics, o = m(x, x_sl, beta=beta, free_nats=fn)
+    loss.backward()
+    arrays.update(x=x, x_sl=x_sl, loss=loss, elbo=o.elbo, log_prob=o.log_prob)
+    for l in range(3):
+        arrays.update({f"eps{l}": eps[l], f"z{l}": o.z[l], f"enc_mu{l}": o.enc_mus[l], f"prior_mu{l}": o.prior_mus[l], f"kld{l}": o.klds[l]})
+    arrays["metric_names"] = np.array([mm.name for mm in metrics])
+    arrays["metric_values"] = np.array([mm.value for mm in metrics], dtype=np.float64)
+    for k, v in m.state_dict().items():
+        arrays[f"sd.{k}"] = v
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            arrays[f"grad.{k}"] = p.grad
+    arrays["nograd"] = np.array([k for k, p in m.named_parameters() if p.grad is None])
+    save("stcn_bottom_up.npz", **arrays)
+
+
 def gen_cwvae_resets():
     """CWVAE(with_resets=True) (clockwork_vae.py:273-275: the state of every level below the top is reset to zeros whenever the
     level above ticks, including t = 0): the reduced CWVAEAudio of gen_cwvae (same seed and configuration, so the same weights)
@@ -780,6 +817,6 @@ def gen_cwvae_resets():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn", "wavenet", "rssm", "cwvae", "stcn", "heads", "generate", "generate16", "wavenet_stacked", "cwvae_resets", "data"]
+    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn", "wavenet", "rssm", "cwvae", "stcn", "heads", "generate", "generate16", "wavenet_stacked", "cwvae_resets", "stcn_bottom_up", "data"]
     for w in which:
         globals()[f"gen_{w}"]()

@@ -141,6 +141,45 @@ def test_stcn_small_matches_reference(g, tag, S, beta, fn_):
         assert rel(p.grad, truth) <= max(2 * ref_err, 1e-3), (k, rel(p.grad, truth), ref_err)
 
 
+def test_stcn_bottom_up_matches_reference():
+    """STCN(top_down=False) (stcn.py:165-170, 284-287, 310-316): levels visited bottom first, each conditioned on the latent below,
+    Monte-Carlo KL at the drawn z — against the reference's outputs (tests/golden/stcn_bottom_up.npz: frame stacks of 8, ragged
+    lengths, free nats 1.5, beta 0.8); gradients against the float64 oracle with the reference's own fp32 gradients as yardstick."""
+    g = np.load(os.path.join(GOLDEN, "stcn_bottom_up.npz"))
+    m = STCN(**SMALL, n_stack_frames=8, top_down=False)
+    sd = {k[3:]: T(g[k]) for k in g.files if k.startswith("sd.")}
+    assert list(m.state_dict().keys()) == list(sd.keys())
+    assert [tuple(v.shape) for v in m.state_dict().values()] == [tuple(v.shape) for v in sd.values()]
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    x, x_sl = T(g["x"]), T(g["x_sl"])
+    eps_ref = [T(g[f"eps{l}"]) for l in range(3)]
+    loss, metrics, o = m(x.to(DEV), x_sl, beta=0.8, free_nats=1.5, eps=[e.transpose(0, 1).contiguous().to(DEV) for e in eps_ref])
+    loss.backward()
+    close(loss, g["loss"], 1e-4)
+    close(o.elbo, g["elbo"], 1e-4)
+    close(o.log_prob, g["log_prob"], 1e-4)
+    for l in range(3):
+        close(o.z[l], g[f"z{l}"], 1e-4, 1e-4)
+        close(o.enc_mus[l], g[f"enc_mu{l}"], 1e-4, 1e-4)
+        close(o.prior_mus[l], g[f"prior_mu{l}"], 1e-4, 1e-4)
+        close(o.klds[l], g[f"kld{l}"], 1e-4, 1e-3)
+    assert [mm.name for mm in metrics] == list(g["metric_names"])
+    np.testing.assert_allclose([mm.value for mm in metrics], g["metric_values"], rtol=1e-4, atol=1e-6)
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    out64 = O.stcn_forward(sd64, x.double(), x_sl, [e.double() for e in eps_ref], n_layers=3, latent_size=[16, 16, 32],
+                           n_stack_frames=8, beta=0.8, free_nats=1.5, top_down=False)
+    out64["loss"].backward()
+    nograd = set(g["nograd"])
+    for k, p in m.named_parameters():
+        if k in nograd:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        truth = sd64[k].grad
+        ref_err = rel(T(g[f"grad.{k}"]), truth)
+        assert rel(p.grad, truth) <= max(2 * ref_err, 1e-3), (k, rel(p.grad, truth), ref_err)
+
+
 FULL = dict(likelihood="DMoL", n_layers=5, latent_size=[256, 128, 64, 32, 16], res_channels=256, n_stack_frames=64, dense=True)
 
 

@@ -303,6 +303,34 @@ def test_stcn_small_forward_backward(tag, S, beta, fn_):
         assert (ref - p.grad).norm() / (p.grad.norm() + 1e-12) < 1e-2, k
 
 
+def test_stcn_bottom_up_forward_backward():
+    """The oracle's bottom-up branch (each latent conditions on the one below, Monte-Carlo KL: stcn.py:165-170, 284-287, 310-316)
+    pinned by the reference's outputs (stcn_bottom_up.npz)."""
+    g = np.load(os.path.join(GOLDEN, "stcn_bottom_up.npz"))
+    sd = {k[3:]: T(g[k]).clone() for k in g.files if k.startswith("sd.")}
+    x, x_sl = T(g["x"]), T(g["x_sl"])
+    eps = [T(g[f"eps{l}"]) for l in range(3)]
+    kw = dict(n_layers=3, latent_size=[16, 16, 32], n_stack_frames=8, beta=0.8, free_nats=1.5, top_down=False)
+    out = O.stcn_forward(sd, x, x_sl, eps, **kw)
+    for l in range(3):
+        close(out["z"][l], g[f"z{l}"], 1e-5, 1e-6)
+        close(out["mu_q"][l], g[f"enc_mu{l}"], 1e-5, 1e-6)
+        close(out["mu_p"][l], g[f"prior_mu{l}"], 1e-5, 1e-6)
+        close(out["klds"][l], g[f"kld{l}"], 2e-5, 1e-4)
+    close(out["loss"], g["loss"], 2e-5, 0)
+    close(out["elbo"], g["elbo"], 2e-5, 0)
+    sd64 = {k: v.detach().double().requires_grad_(True) for k, v in sd.items()}
+    out64 = O.stcn_forward(sd64, x.double(), x_sl, [e.double() for e in eps], **kw)
+    out64["loss"].backward()
+    nograd = set(g["nograd"])
+    for k, p in sd64.items():
+        if k in nograd:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        ref = T(g[f"grad.{k}"]).double()
+        assert (ref - p.grad).norm() / (p.grad.norm() + 1e-12) < 1e-2, k
+
+
 def test_cwvae_generate_matches_reference():
     g = np.load(os.path.join(GOLDEN, "generate.npz"))
     sd = {k[6:]: T(g[k]) for k in g.files if k.startswith("cw_sd.")}
