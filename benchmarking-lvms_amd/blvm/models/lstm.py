@@ -28,8 +28,8 @@ class LSTMAudio(BaseModel):
         self.batch_first = batch_first
         self.num_mix = num_mix
         self.num_bins = num_bins
-        if num_layers != 1 or dropout:
-            raise NotImplementedError("libblvm_hip: LSTMAudio is built for num_layers=1, dropout=0 (the benchmark config)")
+        if dropout:
+            raise NotImplementedError("libblvm_hip: LSTMAudio is built for dropout=0 (every benchmark run)")
 
         def mlp(i, o):
             return nn.Sequential(nn.Linear(i, hidden_size), nn.ReLU(), nn.Linear(hidden_size, hidden_size), nn.ReLU(),
@@ -60,11 +60,17 @@ class LSTMAudio(BaseModel):
         emb = ops.mlp(inp, [m for m in self.embedding if isinstance(m, nn.Linear)], ops.ACT_RELU, 0.0).view(L, B, H)
 
         lens = ops.upload_i32((x_sl_stack - 1).clamp(min=0), dev)
-        h0 = c0 = None
-        if s_0 is not None:
-            h0, c0 = s_0[0].reshape(B, H), s_0[1].reshape(B, H)
-        out, hn, cn = ops.lstm_sequence(emb, h0, c0, lens, self.lstm.weight_ih_l0, self.lstm.weight_hh_l0,
-                                        self.lstm.bias_ih_l0, self.lstm.bias_hh_l0)  # fmt: skip
+        # nn.LSTM(num_layers = n) on packed sequences (lstm.py:93-101): layer l reads layer l-1's outputs (zero beyond a length),
+        # every layer with its own carried state; one K4 sequence launch per layer
+        out, hns, cns = emb, [], []
+        for l in range(self.num_layers):
+            h0 = c0 = None
+            if s_0 is not None:
+                h0, c0 = s_0[0][l].reshape(B, H).contiguous(), s_0[1][l].reshape(B, H).contiguous()
+            w = [getattr(self.lstm, f"{n}_l{l}") for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+            out, hn, cn = ops.lstm_sequence(out, h0, c0, lens, *w)
+            hns.append(hn)
+            cns.append(cn)
         dec = ops.mlp(out.view(L * B, H), [m for m in self.decoder if isinstance(m, nn.Linear)], ops.ACT_RELU, 0.0)
 
         # mask = arange(L*S) < x_sl  (lstm.py:111): lengths are compared with the SHIFTED target axis
@@ -92,7 +98,7 @@ class LSTMAudio(BaseModel):
             reconstruction_mode=lambda ns: lik.mode(ns._parameters),
         )
         outputs = LazyNamespace(lazy, loss=loss, ll=log_prob, z=out.transpose(0, 1), z_sl=x_sl_stack,
-                                s_n=(hn.unsqueeze(0), cn.unsqueeze(0)))  # fmt: skip
+                                s_n=(torch.stack(hns), torch.stack(cns)))  # fmt: skip
         return loss, metrics, outputs
 
     def generate(self, *args, **kwargs):

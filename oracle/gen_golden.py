@@ -728,6 +728,28 @@ def gen_lstm():
     save("lstm.npz", **arrays)
 
 
+def gen_lstm_layers():
+    """LSTMAudio with num_layers = 2 (reduced size, ragged descending lengths): full tensors, carried states of both layers, every
+    gradient; and a second call from the first call's states."""
+    arrays = {}
+    torch.manual_seed(23)
+    m = RM.LSTMAudio(stack_size=8, hidden_size=32, num_layers=2, num_mix=10, num_bins=2**16)
+    x, _ = O.synth_batch(4, 83, seed=6)
+    x_sl = torch.tensor([83, 70, 41, 17])
+    x = x * (torch.arange(83).unsqueeze(0) < x_sl.unsqueeze(1))
+    loss, metrics, o = m(x, x_sl)
+    loss.backward()
+    arrays.update(x=x, x_sl=x_sl, loss=loss, ll=o.ll, z=o.z, hn=o.s_n[0], cn=o.s_n[1])
+    for k, v in m.state_dict().items():
+        arrays[f"sd.{k}"] = v
+    for k, p in m.named_parameters():
+        arrays[f"grad.{k}"] = p.grad
+    with torch.no_grad():
+        loss2, _, o2 = m(x, x_sl, s_0=(o.s_n[0].detach(), o.s_n[1].detach()))
+    arrays.update(c_loss=loss2, c_ll=o2.ll)
+    save("lstm_layers.npz", **arrays)
+
+
 def gen_stcn_bottom_up():
     """STCN(top_down=False) (stcn.py:165-170, 284-287, 310-316): each latent conditions on the one BELOW it, levels are visited
     bottom level first, and the KL is the Monte-Carlo estimate log q(z) - log p(z) at the drawn z.  Reduced size, frame stacks,
@@ -817,6 +839,6 @@ def gen_cwvae_resets():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn", "wavenet", "rssm", "cwvae", "stcn", "heads", "generate", "generate16", "wavenet_stacked", "cwvae_resets", "stcn_bottom_up", "data"]
+    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn", "wavenet", "rssm", "cwvae", "stcn", "heads", "generate", "generate16", "wavenet_stacked", "cwvae_resets", "stcn_bottom_up", "lstm_layers", "data"]
     for w in which:
         globals()[f"gen_{w}"]()

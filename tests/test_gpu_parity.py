@@ -446,6 +446,33 @@ def test_lstm_audio_small_vs_reference_golden():
     assert out.reconstruction_mode.shape == (4, 80, 1)
 
 
+def test_lstm_audio_two_layers_vs_reference_golden():
+    """LSTMAudio(num_layers=2) (`lstm.py:38-64, 93-101`: nn.LSTM stacks on packed sequences): one K4 sequence launch per layer, the
+    second reading the first's outputs; loss, log-likelihood, outputs, the carried states of both layers, every gradient, and a
+    second call from the carried states — against the reference (tests/golden/lstm_layers.npz)."""
+    from blvm.models import LSTMAudio
+
+    g = np.load(os.path.join(GOLDEN, "lstm_layers.npz"))
+    m = LSTMAudio(stack_size=8, hidden_size=32, num_layers=2, num_mix=10, num_bins=2**16)
+    m.load_state_dict({k[3:]: T(g[k]) for k in g.files if k.startswith("sd.")})
+    m.to(DEV)
+    x, x_sl = T(g["x"]).to(DEV), T(g["x_sl"])
+    loss, _, out = m(x, x_sl)
+    loss.backward()
+    assert float(loss.detach()) == pytest.approx(float(g["loss"]), rel=1e-5)
+    torch.testing.assert_close(out.ll.cpu(), T(g["ll"]), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(out.z.cpu(), T(g["z"]), rtol=1e-4, atol=1e-5)
+    assert tuple(out.s_n[0].shape) == tuple(g["hn"].shape) == (2, 4, 32)
+    torch.testing.assert_close(out.s_n[0].cpu(), T(g["hn"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(out.s_n[1].cpu(), T(g["cn"]), rtol=1e-4, atol=1e-5)
+    for k, p in m.named_parameters():
+        assert rel_l2(p.grad, T(g[f"grad.{k}"])) < 1e-3, k
+    with torch.no_grad():
+        loss2, _, out2 = m(x, x_sl, s_0=(out.s_n[0].detach(), out.s_n[1].detach()))
+    assert float(loss2) == pytest.approx(float(g["c_loss"]), rel=1e-5)
+    torch.testing.assert_close(out2.ll.cpu(), T(g["c_ll"]), rtol=1e-5, atol=1e-3)
+
+
 @pytest.mark.parametrize("tag,ragged", [("full", False), ("ragged", True)])
 def test_lstm_audio_c1_vs_reference_golden(tag, ragged):
     """BASELINE configs[0]: experiment_lstm_audio.py, 1-layer LSTM, synthetic mu-law [8,4000]."""
