@@ -21,7 +21,7 @@
 //              A_0 = p[0] and A_i = the T16 output of link i-1: between them only the pointers change, so the walk of the program
 //              (descriptor fetch, decode, tile list) is paid once per visit instead of once per link
 //              p: 0 A_0  1+i W_i  5+i bias_i | gate_i (DF_SEQ_GATE, ld = i[2])  9+i out_i row-major (ld[i])  13+i out_i T16 (n16[0])
-//                 17, 18 (DF_A_SUM3) two more slabs of A_0      i: 0 width of W's rows (0 = K)  1 n  2 ldgate      f: 0 slope
+//              i: 1 n  2 ldgate      f: 0 slope
 //   K_GRUS  p: 0 H16 (state entering the step)  1 Whh (T16)  2 b_hh  3 xg [T,B,3R] (time indexed)  4 lens  5 h_prev row-major
 //              6 h_next row-major (ld[3])  7 h_next T16 (n16[0])  8 out (time indexed)  9 rg  10 ug  11 ng  12 ghn
 //              i: 0 R  1 reverse  2 out_ts  3 out_ld                                   (recurrence step j = s)
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
             if (!nx_done) nx.fetch(ltab, nx_i, nx_s);  // (a visit without tiles)
           } break;
           case K_LINSEQ: {
-            const int n = d.w<RD_I + 1>(), w_width = d.w<RD_I + 0>();
+            const int n = d.w<RD_I + 1>();
             const bool gated = (flags & DF_SEQ_GATE) != 0;
             bool nx_done = false;
             const float* A = d.p<0>(s);
@@ -257,10 +257,9 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
                 return LinLate{gated ? nullptr : aux, nullptr, gated ? aux : nullptr, 0, d.w<RD_I + 2>(), false, (flags & DF_RELU) != 0, d.f<0>(),
                                Out{const_cast<float*>(d.pdyn(9 + li)), d.wdyn(RD_LD + li), false, const_cast<float*>(d.pdyn(13 + li)), d.w<RD_N16>()}};
               };
-              const bool sum3 = li == 0 && (flags & DF_A_SUM3);
-              for (int tk = 0; tk < nt; ++tk) {
+              for (int tk = 0; tk < nt; ++tk) {  // (a run's links are plain: a partial-sum operand or a K-range is a K_LIN in front of the run)
                 const int trc = d.tile(tk), tr0 = trc & 0xffff, tc0 = (trc >> 16) * 16;
-                tile_lin_late<NW, BF>(A, 0, true, W, K, late, tr0, tc0, B, red(), pl, sum3 ? d.p<17>(s) : nullptr, sum3 ? d.p<18>(s) : nullptr, w_width);
+                tile_lin_late<NW, BF>(A, 0, true, W, K, late, tr0, tc0, B, red(), pl);
               }
               A = d.pdyn(13 + li);  // the next link multiplies what this one stored
             }

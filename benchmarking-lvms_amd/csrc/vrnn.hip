@@ -682,8 +682,14 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     const bool seq = pchain_linseq();
     if (seq) {
       const SeqLinkB lf[3] = {{ws.fT[3], rs.FZ[2], ws.DPHI[2], ws.DPHI16[2]}, {ws.fT[2], rs.FZ[1], ws.DPHI[1], ws.DPHI16[1]}, {ws.fT[1], rs.FZ[0], ws.DPHI[0], ws.DPHI16[0]}};
-      Desc& d = linseq_b(ws.DPHI16[3], 3, lf, 0, range_for(ctH * rt, g), split3 ? DF_A_SUM3 : 0);
-      if (split3) { bld.ptr(d, 17, ws.DPHI16b + (long)(T - 1) * xH, -xH); bld.ptr(d, 18, ws.DPHI16c + (long)(T - 1) * xH, -xH); }
+      if (split3) {  // the link that adds the three partial-sum slabs up is a K_LIN of its own (a run's links are plain), the other two a run
+        lin(ws.DPHI16[3], xH, ws.fT[3], H, nullptr, 0, 0, rs.FZ[2], sH, H, ws.DPHI[2], sH, H, ws.DPHI16[2], xH, ctH, ctH, 0, range_for(ctH * rt, g), DF_A_SUM3);
+        Desc& d = bld.p.d[bld.p.ndesc - 1];
+        bld.ptr(d, 8, ws.DPHI16b + (long)(T - 1) * xH, -xH); bld.ptr(d, 9, ws.DPHI16c + (long)(T - 1) * xH, -xH);
+        linseq_b(ws.DPHI16[2], 2, lf + 1, 0, range_for(ctH * rt, g), 0);
+      } else {
+        linseq_b(ws.DPHI16[3], 3, lf, 0, range_for(ctH * rt, g), 0);
+      }
     } else {
       for (int l = 3; l >= 1; --l) {
         lin(ws.DPHI16[l], xH, ws.fT[l], H, nullptr, 0, 0, rs.FZ[l - 1], sH, H, ws.DPHI[l - 1], sH, H, ws.DPHI16[l - 1], xH, ctH, ctH, 0, range_for(ctH * rt, g),
