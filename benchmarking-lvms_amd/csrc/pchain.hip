@@ -243,7 +243,6 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
           case K_LINSEQ: {
             const int n = d.w<RD_I + 1>();
             const bool gated = (flags & DF_SEQ_GATE) != 0;
-            bool nx_done = false;
             const float* A = d.p<0>(s);
             for (int lq = 0; lq < n; ++lq) {  // (links outside, tiles inside: link li+1 of any tile needs link li of ALL tiles of its row tile)
               int li = lq;
@@ -252,7 +251,7 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
               const float* W = d.basedyn(1 + li);
               auto late = [&]() {
                 __builtin_amdgcn_sched_barrier(0);
-                if (!nx_done) { nx.fetch(ltab, nx_i, nx_s); nx_done = true; }
+                if (li == 0) nx.fetch(ltab, nx_i, nx_s);  // the next descriptor, once per visit, behind the first link's operand loads (every tile of it: the same lanes again)
                 const float* aux = gated ? d.pdyn(5 + li) : d.basedyn(5 + li);
                 return LinLate{gated ? nullptr : aux, nullptr, gated ? aux : nullptr, 0, d.w<RD_I + 2>(), false, (flags & DF_RELU) != 0, d.f<0>(),
                                Out{const_cast<float*>(d.pdyn(9 + li)), d.wdyn(RD_LD + li), false, const_cast<float*>(d.pdyn(13 + li)), d.w<RD_N16>()}};
@@ -263,7 +262,7 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
               }
               A = d.pdyn(13 + li);  // the next link multiplies what this one stored
             }
-            if (!nx_done) nx.fetch(ltab, nx_i, nx_s);
+            if (nt == 0) nx.fetch(ltab, nx_i, nx_s);  // (a visit without tiles)
           } break;
 #ifndef PCHAIN_ONLY_LIN
           case K_HEAD: {
