@@ -218,10 +218,9 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
             const unsigned long long tqb = wall_clock64();
             tq[4] += tqb - tqa;
 #endif
-            bool nx_done = false;
             auto late = [&]() {
               __builtin_amdgcn_sched_barrier(0);
-              if (!nx_done) { nx.fetch(ltab, nx_i, nx_s); nx_done = true; }
+              nx.fetch(ltab, nx_i, nx_s);  // (per tile: the same lanes again — cheaper than a flag carried through the visit)
               return LinLate{d.base<2>(), d.p<3>(s), d.p<4>(s), d.w<RD_LD + 1>(), d.w<RD_LD + 2>(), (flags & DF_ADD_POLLED) != 0, (flags & DF_RELU) != 0, d.f<0>(),
                              Out{d.m<5>(s), d.w<RD_LD + 3>(), (flags & DF_RM_SC1) != 0, d.m<6>(s), d.w<RD_N16>(), d.m<7>(s), d.w<RD_N16 + 1>()}};
             };
@@ -238,7 +237,7 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
               tq[1] += tq_end - tq1;
 #endif
             }
-            if (!nx_done) nx.fetch(ltab, nx_i, nx_s);  // (a visit without tiles)
+            if (nt == 0) nx.fetch(ltab, nx_i, nx_s);  // (a visit without tiles)
           } break;
           case K_LINSEQ: {
             const int n = d.w<RD_I + 1>();
