@@ -177,7 +177,13 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
   int par = 0;
   auto red = [&]() { par ^= 1; return par ? red0 : red1; };
   Poll pl{a.ctl, 0u, false, 1};
+  // per-descriptor tick counters (blvm_pchain_profile) only in -DPCHAIN_PROF builds (and the stamped -DPCHAIN_TPROF* ones): in the
+  // product kernel their state would sit in registers the walk needs (tools/probe_engine_chain.py: every live scalar costs)
+#if defined(PCHAIN_PROF) || defined(PCHAIN_TPROF) || defined(PCHAIN_TPROF2)
   const bool profiled = a.prof != nullptr && (w == 0 || w == a.prof_wg) && threadIdx.x == 0;
+#else
+  constexpr bool profiled = false;
+#endif
   unsigned long long tprev = profiled ? wall_clock64() : 0ull;
 #ifdef PCHAIN_TPROF2
   unsigned long long tq[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull}, tq_end = 0ull;
