@@ -257,7 +257,7 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
               auto late = [&]() {
                 __builtin_amdgcn_sched_barrier(0);
                 if (li == 0) nx.fetch(ltab, nx_i, nx_s);  // the next descriptor, once per visit, behind the first link's operand loads (every tile of it: the same lanes again)
-                const float* aux = gated ? d.pdyn(5 + li) : d.basedyn(5 + li);
+                const float* aux = d.pdyn(5 + li);  // bias (stride 0: the stepped pointer IS the base) | gate (stepped)
                 return LinLate{gated ? nullptr : aux, nullptr, gated ? aux : nullptr, 0, d.w<RD_I + 2>(), false, (flags & DF_RELU) != 0, d.f<0>(),
                                Out{const_cast<float*>(d.pdyn(9 + li)), d.wdyn(RD_LD + li), false, const_cast<float*>(d.pdyn(13 + li)), d.w<RD_N16>()}};
               };
