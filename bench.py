@@ -80,9 +80,36 @@ def pmc_traffic(model, B, T):
     return d["cell_stage_kernels_read_bytes_per_step"] + d["cell_stage_kernels_write_bytes_per_step"]
 
 
-def cpu_baseline(B, T, steps, threads):
+def host_cpu():
+    """(CPU model string, physical cores of the machine, logical CPUs this process may run on) from /proc/cpuinfo + the affinity
+    mask.  Physical cores = distinct (physical id, core id) pairs; a container's CPU share may be smaller than either."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                k, _, v = line.partition(":")
+                k, v = k.strip(), v.strip()
+                if k == "model name":
+                    model = v
+                elif k == "physical id":
+                    phys = v
+                elif k == "core id":
+                    core = v
+                elif not k and phys is not None:
+                    cores.add((phys, core))
+                    phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    return model, len(cores) or (os.cpu_count() or 1), len(os.sched_getaffinity(0))
+
+
+def cpu_baseline(B, T, steps, threads, warmup=5, gpu_batch=64):
     """The CPU oracle (a restatement of the reference's PyTorch path, pinned to it by golden vectors) timed on the
-    host cores: forward + backward + Adam on a bounded sample of the same workload."""
+    host cores: forward + backward + clip + Adam on a bounded sample of the same workload, BASELINE.md §4's protocol
+    (5 warm-up steps, median of >= 20 timed steps)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import blvm_oracle as O
     from blvm.models import VRNNAudio
@@ -95,7 +122,7 @@ def cpu_baseline(B, T, steps, threads):
     x, x_sl = O.synth_batch(B, T, seed=0)
     Tp = math.ceil(T / 64)
     times = []
-    for i in range(steps + 1):
+    for i in range(warmup + steps):
         t0 = time.perf_counter()
         eps = torch.randn(Tp, B, 256)
         opt.zero_grad()
@@ -104,12 +131,18 @@ def cpu_baseline(B, T, steps, threads):
         torch.nn.utils.clip_grad_value_(list(sd.values()), 1000.0)
         torch.nn.utils.clip_grad_norm_(list(sd.values()), 3000.0)
         opt.step()
-        log(f"cpu_baseline step {i}: {time.perf_counter() - t0:.2f} s")
-        if i > 0:  # first step is warm-up
+        if i % 5 == 4 or i == 0:
+            log(f"cpu_baseline step {i}: {time.perf_counter() - t0:.2f} s")
+        if i >= warmup:
             times.append(time.perf_counter() - t0)
     dt = sorted(times)[len(times) // 2]
+    cpu_model, physical, usable = host_cpu()
+    why = "" if B == gpu_batch else (f"; [{B},{T}] not the GPU's [{gpu_batch},{T}]: the sample is bounded to ~20 s of CPU work (25 steps), "
+                                     "frames/s of this path is flat in B from 16 up (--cpu-batch 64 runs the GPU's shape)")  # fmt: skip
     return dict(value=B * T / dt, unit="frames/s", cores=threads, kind="port",
-                sample=f"oracle VRNN train step (fwd+bwd+clip+Adam, fp32) on [{B},{T}], median of {steps} steps after 1 warm-up",
+                sample=f"oracle VRNN train step (fwd+bwd+clip+Adam, fp32, seeds data 0 / init 0) on [{B},{T}], median of {steps} steps after "
+                       f"{warmup} warm-up, torch.set_num_threads({threads}){why}",
+                cpu_model=cpu_model, physical_cores=physical, usable_cpus=usable,
                 ms_per_step=dt * 1e3, bits_per_dim=out["bpd"])  # fmt: skip
 
 
@@ -194,7 +227,7 @@ def measure(name, model, B, T, steps, warmup, rank, dev, use_dist, reducer_cls):
     """W untimed + K timed full train steps of `model` on a resident synthetic [B,T] batch.  Returns the wall time of the K
     steps between barrier + synchronize on both sides (MAX over ranks), every step's GPU duration from HIP events on the
     launching stream, and the HIP-event time of the recurrent-cell calls (the dominant kernels)."""
-    from blvm import ops
+    from blvm import _hip, ops
 
     params = list(model.parameters())
     opt = torch.optim.Adam(params, lr=3e-4)
@@ -240,6 +273,7 @@ def measure(name, model, B, T, steps, warmup, rank, dev, use_dist, reducer_cls):
         last["metrics"] = metrics
 
     bpd0 = None
+    _hip.take_async_errors()  # start from a clean count
     for i in range(warmup):
         step()
         if i == 0:
@@ -267,9 +301,17 @@ def measure(name, model, B, T, steps, warmup, rank, dev, use_dist, reducer_cls):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     ops.seq_timer_hook = None
+    # a persistent launch that gave up on a bounded spin DRAINS, i.e. gets faster: a step timed over one is not a measurement
+    n_abort, code = _hip.take_async_errors()
+    if use_dist:
+        t = torch.tensor([n_abort], device=dev, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        n_abort = int(t)
+    if n_abort:
+        log(f"{name} [{B},{T}]: {n_abort} persistent launch(es) ABORTED inside the timed region (last code step {code >> 4}, link {code & 15}): no number")
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
     res = dict(dt=dt, ms_mean=dt / steps * 1e3, ms_median=per_step[len(per_step) // 2], ms_min=per_step[0], ms_max=per_step[-1],
-               host_fwd_ms=host["fwd"] / steps * 1e3, host_bwd_ms=host["bwd"] / steps * 1e3, bpd_step0=bpd0,
+               host_fwd_ms=host["fwd"] / steps * 1e3, host_bwd_ms=host["bwd"] / steps * 1e3, bpd_step0=bpd0, async_errors=n_abort,
                bpd_last={m.name: m.value for m in last["metrics"]}[bpd_name])  # fmt: skip
     if name in ("vrnn", "srnn"):
         cell = [(e[0].elapsed_time(e[1]), e[2].elapsed_time(e[3])) for e in ev]
@@ -292,7 +334,7 @@ def main():
                     "accumulation for the persistent chains and K6 (the reference's --use_amp regime; a separate mode, never the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
-    ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--cpu-steps", type=int, default=20)
     ap.add_argument("--no-sweep", action="store_true", help="skip the large-batch sweep (N=1, vrnn only)")
     ap.add_argument("--dry-launch", action="store_true", help="CPU rehearsal of the N-rank launch: gloo, no GPU call, no model")
     args = ap.parse_args()
@@ -342,6 +384,7 @@ def main():
     achieved = flops_fb / ((m["fwd_ms"] + m["bwd_ms"]) * 1e-3) / 1e12
 
     peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+    async_errors = m["async_errors"]
     if rank == 0:
         res = {
             "metric": f"audio frames/sec training ({args.model.upper()}, 16 kHz mu-law)",
@@ -359,6 +402,7 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
+            "async_errors": 0,  # persistent launches that aborted inside any timed region (filled in below; non-zero = exit 1, no line)
             "bits_per_dim": m["bpd_step0"],
             "bits_per_dim_note": f"ELBO bits/dim of the first forward (random-init weights, seeded); after {args.warmup + args.steps} Adam updates on this one fixed batch: {m['bpd_last']:.4f}",
             "config": {
@@ -392,16 +436,22 @@ def main():
                 ms_ = measure(args.model, model, Bs, T, 5, 2, rank, dev, False, FlatGradAllReduce)
                 mc, _ = model_macs(args.model, model, Bs, T)
                 tf = 6 * mc / ((ms_["fwd_ms"] + ms_["bwd_ms"]) * 1e-3) / 1e12
-                sweep.append(dict(batch_per_gpu=Bs, ms_per_step=ms_["ms_median"], frames_per_s=Bs * T / (ms_["ms_median"] * 1e-3), roofline_frac=tf / peak))
+                async_errors += ms_["async_errors"]
+                sweep.append(dict(batch_per_gpu=Bs, ms_per_step=ms_["ms_median"], frames_per_s=Bs * T / (ms_["ms_median"] * 1e-3), roofline_frac=tf / peak,
+                                  async_errors=ms_["async_errors"]))  # fmt: skip
                 log(f"sweep B={Bs}: {ms_['ms_median']:.1f} ms/step, cell {tf:.1f} TF/s")
             res["sweep"] = sweep
         if n_ranks == 1 and not args.no_cpu_baseline and args.model == "vrnn":
             # the box's CPU share for one GPU is 16 cores (more threads than that only thrash the cgroup quota)
             threads = max(1, min(16, os.cpu_count() or 1, len(os.sched_getaffinity(0))))
-            res["cpu_baseline"] = cpu_baseline(args.cpu_batch, T, args.cpu_steps, threads)
-        print(json.dumps(res), flush=True)
+            res["cpu_baseline"] = cpu_baseline(args.cpu_batch, T, args.cpu_steps, threads, gpu_batch=B)
+        res["async_errors"] = async_errors
+        if not async_errors and math.isfinite(m["bpd_last"]):
+            print(json.dumps(res), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    if async_errors or not math.isfinite(m["bpd_last"]):
+        raise SystemExit(f"bench.py: {async_errors} aborted persistent launch(es), bits/dim after the run {m['bpd_last']}: the timed steps are not valid")
 
 
 if __name__ == "__main__":

@@ -76,6 +76,7 @@ _SIGNATURES = {
     "blvm_last_error": (ctypes.c_char_p, []),
     "blvm_device_ok": (c_int, []),
     "blvm_async_errors": (c_int, [c_void_p]),
+    "blvm_async_errors_take": (c_int, [c_void_p]),
     "blvm_pchain_configure": (c_int, [c_int, c_int]),
     "blvm_pchain_max_batch": (c_int, []),
     "blvm_set_operand_dtype": (c_int, [c_int]),
@@ -195,14 +196,34 @@ def check(rc: int, what: str):
         raise BlvmHipError(f"{what} failed (code {rc}): {msg}")
 
 
-def check_async(what: str = "a persistent recurrent launch"):
-    """Raise if a persistent chain launch of this process gave up on a bounded spin (its results are garbage).  Cheap (a read of
-    pinned host memory): called wherever the host has just synchronised with the device to read results back."""
+def take_async_errors():
+    """(number of persistent launches of this process that gave up on a bounded spin since the previous take, code of the last one).
+    Read-and-clear: an abort is reported once.  A read of pinned host memory — meaningful after the host has synchronised."""
     code = ctypes.c_uint(0)
-    n = load().blvm_async_errors(ctypes.byref(code))
+    n = load().blvm_async_errors_take(ctypes.byref(code))
+    return int(n), int(code.value)
+
+
+def check_async(what: str = "a persistent recurrent launch", group=None):
+    """Raise if a persistent chain launch of this process gave up on a bounded spin since the last check (its results are garbage).
+    Cheap (a read of pinned host memory): called wherever the host has just synchronised with the device to read results back.
+    With a `torch.distributed` process group (`group=True`: the default group) the count is all-reduced (MAX) first, so that every
+    rank raises together instead of one rank leaving the others blocked in their next collective."""
+    n, code = take_async_errors()
+    local = n
+    if group is not None and group is not False:
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            pg = None if group is True else group
+            on_gpu = dist.get_backend(pg) == "nccl"
+            t = torch.tensor([n], dtype=torch.int32, device="cuda" if on_gpu else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=pg)
+            n = int(t.item())
     if n:
+        where = f"last at step {code >> 4}, link {code & 15}" if local else "on another rank"
         raise BlvmHipError(
-            f"{what}: {n} persistent launch(es) aborted on a bounded spin (last at step {code.value >> 4}, link {code.value & 15}): "
+            f"{what}: {n} persistent launch(es) aborted on a bounded spin ({where}): "
             "a workgroup of the launch was not resident (is another process using this GPU?); results are invalid"
         )
 

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.init as init
 
-from blvm import ops
+from blvm import _hip, ops
 from blvm.data.transforms import StackTensor
 from blvm.evaluation import BitsPerDimMetric, DeferredScalars, KLMetric, LatestMeanMetric, LLMetric, LossMetric
 from blvm.models.base_model import BaseModel
@@ -257,12 +257,20 @@ class VRNN(nn.Module):
         runs the K6 / K1 / K7-head kernels at T' = 1; `fused=True` (DMoL head, no stop value) runs ALL steps in one launch (K1c);
         the default (None) takes the one-launch path whenever the model has that structure."""
         S, enc_lin, dec_lin, lik = self._plan()
-        if fused is None:
+        auto = fused is None
+        if auto:
             c = self.vrnn_cell
-            fused = (stop_value is None and isinstance(lik, DiscretizedLogisticMixtureDense) and len(enc_lin) == 3 and len(dec_lin) == 3
-                     and all(v % 16 == 0 for v in (S, c.h_dim, c.z_dim, c.r_dim)))  # fmt: skip
+            fused = (stop_value is None and max_timesteps > 0 and isinstance(lik, DiscretizedLogisticMixtureDense) and len(enc_lin) == 3
+                     and len(dec_lin) == 3 and all(v % 16 == 0 for v in (S, c.h_dim, c.z_dim, c.r_dim)))  # fmt: skip
         if fused:
-            return self._generate_fused(x, h0, n_samples, max_timesteps, stop_value, use_mode, eps, uniforms)
+            try:
+                return self._generate_fused(x, h0, n_samples, max_timesteps, stop_value, use_mode, eps, uniforms)
+            except _hip.BlvmHipError:
+                # the one-launch kernels have limits of their own beyond the structure test above (batch above the persistent
+                # path's and shapes K1c's LDS plan does not take): only an EXPLICIT fused=True insists, the default serves every
+                # shape the step-by-step path serves.  Nothing has run yet: the library validates before it launches.
+                if not auto:
+                    raise
         if x.size(0) > 1:
             assert x.size(0) == n_samples
         else:

@@ -1,39 +1,49 @@
-"""Shape helpers with the reference's names and semantics (blvm/modules/convenience.py:4-41)."""
-import torch.nn as nn
+"""Parameter-free shape / offset layers.  Only the constructor signatures are contract (the reference builds
+`View(-1, n_batch_dims=2)` in front of its frame-stack encoders, blvm/models/vrnn.py:487, and `AddConstant(eps)` behind the
+softplus of its Gaussian heads, blvm/modules/distributions.py:117); none of them owns a parameter, so state_dicts do not see them.
+The HIP path never calls them: stacking is index arithmetic in the kernels, the epsilon is an argument of the head tile."""
+import torch
 
 
-class Permute(nn.Module):
-    def __init__(self, *dims):
+class _Stateless(torch.nn.Module):
+    """A module that is a pure function of its input and of a few constructor constants (shown by `extra_repr`)."""
+
+    _fields = ()
+
+    def extra_repr(self) -> str:
+        return ", ".join(f"{name}={getattr(self, name)!r}" for name in self._fields)
+
+
+class View(_Stateless):
+    """Keep the first `n_batch_dims` axes, reshape the rest to `shape`."""
+
+    _fields = ("shape", "n_batch_dims")
+
+    def __init__(self, *shape: int, n_batch_dims: int = 1):
         super().__init__()
-        self.dims = dims
+        self.shape, self.n_batch_dims = tuple(shape), int(n_batch_dims)
 
-    def forward(self, x):
-        return x.permute(*self.dims)
-
-    def __repr__(self):
-        return f"Permute({self.dims})"
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return x.view(x.shape[: self.n_batch_dims] + self.shape)  # a view, never a copy: incompatible strides raise
 
 
-class View(nn.Module):
-    def __init__(self, *shape, n_batch_dims: int = 1):
+class Permute(_Stateless):
+    _fields = ("dims",)
+
+    def __init__(self, *dims: int):
         super().__init__()
-        self.shape = shape
-        self.n_batch_dims = n_batch_dims
+        self.dims = tuple(dims)
 
-    def forward(self, x):
-        return x.view(*x.shape[0 : self.n_batch_dims], *self.shape)
-
-    def extra_repr(self):
-        return f"{self.shape}, n_batch_dims={self.n_batch_dims}"
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return torch.permute(x, self.dims)
 
 
-class AddConstant(nn.Module):
-    def __init__(self, constant):
+class AddConstant(_Stateless):
+    _fields = ("constant",)
+
+    def __init__(self, constant: float):
         super().__init__()
         self.constant = constant
 
-    def forward(self, tensor1):
-        return tensor1 + self.constant
-
-    def __repr__(self):
-        return f"AddConstant({self.constant})"
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return torch.add(x, self.constant)

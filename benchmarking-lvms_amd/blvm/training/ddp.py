@@ -19,21 +19,28 @@ class FlatGradAllReduce:
         self.group = group
         self.sizes = [p.numel() for p in self.params]
         p0 = self.params[0]
-        self.flat = torch.zeros(sum(self.sizes) + 1, device=p0.device, dtype=torch.float32)
-        self.views = [v.view_as(p) for v, p in zip(self.flat[:-1].split(self.sizes), self.params)]
+        # layout: [gradients ..., status, frames]
+        self.flat = torch.zeros(sum(self.sizes) + 2, device=p0.device, dtype=torch.float32)
+        self.views = [v.view_as(p) for v, p in zip(self.flat[:-2].split(self.sizes), self.params)]
+        self.status = None  # device scalar: the callers' `status` values summed over ranks by the latest exchange
 
     @torch.no_grad()
-    def __call__(self, n_local_frames: float) -> float:
+    def __call__(self, n_local_frames: float, status: float = 0.0) -> float:
         """All-reduce the gradients of a loss normalised by `n_local_frames`; afterwards every rank holds the gradient
         of the same loss normalised by the GLOBAL frame count.  Returns the buffer's last slot holder (device tensor
-        view) so callers can read the global frame count without an extra collective."""
+        view) so callers can read the global frame count without an extra collective.  `status` rides along in a slot of
+        its own (summed, not scaled): the loops put their count of aborted persistent launches there, so every rank learns
+        of an abort on ANY rank from the exchange it takes part in anyway and all of them can leave together
+        (`self.status`, a copy that survives the next call)."""
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
         torch._foreach_copy_(self.views, grads)
-        self.flat[:-1].mul_(float(n_local_frames))
+        self.flat[:-2].mul_(float(n_local_frames))
+        self.flat[-2:-1].fill_(float(status))
         self.flat[-1:].fill_(float(n_local_frames))  # fill kernel; `flat[-1] = x` is a synchronising host-to-device copy
         if dist.is_available() and dist.is_initialized():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-        self.flat[:-1].div_(self.flat[-1])
+        self.flat[:-2].div_(self.flat[-1])
+        self.status = self.flat[-2].clone()
         # hand the bucket's slices out as the gradients (no copy back: 42 small dependent kernels were ~0.2 ms of a 21 ms
         # VRNN step).  They are views of the bucket: valid until the next call, like DDP's gradient_as_bucket_view.
         for p, v in zip(self.params, self.views):

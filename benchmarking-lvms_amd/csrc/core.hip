@@ -176,6 +176,7 @@ struct PchainCtl {
   unsigned* host = nullptr;      // host view
   unsigned* host_dev = nullptr;  // device view of the same words
   unsigned epoch = 0;
+  unsigned taken = 0;  // aborted launches already reported through blvm_async_errors_take()
 };
 PchainCtl& pchain_ctl_state() {
   static PchainCtl c;
@@ -193,6 +194,10 @@ int pchain_max_batch() {
     const char* e = getenv("BLVM_PCHAIN");
     const char* m = getenv("BLVM_PCHAIN_MAX_B");
     g_pchain_max_b = (e && atoi(e) == 0) ? 0 : (m ? atoi(m) : 128);
+    // a CU mask takes CUs away behind the runtime's back: the persistent launches (which need every workgroup resident) are off
+    // and the recurrent chains run as one launch per link
+    for (const char* v : {"HSA_CU_MASK", "ROC_GLOBAL_CU_MASK"})
+      if (const char* cm = getenv(v); cm && *cm) g_pchain_max_b = 0;
   }
   return g_pchain_max_b;
 }
@@ -233,6 +238,7 @@ int pchain_ctl(unsigned** dev, unsigned** host_dev, unsigned* epoch) {
     BLVM_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c.host_dev), c.host, 0));
     c.device = d;
     c.epoch = 0;
+    c.taken = 0;
   }
   *dev = c.dev;
   *host_dev = c.host_dev;
@@ -279,7 +285,21 @@ extern "C" int blvm_async_errors(unsigned* last_code) {
   return (int)h[0];
 }
 
-extern "C" int blvm_version(void) { return 110; /* 0.1.1 */ }
+// Aborted launches since the previous take (read-and-clear view of the same counter): a caller that has handled an abort — dropped
+// the step, re-run it — is not told about it again by every later check.
+extern "C" int blvm_async_errors_take(unsigned* last_code) {
+  blvm::PchainCtl& c = blvm::pchain_ctl_state();
+  std::lock_guard<std::mutex> lock(c.mu);
+  if (!c.host) return 0;
+  const volatile unsigned* h = c.host;
+  const unsigned total = h[0];
+  const unsigned fresh = total - c.taken;
+  c.taken = total;
+  if (last_code) *last_code = fresh ? h[1] : 0u;
+  return (int)fresh;
+}
+
+extern "C" int blvm_version(void) { return 120; /* 0.1.2 */ }
 
 extern "C" const char* blvm_last_error(void) { return blvm::g_err; }
 

@@ -480,14 +480,31 @@ int pchain_launch(const pchain::Program& prog, hipStream_t stream) {
   const int nw = pchain_waves();
   const size_t lds_fixed = sizeof(int) * kDescWords * pchain::kMaxDesc + 32 * sizeof(unsigned long long);
   const size_t lds = lds_fixed + sizeof(float) * 2 * (size_t)prog.lds_products * nw * 256;
-  // the dynamic-LDS limit of the kernels is raised once per process and device (the call is far from free)
+  // the dynamic-LDS limit of the kernels is raised once per process and device (the call is far from free), and the launch's
+  // residency — every workgroup of the grid must be on a CU at the same time — is checked against the occupancy the runtime
+  // computes for this kernel, block size and LDS size (cached per size)
+  static std::mutex attr_mu;
   static int attr_dev[4] = {-1, -1, -1, -1};
+  static size_t occ_lds[4] = {0, 0, 0, 0};
+  static int occ_blocks[4] = {0, 0, 0, 0};
   const size_t lds_max = lds_fixed + sizeof(float) * 2 * 4 * (size_t)nw * 256;
   BLVM_REQUIRE(lds <= lds_max, "pchain: %d products per tile exceed the reduction scratch", prog.lds_products);
   auto go = [&](auto kernel, int slot, int threads) -> int {
-    if (attr_dev[slot] != dev) {
-      BLVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-      attr_dev[slot] = dev;
+    {
+      std::lock_guard<std::mutex> lock(attr_mu);
+      if (attr_dev[slot] != dev) {
+        BLVM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        attr_dev[slot] = dev;
+        occ_lds[slot] = 0;
+      }
+      if (occ_lds[slot] != lds) {
+        int per_cu = 0;
+        BLVM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds));
+        occ_blocks[slot] = per_cu;
+        occ_lds[slot] = lds;
+      }
+      BLVM_REQUIRE((long)occ_blocks[slot] * cus >= grid,
+                   "pchain: %d workgroups of %d threads + %zu B LDS are not co-resident (%d per CU x %d CUs)", grid, threads, lds, occ_blocks[slot], cus);
     }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, stream, (const int*)tab, h);
     return BLVM_OK;

@@ -124,6 +124,20 @@ def setup(args):
     return rank, world, dev
 
 
+def clip_and_step(params, optimizer, max_grad_value, max_grad_norm, skip_nonfinite=False):
+    """clip by value -> clip by norm -> optimizer step (experiment_vrnn_audio.py:224-228).  With `skip_nonfinite` a step whose
+    gradient norm is NaN / inf is NOT taken (experiment_srnn_audio.py:236-240): parameters and optimizer state stay as they are.
+    (Scaling the gradients by a 0/1 flag cannot do this: NaN * 0 is NaN, and `clip_grad_norm_` has already multiplied every
+    gradient by a NaN coefficient.)  Like the reference's `if`, the test reads the norm on the host, i.e. waits for backward; in a
+    data-parallel run the norm is that of the all-reduced gradient, so every rank decides alike.  Returns whether it stepped."""
+    torch.nn.utils.clip_grad_value_(params, max_grad_value)
+    total_norm = torch.nn.utils.clip_grad_norm_(params, max_grad_norm)
+    if skip_nonfinite and not bool(torch.isfinite(total_norm)):
+        return False
+    optimizer.step()
+    return True
+
+
 def run(args, model, forward_train, forward_eval, best_metric, num_bits, split_eval_fn=None, clip=True, skip_nonfinite=False):
     """forward_train(model, x, x_sl) / forward_eval(model, x, x_sl) -> (loss, metrics, outputs)."""
     rank, world, dev = setup(args)
@@ -142,26 +156,34 @@ def run(args, model, forward_train, forward_eval, best_metric, num_bits, split_e
     best = None
     for epoch in tracker.epochs(args.epochs):
         model.train()
-        t0, frames = time.time(), 0
+        t0, frames, skipped, aborted = time.time(), 0, 0, 0
         for x, x_sl in tracker.steps(train, source="train"):
             x = x.to(dev, non_blocking=True)
             loss, metrics, _ = forward_train(model, x, x_sl)
             optimizer.zero_grad(set_to_none=True)
             loss.backward()
             if reducer is not None:
-                reducer(float(x_sl.sum()))
+                reducer(float(x_sl.sum()), status=aborted)
             if clip:
-                torch.nn.utils.clip_grad_value_(params, args.max_grad_value)
-                total_norm = torch.nn.utils.clip_grad_norm_(params, args.max_grad_norm)
-                if skip_nonfinite:  # experiment_srnn_audio.py:236-240 skips the update when the gradient norm is NaN / inf; here
-                    # the gradients are zeroed on the device instead (no host sync): Adam then sees a zero gradient for this step
-                    torch._foreach_mul_([p.grad for p in params if p.grad is not None], torch.isfinite(total_norm).to(torch.float32))
-            optimizer.step()
-            tracker.update(metrics)
+                skipped += not clip_and_step(params, optimizer, args.max_grad_value, args.max_grad_norm, skip_nonfinite)
+            else:
+                optimizer.step()
+            tracker.update(metrics)  # reads this step's sums back: the host has waited for everything enqueued so far
+            # a persistent launch that gave up on a bounded spin leaves garbage: stop HERE, not at the end of the epoch.  One
+            # process: raise at once.  Data-parallel: a rank that raised alone would leave the others blocked in their next
+            # all-reduce, so the local count rides in the next gradient exchange and every rank raises on the summed count.
+            aborted += _hip.take_async_errors()[0]
+            if reducer is None and aborted:
+                raise _hip.BlvmHipError(f"epoch {epoch}, step {tracker.step}: {aborted} persistent launch(es) aborted on a bounded spin; results are invalid")
+            if reducer is not None and float(reducer.status) > 0:
+                raise _hip.BlvmHipError(f"epoch {epoch}, step {tracker.step}: persistent launch(es) aborted on a bounded spin on some rank "
+                                        f"({aborted} here); results are invalid")  # fmt: skip
             frames += int(x_sl.sum())
         scheduler.step()
         torch.cuda.synchronize()
-        _hip.check_async("training epoch")
+        _hip.check_async("training epoch", group=world > 1)  # whatever the last exchange did not carry; collective: all ranks raise together
+        if skipped and rank == 0:
+            print(f"epoch {epoch:4d} | {skipped} step(s) skipped: non-finite gradient norm", flush=True)
         tracker.all_reduce("train")
         if rank == 0:
             vals = ", ".join(f"{k} {v:.4f}" for k, v in tracker.values("train").items())
@@ -177,6 +199,8 @@ def run(args, model, forward_train, forward_eval, best_metric, num_bits, split_e
                         split_eval_fn(model, x, x_sl, tracker)
                     else:
                         tracker.update(forward_eval(model, x, x_sl)[1])
+            torch.cuda.synchronize()
+            _hip.check_async("evaluation", group=world > 1)  # before anyone decides about a checkpoint
             tracker.all_reduce("test")  # the whole test set's value on every rank (rank 0 decides about the checkpoint)
             value = tracker.values("test").get(best_metric)
             if rank == 0 and value is not None:

@@ -38,6 +38,10 @@ int blvm_device_ok(void);
  * the code (step << 4 | link) of the last spin that failed.  Reads pinned host memory; never blocks.  Check it where results are
  * read back (the reference's loops synchronise when they read the loss, `experiments/experiment_vrnn_audio.py:232`). */
 int blvm_async_errors(unsigned* last_code);
+/* The same counter with read-and-clear semantics: aborted launches since the previous take (and the code of the last one, 0 if
+ * none).  For loops that handle an abort (drop the step, all-reduce the count over ranks so that every rank leaves together) and go
+ * on: the sticky total above would fail every later check of the process. */
+int blvm_async_errors_take(unsigned* last_code);
 /* Execution switch of K1-K5 (results agree to fp32 summation order): sequences with at most `max_batch` rows run as one
  * persistent launch, larger ones as one launch per link (0 = always per link; < 0 = leave unchanged; default 128 or env
  * BLVM_PCHAIN_MAX_B / BLVM_PCHAIN=0).  `waves` = 8 or 16 waves per workgroup of the persistent kernels (other values: unchanged). */

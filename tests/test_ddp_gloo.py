@@ -56,7 +56,9 @@ def _worker(rank, world, port, q):
     grads, n_local = _oracle_grads(vals, keys, x[sl, :Ts], x_sl[sl], eps[: (Ts + 7) // 8, sl])
     for p, g in zip(model.parameters(), grads):
         p.grad = g.clone()
-    n_global = FlatGradAllReduce(model.parameters())(n_local)
+    red = FlatGradAllReduce(model.parameters())
+    n_global = red(n_local, status=float(rank == 1))  # rank 1 reports one aborted launch: every rank must see it
+    assert float(red.status) == 1.0
     if rank == 0:
         full, n_full = _oracle_grads(vals, keys, x, x_sl, eps)
         errs = [float((p.grad.double() - g.double()).norm() / (g.double().norm() + 1e-30)) for p, g in zip(model.parameters(), full)]
@@ -102,7 +104,7 @@ def test_reducer_hands_out_bucket_slices_without_a_process_group():
         assert lo <= p.grad.data_ptr() < hi, "gradient is not a slice of the bucket"
         torch.testing.assert_close(p.grad, e, rtol=1e-6, atol=0)
     torch.nn.utils.clip_grad_norm_(params, 1e-3)  # in place on the slices
-    assert float(red.flat[:-1].norm()) <= 1e-3 * 1.001
+    assert float(red.flat[:-2].norm()) <= 1e-3 * 1.001 and float(red.status) == 0.0
     # a second step with fresh gradients (zero_grad(set_to_none=True) semantics) overwrites the bucket
     for p in params:
         p.grad = None
@@ -111,6 +113,39 @@ def test_reducer_hands_out_bucket_slices_without_a_process_group():
     red(10.0)
     for p, e in zip(params, expect2):
         torch.testing.assert_close(p.grad, e, rtol=1e-6, atol=0)
+
+
+def test_clip_and_step_leaves_the_model_alone_when_the_gradient_norm_is_not_finite():
+    """`skip_nonfinite` must do what experiment_srnn_audio.py:236-240 does — no update at all.  (Multiplying the gradients
+    by isfinite(norm) = 0 leaves NaN * 0 = NaN in them, and Adam turns every parameter into NaN.)"""
+    for p in (PKG, os.path.join(ROOT, "experiments"), ROOT):
+        sys.path.insert(0, p)
+    import _common as C
+
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(4, 3)), torch.nn.Parameter(torch.randn(5))]
+    opt = torch.optim.Adam(params, lr=0.1)
+    for p in params:  # one ordinary step first, so that Adam holds moments that a wrong skip would disturb
+        p.grad = torch.ones_like(p)
+    assert C.clip_and_step(params, opt, 1000.0, 3000.0, skip_nonfinite=True)
+    before = [p.detach().clone() for p in params]
+    state = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in opt.state[p].items()} for p in params]
+    for max_value in (1000.0, float("inf")):  # NaN survives the clamp by value; inf only when that clamp is off (inf -> max_value otherwise,
+        for p in params:  #                      in the reference's loop as well: clip_grad_value_ runs first there too)
+            p.grad = torch.ones_like(p)
+        params[1].grad[2] = float("nan") if max_value == 1000.0 else float("inf")
+        assert not C.clip_and_step(params, opt, max_value, 3000.0, skip_nonfinite=True)
+        for p, b, st in zip(params, before, state):
+            assert torch.equal(p.detach(), b) and torch.isfinite(p).all()
+            for k, v in st.items():
+                assert torch.equal(opt.state[p][k], v) if torch.is_tensor(v) else opt.state[p][k] == v
+    for p in params:  # the run recovers: the next finite gradient is applied
+        p.grad = torch.ones_like(p)
+    assert C.clip_and_step(params, opt, 1000.0, 3000.0, skip_nonfinite=True)
+    assert all(not torch.equal(p.detach(), b) and torch.isfinite(p).all() for p, b in zip(params, before))
+    # without the flag the reference's VRNN loop steps regardless (experiment_vrnn_audio.py:224-228)
+    params[0].grad[0, 0] = float("nan")
+    assert C.clip_and_step(params, opt, 1000.0, 3000.0, skip_nonfinite=False)
 
 
 def _steps_worker(rank, world, port, q):
