@@ -95,9 +95,9 @@ class CWVAE(nn.Module):
         return int(self.strides[l + 1]) if (self.with_resets and l < self.num_levels - 1) else 0
 
     def forward_split(self, x, x_sl, is_last_split: bool, state0=None, beta: float = 1, free_nats: float = 0, y=None,
-                      use_mode_global: bool = False):  # fmt: skip
+                      use_mode_global: bool = False, eps=None):  # fmt: skip
         return self.forward(x, x_sl, state0=state0, beta=beta, free_nats=free_nats, y=y, use_mode_global=use_mode_global,
-                            pad_strideable=False, pad_same=is_last_split)  # fmt: skip
+                            pad_strideable=False, pad_same=is_last_split, eps=eps)  # fmt: skip
 
     # ---- forward ---------------------------------------------------------------------------------------------------------
     def forward(self, x, x_sl, state0: List[Tuple[torch.Tensor, torch.Tensor]] = None, beta: float = 1, free_nats: float = 0,
@@ -146,6 +146,13 @@ class CWVAE(nn.Module):
             if enc_l.shape[0] < T_l or (context is not None and context.shape[0] < T_l):
                 raise IndexError(f"level {l}: {T_l} steps but only {enc_l.shape[0]} encodings / "
                                  f"{None if context is None else context.shape[0]} context frames")  # fmt: skip
+            if int(level_sl[l].max()) > T_l:
+                # the reference gathers every example's carried state at step ceil(x_sl / stride_l) - 1 from a list of T_l states
+                # (clockwork_vae.py:283-290): beyond it, IndexError.  Without same padding this is EVERY shape: the (sic) positional
+                # get_same_padding call above leaves x_sl (nearly) unreduced while the un-padded convolutions shorten the level
+                # (tests/golden/split_eval.npz: 98 of 98 probed shapes raise in the reference).  Same error here, before any launch.
+                raise IndexError(f"list index out of range (level {l}: state of step {int(level_sl[l].max()) - 1} wanted, the level has {T_l} "
+                                 f"steps{'' if pad_same else '; pad_same=False never completes in the reference either'})")  # fmt: skip
             Z = self.z_size[l]
             if eps is not None:
                 eps_l = eps[l].to(device=dev, dtype=torch.float32)
@@ -175,7 +182,7 @@ class CWVAE(nn.Module):
             latents[l], enc_mus[l], prior_mus[l] = zs[1:].transpose(0, 1), mu_q.transpose(0, 1), mu_p.transpose(0, 1)
 
             # state to carry into the next split: the one at each example's last valid step (clockwork_vae.py:283-290)
-            stop = ops.upload_i32((level_sl[l] - 1).clamp(0, T_l - 1) + 1, dev).long()
+            stop = ops.upload_i32((level_sl[l] - 1).clamp(0) + 1, dev).long()
             rows = torch.arange(B, device=dev)
             state_n[l] = (zs[stop, rows], hs[stop, rows])
 

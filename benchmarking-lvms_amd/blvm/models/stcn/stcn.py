@@ -140,8 +140,9 @@ class STCN(BaseModel):
     def split_sequence(self, x, x_sl, length: int):
         raise NotImplementedError()
 
-    def forward_split(self, x, x_sl, i_split: int, y=None):
-        return self.forward(x, x_sl, y=y, pad_receptive_field=(i_split == 0))
+    def forward_split(self, x, x_sl, i_split: int, y=None, eps=None):
+        """Receptive-field padding on the first split only (stcn.py:332-342); `eps` as in `forward`."""
+        return self.forward(x, x_sl, y=y, pad_receptive_field=(i_split == 0), eps=eps)
 
     def forward(self, x, x_sl, y=None, pad_receptive_field: bool = True, free_nats: float = 0, beta: float = 1,
                 eps: Optional[List[torch.Tensor]] = None):  # fmt: skip

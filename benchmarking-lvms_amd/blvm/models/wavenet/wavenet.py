@@ -131,7 +131,8 @@ class WaveNet(BaseModel):
         mode = "extend" if overlap >= length else "consume"
         splits_x, splits_x_sl = split_sequence(x, x_sl, length=length, overlap=overlap, mode=mode)
         if mode == "extend":
-            splits_x = [torch.nn.functional.pad(s, (max(overlap + length - s.size(1), 0), 0)) if s.ndim == 2 else s for s in splits_x]
+            # pad_to_length(split, overlap + length, "left", dim=1) (wavenet.py:240): zeros in front of the TIME axis, whatever follows it
+            splits_x = [torch.nn.functional.pad(s, (0, 0) * (s.ndim - 2) + (max(overlap + length - s.size(1), 0), 0)) for s in splits_x]
         return splits_x, splits_x_sl
 
     def forward_split(self, x, x_sl, i_split: int, y=None):

@@ -783,7 +783,8 @@ template <int C, bool DUAL>
 int launch_ts_wgrad(TsArgs a, hipStream_t s) {
   constexpr int NT = C / 16;
   const size_t n_chunks = (a.rows + 15) / 16;
-  static const int forced = [] { const char* e = getenv("BLVM_WN_WGRAD_NPW"); return e ? atoi(e) : 0; }();
+  const char* fe = getenv("BLVM_WN_WGRAD_NPW");  // read per call: the parity test runs both forms on the same inputs in one process
+  const int forced = fe ? atoi(fe) : 0;
   int npw = n_chunks >= 512 * 64 ? NT : (NT >= 2 ? NT / 2 : 1);
   if (forced > 0) npw = forced >= NT ? NT : (forced > 1 && NT >= 2 ? NT / 2 : 1);
   if (npw >= NT) launch_ts_wgrad_npw<C, DUAL, NT>(a, s);

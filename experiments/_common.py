@@ -124,6 +124,31 @@ def setup(args):
     return rank, world, dev
 
 
+def wavenet_split_eval(model, x, x_sl, tracker, length):
+    """The reference's split evaluation of WaveNet (experiments/experiment_wavenet_audio.py:224-231): splits that overlap by the
+    receptive field (wavenet.py:230-242), receptive-field padding on the first one only, every split's metrics merged into the tracker."""
+    out = None
+    for i, (xs, xs_sl) in enumerate(zip(*model.split_sequence(x, x_sl, length=length))):
+        _, metrics, out = model.forward_split(xs.contiguous(), xs_sl, i_split=i)
+        tracker.update(metrics)
+    return out
+
+
+def cwvae_split_eval(model, x, x_sl, tracker, length):
+    """The reference's split evaluation of the Clockwork VAE (experiments/experiment_clockwork_audio.py:255-271): strideable splits
+    overlapping by rf - stride, per-level (z, h) carried from split to split, same padding on the last split only.  As in the
+    reference this completes only for utterances that fit ONE split: `forward(pad_same=False)` raises IndexError there for every
+    shape (tests/golden/split_eval.npz `cw_not_last_raises`), and so does this build."""
+    state0, out, metrics = None, None, []
+    xs_list, sl_list = model.split_sequence(x, x_sl, length=length)
+    for i, (xs, xs_sl) in enumerate(zip(xs_list, sl_list)):
+        _, metrics_, out = model.forward_split(xs.contiguous(), xs_sl, state0=state0, is_last_split=i == len(xs_list) - 1)
+        metrics.extend(metrics_)
+        state0 = [(z.contiguous(), h.contiguous()) for z, h in out.state_n]
+    tracker.update(metrics)  # once per utterance batch, repeated names merged (tracker.update(metrics, check_unique=False), :271)
+    return out
+
+
 def clip_and_step(params, optimizer, max_grad_value, max_grad_norm, skip_nonfinite=False):
     """clip by value -> clip by norm -> optimizer step (experiment_vrnn_audio.py:224-228).  With `skip_nonfinite` a step whose
     gradient norm is NaN / inf is NOT taken (experiment_srnn_audio.py:236-240): parameters and optimizer state stay as they are.

@@ -2,7 +2,7 @@
 """Clockwork VAE on audio waveforms — entry point with the reference's flags (experiments/experiment_clockwork_audio.py:
 flags :31-66, model :84-96, train loop :213-232, split evaluation with carried per-level state :247-262, checkpoint
 criterion "elbo (bpt)" :288)."""
-from _common import run  # noqa: I001
+from _common import cwvae_split_eval, run  # noqa: I001
 
 import torch
 
@@ -59,12 +59,7 @@ if __name__ == "__main__":
         return torch.nn.functional.pad(x, (0, pad)) if pad else x
 
     def split_eval(model, x, x_sl, tracker):  # per-level (z, h) carried between splits, same padding only on the last one
-        state0 = None
-        xs_list, sl_list = model.split_sequence(x, x_sl, length=args.random_segment_size)
-        for i, (xs, xs_sl) in enumerate(zip(xs_list, sl_list)):
-            _, metrics, out = model.forward_split(xs, xs_sl, state0=state0, is_last_split=i == len(xs_list) - 1)
-            tracker.update(metrics)
-            state0 = [(z.contiguous(), h.contiguous()) for z, h in out.state_n]
+        cwvae_split_eval(model, x, x_sl, tracker, args.random_segment_size)
 
     run(args, model, lambda m, x, sl: m(strideable(x), sl, beta=beta.step(), free_nats=fn.step(), pad_strideable=True),
         lambda m, x, sl: m(strideable(x), sl, pad_strideable=True), "elbo (bpt)", args.num_bits,

@@ -23,6 +23,11 @@ g.add_argument("--split_eval", default=False, type=str2bool)
 
 if __name__ == "__main__":
     args = parser.parse_args()
+    if args.split_eval:
+        # experiment_lstm_audio.py:205-207 calls model(xs, xs_sl, s0=s0) and reads output.sn, the model's names are s_0 / s_n
+        # (lstm.py:76,129): the reference's split branch raises TypeError on its first split.  Refused up front here.
+        raise SystemExit("--split_eval True: the reference's LSTM split evaluation cannot run (experiment_lstm_audio.py:205-207 passes "
+                         "`s0=` to a forward whose argument is `s_0`); evaluate whole utterances, or carry `s_0` / `s_n` yourself")
     model = LSTMAudio(stack_size=args.stack_size, hidden_size=args.hidden_size, num_layers=args.num_layers,
                       dropout=args.dropout, num_mix=args.num_mix, num_bins=2**args.num_bits)  # fmt: skip
     run(args, model, lambda m, x, sl: m(x, sl), lambda m, x, sl: m(x, sl), "loss", args.num_bits, clip=False)

@@ -32,6 +32,10 @@ g.add_argument("--split_eval", default=False, type=str2bool)
 
 if __name__ == "__main__":
     args = parser.parse_args()
+    if args.split_eval:
+        # experiment_stcn_audio.py:258 calls model.split_sequence, which raises NotImplementedError (stcn.py:328-330)
+        raise SystemExit("--split_eval True: STCN.split_sequence is not implemented in the reference (stcn.py:328-330: raises "
+                         "NotImplementedError); `STCN.forward_split(x, x_sl, i_split)` itself is available")
     model = STCN(likelihood=args.likelihood, n_layers=args.num_layers, n_stacks=args.num_stacks, latent_size=args.latent_size,
                  res_channels=args.hidden_size, n_stack_frames=args.num_stack_frames, precision_posterior=args.precision_posterior,
                  dense=args.dense, top_down=args.top_down)  # fmt: skip

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """WaveNet on audio waveforms — entry point with the reference's flags (experiments/experiment_wavenet_audio.py);
 no gradient clipping in this loop (:206-209)."""
-from _common import run  # noqa: I001
+from _common import run, wavenet_split_eval  # noqa: I001
 
 from blvm.models import WaveNet
 from blvm.modules.distributions import DiscretizedLogisticMixtureDense
@@ -31,4 +31,11 @@ if __name__ == "__main__":
     lik = DiscretizedLogisticMixtureDense(args.res_channels, 1, num_mix=args.num_mix, num_bins=2**args.num_bits)
     model = WaveNet(likelihood=lik, n_layers=args.n_layers, n_stacks=args.n_stacks, res_channels=args.res_channels,
                     kernel_size=args.kernel_size, base_dilation=args.base_dilation, n_stack_frames=args.n_stack_frames)  # fmt: skip
-    run(args, model, lambda m, x, sl: m(x, sl), lambda m, x, sl: m(x, sl), "loss", args.num_bits, clip=False)
+    if args.split_eval and not args.random_segment_size:
+        raise SystemExit("--split_eval True needs --random_segment_size (the split length, experiment_wavenet_audio.py:226)")
+
+    def split_eval(model, x, x_sl, tracker):  # experiment_wavenet_audio.py:224-231 (benchmarks.txt:7 runs with --split_eval True)
+        wavenet_split_eval(model, x, x_sl, tracker, args.random_segment_size)
+
+    run(args, model, lambda m, x, sl: m(x, sl), lambda m, x, sl: m(x, sl), "loss", args.num_bits, split_eval if args.split_eval else None,
+        clip=False)  # fmt: skip

@@ -716,8 +716,10 @@ def stcn_gaussian(sd, p, x, init_sd_mean, epsilon=1e-3):
 
 
 def stcn_forward(sd, x, x_sl, eps, n_layers, latent_size, n_stack_frames=1, base_dilation=2, beta=1.0, free_nats=0.0,
-                 precision_posterior=True, dense=True, num_mix=10, num_bins=2**16, top_down=True):
-    """STCN.forward, pad_receptive_field=True, DMoL head (stcn.py:346-431).  x [B,T]; eps[l] [B,T',z_l] (one draw per level in
+                 precision_posterior=True, dense=True, num_mix=10, num_bins=2**16, top_down=True, pad_receptive_field=True):
+    """STCN.forward, DMoL head (stcn.py:346-431).  pad_receptive_field=False (`forward_split(i_split > 0)`, stcn.py:332-342, 366-369,
+    383-387): no left padding, the first rf * S samples are conditioned on only (dropped from y), T' - rf latent steps, and x_sl is
+    reduced by rf * S WITHOUT a clamp — a negative length masks everything and still enters the loss's normaliser.  x [B,T]; eps[l] [B,T',z_l] (one draw per level in
     the order the levels are visited, stcn.py:325).  top_down=False (stcn.py:165-170, 284-287, 310-316): the levels are visited
     bottom first, each conditions on the latent BELOW it, and the KL is the Monte-Carlo estimate log q(z) - log p(z).
     fp32 reductions with bool masks as the reference."""
@@ -725,14 +727,23 @@ def stcn_forward(sd, x, x_sl, eps, n_layers, latent_size, n_stack_frames=1, base
     S = n_stack_frames
     dil = wavenet_dilations(n_layers, n, base_dilation)
     rf = sum(dil) + 1 + (sd["causal.conv.weight"].size(2) - 1)
-    y = x.detach().unsqueeze(-1)
+    y = x.detach()
+    if not pad_receptive_field:
+        y = y[:, rf * S :]
+    y = y.unsqueeze(-1)
     if S > 1:
         xs, pad = stack_tensor(x, S)
     else:
         xs = x.unsqueeze(-1)
     h = xs.transpose(1, 2)  # [B,C,T']
-    T = h.size(2)
-    h = F.pad(h, (rf, 0))
+    if pad_receptive_field:
+        T = h.size(2)
+        h = F.pad(h, (rf, 0))
+    else:
+        T = h.size(2) - rf
+        x_sl = x_sl - S * rf
+        if h.size(2) <= rf:
+            raise ValueError("Input must be at least as long as the receptive field if pad_receptive_field=False")
     h = F.conv1d(h, sd["causal.conv.weight"], sd["causal.conv.bias"])
     d = residual_stack_skips(sd, "res_stack", h, dil, T + 1)[n - 1 :: n]  # the last skip of every stack (stcn.py:299)
     d_p = [t[..., :-1].permute(0, 2, 1) for t in d]

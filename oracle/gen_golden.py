@@ -837,8 +837,139 @@ def gen_cwvae_resets():
     save("cwvae_resets.npz", **arrays)
 
 
+def _merge_like_tracker(per_split_metrics):
+    """What `tracker.update(metrics)` after every split leaves behind (tracker.py:377-392): the first metric of a name is copied,
+    later ones merged into it with the metric's own rule.  Done with the REFERENCE's metric objects."""
+    merged = {}
+    for metrics in per_split_metrics:
+        for mm in metrics:
+            if mm.name in merged:
+                merged[mm.name].update(mm)
+            else:
+                merged[mm.name] = mm.copy()
+    names = list(merged)
+    return np.array(names), np.array([merged[n].value for n in names], dtype=np.float64)
+
+
+def gen_split_eval():
+    """Split evaluation, the loops of the reference's entry points run on the reference's models:
+    * WaveNet `split_sequence` + `forward_split` (wavenet.py:230-252, experiment_wavenet_audio.py:224-231) in both modes — "consume"
+      (length > receptive field) and "extend" (length <= receptive field: every split left-padded to overlap + length), ragged batch,
+      examples dropped as they end; per split: inputs, lengths, loss, log-prob, metrics; and the merged tracker values;
+    * STCN `forward_split` (stcn.py:332-342; its `split_sequence` raises NotImplementedError, :328-330) for i_split = 0 and 1;
+    * CWVAE `split_sequence` + `forward_split` (clockwork_vae.py:163-198, experiment_clockwork_audio.py:255-271): the splits the
+      reference cuts, the single-split evaluation (is_last_split -> same padding), and what the reference does on every split that
+      is not the last: `pad_same=False` raises IndexError for every configuration and length probed (the (sic) positional call of
+      get_same_padding, SURVEY quirk 8, leaves x_sl unreduced, so the per-example stop index lies beyond the un-padded level
+      length) — the fixture records the exception type over a sweep of lengths."""
+    from blvm.models import STCN
+
+    arrays = {}
+    # ---- WaveNet ----
+    torch.manual_seed(41)
+    lik = DiscretizedLogisticMixtureDense(16, 1, num_mix=10, num_bins=2**16)
+    m = RM.WaveNet(likelihood=lik, n_layers=3, n_stacks=2, res_channels=16, kernel_size=2, base_dilation=2, n_stack_frames=1)
+    B, T = 3, 120
+    x, _ = O.synth_batch(B, T, seed=8)
+    x_sl = torch.tensor([120, 77, 31])
+    x = x * (torch.arange(T).unsqueeze(0) < x_sl.unsqueeze(1))
+    arrays.update(wn_x=x, wn_x_sl=x_sl, wn_rf=np.int64(m.receptive_field))
+    for k, v in m.state_dict().items():
+        arrays[f"wn_sd.{k}"] = v
+    for tag, length in (("consume", 40), ("extend", 10)):
+        splits_x, splits_x_sl = m.split_sequence(x, x_sl, length=length)
+        per_split = []
+        with torch.no_grad():
+            for i, (xs, xs_sl) in enumerate(zip(splits_x, splits_x_sl)):
+                torch.manual_seed(i)
+                loss, metrics, o = m.forward_split(xs, xs_sl, i_split=i)
+                per_split.append(metrics)
+                arrays.update({f"wn_{tag}_x{i}": xs, f"wn_{tag}_x_sl{i}": xs_sl, f"wn_{tag}_loss{i}": loss, f"wn_{tag}_log_prob{i}": o.log_prob,
+                               f"wn_{tag}_ll_twise{i}": o.log_prob_twise,
+                               f"wn_{tag}_metric_values{i}": np.array([mm.value for mm in metrics], dtype=np.float64)})
+        arrays[f"wn_{tag}_length"] = np.int64(length)
+        arrays[f"wn_{tag}_n"] = np.int64(len(splits_x))
+        arrays[f"wn_{tag}_metric_names"] = np.array([mm.name for mm in per_split[0]])
+        arrays[f"wn_{tag}_merged_names"], arrays[f"wn_{tag}_merged_values"] = _merge_like_tracker(per_split)
+
+    # ---- STCN ----
+    cfg = dict(likelihood="DMoL", n_layers=3, latent_size=[16, 16, 32], res_channels=16, n_stack_frames=8)
+    torch.manual_seed(61)
+    s = STCN(**cfg)
+    B, T = 3, 400
+    x, _ = O.synth_batch(B, T, seed=19)
+    x_sl = torch.tensor([400, 280, 120])
+    x = x * (torch.arange(T).unsqueeze(0) < x_sl.unsqueeze(1))
+    arrays.update(st_x=x, st_x_sl=x_sl, st_rf=np.int64(s.receptive_field))
+    for k, v in s.state_dict().items():
+        arrays[f"st_sd.{k}"] = v
+    try:
+        s.split_sequence(x, x_sl, length=100)
+        arrays["st_split_sequence_raises"] = np.array("")
+    except Exception as e:  # noqa: BLE001
+        arrays["st_split_sequence_raises"] = np.array(type(e).__name__)
+    for i in (0, 1):
+        with torch.no_grad():
+            torch.manual_seed(90 + i)
+            loss, metrics, o = s.forward_split(x, x_sl, i_split=i, )
+        Tp = o.z[0].shape[1]
+        torch.manual_seed(90 + i)  # one randn_like(mu) per level, top level first (stcn.py:309-325)
+        eps = [None] * 3
+        for l in (2, 1, 0):
+            eps[l] = torch.randn(B, Tp, cfg["latent_size"][l])
+        arrays.update({f"st_loss{i}": loss, f"st_elbo{i}": o.elbo, f"st_log_prob{i}": o.log_prob,
+                       f"st_metric_names{i}": np.array([mm.name for mm in metrics]),
+                       f"st_metric_values{i}": np.array([mm.value for mm in metrics], dtype=np.float64)})
+        for l in range(3):
+            arrays.update({f"st_eps{i}_{l}": eps[l], f"st_z{i}_{l}": o.z[l], f"st_kld{i}_{l}": o.klds[l]})
+
+    # ---- CW-VAE ----
+    cfg = dict(z_size=[32, 16, 16], h_size=16, strides=[4, 2, 2], num_level_layers=2, stride_per_layer=2, likelihood="DMoL",
+               num_mix=10, num_bins=2**16)
+    torch.manual_seed(51)  # = the reduced model of gen_cwvae (same weights: cwvae.npz pw_sd.*)
+    c = RM.CWVAEAudio(**cfg, precision_posterior=True)
+    B, T = 3, 700
+    x, _ = O.synth_batch(B, T, seed=17)
+    x_sl = torch.tensor([700, 433, 150])
+    x = x * (torch.arange(T).unsqueeze(0) < x_sl.unsqueeze(1))
+    arrays.update(cw_x=x, cw_x_sl=x_sl, cw_overall_rf=np.int64(c.cwvae.overall_receptive_field), cw_overall_stride=np.int64(c.cwvae.overall_stride))
+    for length in (256, 300):
+        sx, ssl = c.split_sequence(x, x_sl, length=length)
+        arrays[f"cw_split{length}_shapes"] = np.array([list(t.shape) for t in sx])
+        arrays[f"cw_split{length}_x_sl"] = np.stack([npy(t) for t in ssl])
+        arrays[f"cw_split{length}_first"] = np.stack([npy(t[:, 0]) for t in sx])  # first sample of every split: pins the offsets
+    # every split but the last: pad_same=False.  Sweep of lengths, full-length and ragged batches: the exception the reference raises
+    raised = []
+    with torch.no_grad():
+        for L in list(range(157, 480, 7)) + [269, 301]:
+            for sl in (torch.tensor([L, L, L]), torch.tensor([L, L - 40, 50])):
+                try:
+                    c.forward_split(x[:, :L], sl, is_last_split=False)
+                    raised.append("")
+                except Exception as e:  # noqa: BLE001
+                    raised.append(type(e).__name__)
+    arrays["cw_not_last_raises"] = np.array(sorted(set(raised)))
+    arrays["cw_not_last_cases"] = np.int64(len(raised))
+    # the evaluation loop when the utterances fit ONE split (the only case the reference's loop completes): is_last_split=True
+    sx, ssl = c.split_sequence(x, x_sl, length=1024)
+    assert len(sx) == 1
+    T_l, n = [], sx[0].shape[1]
+    for st in cfg["strides"]:
+        n = math.ceil(n / st)
+        T_l.append(n)
+    eps = replay_eps_levels(31, T_l, B, cfg["z_size"])
+    with torch.no_grad():
+        torch.manual_seed(31)
+        loss, metrics, o = c.forward_split(sx[0], ssl[0], state0=None, is_last_split=True)
+    arrays.update(cw_one_x=sx[0], cw_one_x_sl=ssl[0], cw_one_loss=loss, cw_one_elbo=o.elbo, cw_one_log_prob=o.log_prob, cw_one_kld=o.kld)
+    arrays["cw_one_merged_names"], arrays["cw_one_merged_values"] = _merge_like_tracker([metrics])
+    for l in range(3):
+        arrays.update({f"cw_one_eps{l}": eps[l], f"cw_one_z{l}": o.z[l], f"cw_one_state_z{l}": o.state_n[l][0], f"cw_one_state_h{l}": o.state_n[l][1]})
+    save("split_eval.npz", **arrays)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn", "wavenet", "rssm", "cwvae", "stcn", "heads", "generate", "generate16", "wavenet_stacked", "cwvae_resets", "stcn_bottom_up", "lstm_layers", "data"]
+    which = sys.argv[1:] or ["functions", "vrnn_small", "vrnn_full", "lstm", "srnn", "wavenet", "rssm", "cwvae", "stcn", "heads", "generate", "generate16", "wavenet_stacked", "cwvae_resets", "stcn_bottom_up", "lstm_layers", "data", "split_eval"]
     for w in which:
         globals()[f"gen_{w}"]()

@@ -358,3 +358,95 @@ def test_wavenet_generate_matches_reference():
     sd = {k[6:]: T(g[k]) for k in g.files if k.startswith("wn_sd.")}
     x = O.wavenet_generate(sd, 2, 7, 3, 2, list(zip(T(g["wn_u"]), T(g["wn_u2"]))))
     close(x, g["wn_x"], 1e-6, 1e-6)
+
+
+# ---- split evaluation: tests/golden/split_eval.npz = the reference's loops on the reference's models --------------
+def _merge_like_tracker(per_split):
+    from blvm.evaluation import Tracker
+
+    tr = Tracker()
+    for metrics in per_split:
+        tr.update(metrics, source="test")
+    return tr.values("test")
+
+
+@pytest.mark.parametrize("tag", ["consume", "extend"])
+def test_split_eval_wavenet_host_splits_and_oracle(tag):
+    """The product's host side (`WaveNet.split_sequence`: overlap = receptive field, "extend" mode with left padding when the split
+    length does not exceed it, examples dropped as they end) cuts the reference's splits; the oracle evaluated on every split
+    (`forward_split`: pad_causal, receptive-field padding on split 0 only) gives the reference's loss / log-prob per split — zeros
+    and sign changes of the "extend" mode included — and the product's metric objects merge to the reference tracker's values."""
+    from blvm.evaluation import BitsPerDimMetric, LLMetric, LossMetric
+    from blvm.models import WaveNet
+    from blvm.modules.distributions import DiscretizedLogisticMixtureDense
+
+    g = np.load(os.path.join(GOLDEN, "split_eval.npz"))
+    sd = {k[6:]: T(g[k]) for k in g.files if k.startswith("wn_sd.")}
+    m = WaveNet(likelihood=DiscretizedLogisticMixtureDense(16, 1, num_mix=10, num_bins=2**16), n_layers=3, n_stacks=2, res_channels=16,
+                kernel_size=2, base_dilation=2, n_stack_frames=1)  # fmt: skip
+    assert m.receptive_field == int(g["wn_rf"])
+    xs, sls = m.split_sequence(T(g["wn_x"]), T(g["wn_x_sl"]), length=int(g[f"wn_{tag}_length"]))
+    assert len(xs) == int(g[f"wn_{tag}_n"])
+    per_split = []
+    for i, (x_i, sl_i) in enumerate(zip(xs, sls)):
+        assert torch.equal(x_i, T(g[f"wn_{tag}_x{i}"])) and torch.equal(sl_i, T(g[f"wn_{tag}_x_sl{i}"])), i
+        out = O.wavenet_forward(sd, x_i, sl_i, n_layers=3, n_stacks=2, pad_causal=True, pad_receptive_field=(i == 0))
+        close(out["loss"], g[f"wn_{tag}_loss{i}"], 2e-6, 1e-6)
+        close(out["log_prob"], g[f"wn_{tag}_log_prob{i}"], 2e-6, 1e-4)
+        close(out["log_prob_twise"], g[f"wn_{tag}_ll_twise{i}"], 1e-5, 1e-5)
+        n = sl_i - (0 if i == 0 else m.receptive_field)  # forward reduces the lengths it normalises by (wavenet.py:188)
+        per_split.append([LossMetric(out["loss"], weight_by=out["log_prob"].numel()), LLMetric(out["log_prob"]),
+                          BitsPerDimMetric(out["log_prob"], reduce_by=n)])  # fmt: skip
+        np.testing.assert_allclose([mm.value for mm in per_split[-1]], g[f"wn_{tag}_metric_values{i}"], rtol=1e-5, atol=1e-6)
+    merged = _merge_like_tracker(per_split)
+    assert list(merged) == list(g[f"wn_{tag}_merged_names"])
+    np.testing.assert_allclose(list(merged.values()), g[f"wn_{tag}_merged_values"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("i_split", [0, 1])
+def test_split_eval_stcn_oracle(i_split):
+    """STCN.forward_split (stcn.py:332-342): receptive-field padding on split 0 only; on later splits the lengths are reduced by
+    rf * S without a clamp (an utterance shorter than that contributes a NEGATIVE count to the normaliser: kept)."""
+    g = np.load(os.path.join(GOLDEN, "split_eval.npz"))
+    assert str(g["st_split_sequence_raises"]) == "NotImplementedError"
+    sd = {k[6:]: T(g[k]) for k in g.files if k.startswith("st_sd.")}
+    eps = [T(g[f"st_eps{i_split}_{l}"]) for l in range(3)]
+    out = O.stcn_forward(sd, T(g["st_x"]), T(g["st_x_sl"]), eps, n_layers=3, latent_size=[16, 16, 32], n_stack_frames=8,
+                         pad_receptive_field=(i_split == 0))  # fmt: skip
+    for l in range(3):
+        close(out["z"][l], g[f"st_z{i_split}_{l}"], 1e-5, 1e-6)
+        close(out["klds"][l], g[f"st_kld{i_split}_{l}"], 2e-5, 1e-5)
+    close(out["loss"], g[f"st_loss{i_split}"], 2e-5, 0)
+    close(out["elbo"], g[f"st_elbo{i_split}"], 2e-5, 1e-5)
+    close(out["log_prob"], g[f"st_log_prob{i_split}"], 2e-5, 1e-5)
+
+
+def test_split_eval_cwvae_host_splits_and_single_split_oracle():
+    """CWVAE.split_sequence (clockwork_vae.py:163-174: strideable length, overlap rf - stride, nobody dropped) cuts the reference's
+    splits; an utterance that fits ONE split is evaluated with same padding (`is_last_split`), which the oracle reproduces.  Every
+    split that is NOT the last raises IndexError in the reference (fixture: 98 of 98 probed shapes) — nothing numeric to pin there;
+    the product raising the same error is a GPU test (tests/test_gpu_split_eval.py)."""
+    from blvm.models import CWVAEAudio
+
+    g = np.load(os.path.join(GOLDEN, "split_eval.npz"))
+    assert list(g["cw_not_last_raises"]) == ["IndexError"] and int(g["cw_not_last_cases"]) == 98
+    m = CWVAEAudio(**CW_SMALL, z_size=[32, 16, 16], h_size=16, precision_posterior=True, likelihood="DMoL", num_mix=10)
+    assert m.cwvae.overall_receptive_field == int(g["cw_overall_rf"]) and m.cwvae.overall_stride == int(g["cw_overall_stride"])
+    x, x_sl = T(g["cw_x"]), T(g["cw_x_sl"])
+    for length in (256, 300):
+        xs, sls = m.split_sequence(x, x_sl, length=length)
+        assert [list(t.shape) for t in xs] == g[f"cw_split{length}_shapes"].tolist()
+        assert torch.equal(torch.stack(sls), T(g[f"cw_split{length}_x_sl"]))
+        assert torch.equal(torch.stack([t[:, 0] for t in xs]), T(g[f"cw_split{length}_first"]))
+    xs, sls = m.split_sequence(x, x_sl, length=1024)
+    assert len(xs) == 1 and torch.equal(xs[0], T(g["cw_one_x"])) and torch.equal(sls[0], T(g["cw_one_x_sl"]))
+    c = np.load(os.path.join(GOLDEN, "cwvae.npz"))  # the same reduced model (same seed): its weights live in cwvae.npz
+    sd = {k[6:]: T(c[k]) for k in c.files if k.startswith("pw_sd.")}
+    out = O.cwvae_audio_forward(sd, xs[0], sls[0], [T(g[f"cw_one_eps{l}"]) for l in range(3)], precision_posterior=True, **CW_SMALL)
+    close(out["loss"], g["cw_one_loss"], 2e-5, 0)
+    close(out["elbo"], g["cw_one_elbo"], 2e-5, 0)
+    close(out["kld"], g["cw_one_kld"], 2e-5, 1e-5)
+    for l in range(3):
+        close(out["z"][l].transpose(0, 1), g[f"cw_one_z{l}"], 1e-5, 1e-6)
+        close(out["state_n"][l][0], g[f"cw_one_state_z{l}"], 1e-5, 1e-6)
+        close(out["state_n"][l][1], g[f"cw_one_state_h{l}"], 1e-5, 1e-6)
