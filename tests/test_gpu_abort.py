@@ -54,6 +54,7 @@ def test_planted_sentinel_is_reported_not_waited_for(where):
     poisoned = _step(m, x, x_sl)
     dt = time.time() - t0
     n, code = _hip.take_async_errors()
+    print(f"planted sentinel in {where}: {n} aborted launch(es), code step {code >> 4} link {code & 15}, loss {poisoned}, {dt:.2f} s")
     # told either way, never silently wrong and never hung: an aborted launch is counted, or the NaN is visible in the result
     assert n >= 1 or poisoned != poisoned, (n, code, poisoned)
     assert dt < 60, f"{dt:.1f} s: the spins are bounded (~2.5 s each, the abort drains the rest of the grid)"

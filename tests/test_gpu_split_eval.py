@@ -63,24 +63,35 @@ def test_wavenet_split_evaluation_matches_the_reference_loop(g, tag):
 
     m = _wavenet(g)
     x, x_sl, length = T(g["wn_x"]).to(DEV), T(g["wn_x_sl"]), int(g[f"wn_{tag}_length"])
+    sd64 = {k[6:]: T(g[k]).double() for k in g.files if k.startswith("wn_sd.")}
+
+    def near(a, ref, truth, rtol, atol):
+        """|a - ref| within rtol / atol, or a as close to the float64 evaluation as the reference's own fp32 result is (x2): the
+        reference evaluates the DMoL bin mass as a difference of two fp32 sigmoids 2^-16 apart, the kernel cancellation-free — on
+        the "extend" splits every scored frame is the same zero-padded frame, so that rounding does not average out."""
+        a, ref, truth = a.detach().double().cpu(), T(ref).double(), truth.double()
+        tol = torch.maximum(atol + rtol * ref.abs(), 2 * (ref - truth).abs() + atol)
+        assert ((a - ref).abs() <= tol).all() or ((a - truth).abs() <= tol).all(), (a, ref, truth)
+
     with torch.no_grad():
         xs, sls = m.split_sequence(x, x_sl, length=length)
         assert len(xs) == int(g[f"wn_{tag}_n"])
         for i, (x_i, sl_i) in enumerate(zip(xs, sls)):
             assert torch.equal(x_i.cpu(), T(g[f"wn_{tag}_x{i}"])) and torch.equal(sl_i, T(g[f"wn_{tag}_x_sl{i}"])), i
             loss, metrics, out = m.forward_split(x_i.contiguous(), sl_i, i_split=i)
-            close(loss, g[f"wn_{tag}_loss{i}"], 1e-5, 1e-5)
-            close(out.log_prob, g[f"wn_{tag}_log_prob{i}"], 1e-5, 1e-3)
-            close(out.log_prob_twise, g[f"wn_{tag}_ll_twise{i}"], 1e-4, 1e-4)
+            t64 = O.wavenet_forward(sd64, x_i.double().cpu(), sl_i, n_layers=3, n_stacks=2, pad_causal=True, pad_receptive_field=(i == 0))
+            near(loss, g[f"wn_{tag}_loss{i}"], t64["loss"], 1e-5, 1e-5)
+            near(out.log_prob, g[f"wn_{tag}_log_prob{i}"], t64["log_prob"], 1e-5, 1e-3)
+            near(out.log_prob_twise, g[f"wn_{tag}_ll_twise{i}"], t64["log_prob_twise"], 1e-4, 1e-4)
             assert [mm.name for mm in metrics] == list(g[f"wn_{tag}_metric_names"])
-            np.testing.assert_allclose([mm.value for mm in metrics], g[f"wn_{tag}_metric_values{i}"], rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose([mm.value for mm in metrics], g[f"wn_{tag}_metric_values{i}"], rtol=5e-5, atol=1e-5)
         tracker = Tracker()
         tracker.source = "test"
         C.wavenet_split_eval(m, x, x_sl, tracker, length)
     torch.cuda.synchronize()
     merged = tracker.values("test")
     assert list(merged) == list(g[f"wn_{tag}_merged_names"])
-    np.testing.assert_allclose(list(merged.values()), g[f"wn_{tag}_merged_values"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(list(merged.values()), g[f"wn_{tag}_merged_values"], rtol=5e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("i_split", [0, 1])
