@@ -80,6 +80,27 @@ def pmc_traffic(model, B, T):
     return d["cell_stage_kernels_read_bytes_per_step"] + d["cell_stage_kernels_write_bytes_per_step"]
 
 
+def pmc_mfma(model, B, T, dtype):
+    """Matrix-pipe utilisation of the recurrent cell's kernels from the committed rocprofv3 counter pass over this same command
+    (tools/probe_pmc_mfma.sh: SQ_VALU_MFMA_BUSY_CYCLES over 4 SIMDs x 256 CUs x duration x effective clock, tools/pmc_mfma_summary.py):
+    the persistent chain kernel, the batched weight-gradient GEMM, and their duration-weighted mean (what `roofline.frac` estimates
+    from time alone).  Counters cannot be read inside the timed process: valid for the workload the pass was taken on only."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_vrnn_pmc_mfma_v*.json")))
+    if model != "vrnn" or (B, T) != (64, 16000) or dtype != "f32" or not files:
+        return None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    p, w = d.get("pchain"), d.get("wgrad_gemm")
+    if not p or not w:
+        return None
+    ms = p["ms_per_step"] + w["ms_per_step"]
+    return dict(source=os.path.basename(files[-1]), cell=(p["mfma_busy"] * p["ms_per_step"] + w["mfma_busy"] * w["ms_per_step"]) / ms,
+                pchain_kernel=p["mfma_busy"], wgrad_gemm=w["mfma_busy"], pchain_ms_per_step=p["ms_per_step"], wgrad_ms_per_step=w["ms_per_step"],
+                pchain_waves_parked=p["parked"], pchain_clock_GHz=p["clock_GHz"])  # fmt: skip
+
+
 def host_cpu():
     """(CPU model string, physical cores of the machine, logical CPUs this process may run on) from /proc/cpuinfo + the affinity
     mask.  Physical cores = distinct (physical id, core id) pairs; a container's CPU share may be smaller than either."""
@@ -133,17 +154,18 @@ def cpu_baseline(B, T, steps, threads, warmup=5, gpu_batch=64):
         opt.step()
         if i % 5 == 4 or i == 0:
             log(f"cpu_baseline step {i}: {time.perf_counter() - t0:.2f} s")
+        if i == 0:
+            bpd0 = out["bpd"]  # random-init weights: comparable with the GPU line's bits_per_dim
         if i >= warmup:
             times.append(time.perf_counter() - t0)
     dt = sorted(times)[len(times) // 2]
     cpu_model, physical, usable = host_cpu()
-    why = "" if B == gpu_batch else (f"; [{B},{T}] not the GPU's [{gpu_batch},{T}]: the sample is bounded to ~20 s of CPU work (25 steps), "
-                                     "frames/s of this path is flat in B from 16 up (--cpu-batch 64 runs the GPU's shape)")  # fmt: skip
+    why = "" if B == gpu_batch else f"; [{B},{T}] is NOT the GPU's [{gpu_batch},{T}] (the CPU path's frames/s grows with B: 3.5e5 at 16, 6.5e5 at 64 on 16 cores)"
     return dict(value=B * T / dt, unit="frames/s", cores=threads, kind="port",
                 sample=f"oracle VRNN train step (fwd+bwd+clip+Adam, fp32, seeds data 0 / init 0) on [{B},{T}], median of {steps} steps after "
                        f"{warmup} warm-up, torch.set_num_threads({threads}){why}",
                 cpu_model=cpu_model, physical_cores=physical, usable_cpus=usable,
-                ms_per_step=dt * 1e3, bits_per_dim=out["bpd"])  # fmt: skip
+                ms_per_step=dt * 1e3, bits_per_dim=bpd0, bits_per_dim_after_updates=out["bpd"])  # fmt: skip
 
 
 def self_launch(n):
@@ -333,7 +355,7 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="operand type of the matrix products: f32 (headline) or bf16 operands / fp32 "
                     "accumulation for the persistent chains and K6 (the reference's --use_amp regime; a separate mode, never the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-batch", type=int, default=64, help="utterances of the CPU baseline step (default: the GPU's 64; 25 steps of it are ~40 s on 16 cores)")
     ap.add_argument("--cpu-steps", type=int, default=20)
     ap.add_argument("--no-sweep", action="store_true", help="skip the large-batch sweep (N=1, vrnn only)")
     ap.add_argument("--dry-launch", action="store_true", help="CPU rehearsal of the N-rank launch: gloo, no GPU call, no model")
@@ -423,6 +445,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / peak,
                 "traffic": pmc_traffic(args.model, B, T),
+                "mfma_busy": pmc_mfma(args.model, B, T, args.dtype),
                 "flops_per_call": flops_fb,
                 "fwd_ms": m["fwd_ms"],
                 "bwd_ms": m["bwd_ms"],

@@ -68,10 +68,15 @@ int run(int B, int N, int L, int G, int shift, int reps) {
   CK(hipMalloc(&ref, slab * 4 * 2)); CK(hipMalloc(&ref16, slab16 * 4 * 2));
   CK(hipMalloc(&W, (size_t)N * N * 4)); CK(hipMalloc(&Wt, (size_t)N * N * 4)); CK(hipMalloc(&bias, N * 4)); CK(hipMalloc(&ctlw, 64));
   std::vector<float> h(slab), hw((size_t)N * N), hb(N);
+  // The chain must stay finite through thousands of relu layers WHATEVER the draw: uniform weights of scale g / sqrt(N) carry a
+  // variance gain of g^2 / 6 per layer.  g = 2.45 (gain 1.0004) was a coin toss per draw — and the draw depended on B (one rand()
+  // stream for x, W, b), so B = 8, N = 192 diverged to inf - inf = NaN in the probe AND in its launch-per-link reference, and
+  // NaN != NaN was counted as 1536 mismatches (round-2 log).  g = 2.3 (gain 0.88): the chain settles at the bias-driven fixed point.
   srand(1);
-  for (auto& v : h) v = (rand() % 2001 - 1000) * 1e-3f;
-  for (auto& v : hw) v = (rand() % 2001 - 1000) * 1e-3f * 2.45f / sqrtf((float)N);  // activations stay O(1) through thousands of relu layers
+  for (auto& v : hw) v = (rand() % 2001 - 1000) * 1e-3f * 2.3f / sqrtf((float)N);
   for (auto& v : hb) v = (rand() % 2001 - 1000) * 1e-4f;
+  srand(2 + B);
+  for (auto& v : h) v = (rand() % 2001 - 1000) * 1e-3f;
   CK(hipMemcpy(x0, h.data(), slab * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(W, hw.data(), (size_t)N * N * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(bias, hb.data(), N * 4, hipMemcpyHostToDevice));
@@ -107,6 +112,7 @@ int run(int B, int N, int L, int G, int shift, int reps) {
   size_t bad = 0; double mag = 0;
   for (size_t i = 0; i < slab; ++i) { bad += a[i] != b[i]; mag += fabs(b[i]); }
   if (shift < 0) bad = 0;  // compute-only run: results are not the chain's
+  if (!(mag == mag) || mag > 1e30) { printf("probe error: the reference chain is not finite (mean|x| %g) — nothing was compared\n", mag / slab); return 1; }
   printf("B=%3d N=K=%4d L=%4d G=%3d NW=%2d shift=%2d: persistent %6.3f us/link | launches %6.3f us/link | mismatches %zu/%zu (mean|x| %.3g) aborted launches=%u code=%u\n",
          B, N, L, G, NW, shift, best * 1e3 / L, msl * 1e3 / L, bad, slab, mag / slab, hc[4], hc[5]);
   (void)hipFree(x0); (void)hipFree(x0_16); (void)hipFree(slabs); (void)hipFree(slabs16); (void)hipFree(ref); (void)hipFree(ref16); (void)hipFree(W); (void)hipFree(Wt);
