@@ -117,8 +117,11 @@ __device__ __forceinline__ FrameCoord frame_coord(const DmolArgs& a, long long f
 
 // Hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp): the kernel has a budget of ~1700 vector
 // instructions per frame before it stops being HBM-bound; libm-accurate expf/logf/log1pf/division cost 4x that.
-__device__ __forceinline__ float fexp(float x) { return __expf(x); }
-__device__ __forceinline__ float flog(float x) { return __logf(x); }
+// (the bare instructions: `__expf` / `__logf` expand to a range-scaled sequence — compare, select, v_ldexp — around v_exp_f32 /
+// v_log_f32 for denormal results and arguments, ~7 instructions per call and ~60 calls per frame; here results below 2^-126 may
+// flush to zero, where they are added to sums >= 1, and every log argument is >= 1e-10)
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
 __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // Per-frame DMoL math.  p[0..9] logits, p[10..19] locs, p[20..29] raw log-scales.
@@ -367,164 +370,164 @@ __global__ __launch_bounds__(256) void dmol_kernel(DmolArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Row-wise variant for stack sizes that are multiples of 64 (the VRNN / SRNN / LSTM decoders, S = 64 or 256).
-// A workgroup owns ONE utterance and a chunk of its 64-frame units, each wave stages its own unit through a private
-// LDS image (no inter-wave traffic), the per-utterance sum is carried in registers across the chunk and costs ONE fp64
-// atomic per workgroup (the flat kernel above issues one per wave: 250 serialised atomics per utterance address at
-// [64,16000]).  Integer divisions are 32-bit and wave-uniform.
+// Row-wise variant for stack sizes that are multiples of 64 (the VRNN / SRNN / LSTM / STCN decoders, S = 64 or 256).
+// A workgroup owns ONE utterance and a chunk of its 64-frame units; each of its four waves walks every fourth unit on its own —
+// private LDS image, no workgroup barrier inside the loop — carrying the per-utterance sum in registers (ONE fp64 atomic per
+// workgroup; the flat kernel above issues one per wave).  The grid fills the chip once (resident workgroups per CU by registers
+// x CUs): a wave's prologue (lengths, the weight table, its first unit) is two dependent HBM round trips, so few long-lived waves
+// beat many short ones (2 048 workgroups of 2 units per wave: 40 % of all wave cycles parked).  Both products with the head's
+// 30 x 30 Linear (forward p = W d + b; backward d_dec = d_par W) run on the matrix pipe, in place in the image.  Round 3, same
+// shapes [64,16000]: forward 55 -> 42 us (3.0 TB/s of the 124 B/frame), backward 125 -> 93 us (3.9 TB/s of 364 B/frame).  What is
+// left is arithmetic, not HBM: per unit ~640 vector instructions of mixture math (19 us of a SIMD's time per launch) plus 30 (60)
+// fp32 MFMAs (12.5 us per product pass) that do NOT overlap — SQ_VALU_MFMA_COEXEC_CYCLES is 0: the fp32 matrix instructions share
+// the vector issue — against 20 us (58 us) of HBM time.  Integer divisions are 32-bit and wave-uniform.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void stage_unit(const float* __restrict__ src, float* __restrict__ lds, int lane) {
-  // 64 frames x 30 floats = 480 float4, contiguous and 16-byte aligned in HBM -> LDS [64][31]
+// A unit = the 64 frames x 30 floats (7 680 bytes, contiguous and 16-byte aligned in HBM) one wave works on.  Its LDS image is a
+// VERBATIM copy (no padding, no index arithmetic: 480 float4, lane q -> float4 q), private to the wave:
+//   * the lane's own frame is 15 ds_read_b64 at byte 120 * lane (dword stride 30: within each half-wave of a b64 access the 32
+//     lanes fall on 32 distinct even banks — 15 is invertible mod 32 — so the reads are conflict-free),
+//   * the matrix pipe's A operand IN[32 t + li][2 j + lh] is dword 30 (32 t + li) + 2 j + lh: 64 distinct banks again,
+//   * nothing but this wave touches the image, so the only ordering needed is the wave's own program order (LDS executes a
+//     wave's instructions in order): `wave_sync` is a compiler fence, not a barrier — the four waves of a workgroup drift apart,
+//     one wave's MFMAs run under another's exp / log stream.
+constexpr int UNIT_FLOATS = 64 * F_MAX;  // 1920
+// (a compiler-only fence: a release / acquire fence pair, even at wavefront scope, made hipcc wait for ALL outstanding vector
+// memory — the next unit's prefetch included — in front of every image phase)
+__device__ __forceinline__ void wave_sync() { asm volatile("" ::: "memory"); }
+// a unit in flight from HBM: eight plain vector registers (f32x4 k holds float4 lane + 64 k; k = 7: lanes 0..31).  Separate
+// scalars of an ext-vector type on purpose: an array of HIP's float4 (a struct of unions) passed by reference stayed in scratch.
+#define UNIT_REGS(n) f32x4 n##0, n##1, n##2, n##3, n##4, n##5, n##6, n##7
+#define LOAD_UNIT(n, src, lane)                                                                                     \
+  do {                                                                                                              \
+    const f32x4* s4_ = reinterpret_cast<const f32x4*>(src);                                                         \
+    n##0 = s4_[(lane)]; n##1 = s4_[(lane) + 64]; n##2 = s4_[(lane) + 128]; n##3 = s4_[(lane) + 192];                \
+    n##4 = s4_[(lane) + 256]; n##5 = s4_[(lane) + 320]; n##6 = s4_[(lane) + 384];                                   \
+    n##7 = s4_[448 + ((lane) & 31)]; /* unconditional: lanes 32..63 re-read what lanes 0..31 read and never use it */ \
+  } while (0)
+#define PUT_UNIT(n, lds, lane)                                                                                      \
+  do {                                                                                                              \
+    f32x4* d4_ = reinterpret_cast<f32x4*>(lds);                                                                     \
+    d4_[(lane)] = n##0; d4_[(lane) + 64] = n##1; d4_[(lane) + 128] = n##2; d4_[(lane) + 192] = n##3;                \
+    d4_[(lane) + 256] = n##4; d4_[(lane) + 320] = n##5; d4_[(lane) + 384] = n##6;                                   \
+    if ((lane) < 32) d4_[448 + (lane)] = n##7;                                                                      \
+  } while (0)
+__device__ __forceinline__ void store_unit(float* __restrict__ dst, const float* __restrict__ lds, int lane) {
+  const f32x4* s4 = reinterpret_cast<const f32x4*>(lds);
+  f32x4* d4 = reinterpret_cast<f32x4*>(dst);
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int q = lane + 64 * k;
-    if (q < 480) {
-      const float4 v = reinterpret_cast<const float4*>(src)[q];
-      const float e[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int idx = 4 * q + c, fr = (idx * 2185) >> 16;  // idx / 30, exact for idx < 1920
-        lds[fr * (F_MAX + 1) + (idx - fr * F_MAX)] = e[c];
-      }
-    }
-  }
+  for (int k = 0; k < 7; ++k) d4[lane + 64 * k] = s4[lane + 64 * k];
+  if (lane < 32) d4[448 + lane] = s4[448 + lane];
 }
 
-__device__ __forceinline__ void unstage_unit(float* __restrict__ dst, const float* __restrict__ lds, int lane) {
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int q = lane + 64 * k;
-    if (q < 480) {
-      float e[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int idx = 4 * q + c, fr = (idx * 2185) >> 16;
-        e[c] = lds[fr * (F_MAX + 1) + (idx - fr * F_MAX)];
-      }
-      reinterpret_cast<float4*>(dst)[q] = make_float4(e[0], e[1], e[2], e[3]);
-    }
-  }
-}
-
-// The head's 30x30 Linear for a wave's 64 staged frames on the matrix pipe instead of 900 VALU FMAs per frame:
-//   OUT[64 x 30] = IN[64 x 30] * Wmat (+ bias), two 32x32 output tiles, K = 30 as 15 k-pairs of v_mfma_f32_32x32x2_f32.
-// lane (li = lane & 31, lh = lane >> 5): A operand IN[32 t + li][2 j + lh] from the wave's LDS image [64][31] (row stride 31:
-// conflict-free), B operand wreg[j] = Wmat[2 j + lh][li] kept in 15 registers for the whole launch (0 for li >= 30).
-// Result element (row m = (r & 3) + 8 (r >> 2) + 4 lh, column li) goes back INTO the image (tile t only touches rows of tile t,
-// after its own reads), from where every lane picks up its frame's 30 values.  Exact fp32 fma chain, k ascending.
-__device__ __forceinline__ void mfma_linear64(float* __restrict__ lds, const float (&wreg)[15], float bias_n, int lane) {
+// A wave's 64 x 30 image times a 30 x 30 matrix on the matrix pipe, IN PLACE: OUT[f][n] = sum_k IN[f][k] M[k][n] (+ bias[n]), two
+// 32-row tiles, K = 30 as 15 k-pairs of v_mfma_f32_32x32x2_f32 (an exact fp32 fma chain, k ascending) instead of 900 VALU FMAs per
+// frame.  lane (li = lane & 31, lh = lane >> 5): A = IN[32 t + li][2 j + lh], B = M[2 j + lh][li] (0 for li >= 30) from a per-lane
+// table in LDS.  A tile's 15 A reads are issued before its 16 result writes and only touch its own rows.
+__device__ __forceinline__ void mfma_image_30x30(float* __restrict__ lds, const float* __restrict__ mlds, float bias_n, int lane) {
   const int li = lane & 31, lh = lane >> 5;
+  float mreg[15];  // this lane's B operands, from the workgroup's LDS copy [15][64] (30 resident registers per wave cost a wave of occupancy)
+#pragma unroll
+  for (int j = 0; j < 15; ++j) mreg[j] = mlds[j * 64 + lane];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const float* row = lds + (32 * t + li) * (F_MAX + 1) + lh;
+    const float* row = lds + (32 * t + li) * F_MAX + lh;
+    float av[15];  // all fifteen A values requested before the first MFMA (read -> wait -> MFMA pairs expose the LDS latency 15 times)
 #pragma unroll
-    for (int j = 0; j < 15; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(row[2 * j], wreg[j], acc, 0, 0, 0);
+    for (int j = 0; j < 15; ++j) av[j] = row[2 * j];
+    wave_sync();  // (all lanes' A reads are issued before any result lands in the image)
+#pragma unroll
+    for (int j = 0; j < 15; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], mreg[j], acc, 0, 0, 0);
     if (li < F_MAX) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) lds[(32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh) * (F_MAX + 1) + li] = acc[r] + bias_n;
+      for (int r = 0; r < 16; ++r) lds[(32 * t + (r & 3) + 8 * (r >> 2) + 4 * lh) * F_MAX + li] = acc[r] + bias_n;
     }
   }
 }
 
-template <bool BWD>
+template <bool BWD, bool PF>  // PF: the next unit is requested into registers (32 of them) before this one is worked on
 __global__ __launch_bounds__(256) void dmol_rows_kernel(DmolArgs a, int units, int nchunks) {
-  __shared__ __attribute__((aligned(16))) float lds_all[4 * 64 * (F_MAX + 1)];
+  __shared__ __attribute__((aligned(16))) float lds_all[4 * UNIT_FLOATS];
   __shared__ double wsum[4];
+  __shared__ float wtab[2 * 15 * 64];  // the head's Linear as MFMA B operands per lane: [0] forward (W^T), [1] backward (W)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* lds = lds_all + wave * 64 * (F_MAX + 1);
+  float* lds = lds_all + wave * UNIT_FLOATS;
   const int b = blockIdx.x / nchunks, c = blockIdx.x - b * nchunks;
   const int u_begin = (int)((long long)c * units / nchunks), u_end = (int)((long long)(c + 1) * units / nchunks);
-  cfloat* Wc = as_const(a.W);
-  cfloat* bc = as_const(a.bias);
   const int upr = a.S >> 6;  // 64-frame units per row
   const int len = min(a.x_sl[b], a.T);
   const float g = BWD ? a.g_b[b] : 0.f;
-  // head weights for the matrix pipe: B operand W^T[k][n] = W[n][k]
-  float wf[15];
+  const bool lin = a.W != nullptr;  // uniform
+  auto unit_base = [&](int u) {  // float offset of unit u of utterance b (wave-uniform)
+    const int t = u / upr, j0 = (u - t * upr) * 64;
+    const long long row = a.layout == 0 ? (long long)b * a.Tp + t : (long long)t * a.B + b;
+    return ((size_t)row * a.S + j0) * F_MAX;
+  };
+  UNIT_REGS(nxt);
+  int u = u_begin + wave;
+  if (PF && u < u_end) LOAD_UNIT(nxt, a.dec + unit_base(u), lane);  // the first unit travels with the weights
+  // the head's Linear for the matrix pipe: forward B operand W^T[k][n] = W[n][k]; backward (d_dec = d_par W) B operand W[k][n]
   float bias_n = 0.f;
   {
     const int li = lane & 31, lh = lane >> 5;
+    if (wave == 0) {
 #pragma unroll
-    for (int j = 0; j < 15; ++j) {
-      wf[j] = (a.W != nullptr && li < F_MAX) ? a.W[li * F_MAX + 2 * j + lh] : 0.f;
-    }
-    if (a.W != nullptr && li < F_MAX) bias_n = a.bias[li];
-  }
-  double acc = 0.0;
-  for (int u0 = u_begin; u0 < u_end; u0 += 4) {
-    const int u = u0 + wave;
-    const bool active = u < u_end;  // wave-uniform
-    const int t = active ? u / upr : 0;
-    const int j0 = active ? (u - t * upr) * 64 : 0;
-    const long long row = a.layout == 0 ? (long long)b * a.Tp + t : (long long)t * a.B + b;
-    const size_t base = ((size_t)row * a.S + j0) * F_MAX;
-    if (active) stage_unit(a.dec + base, lds, lane);
-    __syncthreads();
-    const int tau = t * a.S + j0 + lane;
-    const bool valid = active && tau < len;
-    // forward: p = W d + bias on the matrix pipe, in place in the LDS image (64.7 -> 55 us on [64,16000]); the backward
-    // kernel, whose registers already hold dp / dd, measured faster with the recompute on the VALU (122.7 vs 127.4 us)
-    if (!BWD && a.W != nullptr) {
-      mfma_linear64(lds, wf, bias_n, lane);
-      __syncthreads();
-    }
-    float p[F_MAX];
-#pragma unroll
-    for (int i = 0; i < F_MAX; ++i) p[i] = lds[lane * (F_MAX + 1) + i];
-    if (BWD && a.W != nullptr) {
-      float d[F_MAX];
-#pragma unroll
-      for (int i = 0; i < F_MAX; ++i) d[i] = p[i];
-#pragma unroll
-      for (int o = 0; o < F_MAX; ++o) {
-        float s = bc[o];
-#pragma unroll
-        for (int i = 0; i < F_MAX; ++i) s = fmaf(Wc[o * F_MAX + i], d[i], s);
-        p[o] = s;
+      for (int j = 0; j < 15; ++j) {
+        wtab[j * 64 + lane] = (lin && li < F_MAX) ? a.W[li * F_MAX + 2 * j + lh] : 0.f;
+        if (BWD) wtab[(15 + j) * 64 + lane] = (lin && li < F_MAX) ? a.W[(2 * j + lh) * F_MAX + li] : 0.f;
       }
     }
+    if (lin && li < F_MAX) bias_n = a.bias[li];
+  }
+  __syncthreads();
+  double acc = 0.0;
+  for (; u < u_end; u += 4) {
+    const int t = u / upr, j0 = (u - t * upr) * 64;
+    const size_t base = unit_base(u);
+    const int tau = t * a.S + j0 + lane;
+    const bool valid = tau < len;
     const float yv = valid ? a.y[(size_t)b * a.T + tau] : 0.f;
+    wave_sync();  // the previous unit's last image reads (its stores to HBM) are issued
+    if (!PF) LOAD_UNIT(nxt, a.dec + base, lane);
+    PUT_UNIT(nxt, lds, lane);
+    if (PF && u + 4 < u_end) LOAD_UNIT(nxt, a.dec + unit_base(u + 4), lane);  // the next unit travels while this one is worked on
+    wave_sync();
+    if (lin) {
+      mfma_image_30x30(lds, wtab, bias_n, lane);  // p = W d + bias, in place
+      wave_sync();
+    }
+    float p[F_MAX];
+    {
+      const float2* fp = reinterpret_cast<const float2*>(lds + lane * F_MAX);
+#pragma unroll
+      for (int i = 0; i < F_MAX / 2; ++i) { const float2 q = fp[i]; p[2 * i] = q.x; p[2 * i + 1] = q.y; }
+    }
     const float ll = head_frame<BWD>(a, yv, p);
     if (!BWD) {
       if (valid) {
         acc += (double)ll;
         if (a.ll_twise != nullptr) a.ll_twise[(size_t)b * a.T + tau] = ll;
       }
-      __syncthreads();
     } else {
       const float gv = valid ? g : 0.f;
+      wave_sync();  // every lane has its frame: the image may be overwritten
+      {
+        float2* fp = reinterpret_cast<float2*>(lds + lane * F_MAX);
 #pragma unroll
-      for (int o = 0; o < F_MAX; ++o) p[o] *= gv;
-      // d_dec = W^T dp stays on the VALU (measured: a second matrix-pipe pass + its LDS round trip made the backward slower)
-      float dd[F_MAX];
-      if (a.W != nullptr) {
-#pragma unroll
-        for (int i = 0; i < F_MAX; ++i) dd[i] = 0.f;
-#pragma unroll
-        for (int o = 0; o < F_MAX; ++o) {
-#pragma unroll
-          for (int i = 0; i < F_MAX; ++i) dd[i] = fmaf(Wc[o * F_MAX + i], p[o], dd[i]);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < F_MAX; ++i) dd[i] = p[i];
+        for (int i = 0; i < F_MAX / 2; ++i) fp[i] = make_float2(p[2 * i] * gv, p[2 * i + 1] * gv);
       }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < F_MAX; ++i) lds[lane * (F_MAX + 1) + i] = dd[i];
-      __syncthreads();
-      if (active) unstage_unit(a.d_dec + base, lds, lane);
+      wave_sync();
       if (a.d_par != nullptr) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < F_MAX; ++i) lds[lane * (F_MAX + 1) + i] = p[i];
-        __syncthreads();
-        if (active) unstage_unit(a.d_par + base, lds, lane);
+        store_unit(a.d_par + base, lds, lane);      // d(loss)/d(head output): what the weight / bias gradient GEMM reads
+        wave_sync();
       }
-      __syncthreads();
+      if (lin) {
+        mfma_image_30x30(lds, wtab + 15 * 64, 0.f, lane);  // d_dec = d_par W, in place
+        wave_sync();
+      }
+      store_unit(a.d_dec + base, lds, lane);
     }
   }
   if (!BWD) {
@@ -541,11 +544,29 @@ int launch_dmol(DmolArgs& a, hipStream_t s) {
   if (a.S % 64 == 0 && aligned16(a.dec) && (!BWD || (aligned16(a.d_dec) && (a.d_par == nullptr || aligned16(a.d_par))))) {
     const long long units = (long long)a.Tp * (a.S / 64);
     BLVM_REQUIRE(units < (1ll << 31), "dmol: too many frames");
+    // Few, long-lived workgroups: a wave's prologue (x_sl, 30 weight registers, its first unit: two dependent HBM round trips) is
+    // ~4 us, a unit ~1.5 us of its time — at 2 units per wave (2048 workgroups) the waves spent 40 % of their lives parked.  About
+    // three workgroups per CU (what the registers allow), every wave walking its chunk with the next unit in flight.
     int nchunks = (int)((units + 3) / 4);
-    const int cap = (2048 + a.B - 1) / a.B;
+    // PF (the next unit requested into 32 registers ahead of time) costs a wave of occupancy in both kernels and measured no faster
+    // than one more resident wave per SIMD covering the load (same box: forward 44.8 vs 42.3 us, backward 95.6 vs 92.7): off
+    static const int pf = [] { const char* e = getenv("BLVM_DMOL_PF"); return e ? atoi(e) : 0; }();
+    static const int wg_env = [] { const char* e = getenv("BLVM_DMOL_WGS"); return e ? atoi(e) : 0; }();
+    static int wg_fill[2] = {0, 0};  // workgroups that fill the chip once: resident workgroups per CU (by registers) x CUs
+    if (wg_fill[pf ? 1 : 0] == 0) {
+      int per_cu = 0, dev = 0, cus = 0;
+      const void* k = pf ? reinterpret_cast<const void*>(&dmol_rows_kernel<BWD, true>) : reinterpret_cast<const void*>(&dmol_rows_kernel<BWD, false>);
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+      (void)hipGetLastError();
+      wg_fill[pf ? 1 : 0] = per_cu * cus;
+    }
+    const int wg_target = wg_env > 0 ? wg_env : wg_fill[pf ? 1 : 0];
+    const int cap = (wg_target + a.B - 1) / a.B;
     if (nchunks > cap) nchunks = cap;
     if (nchunks < 1) nchunks = 1;
-    hipLaunchKernelGGL((dmol_rows_kernel<BWD>), dim3((unsigned)(a.B * nchunks)), dim3(256), 0, s, a, (int)units, nchunks);
+    if (pf) hipLaunchKernelGGL((dmol_rows_kernel<BWD, true>), dim3((unsigned)(a.B * nchunks)), dim3(256), 0, s, a, (int)units, nchunks);
+    else hipLaunchKernelGGL((dmol_rows_kernel<BWD, false>), dim3((unsigned)(a.B * nchunks)), dim3(256), 0, s, a, (int)units, nchunks);
   } else {
     const long long blocks = (a.n_frames + FPB - 1) / FPB;
     BLVM_REQUIRE(blocks < (1ll << 31), "dmol: too many frames");
