@@ -252,7 +252,10 @@ def measure(name, model, B, T, steps, warmup, rank, dev, use_dist, reducer_cls):
     from blvm import _hip, ops
 
     params = list(model.parameters())
-    opt = torch.optim.Adam(params, lr=3e-4)
+    # the reference's optimizer (experiment_vrnn_audio.py:136: torch.optim.Adam) in torch's single-launch form: the same update
+    # rule, one multi-tensor kernel instead of ~10 per step (BLVM_FUSED_ADAM=0: the foreach form)
+    fused = os.environ.get("BLVM_FUSED_ADAM", "1") != "0"
+    opt = torch.optim.Adam(params, lr=3e-4, fused=True) if fused else torch.optim.Adam(params, lr=3e-4, foreach=True)
     reducer = reducer_cls(params) if use_dist else None
     # synthetic mu-law batch, resident in HBM before the timed region (rank-offset seed: different utterances per GPU)
     g = torch.Generator().manual_seed(1000 + rank)
@@ -455,7 +458,9 @@ def main():
             # the large-batch regime of the same kernels (the chain's cost per link does not depend on B until B ~ 256): same
             # model, same step, fewer timed steps.  Not the headline: `value` above stays the B = 64 configuration.
             sweep = [dict(batch_per_gpu=B, ms_per_step=m["ms_median"], frames_per_s=B * T / (m["ms_median"] * 1e-3), roofline_frac=achieved / peak)]
-            for Bs in (128, 256, 1024):  # 128: still the persistent launches; 256 and up: a launch per link on 32x32 tiles
+            # 128: the persistent launches on 16-row tiles; 256, 512: on row groups of four row tiles (csrc/pchain_rt.h); beyond:
+            # a launch per link on 32x32 tiles, where the chain turns from latency- into throughput-bound
+            for Bs in (128, 256, 512, 1024, 4096):
                 ms_ = measure(args.model, model, Bs, T, 5, 2, rank, dev, False, FlatGradAllReduce)
                 mc, _ = model_macs(args.model, model, Bs, T)
                 tf = 6 * mc / ((ms_["fwd_ms"] + ms_["bwd_ms"]) * 1e-3) / 1e12

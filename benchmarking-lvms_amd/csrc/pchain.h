@@ -1008,6 +1008,7 @@ struct Desc {
 };
 struct Program {
   int bf16 = 0;  // weights are bf16 T16 packs, products on the bf16 matrix pipe (see mgemm_trip)
+  int rt_group = 1;  // row tiles per tile: 1 = pchain.h's 16-row tiles; 4 = row groups (pchain_rt.h; the VRNN tile kinds only, B > 128)
   int s_first = 0;  // the launch walks steps [s_first, S): a sequence may be cut into several launches (everything a later one needs is in the slabs)
   int ndesc, S, B, xcd;
   long stride[16];

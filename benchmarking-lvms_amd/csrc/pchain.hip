@@ -37,6 +37,7 @@
 
 #include "common.h"
 #include "pchain.h"
+#include "pchain_rt.h"
 
 namespace blvm {
 namespace {
@@ -419,6 +420,144 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
   }
 }
 
+// The same walk on ROW GROUPS (pchain_rt.h): a tile is up to RT row tiles of one column tile, the program's tile lists count
+// groups (rt = row groups here), and only the tile kinds of the VRNN programs exist.  A separate kernel on purpose: the 16-row
+// kernel above is sensitive to every live scalar (tools/probe_engine_chain.py) and must not change when this one does.
+template <int NW, bool BF, int RT>
+__global__ __launch_bounds__(NW * 64, 1) void pchain_rt_kernel(const int* __restrict__ tab, Hdr a) {
+  extern __shared__ __attribute__((aligned(16))) char lds_all[];
+  int* const ltab = reinterpret_cast<int*>(lds_all);
+  float* const red0 = reinterpret_cast<float*>(lds_all + sizeof(int) * kDescWords * kMaxDesc + 32 * sizeof(unsigned long long));
+  float* const red1 = red0 + a.lds_products * NW * 256;
+  const int w = blockIdx.x, B = a.B, rt = ((B + 15) / 16 + RT - 1) / RT;  // row groups
+  const bool xcd = a.xcd != 0;
+  for (int e = threadIdx.x; e < a.ndesc * kDescWords; e += NW * 64) ltab[e] = tab[e];
+  unsigned mine = 0;
+  for (int i = 0; i < a.ndesc; ++i) {
+    const int* q = tab + (size_t)i * kDescWords;
+    if (TileIter(w, q[RD_WG0], q[RD_NWG], rt, q[RD_CT], xcd).valid()) mine |= 1u << i;
+  }
+  __syncthreads();
+  if (threadIdx.x < a.ndesc) {
+    int* q = ltab + threadIdx.x * kDescWords;
+    int k = 0;
+    for (TileIter it(w, q[RD_WG0], q[RD_NWG], rt, q[RD_CT], xcd); it.valid() && k < kMaxTilesPerWg; it.next()) q[RD_TILE + k++] = (it.r0() * RT) | (it.c() << 16);
+    q[RD_NT] = k;
+  }
+  __syncthreads();
+  if (mine == 0) return;
+  int par = 0;
+  auto red = [&]() { par ^= 1; return par ? red0 : red1; };
+  Poll pl{a.ctl, 0u, false, 1};
+  DescRegs d, nx;
+  d.fetch(ltab, __builtin_ctz(mine), a.s0);
+  for (int s = a.s0; s < a.S; ++s) {
+    for (unsigned m = mine; m != 0; m &= m - 1) {
+      const int i = __builtin_ctz(m);
+      const unsigned rest = m & (m - 1);
+      const int nx_i = __builtin_ctz(rest != 0 ? rest : mine), nx_s = rest != 0 ? s : s + 1;
+      const int kind = d.w<RD_KIND>(), flags = d.w<RD_FLAGS>(), K = d.w<RD_K>();
+      const bool active = s >= d.w<RD_SBEGIN>() && s < d.w<RD_SEND>();
+      nx.fetch(ltab, nx_i, nx_s);
+      if (active) {
+        const int nt = d.w<RD_NT>();
+        pl.nap = (flags & DF_GENTLE) ? 16 : 1;
+        pl.code = ((unsigned)s << 4) | (unsigned)i;
+        const int ld0 = d.w<RD_LD + 0>(), ld1 = d.w<RD_LD + 1>(), ld3 = d.w<RD_LD + 3>(), n16 = d.w<RD_N16>();
+        switch (kind) {
+          case K_LIN: {
+            const bool a_polled = !(flags & DF_A_PLAIN);
+            const float *A = d.p<0>(s), *W = d.base<1>();
+            const float *A2 = (flags & DF_A_SUM3) ? d.p<8>(s) : nullptr, *A3 = (flags & DF_A_SUM3) ? d.p<9>(s) : nullptr;
+            const int w_width = d.w<RD_I + 0>();
+            auto late = [&]() {
+              return LinLate{d.base<2>(), d.p<3>(s), d.p<4>(s), ld1, d.w<RD_LD + 2>(), (flags & DF_ADD_POLLED) != 0, (flags & DF_RELU) != 0, d.f<0>(),
+                             Out{d.m<5>(s), ld3, (flags & DF_RM_SC1) != 0, d.m<6>(s), n16, d.m<7>(s), d.w<RD_N16 + 1>()}};
+            };
+            for (int tk = 0; tk < nt; ++tk) {
+              const int trc = d.tile(tk), tr0 = trc & 0xffff, tc0 = (trc >> 16) * 16;
+              if ((flags & DF_CANARY) && a_polled) {
+                for (int q = 0; q < RT && tr0 + 16 * q < B; ++q) canary_wait(A, tr0 + 16 * q, K, pl, ld0);
+              }
+              tile_lin_rt<NW, BF, RT>(A, ld0, a_polled, W, K, late, tr0, tc0, B, red, pl, A2, A3, w_width);
+            }
+          } break;
+          case K_LINSEQ: {
+            const int n = d.w<RD_I + 1>();
+            const bool gated = (flags & DF_SEQ_GATE) != 0;
+            const float* A = d.p<0>(s);
+            for (int li = 0; li < n; ++li) {
+              pl.code = ((unsigned)s << 4) | (unsigned)i | ((unsigned)li << 28);
+              const float* W = d.basedyn(1 + li);
+              auto late = [&]() {
+                const float* aux = d.pdyn(5 + li);
+                return LinLate{gated ? nullptr : aux, nullptr, gated ? aux : nullptr, 0, d.w<RD_I + 2>(), false, (flags & DF_RELU) != 0, d.f<0>(),
+                               Out{const_cast<float*>(d.pdyn(9 + li)), d.wdyn(RD_LD + li), false, const_cast<float*>(d.pdyn(13 + li)), n16}};
+              };
+              for (int tk = 0; tk < nt; ++tk) {
+                const int trc = d.tile(tk), tr0 = trc & 0xffff, tc0 = (trc >> 16) * 16;
+                tile_lin_rt<NW, BF, RT>(A, 0, true, W, K, late, tr0, tc0, B, red, pl);
+              }
+              A = d.pdyn(13 + li);
+            }
+          } break;
+          case K_HEAD: {
+            const HeadOut o{d.m<7>(s), d.m<8>(s), d.m<9>(s), d.m<10>(s), d.m<11>(s), d.m<12>(s), d.m<13>(s),
+                            Out{d.m<14>(s), ld3, false, d.m<15>(s), n16, d.m<16>(s), d.w<RD_N16 + 1>()}};
+            const int Z = d.w<RD_I + 0>(), residual = d.w<RD_I + 1>();
+            for (int tk = 0; tk < nt; ++tk) {
+              const int trc = d.tile(tk);
+              tile_head_rt<NW, BF, RT>(d.p<0>(s), d.p<1>(s), true, d.base<2>(), d.base<3>(), d.base<4>(), d.base<5>(), d.p<6>(s), o, K, Z, residual, d.f<0>(),
+                                       d.f<1>(), d.f<2>(), trc & 0xffff, (trc >> 16) * 16, B, red, pl);
+            }
+          } break;
+          case K_GRU: {
+            const Out o{d.m<5>(s), ld3, true, d.m<6>(s), n16, d.m<11>(s), d.w<RD_N16 + 1>()};
+            const int R = d.w<RD_I + 0>();
+            for (int tk = 0; tk < nt; ++tk) {
+              const int trc = d.tile(tk);
+              tile_gru_rt<NW, BF, RT>(d.p<0>(s), 0, true, d.base<1>(), K, d.p<2>(s), d.base<10>(), d.p<3>(s), d.p<4>(s), ld0, R, o, d.m<7>(s), d.m<8>(s),
+                                      d.m<9>(s), trc & 0xffff, (trc >> 16) * 16, B, red, pl);
+            }
+          } break;
+          case K_DZ: {
+            DzIn z;
+            z.mu_q = d.p<5>(s); z.sd_q = d.p<6>(s); z.mu_p = d.p<7>(s); z.sd_p = d.p<8>(s); z.eps = d.p<9>(s); z.raw_q = d.p<10>(s); z.raw_p = d.p<11>(s);
+            z.muq_raw = d.p<12>(s);
+            z.x_sl = reinterpret_cast<const int32_t*>(d.base<13>()); z.c_raw = d.base<14>(); z.c_fn = d.base<15>();
+            z.t = d.w<RD_I + 3>() - s; z.stride = d.w<RD_I + 2>(); z.residual = d.w<RD_I + 1>();
+            z.fn_floor = d.f<0>(); z.beta = d.f<1>(); z.sd_eps = d.f<2>();
+            z.has_gemm = s >= (int)d.f<3>();
+            const int Z = d.w<RD_I + 0>();
+            const Out oq{d.m<16>(s), ld3, false, d.m<17>(s), n16}, op{d.m<18>(s), ld3, false, d.m<19>(s), n16};
+            for (int tk = 0; tk < nt; ++tk) {
+              const int trc = d.tile(tk);
+              tile_dz_rt<NW, BF, RT>(d.p<0>(s), d.base<1>(), true, d.p<4>(s), ld1, (flags & DF_ADD_POLLED) != 0, z, oq, op, K, Z, trc & 0xffff, (trc >> 16) * 16, B,
+                                     red, pl);
+            }
+          } break;
+          case K_GRUB: {
+            GrubIn g;
+            g.D0 = d.p<0>(s); g.D1 = d.p<1>(s); g.W0 = d.base<2>(); g.W1 = d.base<3>(); g.g_in = d.p<4>(s); g.g_add = d.p<17>(s); g.ld_gadd = ld1;
+            g.rg = d.p<5>(s); g.ug = d.p<6>(s); g.ng = d.p<7>(s); g.gh = d.p<8>(s); g.hprev = d.p<9>(s); g.dd = d.p<10>(s); g.ldh = ld0;
+            g.dgi = Out{d.m<11>(s), ld3, false, d.m<12>(s), n16};
+            g.dgh = Out{d.m<13>(s), ld3, false, d.m<14>(s), n16};
+            g.ga = d.m<15>(s); g.g_out = const_cast<float*>(d.base<16>());
+            g.has_gemm = s >= d.w<RD_I + 1>(); g.has_gates = s < d.w<RD_I + 2>(); g.has_gin = s >= d.w<RD_I + 3>();
+            const int R = d.w<RD_I + 0>();
+            for (int tk = 0; tk < nt; ++tk) {
+              const int trc = d.tile(tk);
+              tile_grub_rt<NW, BF, RT>(g, K, R, trc & 0xffff, (trc >> 16) * 16, B, red, pl);
+            }
+          } break;
+          default: break;
+        }
+      }
+      d = nx;
+    }
+  }
+}
+
 __global__ void rows_to_t16_kernel(const float* src, int ld, int B, int K, float* dst, int n16) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * K) return;
@@ -443,7 +582,7 @@ int pchain_launch(const pchain::Program& prog, hipStream_t stream) {
     BLVM_REQUIRE(d.nwg > 0 && d.wg0 >= 0 && d.ct > 0 && d.K > 0 && d.K % 16 == 0, "pchain: bad descriptor %d", i);
     BLVM_REQUIRE(!prog.xcd || d.nwg % 8 == 0, "pchain: XCD-aware placement needs ranges of 8 k workgroups (descriptor %d has %d)", i, d.nwg);
     grid = std::max(grid, d.wg0 + d.nwg);
-    const int rt = (prog.B + 15) / 16;
+    const int rt = ((prog.B + 15) / 16 + prog.rt_group - 1) / prog.rt_group;  // row tiles, or row groups
     const int per_wg = prog.xcd ? (((d.ct + 7) / 8) * rt + d.nwg / 8 - 1) / (d.nwg / 8) : (d.ct * rt + d.nwg - 1) / d.nwg;
     BLVM_REQUIRE(per_wg <= kMaxTilesPerWg, "pchain: descriptor %d gives a workgroup %d tiles (at most %d)", i, per_wg, kMaxTilesPerWg);
   }
@@ -484,10 +623,10 @@ int pchain_launch(const pchain::Program& prog, hipStream_t stream) {
   // residency — every workgroup of the grid must be on a CU at the same time — is checked against the occupancy the runtime
   // computes for this kernel, block size and LDS size (cached per size)
   static std::mutex attr_mu;
-  static int attr_dev[4] = {-1, -1, -1, -1};
-  static size_t occ_lds[4] = {0, 0, 0, 0};
-  static int occ_blocks[4] = {0, 0, 0, 0};
-  const size_t lds_max = lds_fixed + sizeof(float) * 2 * 4 * (size_t)nw * 256;
+  static int attr_dev[6] = {-1, -1, -1, -1, -1, -1};
+  static size_t occ_lds[6] = {0, 0, 0, 0, 0, 0};
+  static int occ_blocks[6] = {0, 0, 0, 0, 0, 0};
+  const size_t lds_max = lds_fixed + sizeof(float) * 2 * (prog.rt_group > 1 ? 8 : 4) * (size_t)nw * 256;  // (row groups reduce two row tiles per barrier)
   BLVM_REQUIRE(lds <= lds_max, "pchain: %d products per tile exceed the reduction scratch", prog.lds_products);
   auto go = [&](auto kernel, int slot, int threads) -> int {
     {
@@ -509,6 +648,21 @@ int pchain_launch(const pchain::Program& prog, hipStream_t stream) {
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, stream, (const int*)tab, h);
     return BLVM_OK;
   };
+  BLVM_REQUIRE(prog.rt_group == 1 || prog.rt_group == 2 || prog.rt_group == 4, "pchain: row groups of %d row tiles are not built", prog.rt_group);
+  if (prog.rt_group > 1) {
+    for (int i = 0; i < prog.ndesc; ++i) {
+      const int k = prog.d[i].kind;
+      BLVM_REQUIRE(k == pchain::K_LIN || k == pchain::K_LINSEQ || k == pchain::K_HEAD || k == pchain::K_GRU || k == pchain::K_DZ || k == pchain::K_GRUB,
+                   "pchain: tile kind %d has no row-group form", k);
+      BLVM_REQUIRE(k != pchain::K_DZ || prog.d[i].p[2] == nullptr, "pchain: the row-group dz tile is the single-product form");
+    }
+    BLVM_REQUIRE(nw == 8, "pchain: the row-group kernel runs 8 waves per workgroup");
+    BLVM_REQUIRE(!prog.bf16, "pchain: row groups multiply fp32 operands only");
+    const int rcg = prog.rt_group == 4 ? go(&pchain_rt_kernel<8, false, 4>, 4, 512) : go(&pchain_rt_kernel<8, false, 2>, 5, 512);
+    if (rcg) return rcg;
+    BLVM_CHECK_LAUNCH("pchain_launch (row groups)");
+    return BLVM_OK;
+  }
   int rc;
   if (nw == 16) rc = prog.bf16 ? go(&pchain_kernel<16, true>, 3, 1024) : go(&pchain_kernel<16, false>, 1, 1024);
   else rc = prog.bf16 ? go(&pchain_kernel<8, true>, 2, 512) : go(&pchain_kernel<8, false>, 0, 512);

@@ -134,6 +134,30 @@ __global__ __launch_bounds__(NW * 64) void dh_stage_kernel(const float* DP0, con
   G[o] = g * u + dd;
 }
 
+// Batches of 65 .. 256 utterances run the VRNN programs on ROW GROUPS of two row tiles (pchain_rt.h: 32-row tiles, the weight
+// fragments fetched once per group).  Measured per train step on one box, [B,16000] fp32: B = 128 22.6 ms (24.7 on 16-row tiles,
+// two per workgroup and link), B = 192 28.7 (36.9 as a launch per link), B = 256 38.6 (40.1).  Groups of FOUR row tiles are slower
+// everywhere (B = 128: 34.8, 256: 40.7): a tile costs ~1.3 us + ~1.1 us per row tile it carries (polled fragments, MFMAs, reduction,
+// epilogue stores), so fatter tiles only trade workgroups for latency; beyond 256 utterances a link has more 32-row tiles than the
+// chip has workgroups for it and the launch-per-link path on 32 x 32 tiles takes over.  fp32 operands only.
+// env BLVM_PCHAIN_RT_MIN_B / BLVM_PCHAIN_RT_MAX_B: the batch range (default 65 .. 256; MAX_B = 0: never); BLVM_PCHAIN_RT = 2 | 4.
+inline int vrnn_rt_max_b() {
+  static int v = [] {
+    const char* e = getenv("BLVM_PCHAIN_RT_MAX_B");
+    return e ? atoi(e) : 256;
+  }();
+  return v;
+}
+inline int vrnn_rt(int B) {
+  static const int min_b = [] { const char* e = getenv("BLVM_PCHAIN_RT_MIN_B"); return e ? atoi(e) : 65; }();
+  static const int forced = [] { const char* e = getenv("BLVM_PCHAIN_RT"); return e ? atoi(e) : 0; }();
+  if (B < min_b || B > vrnn_rt_max_b() || pchain_max_batch() <= 0 || operand_bf16()) return 0;
+  if (B <= kPchainCarveMaxB && B > pchain_max_batch()) return 0;
+  return forced == 4 ? 4 : 2;
+}
+inline bool vrnn_row_groups(int B) { return vrnn_rt(B) > 0; }
+inline bool vrnn_persistent(int B) { return pchain_applies(B) || vrnn_row_groups(B); }
+
 // ---------------------------------------------------------------------------------------------------------------
 // reserve / workspace carving
 // ---------------------------------------------------------------------------------------------------------------
@@ -164,7 +188,7 @@ size_t carve_reserve(float* base, int Tp, int B, int H, int Z, int R, Reserve* r
   for (int i = 1; i < 4; ++i) tmp.Wf[i] = take((size_t)H * H);
   tmp.Wih = take((size_t)3 * R * H); tmp.Whh = take((size_t)3 * R * R);
   tmp.H16 = nullptr;
-  if (B <= kPchainCarveMaxB) {
+  if (B <= kPchainCarveMaxB || B <= vrnn_rt_max_b()) {
     const size_t rows = (size_t)((B + 15) / 16) * 16, m = (size_t)Tp * rows;
     tmp.H16 = take((m + rows) * R);
     for (int i = 0; i < 3; ++i) tmp.P16[i] = take(m * H);
@@ -208,7 +232,7 @@ size_t carve_ws(float* base, int Tp, int B, int X, int H, int Z, int R, BwdWs* w
   for (int i = 0; i < 3; ++i) t.DQ[i] = take(n * H);
   t.G = take((size_t)B * R);
   t.GA = nullptr;
-  if (B <= kPchainCarveMaxB) {
+  if (B <= kPchainCarveMaxB || B <= vrnn_rt_max_b()) {
     const size_t m = (size_t)Tp * ((B + 15) / 16) * 16;
     t.GA = take(n * R); t.GB = take(n * R);
     for (int i = 0; i < 3; ++i) { t.DP16[i] = take(m * H); t.DQ16[i] = take(m * H); }
@@ -356,7 +380,7 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
   else BLVM_HIP(hipMemset2DAsync(decin + H, sizeof(float) * ldd, 0, sizeof(float) * R, B, s));
 
   const int rt = (B + 15) / 16;
-  if (pchain_applies(B) && device_cus() >= 32) {
+  if (vrnn_persistent(B) && device_cus() >= 32) {
     // Persistent path (pchain.h / pchain.hip): the nine links of a step as a program of 13 descriptors, one launch for the whole
     // sequence.  Links on the critical path share the workgroups [0, g); the GRU's hidden projection gh_t = h_{t-1} W_hh^T + b_hh
     // (3R columns, first needed by the GRU link's epilogue eight links later) has its own range behind them and polls gently.
@@ -364,12 +388,18 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     const int ctH = H / 16, ctZ = Z / 16, ctR = R / 16, cus = device_cus() & ~7;
     const long sH = (long)B * H, sZ = (long)B * Z, sR = (long)B * R, s3R = 3 * sR, sD = (long)B * ldd;
     const long xH = (long)rt * 16 * H, xZ = (long)rt * 16 * Z, xR = (long)rt * 16 * R;
-    const int def_n = range_for(3 * ctR * rt, std::min(cus / 4, 64));        // hidden projection: up to a quarter of the chip
-    const int half = range_for(ctH * rt, (cus - def_n) / 2);                   // prior | posterior halves of a link
+    // tiles of a link per column tile: row tiles, or (65 <= B <= 256) groups of row tiles (pchain_rt.h)
+    const bool groups = vrnn_row_groups(B);
+    const int RTG = groups ? vrnn_rt(B) : 1;
+    const int tl = (rt + RTG - 1) / RTG;
+    // hidden projection: up to a quarter of the chip (groups of four row tiles: up to half)
+    const int def_n = range_for(3 * ctR * tl, std::min(RTG >= 4 ? cus / 2 : cus / 4, RTG >= 4 ? 128 : 64));
+    const int half = range_for(ctH * tl, (cus - def_n) / 2);                   // prior | posterior halves of a link
     const int g = 2 * half;
     Builder bld;
     bld.p.bf16 = pchain_bf16(B);
-    bld.p.S = Tp; bld.p.B = B; bld.p.xcd = (pchain_tune() & 4) ? 1 : 0; bld.p.lds_products = 4;
+    bld.p.rt_group = RTG;
+    bld.p.S = Tp; bld.p.B = B; bld.p.xcd = (pchain_tune() & 4) ? 1 : 0; bld.p.lds_products = groups ? 8 : 4;
     bld.p.prof = pchain_profile_buffer(); bld.p.prof_wg = g;
     auto lin = [&](const float* A16, long a_step, const float* W, int K, const float* bias, const float* add, long add_step, int ldadd, float* orm,
                    long rm_step, int ldo, float* o16, long o16_step, int n16, int ct, int wg0, int nwg, int flags) {
@@ -408,7 +438,7 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
       }
     }
     {  // F4: heads + sample
-      Desc& d = bld.add(K_HEAD, ctZ, 0, range_for(ctZ * rt, g), H, 0, 0, Tp);
+      Desc& d = bld.add(K_HEAD, ctZ, 0, range_for(ctZ * tl, g), H, 0, 0, Tp);
       bld.ptr(d, 0, rs.P16[2], xH); bld.ptr(d, 1, rs.Q16[2], xH); bld.ptr(d, 2, rs.Wph); bld.ptr(d, 3, w->prior_hb); bld.ptr(d, 4, rs.Wqh);
       bld.ptr(d, 5, w->post_hb); bld.ptr(d, 6, eps, sZ); bld.ptr(d, 7, mu_p, sZ); bld.ptr(d, 8, sd_p, sZ); bld.ptr(d, 9, mu_q, sZ);
       bld.ptr(d, 10, sd_q, sZ); bld.ptr(d, 11, rs.RAWP, sZ); bld.ptr(d, 12, rs.RAWQ, sZ); bld.ptr(d, 13, nullptr);
@@ -420,16 +450,16 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     for (int l = 0; l < first_seq; ++l) {
       const float* A = l == 0 ? rs.Z16 : rs.FZ16[l - 1];
       lin(A, l == 0 ? xZ : xH, rs.Wf[l], l == 0 ? Z : H, w->phi_b[l], nullptr, 0, 0, l == 3 ? decin : rs.FZ[l], l == 3 ? sD : sH, l == 3 ? ldd : H,
-          l == 3 ? rs.PHI16 : rs.FZ16[l], xH, ctH, ctH, 0, range_for(ctH * rt, g), DF_RELU);
+          l == 3 ? rs.PHI16 : rs.FZ16[l], xH, ctH, ctH, 0, range_for(ctH * tl, g), DF_RELU);
     }
     if (first_seq < 4) {
       SeqLink lf[4];
       for (int l = first_seq; l < 4; ++l)
         lf[l - first_seq] = SeqLink{rs.Wf[l], w->phi_b[l], l == 3 ? decin : rs.FZ[l], l == 3 ? sD : sH, l == 3 ? ldd : H, l == 3 ? rs.PHI16 : rs.FZ16[l]};
-      linseq(first_seq == 0 ? rs.Z16 : rs.FZ16[first_seq - 1], first_seq == 0 ? xZ : xH, H, 4 - first_seq, lf, 0, range_for(ctH * rt, g));
+      linseq(first_seq == 0 ? rs.Z16 : rs.FZ16[first_seq - 1], first_seq == 0 ? xZ : xH, H, 4 - first_seq, lf, 0, range_for(ctH * tl, g));
     }
     {  // F9: GRU
-      Desc& d = bld.add(K_GRU, ctR, 0, range_for(ctR * rt, g), H, 0, 0, Tp);
+      Desc& d = bld.add(K_GRU, ctR, 0, range_for(ctR * tl, g), H, 0, 0, Tp);
       bld.ptr(d, 0, rs.PHI16, xH); bld.ptr(d, 1, rs.Wih); bld.ptr(d, 2, rs.XG, s3R); bld.ptr(d, 3, rs.GHb, s3R); bld.ptr(d, 4, decin + H, sD);
       bld.ptr(d, 5, decin + sD + H, sD); bld.ptr(d, 6, rs.H16 + xR, xR); bld.ptr(d, 7, rs.RG, sR); bld.ptr(d, 8, rs.UG, sR); bld.ptr(d, 9, rs.NG, sR);
       d.ld[0] = ldd; d.ld[3] = ldd; d.n16[0] = ctR; d.i[0] = R;
@@ -609,7 +639,7 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
 #undef TRY
     return BLVM_OK;
   };
-  if (pchain_applies(B) && device_cus() >= 32) {
+  if (vrnn_persistent(B) && device_cus() >= 32) {
     // Persistent path: the whole BPTT chain as a program of 13 descriptors walked for s = 0 .. T' (t = T'-1-s: last-step slabs and
     // negative strides), then the batched weight-gradient GEMMs.  The running gradient wrt the recurrent state lives in per-step
     // slabs so that every location is written once: GA[t] = g_t * u_t + decoder gradient (written by the GRU-backward link),
@@ -618,15 +648,19 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     const int ctH = H / 16, ctZ = Z / 16, ctR = R / 16, cus = device_cus() & ~7, T = Tp;
     const long sH = (long)B * H, sZ = (long)B * Z, sR = (long)B * R, s3R = 3 * sR, s2Z = 2 * sZ, sD = (long)B * ldd;
     const long xH = (long)rt * 16 * H, x2Z = (long)rt * 16 * 2 * Z, x3R = (long)rt * 16 * 3 * R;
-    const int def_n = range_for(ctR * rt, std::min(cus / 4, 64));
-    const int half = range_for(ctH * rt, (cus - def_n) / 2), g = 2 * half;
+    const bool groups = vrnn_row_groups(B);
+    const int RTG = groups ? vrnn_rt(B) : 1;
+    const int tl = (rt + RTG - 1) / RTG;  // tiles of a link per column tile: row tiles, or groups of them (pchain_rt.h)
+    const int def_n = range_for(ctR * tl, std::min(cus / 4, 64));  // GB link
+    const int half = range_for(ctH * tl, (cus - def_n) / 2), g = 2 * half;
     Builder bld;
     bld.p.bf16 = pchain_bf16(B);
-    bld.p.S = T + 1; bld.p.B = B; bld.p.xcd = (pchain_tune() & 4) ? 1 : 0; bld.p.lds_products = 2;
+    bld.p.rt_group = RTG;
+    bld.p.S = T + 1; bld.p.B = B; bld.p.xcd = (pchain_tune() & 4) ? 1 : 0; bld.p.lds_products = groups ? 8 : 2;
     bld.p.prof = pchain_profile_buffer() ? pchain_profile_buffer() + 64 : nullptr; bld.p.prof_wg = g;
     auto last = [&](const float* base, long step) { return base ? base + (long)(T - 1) * step : nullptr; };  // slab of t = T'-1
     {  // Ba: complete the gradient wrt h_t, GRU gate derivatives of step t (s = T': only the gradient wrt the initial state)
-      Desc& d = bld.add(K_GRUB, ctR, 0, range_for(ctR * rt, g), H, 0, 0, T + 1);
+      Desc& d = bld.add(K_GRUB, ctR, 0, range_for(ctR * tl, g), H, 0, 0, T + 1);
       bld.ptr(d, 0, ws.DP16[0] + (long)T * xH, -xH); bld.ptr(d, 1, ws.DQ16[0] + (long)T * xH, -xH); bld.ptr(d, 2, ws.pT[0]); bld.ptr(d, 3, ws.qT[0]);
       bld.ptr(d, 4, ws.GB + (long)T * sR, -sR);
       bld.ptr(d, 5, last(rs.RG, sR), -sR); bld.ptr(d, 6, last(rs.UG, sR), -sR); bld.ptr(d, 7, last(rs.NG, sR), -sR); bld.ptr(d, 8, last(rs.GHb, s3R), -s3R);
@@ -653,7 +687,7 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
       const size_t wthird = (size_t)ctR * 256 / (bld.p.bf16 ? 2 : 1);  // the packed weight's k-chunks [ctR * part, ...) (bf16 packs: half the floats)
       float* const orm[3] = {ws.DPHI[3], ws.DPHI3b, ws.DPHI3c};
       float* const o16[3] = {ws.DPHI16[3], ws.DPHI16b, ws.DPHI16c};
-      const int wg0s[3] = {0, half, g + def_n}, nwgs[3] = {range_for(ctH * rt, half), range_for(ctH * rt, half), range_for(ctH * rt, spare)};
+      const int wg0s[3] = {0, half, g + def_n}, nwgs[3] = {range_for(ctH * tl, half), range_for(ctH * tl, half), range_for(ctH * tl, spare)};
       for (int part = 0; part < 3; ++part) {
         lin(ws.DGI16 + (size_t)part * ctR * 256, x3R, ws.wihT + part * wthird, R, part == 0 ? d_decin : nullptr, sD, ldd, decin, sD, ldd, orm[part], sH, H, o16[part], xH,
             ctH, ctH, wg0s[part], nwgs[part], 0);
@@ -661,7 +695,7 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
         d.ld[0] = 3 * R; d.i[0] = 3 * R;  // widths of the slab / of the packed rows the K-range is taken from
       }
     } else {
-      lin(ws.DGI16, x3R, ws.wihT, 3 * R, d_decin, sD, ldd, decin, sD, ldd, ws.DPHI[3], sH, H, ws.DPHI16[3], xH, ctH, ctH, 0, range_for(ctH * rt, g), 0);
+      lin(ws.DGI16, x3R, ws.wihT, 3 * R, d_decin, sD, ldd, decin, sD, ldd, ws.DPHI[3], sH, H, ws.DPHI16[3], xH, ctH, ctH, 0, range_for(ctH * tl, g), 0);
     }
     lin(ws.DGH16, x3R, ws.whhT, 3 * R, ws.GA, sR, R, nullptr, 0, 0, ws.GB, sR, R, nullptr, 0, 0, ctR, g, def_n,
         DF_ADD_POLLED | DF_RM_SC1 | DF_GENTLE | ((pchain_tune() & 16) ? DF_CANARY : 0));
@@ -683,16 +717,16 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     if (seq) {
       const SeqLinkB lf[3] = {{ws.fT[3], rs.FZ[2], ws.DPHI[2], ws.DPHI16[2]}, {ws.fT[2], rs.FZ[1], ws.DPHI[1], ws.DPHI16[1]}, {ws.fT[1], rs.FZ[0], ws.DPHI[0], ws.DPHI16[0]}};
       if (split3) {  // the link that adds the three partial-sum slabs up is a K_LIN of its own (a run's links are plain), the other two a run
-        lin(ws.DPHI16[3], xH, ws.fT[3], H, nullptr, 0, 0, rs.FZ[2], sH, H, ws.DPHI[2], sH, H, ws.DPHI16[2], xH, ctH, ctH, 0, range_for(ctH * rt, g), DF_A_SUM3);
+        lin(ws.DPHI16[3], xH, ws.fT[3], H, nullptr, 0, 0, rs.FZ[2], sH, H, ws.DPHI[2], sH, H, ws.DPHI16[2], xH, ctH, ctH, 0, range_for(ctH * tl, g), DF_A_SUM3);
         Desc& d = bld.p.d[bld.p.ndesc - 1];
         bld.ptr(d, 8, ws.DPHI16b + (long)(T - 1) * xH, -xH); bld.ptr(d, 9, ws.DPHI16c + (long)(T - 1) * xH, -xH);
-        linseq_b(ws.DPHI16[2], 2, lf + 1, 0, range_for(ctH * rt, g), 0);
+        linseq_b(ws.DPHI16[2], 2, lf + 1, 0, range_for(ctH * tl, g), 0);
       } else {
-        linseq_b(ws.DPHI16[3], 3, lf, 0, range_for(ctH * rt, g), 0);
+        linseq_b(ws.DPHI16[3], 3, lf, 0, range_for(ctH * tl, g), 0);
       }
     } else {
       for (int l = 3; l >= 1; --l) {
-        lin(ws.DPHI16[l], xH, ws.fT[l], H, nullptr, 0, 0, rs.FZ[l - 1], sH, H, ws.DPHI[l - 1], sH, H, ws.DPHI16[l - 1], xH, ctH, ctH, 0, range_for(ctH * rt, g),
+        lin(ws.DPHI16[l], xH, ws.fT[l], H, nullptr, 0, 0, rs.FZ[l - 1], sH, H, ws.DPHI[l - 1], sH, H, ws.DPHI16[l - 1], xH, ctH, ctH, 0, range_for(ctH * tl, g),
             l == 3 && split3 ? DF_A_SUM3 : 0);
         if (l == 3 && split3) {
           Desc& d = bld.p.d[bld.p.ndesc - 1];
@@ -701,7 +735,7 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
       }
     }
     {  // B6: dz and the heads
-      Desc& d = bld.add(K_DZ, ctZ, 0, range_for(ctZ * rt, g), H, 0, 0, T);
+      Desc& d = bld.add(K_DZ, ctZ, 0, range_for(ctZ * tl, g), H, 0, 0, T);
       bld.ptr(d, 0, last(ws.DPHI16[0], xH), -xH); bld.ptr(d, 1, ws.fT[0]); bld.ptr(d, 2, nullptr); bld.ptr(d, 3, nullptr); bld.ptr(d, 4, nullptr);
       bld.ptr(d, 5, last(mu_q, sZ), -sZ); bld.ptr(d, 6, last(sd_q, sZ), -sZ); bld.ptr(d, 7, last(mu_p, sZ), -sZ); bld.ptr(d, 8, last(sd_p, sZ), -sZ);
       bld.ptr(d, 9, last(eps, sZ), -sZ); bld.ptr(d, 10, last(rs.RAWQ, sZ), -sZ); bld.ptr(d, 11, last(rs.RAWP, sZ), -sZ); bld.ptr(d, 12, nullptr);

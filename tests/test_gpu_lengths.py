@@ -117,3 +117,45 @@ def test_struct_argument_fallback_of_the_packed_link_kernels_vs_oracle(model):
     torch.testing.assert_close(out.elbo.cpu(), ref["elbo"].detach(), rtol=1e-5, atol=1e-3)
     for k, p in m.named_parameters():
         assert rel_l2(p.grad, sd[k].grad) < 1e-3, k
+
+
+@pytest.mark.parametrize("B,T_", [(256, 64 * 20), (200, 64 * 12 - 7), (128, 64 * 30), (72, 64 * 9 + 5)])
+def test_vrnn_row_group_engine_equals_launch_per_link(B, T_):
+    """65 <= B <= 256 (round 3): the persistent programs on ROW GROUPS of two row tiles (csrc/pchain_rt.h) against the launch-per-link
+    path on the same inputs — headline widths, ragged lengths, batches whose last group is partial (200 rows = 13 row tiles = 6
+    groups + 1 tile; 72 rows = 2 groups + half a row tile) — loss, per-utterance ELBO / KL, latents, the final state and every
+    gradient, to fp32 summation order."""
+    torch.manual_seed(0)
+    m = VRNNAudio(likelihood="DMoL", input_size=64, hidden_size=256, latent_size=256, residual_posterior=True).to(DEV)
+    x, x_sl = O.synth_batch(B, T_, seed=2, ragged=True)
+    Tp = (T_ + 63) // 64
+    eps = torch.randn(Tp, B, 256, generator=torch.Generator().manual_seed(1)).to(DEV)
+    loss_p, _, out_p, g_p = _train_step(m, x.to(DEV), x_sl, eps, persistent=True)
+    loss_l, _, out_l, g_l = _train_step(m, x.to(DEV), x_sl, eps, persistent=False)
+    assert float(loss_p) == pytest.approx(float(loss_l), rel=1e-6)
+    torch.testing.assert_close(out_p.elbo, out_l.elbo, rtol=1e-6, atol=0)
+    torch.testing.assert_close(out_p.kl, out_l.kl, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(out_p.z, out_l.z, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(out_p.h_n, out_l.h_n, rtol=1e-4, atol=1e-5)
+    for k in g_p:
+        assert torch.isfinite(g_p[k]).all(), k
+        assert rel_l2(g_p[k], g_l[k]) < 1e-3, k
+
+
+def test_vrnn_row_group_engine_vs_oracle():
+    """The row-group engine against the CPU oracle on a narrow model: B = 150 (10 row tiles, the last one partial), ragged, T not a
+    multiple of the stack."""
+    torch.manual_seed(4)
+    S, Hd, Z, B, Tp = 8, 32, 16, 150, 9
+    m = VRNNAudio(likelihood="DMoL", input_size=S, hidden_size=Hd, latent_size=Z, residual_posterior=True)
+    sd = {k: v.clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    x, x_sl = O.synth_batch(B, S * Tp - 3, seed=6, ragged=True)
+    eps = torch.randn(Tp, B, Z, generator=torch.Generator().manual_seed(7))
+    ref = O.vrnn_audio_forward(sd, x, x_sl, eps, beta=1.0, free_nats=2.0, stack=S)
+    ref["loss"].backward()
+    m.to(DEV)
+    loss, _, out, g = _train_step(m, x.to(DEV), x_sl, eps.to(DEV), persistent=True)
+    assert float(loss) == pytest.approx(float(ref["loss"]), rel=1e-5)
+    torch.testing.assert_close(out.elbo.cpu(), ref["elbo"].detach(), rtol=1e-5, atol=1e-3)
+    for k in g:
+        assert rel_l2(g[k], sd[k].grad) < 1e-3, k
