@@ -215,6 +215,10 @@ def run(args, model, forward_train, forward_eval, best_metric, num_bits, split_e
             print(f"epoch {epoch:4d} | {frames * world / (time.time() - t0):.3e} frames/s | {vals}", flush=True)
         if (epoch - 1) % args.test_every == 0:
             model.eval()
+            # the test ELBO decides about checkpoints and is what runs are compared by: always in fp32 operands, also under --use_amp
+            # (the bf16-operand mode is a training-speed mode whose parity is unpinned)
+            train_dtype = _hip.get_operand_dtype()
+            _hip.set_operand_dtype("f32")
             with torch.no_grad():
                 for x, x_sl in tracker.steps(test, source="test"):
                     if x is None:  # this rank's shard of the batch is empty
@@ -225,6 +229,7 @@ def run(args, model, forward_train, forward_eval, best_metric, num_bits, split_e
                     else:
                         tracker.update(forward_eval(model, x, x_sl)[1])
             torch.cuda.synchronize()
+            _hip.set_operand_dtype(train_dtype)
             _hip.check_async("evaluation", group=world > 1)  # before anyone decides about a checkpoint
             tracker.all_reduce("test")  # the whole test set's value on every rank (rank 0 decides about the checkpoint)
             value = tracker.values("test").get(best_metric)
