@@ -37,7 +37,7 @@ def build_parser() -> argparse.ArgumentParser:
     g = parser.add_argument_group("setup")
     g.add_argument("--seed", type=int, default=random.randint(0, 2**31 - 1))
     g.add_argument("--device", type=int_or_str, default="auto")
-    g.add_argument("--use_amp", type=str2bool, default=False, help="accepted for CLI parity; this build computes in fp32")
+    g.add_argument("--use_amp", type=str2bool, default=False, help="bf16 matrix operands with fp32 accumulation while training (NOT the reference's fp16 autocast + GradScaler; evaluation stays fp32)")
     g.add_argument("--num_workers", type=int, default=8)
     g.add_argument("--save_checkpoints", type=str2bool, default=False)
     g.add_argument("--test_every", type=int, default=10)
