@@ -72,10 +72,12 @@ def pmc_traffic(model, B, T):
     """HBM-side bytes per train step of the dominant kernel, from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE in separate runs, FETCH_SIZE doubled on gfx950 per MI355X_MICROARCH.md) — counters cannot be read from inside
     the timed process, so this is the profile of the same command, valid for the workload it was taken on only."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_vrnn_pmc_traffic.json")
-    if model != "vrnn" or (B, T) != (64, 16000) or not os.path.exists(path):
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[0-9]_vrnn_pmc_traffic.json")))  # the latest round's passes
+    if model != "vrnn" or (B, T) != (64, 16000) or not files:
         return None
-    with open(path) as f:
+    with open(files[-1]) as f:
         d = json.load(f)
     return d["cell_stage_kernels_read_bytes_per_step"] + d["cell_stage_kernels_write_bytes_per_step"]
 

@@ -59,6 +59,11 @@ def _worker(rank, world, port, q):
     red = FlatGradAllReduce(model.parameters())
     n_global = red(n_local, status=float(rank == 1))  # rank 1 reports one aborted launch: every rank must see it
     assert float(red.status) == 1.0
+    # the collective form of the abort check (every rank raises together on the MAX of the counts): no abort -> no raise, on gloo too
+    from blvm import _hip
+
+    assert _hip.take_async_errors() == (0, 0)
+    _hip.check_async("two-rank test", group=True)
     if rank == 0:
         full, n_full = _oracle_grads(vals, keys, x, x_sl, eps)
         errs = [float((p.grad.double() - g.double()).norm() / (g.double().norm() + 1e-30)) for p, g in zip(model.parameters(), full)]
