@@ -211,8 +211,10 @@ bool operand_bf16() {
 }
 int pchain_waves() {
   if (g_pchain_nw < 0) {
+    // 16 waves (a tile's K split 16 ways) since round 3: same-box A/B of the train steps, 8 -> 16 waves: VRNN 15.59 -> 15.50 ms,
+    // SRNN 15.71 -> 15.59, CW-VAE (K = 192: one chunk per wave) 87.5 -> 86.1.  BLVM_PCHAIN_NW=8 selects the former default.
     const char* e = getenv("BLVM_PCHAIN_NW");
-    g_pchain_nw = (e && atoi(e) == 16) ? 16 : 8;
+    g_pchain_nw = (e && atoi(e) == 8) ? 8 : 16;
   }
   return g_pchain_nw;
 }

@@ -616,7 +616,7 @@ int pchain_launch(const pchain::Program& prog, hipStream_t stream) {
   }
   BLVM_REQUIRE(prog.s_first >= 0 && prog.s_first < prog.S, "pchain: empty step range [%d, %d)", prog.s_first, prog.S);
   Hdr h{prog.ndesc, prog.s_first, prog.S, prog.B, prog.xcd, prog.prof_wg, prog.lds_products, prog.ctl, prog.prof};
-  const int nw = pchain_waves();
+  const int nw = prog.rt_group > 1 ? 8 : pchain_waves();  // (the row-group kernel is built for 8 waves: 512 threads finish row-tile pairs)
   const size_t lds_fixed = sizeof(int) * kDescWords * pchain::kMaxDesc + 32 * sizeof(unsigned long long);
   const size_t lds = lds_fixed + sizeof(float) * 2 * (size_t)prog.lds_products * nw * 256;
   // the dynamic-LDS limit of the kernels is raised once per process and device (the call is far from free), and the launch's
@@ -656,7 +656,6 @@ int pchain_launch(const pchain::Program& prog, hipStream_t stream) {
                    "pchain: tile kind %d has no row-group form", k);
       BLVM_REQUIRE(k != pchain::K_DZ || prog.d[i].p[2] == nullptr, "pchain: the row-group dz tile is the single-product form");
     }
-    BLVM_REQUIRE(nw == 8, "pchain: the row-group kernel runs 8 waves per workgroup");
     BLVM_REQUIRE(!prog.bf16, "pchain: row groups multiply fp32 operands only");
     const int rcg = prog.rt_group == 4 ? go(&pchain_rt_kernel<8, false, 4>, 4, 512) : go(&pchain_rt_kernel<8, false, 2>, 5, 512);
     if (rcg) return rcg;

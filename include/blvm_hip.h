@@ -44,7 +44,8 @@ int blvm_async_errors(unsigned* last_code);
 int blvm_async_errors_take(unsigned* last_code);
 /* Execution switch of K1-K5 (results agree to fp32 summation order): sequences with at most `max_batch` rows run as one
  * persistent launch, larger ones as one launch per link (0 = always per link; < 0 = leave unchanged; default 128 or env
- * BLVM_PCHAIN_MAX_B / BLVM_PCHAIN=0).  `waves` = 8 or 16 waves per workgroup of the persistent kernels (other values: unchanged). */
+ * BLVM_PCHAIN_MAX_B / BLVM_PCHAIN=0; the VRNN pair also runs batches of 65 .. 256 rows persistently, on 32-row tiles).  `waves` = 8 or
+ * 16 waves per workgroup of the persistent kernels (other values: unchanged; default 16, env BLVM_PCHAIN_NW). */
 int blvm_pchain_configure(int max_batch, int waves);
 int blvm_pchain_max_batch(void); /* the current limit (at most 128) */
 /* Operand type of the matrix products — the reference's `--use_amp True` switch (`experiments/experiment_vrnn_audio.py:198,219-230`:

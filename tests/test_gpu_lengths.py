@@ -21,7 +21,7 @@ def _require_hip():
     assert torch.cuda.is_available(), "GPU tests need a HIP device"
     assert _hip.load().blvm_device_ok() == 1, "libblvm_hip: no gfx950 device visible"
     yield
-    _hip.load().blvm_pchain_configure(128, 8)
+    _hip.load().blvm_pchain_configure(128, -1)
 
 
 def rel_l2(a, b):
