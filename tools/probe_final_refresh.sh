@@ -18,3 +18,5 @@ head -4 gpurun_out/final_pmc_fetch.csv gpurun_out/final_pmc_write.csv | cut -c1-
 bash tools/probe_pmc_mfma.sh > gpurun_out/final_pmc_mfma.log 2>&1 || { tail -5 gpurun_out/final_pmc_mfma.log; exit 1; }
 python tools/pmc_mfma_summary.py gpurun_out/pmc_mfma/p_results.db 3 gpurun_out/final_pmc_mfma.json > gpurun_out/final_pmc_mfma.csv
 cat gpurun_out/final_pmc_mfma.json
+python tools/pmc_traffic_summary.py gpurun_out/final_pmc_fetch.csv gpurun_out/final_pmc_write.csv gpurun_out/final_pmc_traffic.json "final tree of round ${RN#r0}" > gpurun_out/final_pmc_traffic.csv
+rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_mfma  # the result databases (tens of MB each) stay on the box: gpurun returns at most 64 MiB
