@@ -38,7 +38,7 @@ def test_planted_sentinel_is_reported_not_waited_for(where):
     B, T_ = 5, 16 * 12
     x = (torch.rand(B, T_, generator=torch.Generator().manual_seed(1)) - 0.5).to(DEV)
     x_sl = torch.full((B,), T_, dtype=torch.int64)
-    assert _hip.take_async_errors()[0] == 0 or True  # start from a clean count whatever ran before
+    _hip.take_async_errors()  # start from a clean count whatever ran before
     clean = _step(m, x, x_sl)
     assert torch.isfinite(torch.tensor(clean)) and _hip.take_async_errors() == (0, 0)
 
