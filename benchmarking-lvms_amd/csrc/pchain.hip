@@ -479,7 +479,7 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_rt_kernel(const int* __rest
               if ((flags & DF_CANARY) && a_polled) {
                 for (int q = 0; q < RT && tr0 + 16 * q < B; ++q) canary_wait(A, tr0 + 16 * q, K, pl, ld0);
               }
-              tile_lin_rt<NW, BF, RT>(A, ld0, a_polled, W, K, late, tr0, tc0, B, red, pl, A2, A3, w_width);
+              tile_lin_rt<NW, BF, RT, 1>(A, ld0, a_polled, W, K, late, tr0, tc0, B, red, pl, A2, A3, w_width);
             }
           } break;
           case K_LINSEQ: {
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_rt_kernel(const int* __rest
               };
               for (int tk = 0; tk < nt; ++tk) {
                 const int trc = d.tile(tk), tr0 = trc & 0xffff, tc0 = (trc >> 16) * 16;
-                tile_lin_rt<NW, BF, RT>(A, 0, true, W, K, late, tr0, tc0, B, red, pl);
+                tile_lin_rt<NW, BF, RT, 1>(A, 0, true, W, K, late, tr0, tc0, B, red, pl);
               }
               A = d.pdyn(13 + li);
             }

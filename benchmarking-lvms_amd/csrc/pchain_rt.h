@@ -14,6 +14,11 @@
 namespace blvm {
 namespace pchain {
 
+#ifndef BLVM_RT_FRAGS
+#define BLVM_RT_FRAGS 16
+#endif
+constexpr int kRtFrags = BLVM_RT_FRAGS;
+
 // acc[rt][g] += A[AMap(g)][r0 + 16 rt + i][k] W[g][c0[g] + j][k] for the row tiles rt < RT of a group (mgemm_trip of pchain.h with
 // the activation side repeated per row tile).  rt_off[rt]: byte offset of row tile rt's T16 slab from the group's first (clamped to
 // the last row tile that exists, so no load leaves the step's slab; aok[rt] is false for every lane of a row tile beyond B).
@@ -104,7 +109,7 @@ template <int NW, bool BF, int RT, int GA, int G, class AMap, class Mid = NoMid>
 __device__ __forceinline__ void mgemm16_rt(const float* const (&A)[GA], const int (&lda)[GA], bool polled, int r0, int nrows, const float* const (&W)[G],
                                            const int (&c0)[G], int K, f32x4 (&acc)[RT][G], Poll& pl, Mid mid = Mid(), int a_width = 0, int w_width = 0) {
   constexpr int STEP = NW * 16;
-  constexpr int FR = (NW >= 16 ? 6 : 12) / (G + GA * RT);
+  constexpr int FR = kRtFrags / (G + GA * RT);  // fragments in flight per trip (512 threads: 256 VGPRs a lane)
   constexpr int MAXCH = FR >= 6 ? 6 : (FR >= 4 ? 4 : (FR >= 2 ? 2 : 1));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rr = lane & 15, q = lane >> 4;
@@ -170,67 +175,87 @@ __device__ __forceinline__ void reduce_pair(const f32x4 (&acc0)[G], const f32x4 
   }
 }
 
-template <int NW, bool BF, int RT, class Late, class Red>
+// CT: adjacent column tiles per tile (CT products of the same activation fragments against the weight rows c0 + 16 c ...).  Only
+// CT = 1 is instantiated: measured (r03, B = 128 / 192 / 256, same box) a 32-column tile costs twice a 16-column one -- the fp32
+// MFMAs of a tile are ~0.85 us of its ~3.1 us on a CU whose two waves per SIMD share the matrix pipe, the rest scales with the
+// outputs too -- so pairs only halve the tiles a link can be spread over (B = 128: 22.7 -> 28.6 ms/step).
+template <int NW, bool BF, int RT, int CT, class Late, class Red>
 __device__ __forceinline__ void tile_lin_rt(const float* A, int lda, bool a_polled, const float* W, int K, Late& late, int r0, int c0, int B, Red& red,
                                             Poll& pl, const float* A2 = nullptr, const float* A3 = nullptr, int w_width = 0) {
   const int t = threadIdx.x & 255;
   const int col = c0 + (t & 15);
-  float e_bias = 0.f, e_gate[RT], e_add[RT];
+  float e_bias[CT], e_gate[RT][CT], e_add[RT][CT];
   int rowc[RT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     const int row = r0 + 16 * rt + (t >> 4);
     rowc[rt] = row < B ? row : r0;
-    e_gate[rt] = 1.f; e_add[rt] = 0.f;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) { e_gate[rt][c] = 1.f; e_add[rt][c] = 0.f; }
   }
+#pragma unroll
+  for (int c = 0; c < CT; ++c) e_bias[c] = 0.f;
   LinLate L;
   auto prefetch = [&]() {
     L = late();
-    if (L.bias) e_bias = L.bias[col];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      if (L.gate) e_gate[rt] = L.gate[(size_t)rowc[rt] * L.ldgate + col];
-      if (L.add && !L.add_polled) e_add[rt] = L.add[(size_t)rowc[rt] * L.ldadd + col];
+    for (int c = 0; c < CT; ++c) {
+      if (L.bias) e_bias[c] = L.bias[col + 16 * c];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        if (L.gate) e_gate[rt][c] = L.gate[(size_t)rowc[rt] * L.ldgate + col + 16 * c];
+        if (L.add && !L.add_polled) e_add[rt][c] = L.add[(size_t)rowc[rt] * L.ldadd + col + 16 * c];
+      }
     }
   };
-  f32x4 acc[RT][1];
+  f32x4 acc[RT][CT];
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) acc[rt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[rt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* Ws[CT];
+  int cs[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) { Ws[c] = W; cs[c] = c0 + 16 * c; }
   if (A2 != nullptr) {  // (uniform) the operand arrives as three partial-sum slabs
     const float* const As[3] = {A, A2, A3};
-    const float* const Ws[1] = {W};
-    const int la[3] = {0, 0, 0}, cs[1] = {c0};
-    mgemm16_rt<NW, BF, RT, 3, 1, MapSum>(As, la, true, r0, B, Ws, cs, K, acc, pl, prefetch, lda, w_width);
+    const int la[3] = {0, 0, 0};
+    mgemm16_rt<NW, BF, RT, 3, CT, MapSum>(As, la, true, r0, B, Ws, cs, K, acc, pl, prefetch, lda, w_width);
   } else {
     const float* const As[1] = {A};
-    const float* const Ws[1] = {W};
-    const int la[1] = {lda}, cs[1] = {c0};
-    mgemm16_rt<NW, BF, RT, 1, 1, MapSame>(As, la, a_polled, r0, B, Ws, cs, K, acc, pl, prefetch, a_polled ? lda : 0, w_width);
+    const int la[1] = {lda};
+    mgemm16_rt<NW, BF, RT, 1, CT, MapSame>(As, la, a_polled, r0, B, Ws, cs, K, acc, pl, prefetch, a_polled ? lda : 0, w_width);
   }
   static_assert(RT % 2 == 0 && NW == 8, "row groups are finished in pairs by 512 threads");
 #pragma unroll
   for (int pr = 0; pr < RT / 2; ++pr) {
     if (r0 + 32 * pr >= B) break;  // (uniform)
-    float v[1];
-    reduce_pair<1, NW>(acc[2 * pr], acc[2 * pr + 1], red(), v);
-    const int rt = 2 * pr + (int)(threadIdx.x >> 8), rb = r0 + 16 * rt;
+    float v[CT];
+    reduce_pair<CT, NW>(acc[2 * pr], acc[2 * pr + 1], red(), v);
+    const bool hi = (threadIdx.x >> 8) != 0;
+    const int rt = 2 * pr + (int)hi, rb = r0 + 16 * rt;
     const int row = rb + (t >> 4);
     const bool own = row < B;
-    const float gate_v = (threadIdx.x >> 8) ? e_gate[2 * pr + 1] : e_gate[2 * pr];
-    float add = (threadIdx.x >> 8) ? e_add[2 * pr + 1] : e_add[2 * pr];
-    const int rc = (threadIdx.x >> 8) ? rowc[2 * pr + 1] : rowc[2 * pr];
+    const int rc = hi ? rowc[2 * pr + 1] : rowc[2 * pr];
+    float add[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) add[c] = hi ? e_add[2 * pr + 1][c] : e_add[2 * pr][c];
     if (L.add && L.add_polled) {
-      const rsrc_t rs[1] = {make_rsrc(L.add)};
-      const unsigned os[1] = {4u * ((unsigned)rc * (unsigned)L.ldadd + (unsigned)col)};
-      float ws[1];
-      poll_words<1>(rs, os, ws, own, pl);
-      add = ws[0];
+      rsrc_t rs[CT];
+      unsigned os[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) { rs[c] = make_rsrc(L.add); os[c] = 4u * ((unsigned)rc * (unsigned)L.ldadd + (unsigned)(col + 16 * c)); }
+      poll_words<CT>(rs, os, add, own, pl);
     }
     if (own) {
-      float x = v[0] + e_bias + add;
-      if (L.relu) x = x > 0.f ? x : x * L.slope;
-      if (L.gate) x = gate_v > 0.f ? x : x * L.slope;
-      put(L.out, rb, c0, row, col, x);
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const float gate_v = hi ? e_gate[2 * pr + 1][c] : e_gate[2 * pr][c];
+        float x = v[c] + e_bias[c] + add[c];
+        if (L.relu) x = x > 0.f ? x : x * L.slope;
+        if (L.gate) x = gate_v > 0.f ? x : x * L.slope;
+        put(L.out, rb, c0 + 16 * c, row, col + 16 * c, x);
+      }
     }
   }
 }

@@ -156,6 +156,16 @@ inline int vrnn_rt(int B) {
   return forced == 4 ? 4 : 2;
 }
 inline bool vrnn_row_groups(int B) { return vrnn_rt(B) > 0; }
+// row groups per link from which the gentle links (hidden projection; backward: the hidden-gradient product) stop owning a range of
+// workgroups and run on the posterior half instead, in the window that half waits in (env BLVM_PCHAIN_RT_SHARED_TL; 0 = never)
+inline int vrnn_rt_shared_tl() {
+  static int v = [] {
+    const char* e = getenv("BLVM_PCHAIN_RT_SHARED_TL");
+    const int t = e ? atoi(e) : 7;
+    return t > 0 ? t : 1 << 30;
+  }();
+  return v;
+}
 inline bool vrnn_persistent(int B) { return pchain_applies(B) || vrnn_row_groups(B); }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -393,8 +403,11 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     const int RTG = groups ? vrnn_rt(B) : 1;
     const int tl = (rt + RTG - 1) / RTG;
     // hidden projection: up to a quarter of the chip (groups of four row tiles: up to half)
-    const int def_n = range_for(3 * ctR * tl, std::min(RTG >= 4 ? cus / 2 : cus / 4, RTG >= 4 ? 128 : 64));
-    const int half = range_for(ctH * tl, (cus - def_n) / 2);                   // prior | posterior halves of a link
+    // shared deal (row groups, many row tiles): no range of its own for the hidden projection -- it runs on the posterior half after that
+    // half's run, in the window where only the prior half works on the heads and the phi_z run
+    const bool shared = groups && tl >= vrnn_rt_shared_tl();
+    const int def_n = shared ? 0 : range_for(3 * ctR * tl, std::min(RTG >= 4 ? cus / 2 : cus / 4, RTG >= 4 ? 128 : 64));
+    const int half = range_for(ctH * tl, (cus - def_n) / 2);            // prior | posterior halves of a link
     const int g = 2 * half;
     Builder bld;
     bld.p.bf16 = pchain_bf16(B);
@@ -411,8 +424,11 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     // F1: first prior layer | h-half of the first posterior layer | hidden projection
     lin(rs.H16, xR, rs.Wp[0], R, w->prior_b[0], nullptr, 0, 0, rs.P[0], sH, H, rs.P16[0], xH, ctH, ctH, 0, half, DF_RELU);
     lin(rs.H16, xR, rs.Wq[0], R, nullptr, rs.XQ, sH, H, rs.Q[0], sH, H, rs.Q16[0], xH, ctH, ctH, half, half, DF_RELU);
-    lin(rs.H16, xR, rs.Whh, R, w->gru_bhh, nullptr, 0, 0, rs.GHb, s3R, 3 * R, nullptr, 0, 0, 3 * ctR, g, def_n,
-        DF_RM_SC1 | DF_GENTLE | ((pchain_tune() & 16) ? DF_CANARY : 0));
+    auto hproj = [&](int wg0, int nwg) {
+      lin(rs.H16, xR, rs.Whh, R, w->gru_bhh, nullptr, 0, 0, rs.GHb, s3R, 3 * R, nullptr, 0, 0, 3 * ctR, wg0, nwg,
+          DF_RM_SC1 | DF_GENTLE | ((pchain_tune() & 16) ? DF_CANARY : 0));
+    };
+    if (!shared) hproj(g, def_n);
     // a run of consecutive links of one shape as one descriptor: out_i = relu(A_i W_i^T + b_i), A_{i+1} = out_i
     struct SeqLink { const float* W; const float* bias; float* orm; long rm_step; int ldo; float* o16; };
     auto linseq = [&](const float* A16, long a_step, int K, int n, const SeqLink* L, int wg0, int nwg) {
@@ -437,8 +453,9 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
         lin(rs.Q16[l - 1], xH, rs.Wq[l], H, w->post_b[l], nullptr, 0, 0, rs.Q[l], sH, H, rs.Q16[l], xH, ctH, ctH, half, half, DF_RELU);
       }
     }
+    if (shared) hproj(half, half);
     {  // F4: heads + sample
-      Desc& d = bld.add(K_HEAD, ctZ, 0, range_for(ctZ * tl, g), H, 0, 0, Tp);
+      Desc& d = bld.add(K_HEAD, ctZ, 0, range_for(ctZ * tl, shared ? half : g), H, 0, 0, Tp);
       bld.ptr(d, 0, rs.P16[2], xH); bld.ptr(d, 1, rs.Q16[2], xH); bld.ptr(d, 2, rs.Wph); bld.ptr(d, 3, w->prior_hb); bld.ptr(d, 4, rs.Wqh);
       bld.ptr(d, 5, w->post_hb); bld.ptr(d, 6, eps, sZ); bld.ptr(d, 7, mu_p, sZ); bld.ptr(d, 8, sd_p, sZ); bld.ptr(d, 9, mu_q, sZ);
       bld.ptr(d, 10, sd_q, sZ); bld.ptr(d, 11, rs.RAWP, sZ); bld.ptr(d, 12, rs.RAWQ, sZ); bld.ptr(d, 13, nullptr);
@@ -450,13 +467,13 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     for (int l = 0; l < first_seq; ++l) {
       const float* A = l == 0 ? rs.Z16 : rs.FZ16[l - 1];
       lin(A, l == 0 ? xZ : xH, rs.Wf[l], l == 0 ? Z : H, w->phi_b[l], nullptr, 0, 0, l == 3 ? decin : rs.FZ[l], l == 3 ? sD : sH, l == 3 ? ldd : H,
-          l == 3 ? rs.PHI16 : rs.FZ16[l], xH, ctH, ctH, 0, range_for(ctH * tl, g), DF_RELU);
+          l == 3 ? rs.PHI16 : rs.FZ16[l], xH, ctH, ctH, 0, range_for(ctH * tl, shared ? half : g), DF_RELU);
     }
     if (first_seq < 4) {
       SeqLink lf[4];
       for (int l = first_seq; l < 4; ++l)
         lf[l - first_seq] = SeqLink{rs.Wf[l], w->phi_b[l], l == 3 ? decin : rs.FZ[l], l == 3 ? sD : sH, l == 3 ? ldd : H, l == 3 ? rs.PHI16 : rs.FZ16[l]};
-      linseq(first_seq == 0 ? rs.Z16 : rs.FZ16[first_seq - 1], first_seq == 0 ? xZ : xH, H, 4 - first_seq, lf, 0, range_for(ctH * tl, g));
+      linseq(first_seq == 0 ? rs.Z16 : rs.FZ16[first_seq - 1], first_seq == 0 ? xZ : xH, H, 4 - first_seq, lf, 0, range_for(ctH * tl, shared ? half : g));
     }
     {  // F9: GRU
       Desc& d = bld.add(K_GRU, ctR, 0, range_for(ctR * tl, g), H, 0, 0, Tp);
@@ -651,8 +668,12 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     const bool groups = vrnn_row_groups(B);
     const int RTG = groups ? vrnn_rt(B) : 1;
     const int tl = (rt + RTG - 1) / RTG;  // tiles of a link per column tile: row tiles, or groups of them (pchain_rt.h)
-    const int def_n = range_for(ctR * tl, std::min(cus / 4, 64));  // GB link
+    // (shared deal: see vrnn_fwd -- here the gentle link is GB, which the posterior half runs while the prior half
+    // takes the gradient back through the phi_z run and the heads)
+    const bool shared = groups && tl >= vrnn_rt_shared_tl();
+    const int def_n = shared ? 0 : range_for(ctR * tl, std::min(cus / 4, 64));  // GB link
     const int half = range_for(ctH * tl, (cus - def_n) / 2), g = 2 * half;
+    const int wide = shared ? half : g;  // range of the links between the GRU backward and the heads
     Builder bld;
     bld.p.bf16 = pchain_bf16(B);
     bld.p.rt_group = RTG;
@@ -682,7 +703,7 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     // (the derivative mask distributes over the sum; the decoder's gradient joins the first), and B3 adds the three slabs up as it
     // loads them.
     const int spare = cus - g - def_n;
-    const bool split3 = spare >= 8 && half >= 8 && pchain_split3();
+    const bool split3 = !shared && spare >= 8 && half >= 8 && pchain_split3();
     if (split3) {
       const size_t wthird = (size_t)ctR * 256 / (bld.p.bf16 ? 2 : 1);  // the packed weight's k-chunks [ctR * part, ...) (bf16 packs: half the floats)
       float* const orm[3] = {ws.DPHI[3], ws.DPHI3b, ws.DPHI3c};
@@ -695,9 +716,9 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
         d.ld[0] = 3 * R; d.i[0] = 3 * R;  // widths of the slab / of the packed rows the K-range is taken from
       }
     } else {
-      lin(ws.DGI16, x3R, ws.wihT, 3 * R, d_decin, sD, ldd, decin, sD, ldd, ws.DPHI[3], sH, H, ws.DPHI16[3], xH, ctH, ctH, 0, range_for(ctH * tl, g), 0);
+      lin(ws.DGI16, x3R, ws.wihT, 3 * R, d_decin, sD, ldd, decin, sD, ldd, ws.DPHI[3], sH, H, ws.DPHI16[3], xH, ctH, ctH, 0, range_for(ctH * tl, wide), 0);
     }
-    lin(ws.DGH16, x3R, ws.whhT, 3 * R, ws.GA, sR, R, nullptr, 0, 0, ws.GB, sR, R, nullptr, 0, 0, ctR, g, def_n,
+    lin(ws.DGH16, x3R, ws.whhT, 3 * R, ws.GA, sR, R, nullptr, 0, 0, ws.GB, sR, R, nullptr, 0, 0, ctR, shared ? half : g, shared ? half : def_n,
         DF_ADD_POLLED | DF_RM_SC1 | DF_GENTLE | ((pchain_tune() & 16) ? DF_CANARY : 0));
     // B3..B5: back through phi_z layers 3, 2, 1
     // a run of consecutive backward links of one shape as one descriptor (K_LINSEQ): D_{i+1} = (D_i W_i) masked by the saved activation
@@ -717,16 +738,16 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     if (seq) {
       const SeqLinkB lf[3] = {{ws.fT[3], rs.FZ[2], ws.DPHI[2], ws.DPHI16[2]}, {ws.fT[2], rs.FZ[1], ws.DPHI[1], ws.DPHI16[1]}, {ws.fT[1], rs.FZ[0], ws.DPHI[0], ws.DPHI16[0]}};
       if (split3) {  // the link that adds the three partial-sum slabs up is a K_LIN of its own (a run's links are plain), the other two a run
-        lin(ws.DPHI16[3], xH, ws.fT[3], H, nullptr, 0, 0, rs.FZ[2], sH, H, ws.DPHI[2], sH, H, ws.DPHI16[2], xH, ctH, ctH, 0, range_for(ctH * tl, g), DF_A_SUM3);
+        lin(ws.DPHI16[3], xH, ws.fT[3], H, nullptr, 0, 0, rs.FZ[2], sH, H, ws.DPHI[2], sH, H, ws.DPHI16[2], xH, ctH, ctH, 0, range_for(ctH * tl, wide), DF_A_SUM3);
         Desc& d = bld.p.d[bld.p.ndesc - 1];
         bld.ptr(d, 8, ws.DPHI16b + (long)(T - 1) * xH, -xH); bld.ptr(d, 9, ws.DPHI16c + (long)(T - 1) * xH, -xH);
-        linseq_b(ws.DPHI16[2], 2, lf + 1, 0, range_for(ctH * tl, g), 0);
+        linseq_b(ws.DPHI16[2], 2, lf + 1, 0, range_for(ctH * tl, wide), 0);
       } else {
-        linseq_b(ws.DPHI16[3], 3, lf, 0, range_for(ctH * tl, g), 0);
+        linseq_b(ws.DPHI16[3], 3, lf, 0, range_for(ctH * tl, wide), 0);
       }
     } else {
       for (int l = 3; l >= 1; --l) {
-        lin(ws.DPHI16[l], xH, ws.fT[l], H, nullptr, 0, 0, rs.FZ[l - 1], sH, H, ws.DPHI[l - 1], sH, H, ws.DPHI16[l - 1], xH, ctH, ctH, 0, range_for(ctH * tl, g),
+        lin(ws.DPHI16[l], xH, ws.fT[l], H, nullptr, 0, 0, rs.FZ[l - 1], sH, H, ws.DPHI[l - 1], sH, H, ws.DPHI16[l - 1], xH, ctH, ctH, 0, range_for(ctH * tl, wide),
             l == 3 && split3 ? DF_A_SUM3 : 0);
         if (l == 3 && split3) {
           Desc& d = bld.p.d[bld.p.ndesc - 1];
@@ -735,7 +756,7 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
       }
     }
     {  // B6: dz and the heads
-      Desc& d = bld.add(K_DZ, ctZ, 0, range_for(ctZ * tl, g), H, 0, 0, T);
+      Desc& d = bld.add(K_DZ, ctZ, 0, range_for(ctZ * tl, wide), H, 0, 0, T);
       bld.ptr(d, 0, last(ws.DPHI16[0], xH), -xH); bld.ptr(d, 1, ws.fT[0]); bld.ptr(d, 2, nullptr); bld.ptr(d, 3, nullptr); bld.ptr(d, 4, nullptr);
       bld.ptr(d, 5, last(mu_q, sZ), -sZ); bld.ptr(d, 6, last(sd_q, sZ), -sZ); bld.ptr(d, 7, last(mu_p, sZ), -sZ); bld.ptr(d, 8, last(sd_p, sZ), -sZ);
       bld.ptr(d, 9, last(eps, sZ), -sZ); bld.ptr(d, 10, last(rs.RAWQ, sZ), -sZ); bld.ptr(d, 11, last(rs.RAWP, sZ), -sZ); bld.ptr(d, 12, nullptr);
