@@ -156,15 +156,18 @@ inline int vrnn_rt(int B) {
   return forced == 4 ? 4 : 2;
 }
 inline bool vrnn_row_groups(int B) { return vrnn_rt(B) > 0; }
-// row groups per link from which the gentle links (hidden projection; backward: the hidden-gradient product) stop owning a range of
-// workgroups and run on the posterior half instead, in the window that half waits in (env BLVM_PCHAIN_RT_SHARED_TL; 0 = never)
-inline int vrnn_rt_shared_tl() {
-  static int v = [] {
-    const char* e = getenv("BLVM_PCHAIN_RT_SHARED_TL");
-    const int t = e ? atoi(e) : 7;
-    return t > 0 ? t : 1 << 30;
-  }();
-  return v;
+// SHARED deal of the row-group programs: the gentle link (hidden projection; backward: the hidden-gradient product) owns no range of
+// workgroups -- the chip is two halves (prior | posterior) and the gentle link runs on the posterior half right after that half's
+// run, in the window in which only the prior half works (heads + phi_z run; backward: dphi + phi_z run + dz).  Pays from 7 row groups
+// per link (B > 208), where a link is throughput-bound and an own range for the gentle link starves the halves; at 4..6 groups the
+// own range is as good or better, and on 16-row tiles (B <= 64: a link is one hand-off latency, not tile throughput) it LOSES --
+// measured r03, [64,16000]: forward 5.68 -> 7.30 ms, the three serial gentle tiles end after the prior half's run and the GRU waits.
+// env BLVM_PCHAIN_SHARED = 0 | 1 overrides (any batch); BLVM_PCHAIN_RT_SHARED_TL: the row-group threshold.
+inline bool vrnn_shared_deal(bool groups, int tl) {
+  static const int forced = [] { const char* e = getenv("BLVM_PCHAIN_SHARED"); return e ? atoi(e) : -1; }();
+  static const int rt_tl = [] { const char* e = getenv("BLVM_PCHAIN_RT_SHARED_TL"); return e ? atoi(e) : 7; }();
+  if (forced >= 0) return forced != 0;
+  return groups && rt_tl > 0 && tl >= rt_tl;  // (threshold 0: never)
 }
 inline bool vrnn_persistent(int B) { return pchain_applies(B) || vrnn_row_groups(B); }
 
@@ -405,7 +408,7 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     // hidden projection: up to a quarter of the chip (groups of four row tiles: up to half)
     // shared deal (row groups, many row tiles): no range of its own for the hidden projection -- it runs on the posterior half after that
     // half's run, in the window where only the prior half works on the heads and the phi_z run
-    const bool shared = groups && tl >= vrnn_rt_shared_tl();
+    const bool shared = vrnn_shared_deal(groups, tl);
     const int def_n = shared ? 0 : range_for(3 * ctR * tl, std::min(RTG >= 4 ? cus / 2 : cus / 4, RTG >= 4 ? 128 : 64));
     const int half = range_for(ctH * tl, (cus - def_n) / 2);            // prior | posterior halves of a link
     const int g = 2 * half;
@@ -670,7 +673,7 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     const int tl = (rt + RTG - 1) / RTG;  // tiles of a link per column tile: row tiles, or groups of them (pchain_rt.h)
     // (shared deal: see vrnn_fwd -- here the gentle link is GB, which the posterior half runs while the prior half
     // takes the gradient back through the phi_z run and the heads)
-    const bool shared = groups && tl >= vrnn_rt_shared_tl();
+    const bool shared = vrnn_shared_deal(groups, tl);
     const int def_n = shared ? 0 : range_for(ctR * tl, std::min(cus / 4, 64));  // GB link
     const int half = range_for(ctH * tl, (cus - def_n) / 2), g = 2 * half;
     const int wide = shared ? half : g;  // range of the links between the GRU backward and the heads
