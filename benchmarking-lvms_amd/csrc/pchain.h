@@ -39,6 +39,13 @@ constexpr unsigned SPIN_LIMIT = 1u << 22;           // polls before a wave gives
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 constexpr int AUX_SC1 = 16;
+// (tools/pchain_probe.hip compiles the hand-off with other cache bits: -DPCHAIN_POLL_AUX=1 = sc0 loads, -DPCHAIN_STORE_AUX=0 = plain stores)
+#ifndef PCHAIN_POLL_AUX
+#define PCHAIN_POLL_AUX AUX_SC1
+#endif
+#ifndef PCHAIN_STORE_AUX
+#define PCHAIN_STORE_AUX AUX_SC1
+#endif
 __device__ __forceinline__ rsrc_t make_rsrc(const void* base) {  // base must be wave-uniform
   // (said to the compiler, too: a pointer that reached here through a struct assigned under control flow counts as divergent, and
   // every buffer access through it became a waterfall loop over the "different" resources)
@@ -47,13 +54,13 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* base) {  // base must be
   return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, 0xFFFFFFFFu, 0x00020000);
 }
 __device__ __forceinline__ f32x4 ld_sc1_x4(rsrc_t r, unsigned byte_off) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, AUX_SC1));
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, PCHAIN_POLL_AUX));
 }
 __device__ __forceinline__ float ld_sc1(rsrc_t r, unsigned byte_off) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, AUX_SC1));
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, PCHAIN_POLL_AUX));
 }
 __device__ __forceinline__ void st_sc1(rsrc_t r, unsigned byte_off, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)byte_off, 0, AUX_SC1);
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)byte_off, 0, PCHAIN_STORE_AUX);
 }
 
 __device__ __forceinline__ bool is_sentinel(float x) { return __float_as_uint(x) == SENTINEL; }

@@ -41,9 +41,17 @@ __global__ __launch_bounds__(NW * 64) void k_persistent(const float* x0_16, floa
   const size_t slab = (size_t)B * N, slab16 = (size_t)rt * 16 * N;
   int par = 0;
   for (int l = 0; l < L; ++l) {
-    const float* A = (l == 0 || shift < 0) ? x0_16 : slabs16 + (size_t)(l - 1) * slab16;
+    const float* A = (l == 0 || shift == -1) ? x0_16 : slabs16 + (size_t)(l - 1) * slab16;
     const Out o = out_both(slabs + (size_t)l * slab, N, slabs16 + (size_t)l * slab16, ct);
     pl.code = (unsigned)l;
+    if (shift == -2) {  // every row tile's chain on ONE XCD (workgroup w sits on XCD w % 8): row tile w % 8, column tile w / 8
+      const int r = w & 7, c = w >> 3;
+      if (r < rt && c < ct) {
+        tile_lin<NW>(A, 0, true, W, N, bias, nullptr, 0, false, nullptr, 0, true, 0.f, o, r * 16, c * 16, B, red[par], pl);
+        par ^= 1;
+      }
+      continue;
+    }
     const int first = shift < 0 ? w : (w - (l * shift) % G + G) % G;
     for (int i = first; i < ntiles; i += G) {
       tile_lin<NW>(A, 0, true, W, N, bias, nullptr, 0, false, nullptr, 0, true, 0.f, o, (i % rt) * 16, (i / rt) * 16, B, red[par], pl);
@@ -111,7 +119,7 @@ int run(int B, int N, int L, int G, int shift, int reps) {
   CK(hipMemcpy(b.data(), ref + ((L - 1) & 1) * slab, slab * 4, hipMemcpyDeviceToHost));
   size_t bad = 0; double mag = 0;
   for (size_t i = 0; i < slab; ++i) { bad += a[i] != b[i]; mag += fabs(b[i]); }
-  if (shift < 0) bad = 0;  // compute-only run: results are not the chain's
+  if (shift == -1) bad = 0;  // compute-only run: results are not the chain's
   if (!(mag == mag) || mag > 1e30) { printf("probe error: the reference chain is not finite (mean|x| %g) — nothing was compared\n", mag / slab); return 1; }
   printf("B=%3d N=K=%4d L=%4d G=%3d NW=%2d shift=%2d: persistent %6.3f us/link | launches %6.3f us/link | mismatches %zu/%zu (mean|x| %.3g) aborted launches=%u code=%u\n",
          B, N, L, G, NW, shift, best * 1e3 / L, msl * 1e3 / L, bad, slab, mag / slab, hc[4], hc[5]);
@@ -120,8 +128,34 @@ int run(int B, int N, int L, int G, int shift, int reps) {
   return 0;
 }
 
+// the XCD every workgroup of a 256-workgroup launch runs on (HW_REG_XCC_ID): the placement `shift = -2` relies on
+__global__ void k_xcc(int* out) {
+  if (threadIdx.x == 0) out[blockIdx.x] = (int)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf);  // id 20 = XCC_ID, bits [3:0]
+}
+static int check_xcc() {
+  int* d; int h[256];
+  CK(hipMalloc(&d, sizeof(h)));
+  hipLaunchKernelGGL(k_xcc, dim3(256), dim3(1024), 0, 0, d);
+  CK(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+  int off = 0;
+  for (int w = 0; w < 256; ++w) off += h[w] != (w & 7);
+  printf("XCC_ID of workgroup w == w %% 8 for %d of 256 workgroups (first eight: %d %d %d %d %d %d %d %d)\n", 256 - off, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+  (void)hipFree(d);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   const int L = argc > 1 ? atoi(argv[1]) : 2000;
+  if (argc > 2 && atoi(argv[2]) == 1) {  // the XCD-local hand-off experiment (build with -DPCHAIN_POLL_AUX=... -DPCHAIN_STORE_AUX=...)
+    if (check_xcc()) return 1;
+    for (int N : {256, 512}) {
+      if (run<8>(64, N, L, 256, 0, 3)) return 1;
+      if (run<8>(64, N, L, 256, -2, 3)) return 1;
+      if (run<16>(64, N, L, 256, 0, 3)) return 1;
+      if (run<16>(64, N, L, 256, -2, 3)) return 1;
+    }
+    return 0;
+  }
   for (int B : {8, 64})
     for (int N : {256, 512, 192}) {
       if (run<8>(B, N, L, 256, 0, 3)) return 1;
