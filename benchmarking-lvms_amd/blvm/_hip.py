@@ -90,6 +90,7 @@ _SIGNATURES = {
     "blvm_act_bwd_f32": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
     "blvm_colsum_f32": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "blvm_wgrad_f32": (c_int, [c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "blvm_wgrad_group_f32": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "blvm_dmol_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                               c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "blvm_dmol_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

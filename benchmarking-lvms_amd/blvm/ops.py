@@ -60,6 +60,39 @@ def upload_i32(host, device):
     return out
 
 
+def wgrad_group(jobs, rows: int):
+    """Weight (+ bias) gradients over the same `rows` as ONE launch (blvm_wgrad_group_f32): jobs = [(D [rows, N], X [rows, K], dW [N, K]
+    or None, db [N] or None), ...], each dW += D^T X, db += D.sum(0); D and X may be row-strided views."""
+    import ctypes
+
+    jobs = [j for j in jobs if j[2] is not None or j[3] is not None]
+    if not jobs:
+        return
+    n = len(jobs)
+    ints = lambda v: (ctypes.c_int * n)(*v)  # noqa: E731
+
+    def row_ptr(t):  # (row-strided views are fine: the leading dimension travels beside the pointer)
+        if t is None:
+            return None
+        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+            raise _hip.BlvmHipError("wgrad_group: operands must be float32 [rows, cols] HIP tensors with unit column stride")
+        return t.data_ptr()
+
+    ptrs = lambda v: (ctypes.c_void_p * n)(*[ptr(t) for t in v])  # noqa: E731
+    rptrs = lambda v: (ctypes.c_void_p * n)(*[row_ptr(t) for t in v])  # noqa: E731
+    for D, X, dW, db in jobs:
+        if D.shape[0] != rows or X.shape[0] != rows:
+            raise _hip.BlvmHipError(f"wgrad_group: operands must be [rows={rows}, *], got {tuple(D.shape)} / {tuple(X.shape)}")
+    check(
+        load().blvm_wgrad_group_f32(n, ints([j[0].shape[1] for j in jobs]), ints([j[1].shape[1] for j in jobs]), rows,
+                                    rptrs([j[0] for j in jobs]), ints([j[0].stride(0) for j in jobs]), rptrs([j[1] for j in jobs]),
+                                    ints([j[1].stride(0) for j in jobs]), ptrs([j[2] for j in jobs]),
+                                    ints([j[2].stride(0) if j[2] is not None else j[1].shape[1] for j in jobs]), ptrs([j[3] for j in jobs]),
+                                    stream_ptr()),
+        "blvm_wgrad_group_f32",
+    )  # fmt: skip
+
+
 def _zeros_like_many(tensors):
     """Zero-initialised gradient buffers for `tensors` carved out of ONE allocation (one fill launch instead of one per
     tensor; offsets kept 16-byte aligned)."""
@@ -132,6 +165,7 @@ class _MLPFunction(torch.autograd.Function):
         for i in range(2 * n):
             views.append(flat[off : off + params[i].numel()].view(params[i].shape) if want[i] else None)
             off += sizes[i]
+        jobs = []  # every layer's weight + bias gradient: ONE grouped launch after the chain of dgrads (all share the rows)
         for l in range(n - 1, -1, -1):
             W, b = params[2 * l], params[2 * l + 1]
             inp = acts[l]
@@ -139,9 +173,7 @@ class _MLPFunction(torch.autograd.Function):
             N = W.shape[0]
             # weight and bias gradient in one launch (the GEMM's first column block also sums the dz tiles it stages)
             dW, db = views[2 * l], views[2 * l + 1]
-            if dW is not None or db is not None:
-                check(load().blvm_wgrad_f32(N, K, M, ptr(dz), N, ptr(inp), inp.stride(0), ptr(dW), K, ptr(db), _pick_split(N, K, M), stream_ptr()),
-                      "blvm_wgrad_f32")  # fmt: skip
+            jobs.append((dz, inp, dW, db))  # (keeps this layer's dz alive until the grouped launch below)
             grads[2 * l], grads[2 * l + 1] = dW, db
             if l > 0 or ctx.needs_input_grad[0]:
                 dx = torch.empty(M, K, device=dz.device, dtype=torch.float32)
@@ -149,6 +181,7 @@ class _MLPFunction(torch.autograd.Function):
                 gate = acts[l] if (l > 0 and ctx.act != ACT_NONE) else None
                 gemm(0, 1, M, K, N, dz, N, _f32c(W), K, dx, K, slope=slope, gate=gate, ldg=K)
                 dz = dx
+        wgrad_group(jobs, acts[0].shape[0])
         return (dz if ctx.needs_input_grad[0] else None, None, None, *grads)
 
 
@@ -185,6 +218,18 @@ def _head_linear_grads(d_par, dec, W, b, F, n_frames, need_w, need_b):
     """Gradients of a likelihood head's per-frame Linear(F, F): dW = d_par^T dec and db = column sums of d_par over all frames, in one
     launch when both are wanted (the bias gradient rides in the weight-gradient GEMM)."""
     dW = db = None
+    if need_w and F % 4 != 0 and F % 2 == 0 and n_frames % 2 == 0 and n_frames >= 4096:
+        # F = 30: rows of 120 bytes are not 16-byte aligned and a 30 x 30 output uses a fifth of the GEMM's 64 x 64 tile (measured:
+        # 147 us for 246 MB at [64,16000], scalar loads).  Two frames per row -> [n/2, 2F] operands with aligned 240-byte rows and a
+        # 60 x 60 product over half the rows whose two diagonal blocks are the wanted sums (even frames | odd frames).
+        T2 = torch.zeros(2 * F, 2 * F, device=W.device, dtype=torch.float32)
+        tb = torch.zeros(2 * F, device=W.device, dtype=torch.float32) if need_b else None
+        half = n_frames // 2
+        check(load().blvm_wgrad_f32(2 * F, 2 * F, half, ptr(d_par), 2 * F, ptr(dec), 2 * F, ptr(T2), T2.stride(0), ptr(tb),
+                                    max(128, min(512, half // 1024)), stream_ptr()), "blvm_wgrad_f32")  # fmt: skip
+        dW = T2[:F, :F] + T2[F : 2 * F, F : 2 * F]
+        db = tb[:F] + tb[F:] if need_b else None
+        return dW, db
     if need_w:
         dW = torch.zeros_like(W)
         db = torch.zeros_like(b) if need_b else None

@@ -348,6 +348,16 @@ int gemm_f32(int op_a, int op_b, int M, int N, int K, const float* A, int lda, c
              int ldc, const float* bias, int act, float slope, const float* gate, int ldg, int accumulate,
              int split_k, hipStream_t stream, float* colsum = nullptr);  // colsum (op_a == 1): [M] += sum over k of A[k][:]
 int colsum_f32(int M, int N, const float* X, int ldx, float* out, int accumulate, hipStream_t stream);
+// Weight gradients of one reduction length as ONE launch (gemm.hip gemm_group_kernel): dW[M,N] += D^T[M,K] Act[K,N] and, with db,
+// db[M] += column sums of D, for every job with dW (a job without dW only sums its columns).  Falls back to one gemm_f32 per job
+// for bf16 operands, short reductions or more than 20 jobs (env BLVM_WGRAD_GROUP=0: always).
+struct WgradJob {
+  const float* D; int ldd, M;
+  const float* Act; int lda, N;
+  float* dW; int ldw;
+  float* db;
+};
+int gemm_wgrad_group(const WgradJob* jobs, int njobs, int K, hipStream_t stream);
 int transpose_f32(int M, int N, const float* X, int ldx, float* out, int ldo, hipStream_t stream);
 // Operand type of the matrix products (core.hip; blvm_set_operand_dtype / env BLVM_DTYPE=bf16): false = fp32 (the default), true =
 // bf16 operands with fp32 accumulation for the persistent chains and K6 — the reference's `--use_amp True` regime

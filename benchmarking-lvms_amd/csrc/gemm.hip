@@ -12,6 +12,8 @@
 #include <algorithm>
 #include <type_traits>
 
+#include <vector>
+
 #include "common.h"
 
 namespace blvm {
@@ -54,8 +56,9 @@ __device__ __forceinline__ float4 ld4(const float* p, int n_valid, bool vec) {
   return v;
 }
 
+// one BM x BN output tile over the k range of split `bz` of `nz` (the body of gemm_kernel and of gemm_group_kernel)
 template <int BM, int BN, int OPA, int OPB>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, const int bz, const int nz) {
   constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD;
   constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave in m / n
   constexpr int A_V = BM * BK / 4 / 256;     // float4 per thread per stage
@@ -65,8 +68,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int kbeg = blockIdx.z * g.k_per_split;
+  const int m0 = by * BM, n0 = bx * BN;
+  const int kbeg = bz * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
 
   f32x16 acc[TM][TN];
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int li = lane & 31, lh = lane >> 5;
   // bias gradient riding on a weight-gradient GEMM: the workgroups of the first column block also sum their A tiles over k
   // (A = the pre-activation gradients [rows, M]; the staged tile is k-major, so thread m reads a conflict-free column)
-  const bool do_csum = OPA == 1 && g.colsum != nullptr && blockIdx.x == 0;
+  const bool do_csum = OPA == 1 && g.colsum != nullptr && bx == 0;
   constexpr int CS = BM <= 64 ? 4 : (BM <= 128 ? 2 : 1);
   float csum = 0.f;
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
@@ -176,14 +179,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 
   if (do_csum && tid / BM < CS && m0 + tid % BM < g.M) atomicAdd(g.colsum + m0 + tid % BM, csum);
   // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  const bool atomic = gridDim.z > 1;
+  const bool atomic = nz > 1;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * (BN / 2) + j * 32 + li;
       if (n >= g.N) continue;
-      const float bv = (g.bias != nullptr && blockIdx.z == 0) ? g.bias[n] : 0.f;
+      const float bv = (g.bias != nullptr && bz == 0) ? g.bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -198,6 +201,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         else *cp = v;
       }
     }
+}
+
+template <int BM, int BN, int OPA, int OPB>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  gemm_tile<BM, BN, OPA, OPB>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z);
+}
+
+// ---- grouped weight gradients --------------------------------------------------------------------------------------------------
+// Up to kMaxGroup problems dW_p (+)= D_p^T Act_p of ONE reduction length K (the rows of a sequence) as one launch: the small ones
+// (256 x 256 outputs: 16 tiles) cannot fill 256 CUs on their own without a split so fine that a workgroup's k range is ~20 stages
+// and 48 workgroups contend for every output word (tools/gemm_wgrad_sweep.py: 54 TF/s against 81-86 for the 768- and 1920-row
+// forms).  Together they are hundreds of tiles: a coarse split, long k ranges, one launch.  Work item = (problem, tile, split):
+// first[p] = first work item of problem p (first[n] = all); a workgroup finds its problem by scanning that table.
+constexpr int kMaxGroup = 20;
+struct GemmGroup {
+  GemmArgs p[kMaxGroup];
+  int first[kMaxGroup + 1];
+  int n, split;
+};
+__global__ __launch_bounds__(256) void gemm_group_kernel(GemmGroup gg) {
+  const int item = blockIdx.x;
+  int p = 0;
+  while (p + 1 < gg.n && item >= gg.first[p + 1]) ++p;
+  const GemmArgs g = gg.p[p];
+  const int local = item - gg.first[p];
+  const int tiles_n = (g.N + 63) / 64, tiles = tiles_n * ((g.M + 63) / 64);
+  const int bz = local / tiles, t = local - bz * tiles;
+  gemm_tile<64, 64, 1, 1>(g, t % tiles_n, t / tiles_n, bz, gg.split);
 }
 
 // ---- bf16-operand variant (operand_bf16(): the reference's --use_amp regime) -----------------------------------------------------
@@ -480,6 +511,60 @@ int gemm_f32(int op_a, int op_b, int M, int N, int K, const float* A, int lda, c
   return BLVM_OK;
 }
 
+int gemm_wgrad_group(const WgradJob* jobs, int njobs, int K, hipStream_t stream) {
+  static const int enabled = [] { const char* e = getenv("BLVM_WGRAD_GROUP"); return e ? atoi(e) : 1; }();
+  int live = 0;
+  for (int i = 0; i < njobs; ++i) live += jobs[i].dW != nullptr;
+  if (!enabled || operand_bf16() || live < 2 || live > kMaxGroup || K < 1024) {  // one launch per problem (gemm_f32 picks tile and kernel)
+    for (int i = 0; i < njobs; ++i) {
+      const WgradJob& j = jobs[i];
+      const int rc = j.dW ? gemm_f32(1, 1, j.M, j.N, K, j.D, j.ldd, j.Act, j.lda, j.dW, j.ldw, nullptr, 0, 0.f, nullptr, 0, 1, gemm_pick_split(j.M, j.N, K), stream, j.db)
+                          : (j.db ? colsum_f32(K, j.M, j.D, j.ldd, j.db, 1, stream) : BLVM_OK);
+      if (rc) return rc;
+    }
+    return BLVM_OK;
+  }
+  GemmGroup gg;
+  gg.n = 0;
+  long tiles = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const WgradJob& j = jobs[i];
+    if (!j.dW) {
+      if (j.db) { const int rc = colsum_f32(K, j.M, j.D, j.ldd, j.db, 1, stream); if (rc) return rc; }
+      continue;
+    }
+    BLVM_REQUIRE(j.D && j.Act && j.M > 0 && j.N > 0 && j.ldd >= j.M && j.lda >= j.N && j.ldw >= j.N, "gemm_wgrad_group: bad job %d", i);
+    GemmArgs& g = gg.p[gg.n];
+    g = GemmArgs{};
+    g.A = j.D; g.B = j.Act; g.C = j.dW; g.bias = nullptr; g.gate = nullptr;
+    g.M = j.M; g.N = j.N; g.K = K; g.lda = j.ldd; g.ldb = j.lda; g.ldc = j.ldw; g.ldg = 0;
+    g.act = 0; g.slope = 0.f; g.accumulate = 1;
+    g.a_vec = aligned16(j.D) && (j.ldd % 4 == 0);
+    g.b_vec = aligned16(j.Act) && (j.lda % 4 == 0);
+    g.colsum = j.db;
+    tiles += (long)((j.M + 63) / 64) * ((j.N + 63) / 64);
+    ++gg.n;
+  }
+  // ~6 workgroups per CU, k ranges of at least 32 stages
+  const int ksteps = (K + BK - 1) / BK;
+  static const int want = [] { const char* e = getenv("BLVM_WGRAD_GROUP_WGS"); return e ? atoi(e) : 1536; }();
+  int split = (int)((want + tiles - 1) / tiles);
+  split = std::max(1, std::min(split, ksteps / 32));
+  const int k_per_split = ((ksteps + split - 1) / split) * BK;
+  split = (K + k_per_split - 1) / k_per_split;
+  gg.split = split;
+  int first = 0;
+  for (int p = 0; p < gg.n; ++p) {
+    gg.p[p].k_per_split = k_per_split;
+    gg.first[p] = first;
+    first += ((gg.p[p].M + 63) / 64) * ((gg.p[p].N + 63) / 64) * split;
+  }
+  gg.first[gg.n] = first;
+  hipLaunchKernelGGL(gemm_group_kernel, dim3((unsigned)first), dim3(256), 0, stream, gg);
+  BLVM_CHECK_LAUNCH("gemm_wgrad_group");
+  return BLVM_OK;
+}
+
 int colsum_f32(int M, int N, const float* X, int ldx, float* out, int accumulate, hipStream_t stream) {
   if (N == 0) return BLVM_OK;
   BLVM_REQUIRE(X && out, "colsum: null operand");
@@ -655,6 +740,19 @@ extern "C" int blvm_wgrad_f32(int N_out, int K_in, int rows, const float* D, int
   if (dW == nullptr) return db ? colsum_f32(rows, N_out, D, ldd, db, 1, s) : BLVM_OK;
   if (split_k < 1) split_k = gemm_pick_split(N_out, K_in, rows);
   return gemm_f32(1, 1, N_out, K_in, rows, D, ldd, X, ldx, dW, lddw, nullptr, 0, 0.f, nullptr, 0, 1, split_k, s, db);
+}
+
+extern "C" int blvm_wgrad_group_f32(int n, const int* N_out, const int* K_in, int rows, const float* const* D, const int* ldd, const float* const* X,
+                                    const int* ldx, float* const* dW, const int* lddw, float* const* db, void* stream) {
+  using namespace blvm;
+  BLVM_REQUIRE(n >= 0 && rows >= 0 && (n == 0 || (N_out && K_in && D && ldd && X && ldx && dW && lddw && db)), "wgrad_group: bad arguments");
+  if (n == 0 || rows == 0) return BLVM_OK;
+  std::vector<WgradJob> jobs((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    BLVM_REQUIRE(N_out[i] > 0 && K_in[i] > 0 && D[i] && (dW[i] == nullptr || X[i]), "wgrad_group: bad job %d", i);
+    jobs[(size_t)i] = WgradJob{D[i], ldd[i], N_out[i], X[i], ldx[i], K_in[i], dW[i], lddw[i], db[i]};
+  }
+  return gemm_wgrad_group(jobs.data(), n, rows, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int blvm_act_bwd_f32(const float* dy, const float* y, float slope, float* dz, size_t n, void* stream) {

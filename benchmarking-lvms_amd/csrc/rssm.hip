@@ -529,19 +529,21 @@ extern "C" int blvm_rssm_seq_bwd(const BlvmRssmWeights* w, const float* enc, con
   const float* hnew_all = hs + bh;  // h_1..h_T
   if (d_ctx && C > 0) TRY(gemm_f32(0, 1, (int)n, C, H, ws.DGIN, H, w->gin_w + Z, ldg, d_ctx, C, nullptr, 0, 0.f, nullptr, 0, 0, 1, s));
   if (d_enc) TRY(gemm_f32(0, 1, (int)n, E, H, ws.DQ[0], H, w->post_w[0] + H, ldq, d_enc, E, nullptr, 0, 0.f, nullptr, 0, 0, 1, s));
-  TRY(wgrad(ws.DGIN, H, H, zs, Z, Z, gr->gin_w, ldg, n, s, gr->gin_b));
-  if (C > 0) TRY(wgrad(ws.DGIN, H, H, ctx, C, C, gr->gin_w ? gr->gin_w + Z : nullptr, ldg, n, s));
-  TRY(wgrad(ws.DGI, 3 * H, 3 * H, rs.GIN, H, H, gr->gru_wih, H, n, s, gr->gru_bih));
-  TRY(wgrad(ws.DGH, 3 * H, 3 * H, hs, H, H, gr->gru_whh, H, n, s, gr->gru_bhh));
-  TRY(wgrad(ws.DQ[0], H, H, hnew_all, H, H, gr->post_w[0], ldq, n, s));
-  TRY(wgrad(ws.DQ[0], H, H, enc, E, E, gr->post_w[0] ? gr->post_w[0] + H : nullptr, ldq, n, s, gr->post_b[0]));
-  TRY(wgrad(ws.DP[0], H, H, hnew_all, H, H, gr->prior_w[0], H, n, s, gr->prior_b[0]));
+  WgradGroup grp;  // every weight gradient of the sequence: one grouped launch
+  grp.add(ws.DGIN, H, H, zs, Z, Z, gr->gin_w, ldg, gr->gin_b);
+  if (C > 0) grp.add(ws.DGIN, H, H, ctx, C, C, gr->gin_w ? gr->gin_w + Z : nullptr, ldg);
+  grp.add(ws.DGI, 3 * H, 3 * H, rs.GIN, H, H, gr->gru_wih, H, gr->gru_bih);
+  grp.add(ws.DGH, 3 * H, 3 * H, hs, H, H, gr->gru_whh, H, gr->gru_bhh);
+  grp.add(ws.DQ[0], H, H, hnew_all, H, H, gr->post_w[0], ldq);
+  grp.add(ws.DQ[0], H, H, enc, E, E, gr->post_w[0] ? gr->post_w[0] + H : nullptr, ldq, gr->post_b[0]);
+  grp.add(ws.DP[0], H, H, hnew_all, H, H, gr->prior_w[0], H, gr->prior_b[0]);
   for (int k = 1; k < 3; ++k) {
-    TRY(wgrad(ws.DQ[k], H, H, rs.Q[k - 1], H, H, gr->post_w[k], H, n, s, gr->post_b[k]));
-    TRY(wgrad(ws.DP[k], H, H, rs.P[k - 1], H, H, gr->prior_w[k], H, n, s, gr->prior_b[k]));
+    grp.add(ws.DQ[k], H, H, rs.Q[k - 1], H, H, gr->post_w[k], H, gr->post_b[k]);
+    grp.add(ws.DP[k], H, H, rs.P[k - 1], H, H, gr->prior_w[k], H, gr->prior_b[k]);
   }
-  TRY(wgrad(ws.DQH, 2 * Z, 2 * Z, rs.Q[2], H, H, gr->post_hw, H, n, s, gr->post_hb));
-  TRY(wgrad(ws.DPH, 2 * Z, 2 * Z, rs.P[2], H, H, gr->prior_hw, H, n, s, gr->prior_hb));
+  grp.add(ws.DQH, 2 * Z, 2 * Z, rs.Q[2], H, H, gr->post_hw, H, gr->post_hb);
+  grp.add(ws.DPH, 2 * Z, 2 * Z, rs.P[2], H, H, gr->prior_hw, H, gr->prior_hb);
+  TRY(grp.run(n, s));
 #undef TRY
   return BLVM_OK;
 }

@@ -329,16 +329,18 @@ extern "C" int blvm_srnn_latent_bwd(const BlvmSrnnWeights* w, const float* d, co
   // batched, state-independent part
   if (d_d) TRY(gemm_f32(0, 1, (int)n, R, H, ws.DP[0], H, w->prior_w[0], ldw0, d_d, R, nullptr, 0, 0.f, nullptr, 0, 0, 1, s));
   if (d_a) TRY(gemm_f32(0, 1, (int)n, R, H, ws.DQ[0], H, w->post_w[0], ldw0, d_a, R, nullptr, 0, 0.f, nullptr, 0, 0, 1, s));
-  TRY(wgrad(ws.DP[0], H, H, d, R, R, gr->prior_w[0], ldw0, n, s));
-  TRY(wgrad(ws.DP[0], H, H, zs, Z, Z, gr->prior_w[0] ? gr->prior_w[0] + R : nullptr, ldw0, n, s, gr->prior_b[0]));
-  TRY(wgrad(ws.DQ[0], H, H, a, R, R, gr->post_w[0], ldw0, n, s));
-  TRY(wgrad(ws.DQ[0], H, H, zs, Z, Z, gr->post_w[0] ? gr->post_w[0] + R : nullptr, ldw0, n, s, gr->post_b[0]));
+  WgradGroup grp;  // every weight gradient of the sequence: one grouped launch
+  grp.add(ws.DP[0], H, H, d, R, R, gr->prior_w[0], ldw0);
+  grp.add(ws.DP[0], H, H, zs, Z, Z, gr->prior_w[0] ? gr->prior_w[0] + R : nullptr, ldw0, gr->prior_b[0]);
+  grp.add(ws.DQ[0], H, H, a, R, R, gr->post_w[0], ldw0);
+  grp.add(ws.DQ[0], H, H, zs, Z, Z, gr->post_w[0] ? gr->post_w[0] + R : nullptr, ldw0, gr->post_b[0]);
   for (int k = 1; k < 3; ++k) {
-    TRY(wgrad(ws.DP[k], H, H, rs.P[k - 1], H, H, gr->prior_w[k], H, n, s, gr->prior_b[k]));
-    TRY(wgrad(ws.DQ[k], H, H, rs.Q[k - 1], H, H, gr->post_w[k], H, n, s, gr->post_b[k]));
+    grp.add(ws.DP[k], H, H, rs.P[k - 1], H, H, gr->prior_w[k], H, gr->prior_b[k]);
+    grp.add(ws.DQ[k], H, H, rs.Q[k - 1], H, H, gr->post_w[k], H, gr->post_b[k]);
   }
-  TRY(wgrad(ws.DPH, 2 * Z, 2 * Z, rs.P[2], H, H, gr->prior_hw, H, n, s, gr->prior_hb));
-  TRY(wgrad(ws.DQH, 2 * Z, 2 * Z, rs.Q[2], H, H, gr->post_hw, H, n, s, gr->post_hb));
+  grp.add(ws.DPH, 2 * Z, 2 * Z, rs.P[2], H, H, gr->prior_hw, H, gr->prior_hb);
+  grp.add(ws.DQH, 2 * Z, 2 * Z, rs.Q[2], H, H, gr->post_hw, H, gr->post_hb);
+  TRY(grp.run(n, s));
 #undef TRY
   return BLVM_OK;
 }

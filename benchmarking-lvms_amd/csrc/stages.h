@@ -2,6 +2,7 @@
 // link, the Gaussian-heads link and the dz/KL link, plus their host-side launch helpers.  Included inside
 // `namespace blvm { namespace {` of each translation unit.
 #pragma once
+#include <vector>
 
 // ---------------------------------------------------------------------------------------------------------------
 // Launch-latency notes (measured, profiles/r01_*): a link of the chain costs the kernel boundary (~1.5 us) plus every
@@ -597,6 +598,16 @@ inline int wgrad(const float* D, int ldd, int n_out, const float* Act, int lda, 
   return gemm_f32(1, 1, n_out, k_in, (int)rows, D, ldd, Act, lda, dW, ldw, nullptr, 0, 0.f, nullptr, 0, 1,
                   pick_split(n_out, k_in, (int)rows), s, db);
 }
+
+// the weight gradients of one sequence collected and run as ONE grouped launch (gemm.hip gemm_wgrad_group); add() takes wgrad()'s
+// arguments without the row count and the stream
+struct WgradGroup {
+  std::vector<WgradJob> jobs;
+  void add(const float* D, int ldd, int n_out, const float* Act, int lda, int k_in, float* dW, int ldw, float* db = nullptr) {
+    jobs.push_back(WgradJob{D, ldd, n_out, Act, lda, k_in, dW, ldw, db});
+  }
+  int run(size_t rows, hipStream_t s) { return gemm_wgrad_group(jobs.data(), (int)jobs.size(), (int)rows, s); }
+};
 
 inline int bgrad(const float* D, int ldd, int n_out, float* db, size_t rows, hipStream_t s) {
   if (!db) return BLVM_OK;

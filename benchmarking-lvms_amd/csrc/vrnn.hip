@@ -14,6 +14,7 @@
 // first layer and of the GRU input projection before the loop; all weight gradients and d(enc) after it.
 //
 // Numerics: fp32 operands, fp32 MFMA accumulation (an exact fma chain), so a sequence is reproducible run-to-run.
+#include <vector>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -640,22 +641,28 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
       TRY(gemm_f32(0, 1, (int)nr, X, H, ws.DQ[0] + r0 * H, H, w->post_w[0] + R, R + X, d_enc + r0 * X, X, nullptr, 0, 0.f, nullptr, 0, 0, 1, st));
       TRY(gemm_f32(0, 1, (int)nr, X, 3 * R, DGI, 3 * R, w->gru_wih, X + H, d_enc + r0 * X, X, nullptr, 0, 0.f, nullptr, 0, 1, 1, st));
     }
-    TRY(wgrad(DGI, 3 * R, 3 * R, encr, X, X, gr->gru_wih, X + H, nr, st, gr->gru_bih));
-    TRY(wgrad(DGI, 3 * R, 3 * R, decr, ldd, H, gr->gru_wih ? gr->gru_wih + X : nullptr, X + H, nr, st));
-    TRY(wgrad(DGH, 3 * R, 3 * R, hpr, ldd, R, gr->gru_whh, R, nr, st, gr->gru_bhh));
-    TRY(wgrad(ws.DPHI[0] + r0 * H, H, H, z + r0 * Z, Z, Z, gr->phi_w[0], Z, nr, st, gr->phi_b[0]));
-    for (int l = 1; l < 4; ++l) {
-      TRY(wgrad(ws.DPHI[l] + r0 * H, H, H, rs.FZ[l - 1] + r0 * H, H, H, gr->phi_w[l], H, nr, st, gr->phi_b[l]));
+    // every weight gradient of the chain as ONE grouped launch (gemm.hip gemm_wgrad_group; D [rows, M] x Act [rows, N] -> dW [M, N], db [M])
+    {
+      WgradGroup grp;
+      auto job = [&](const float* D, int ldd_, int n_out, const float* Act, int lda, int k_in, float* dW, int ldw, float* db = nullptr) {
+        grp.add(D, ldd_, n_out, Act, lda, k_in, dW, ldw, db);
+      };
+      job(DGI, 3 * R, 3 * R, encr, X, X, gr->gru_wih, X + H, gr->gru_bih);
+      job(DGI, 3 * R, 3 * R, decr, ldd, H, gr->gru_wih ? gr->gru_wih + X : nullptr, X + H);
+      job(DGH, 3 * R, 3 * R, hpr, ldd, R, gr->gru_whh, R, gr->gru_bhh);
+      job(ws.DPHI[0] + r0 * H, H, H, z + r0 * Z, Z, Z, gr->phi_w[0], Z, gr->phi_b[0]);
+      for (int l = 1; l < 4; ++l) job(ws.DPHI[l] + r0 * H, H, H, rs.FZ[l - 1] + r0 * H, H, H, gr->phi_w[l], H, gr->phi_b[l]);
+      job(ws.DPH + r0 * 2 * Z, 2 * Z, 2 * Z, rs.P[2] + r0 * H, H, H, gr->prior_hw, H, gr->prior_hb);
+      job(ws.DQH + r0 * 2 * Z, 2 * Z, 2 * Z, rs.Q[2] + r0 * H, H, H, gr->post_hw, H, gr->post_hb);
+      for (int l = 2; l >= 1; --l) {
+        job(ws.DP[l] + r0 * H, H, H, rs.P[l - 1] + r0 * H, H, H, gr->prior_w[l], H, gr->prior_b[l]);
+        job(ws.DQ[l] + r0 * H, H, H, rs.Q[l - 1] + r0 * H, H, H, gr->post_w[l], H, gr->post_b[l]);
+      }
+      job(ws.DP[0] + r0 * H, H, H, hpr, ldd, R, gr->prior_w[0], R, gr->prior_b[0]);
+      job(ws.DQ[0] + r0 * H, H, H, hpr, ldd, R, gr->post_w[0], R + X);
+      job(ws.DQ[0] + r0 * H, H, H, encr, X, X, gr->post_w[0] ? gr->post_w[0] + R : nullptr, R + X, gr->post_b[0]);
+      TRY(grp.run(nr, st));
     }
-    TRY(wgrad(ws.DPH + r0 * 2 * Z, 2 * Z, 2 * Z, rs.P[2] + r0 * H, H, H, gr->prior_hw, H, nr, st, gr->prior_hb));
-    TRY(wgrad(ws.DQH + r0 * 2 * Z, 2 * Z, 2 * Z, rs.Q[2] + r0 * H, H, H, gr->post_hw, H, nr, st, gr->post_hb));
-    for (int l = 2; l >= 1; --l) {
-      TRY(wgrad(ws.DP[l] + r0 * H, H, H, rs.P[l - 1] + r0 * H, H, H, gr->prior_w[l], H, nr, st, gr->prior_b[l]));
-      TRY(wgrad(ws.DQ[l] + r0 * H, H, H, rs.Q[l - 1] + r0 * H, H, H, gr->post_w[l], H, nr, st, gr->post_b[l]));
-    }
-    TRY(wgrad(ws.DP[0] + r0 * H, H, H, hpr, ldd, R, gr->prior_w[0], R, nr, st, gr->prior_b[0]));
-    TRY(wgrad(ws.DQ[0] + r0 * H, H, H, hpr, ldd, R, gr->post_w[0], R + X, nr, st));
-    TRY(wgrad(ws.DQ[0] + r0 * H, H, H, encr, X, X, gr->post_w[0] ? gr->post_w[0] + R : nullptr, R + X, nr, st, gr->post_b[0]));
 #undef TRY
     return BLVM_OK;
   };

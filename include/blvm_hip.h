@@ -104,6 +104,14 @@ int blvm_act_bwd_f32(const float* dy, const float* y, float slope, float* dz, si
 int blvm_wgrad_f32(int N_out, int K_in, int rows, const float* D, int ldd, const float* X, int ldx, float* dW, int lddw, float* db,
                    int split_k, void* stream);
 
+/* n weight (+ bias) gradients over the SAME rows as ONE launch: job i is blvm_wgrad_f32(N_out[i], K_in[i], rows, D[i], ldd[i], X[i],
+ * ldx[i], dW[i], lddw[i], db[i]) — the layers of one MLP chain, the links of one recurrent sequence (reference: autograd's per-layer
+ * `grad_weight = dy^T x`, torch/nn/functional.linear backward, called once per nn.Linear of blvm/models/vrnn.py:60-75).  Small
+ * outputs (256 x 256) cannot fill the chip alone without a split so fine that the atomics dominate; together they share one coarse
+ * split.  dW[i] / db[i] may be NULL.  Falls back to one launch per job for bf16 operands, rows < 1024 or more than 20 jobs. */
+int blvm_wgrad_group_f32(int n, const int* N_out, const int* K_in, int rows, const float* const* D, const int* ldd, const float* const* X,
+                         const int* ldx, float* const* dW, const int* lddw, float* const* db, void* stream);
+
 /* out[n] (=|+=) sum_m X[m*ldx + n]   (bias gradients). */
 int blvm_colsum_f32(int M, int N, const float* X, int ldx, float* out, int accumulate, void* stream);
 

@@ -103,6 +103,28 @@ def test_wgrad_with_bias_gradient_in_one_launch(N, K, rows, split):
     assert rel_l2(db2, D[:, :N].double().sum(0)) < 3e-6
 
 
+@pytest.mark.parametrize("rows", [16000, 4099, 600])
+def test_wgrad_group_one_launch_equals_float64(rows):
+    """blvm_wgrad_group_f32: the weight + bias gradients of several layers over the same rows as one grouped launch (rows < 1024: the
+    per-job fallback) — every dW += D^T X, db += D.sum(0), against float64; strided operands, a job without dW, a job without db."""
+    g = torch.Generator().manual_seed(rows)
+    shapes = [(256, 256), (768, 256), (30, 30), (96, 80), (512, 200), (256, 64)]
+    jobs, want = [], []
+    for i, (N, K) in enumerate(shapes):
+        D, X = torch.randn(rows, N + 4, generator=g), torch.randn(rows, K + 8, generator=g)
+        Dd, Xd = D.to(DEV)[:, :N], X.to(DEV)[:, 4 : 4 + K]
+        dW = None if i == 3 else torch.ones(N, K, device=DEV)
+        db = None if i == 4 else torch.full((N,), 2.0, device=DEV)
+        jobs.append((Dd, Xd, dW, db))
+        want.append((D[:, :N].double().t() @ X[:, 4 : 4 + K].double() + 1, D[:, :N].double().sum(0) + 2))
+    ops.wgrad_group(jobs, rows)
+    for (Dd, Xd, dW, db), (w, b) in zip(jobs, want):
+        if dW is not None:
+            assert rel_l2(dW, w) < 3e-6
+        if db is not None:
+            assert rel_l2(db, b) < 3e-6
+
+
 def test_mlp_function_forward_backward_vs_torch():
     torch.manual_seed(3)
     lins = [torch.nn.Linear(24, 64), torch.nn.Linear(64, 64), torch.nn.Linear(64, 48)]
