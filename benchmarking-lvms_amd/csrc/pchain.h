@@ -1088,6 +1088,9 @@ inline int range_for(int tiles, int avail) { return std::max(8, std::min(avail &
 
 }  // namespace pchain
 
+// sentinel-fill `bytes` (a multiple of 4) at p (4-byte aligned) on `stream`: what hipMemsetAsync(p, 0xFF, bytes) does, as 16-byte
+// stores from 2048 workgroups (the runtime's fill kernel runs 256 workgroups: 72 us for the VRNN backward slabs of [64,16000])
+hipError_t pchain_fill_sentinel(void* p, size_t bytes, hipStream_t stream);
 // enqueue the persistent launch of a program (pchain.hip); grid = highest workgroup any descriptor names
 int pchain_launch(const pchain::Program& prog, hipStream_t stream);
 // dst = T16 copy [ceil(B/16)*16, K] of the rows of src [B, K] (row stride ld; null: zeros); rows >= B are left alone (never read).

@@ -574,6 +574,30 @@ int pchain_rows_to_t16(const float* src, int ld, int B, int K, float* dst, hipSt
   return BLVM_OK;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void fill_sentinel_kernel(unsigned* __restrict__ p, size_t n) {
+  const size_t head = std::min<size_t>(n, ((16 - (reinterpret_cast<unsigned long long>(p) & 15)) & 15) / 4);  // words in front of the first 16-byte boundary
+  uint4* const v = reinterpret_cast<uint4*>(p + head);
+  const size_t nv = (n - head) / 4;
+  const uint4 ff = make_uint4(pchain::SENTINEL, pchain::SENTINEL, pchain::SENTINEL, pchain::SENTINEL);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) v[i] = ff;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < head) p[threadIdx.x] = pchain::SENTINEL;
+    const size_t t0 = head + nv * 4;
+    if (t0 + threadIdx.x < n) p[t0 + threadIdx.x] = pchain::SENTINEL;
+  }
+}
+}  // namespace
+
+hipError_t pchain_fill_sentinel(void* p, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return hipSuccess;
+  if ((reinterpret_cast<unsigned long long>(p) & 3) != 0 || (bytes & 3) != 0) return hipMemsetAsync(p, 0xFF, bytes, stream);
+  const size_t n = bytes / 4;
+  const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>((n / 4 + 255) / 256, 2048));
+  hipLaunchKernelGGL(fill_sentinel_kernel, dim3(grid), dim3(256), 0, stream, static_cast<unsigned*>(p), n);
+  return hipGetLastError();
+}
+
 int pchain_launch(const pchain::Program& prog, hipStream_t stream) {
   BLVM_REQUIRE(prog.ndesc > 0 && prog.ndesc <= pchain::kMaxDesc && prog.S > 0 && prog.B > 0, "pchain: bad program (%d descriptors, %d steps)", prog.ndesc, prog.S);
   int grid = 0;
@@ -699,7 +723,7 @@ extern "C" int blvm_pchain_chain_probe(const float* W16, const float* bias, floa
   }
   int rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
   if (rc) return rc;
-  BLVM_HIP(hipMemsetAsync(x16 + x, 0xFF, sizeof(float) * (size_t)x * L, s));
+  BLVM_HIP(pchain_fill_sentinel(x16 + x, sizeof(float) * (size_t)x * L, s));
   return pchain_launch(bld.p, s);
 }
 

@@ -375,7 +375,7 @@ extern "C" int blvm_lstm_seq_fwd(const float* Wih, const float* Whh, const float
     SeqLstmFwd q{rs.H16, rs.WhhP, bhh, rs.XG, lens, rs.Hs, rs.Cs, out, rs.GATES, T, B, H, bf16_seq ? 1 : 0, {}};
     rc = pchain_ctl(&q.ctl.dev, &q.ctl.host, &q.ctl.epoch);
     if (rc) return rc;
-    BLVM_HIP(hipMemsetAsync(rs.H16 + xH, 0xFF, sizeof(float) * (size_t)T * xH, s));
+    BLVM_HIP(pchain_fill_sentinel(rs.H16 + xH, sizeof(float) * (size_t)T * xH, s));
     rc = pchain_rows_to_t16(rs.Hs, H, B, H, rs.H16, s);
     if (rc) return rc;
     rc = seq_lstm_fwd(q, s);
@@ -399,7 +399,7 @@ extern "C" int blvm_lstm_seq_fwd(const float* Wih, const float* Whh, const float
     d.ld[3] = H; d.n16[0] = ctH; d.i[0] = H;
     rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
     if (rc) return rc;
-    BLVM_HIP(hipMemsetAsync(rs.H16 + xH, 0xFF, sizeof(float) * (size_t)T * xH, s));
+    BLVM_HIP(pchain_fill_sentinel(rs.H16 + xH, sizeof(float) * (size_t)T * xH, s));
     rc = pchain_rows_to_t16(rs.Hs, H, B, H, rs.H16, s);
     if (rc) return rc;
     rc = pchain_launch(bld.p, s);
@@ -450,7 +450,7 @@ extern "C" int blvm_lstm_seq_bwd(const float* Wih, const float* Whh, const float
     SeqLstmBwd q{ws.DG16, ws.WhhT, d_out, rs.GATES, rs.Cs, ws.DC, ws.DG, d_h0 ? d_h0 : ws.DC, T, B, H, d_h0 ? T + 1 : T, bf16_seq ? 1 : 0, {}};
     rc = pchain_ctl(&q.ctl.dev, &q.ctl.host, &q.ctl.epoch);
     if (rc) return rc;
-    BLVM_HIP(hipMemsetAsync(ws.DG16, 0xFF, sizeof(float) * (size_t)T * x4H, s));
+    BLVM_HIP(pchain_fill_sentinel(ws.DG16, sizeof(float) * (size_t)T * x4H, s));
     rc = seq_lstm_bwd(q, s);
     if (rc) return rc;
   } else if (seq_persistent(T, B)) {
@@ -468,7 +468,7 @@ extern "C" int blvm_lstm_seq_bwd(const float* Wih, const float* Whh, const float
     d.ld[3] = 4 * H; d.n16[0] = 4 * ctH; d.n16[1] = T; d.i[0] = H;
     rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
     if (rc) return rc;
-    BLVM_HIP(hipMemsetAsync(ws.DG16, 0xFF, sizeof(float) * (size_t)T * x4H, s));
+    BLVM_HIP(pchain_fill_sentinel(ws.DG16, sizeof(float) * (size_t)T * x4H, s));
     rc = pchain_launch(bld.p, s);
     if (rc) return rc;
   } else {
@@ -534,7 +534,7 @@ extern "C" int blvm_gru_seq_fwd(const float* Wih, const float* Whh, const float*
     SeqGruFwd q{rs.H16, rs.WhhP, bhh, rs.XG, lens, rs.Hs, out, rs.RG, rs.UG, rs.NG, rs.GHN, (long)out_ts, out_ld, T, B, R, reverse ? 1 : 0, bf16_seq ? 1 : 0, {}};
     rc = pchain_ctl(&q.ctl.dev, &q.ctl.host, &q.ctl.epoch);
     if (rc) return rc;
-    BLVM_HIP(hipMemsetAsync(rs.H16 + xR, 0xFF, sizeof(float) * (size_t)T * xR, s));
+    BLVM_HIP(pchain_fill_sentinel(rs.H16 + xR, sizeof(float) * (size_t)T * xR, s));
     rc = pchain_rows_to_t16(rs.Hs, R, B, R, rs.H16, s);
     if (rc) return rc;
     rc = seq_gru_fwd(q, s);
@@ -557,7 +557,7 @@ extern "C" int blvm_gru_seq_fwd(const float* Wih, const float* Whh, const float*
     d.ld[3] = R; d.n16[0] = ctR; d.i[0] = R; d.i[1] = reverse ? 1 : 0; d.i[2] = (int)out_ts; d.i[3] = out_ld;
     rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
     if (rc) return rc;
-    BLVM_HIP(hipMemsetAsync(rs.H16 + xR, 0xFF, sizeof(float) * (size_t)T * xR, s));
+    BLVM_HIP(pchain_fill_sentinel(rs.H16 + xR, sizeof(float) * (size_t)T * xR, s));
     rc = pchain_rows_to_t16(rs.Hs, R, B, R, rs.H16, s);
     if (rc) return rc;
     rc = pchain_launch(bld.p, s);
@@ -609,7 +609,7 @@ extern "C" int blvm_gru_seq_bwd(const float* Wih, const float* Whh, const float*
                 reverse ? 1 : 0, d_h0 ? T + 1 : T, bf16_seq ? 1 : 0, {}};
     rc = pchain_ctl(&q.ctl.dev, &q.ctl.host, &q.ctl.epoch);
     if (rc) return rc;
-    BLVM_HIP(hipMemsetAsync(ws.DGH16, 0xFF, sizeof(float) * (size_t)T * x3R, s));
+    BLVM_HIP(pchain_fill_sentinel(ws.DGH16, sizeof(float) * (size_t)T * x3R, s));
     rc = seq_gru_bwd(q, s);
     if (rc) return rc;
   } else if (seq_persistent(T, B)) {
@@ -629,7 +629,7 @@ extern "C" int blvm_gru_seq_bwd(const float* Wih, const float* Whh, const float*
     d.ld[3] = 3 * R; d.n16[0] = 3 * ctR; d.n16[1] = T; d.i[0] = R; d.i[1] = reverse ? 1 : 0; d.i[2] = (int)out_ts; d.i[3] = out_ld;
     rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
     if (rc) return rc;
-    BLVM_HIP(hipMemsetAsync(ws.DGH16, 0xFF, sizeof(float) * (size_t)T * x3R, s));
+    BLVM_HIP(pchain_fill_sentinel(ws.DGH16, sizeof(float) * (size_t)T * x3R, s));
     rc = pchain_launch(bld.p, s);
     if (rc) return rc;
   } else {

@@ -292,9 +292,9 @@ extern "C" int blvm_rssm_seq_fwd(const BlvmRssmWeights* w, const float* enc, con
     rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
     if (rc) return rc;
     // sentinel-fill what the launch polls: the T16 copies, the hidden projection, the states h_1 .. h_T (the GRU link polls words)
-    BLVM_HIP(hipMemsetAsync(rs.Z16, 0xFF, (size_t)(reinterpret_cast<char*>(rs.x16_end) - reinterpret_cast<char*>(rs.Z16)), s));
-    BLVM_HIP(hipMemsetAsync(rs.GHb, 0xFF, sizeof(float) * n * 3 * H, s));
-    BLVM_HIP(hipMemsetAsync(hs + sH, 0xFF, sizeof(float) * n * H, s));
+    BLVM_HIP(pchain_fill_sentinel(rs.Z16, (size_t)(reinterpret_cast<char*>(rs.x16_end) - reinterpret_cast<char*>(rs.Z16)), s));
+    BLVM_HIP(pchain_fill_sentinel(rs.GHb, sizeof(float) * n * 3 * H, s));
+    BLVM_HIP(pchain_fill_sentinel(hs + sH, sizeof(float) * n * H, s));
     rc = pchain_rows_to_t16(zs, Z, B, Z, rs.Z16, s); if (rc) return rc;
     rc = pchain_rows_to_t16(hs, H, B, H, rs.H16, s); if (rc) return rc;
     return pchain_launch(bld.p, s);
@@ -458,7 +458,7 @@ extern "C" int blvm_rssm_seq_bwd(const BlvmRssmWeights* w, const float* enc, con
     BLVM_REQUIRE(!bld.overflow, "rssm_bwd: persistent program overflow");
     rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
     if (rc) return rc;
-    BLVM_HIP(hipMemsetAsync(ws.GA, 0xFF, (size_t)(reinterpret_cast<char*>(ws.x16_end) - reinterpret_cast<char*>(ws.GA)), s));
+    BLVM_HIP(pchain_fill_sentinel(ws.GA, (size_t)(reinterpret_cast<char*>(ws.x16_end) - reinterpret_cast<char*>(ws.GA)), s));
     TRY(pchain_launch(bld.p, s));
   }
   for (int t = T - 1; t >= 0 && !persistent; --t) {

@@ -164,7 +164,7 @@ extern "C" int blvm_srnn_latent_fwd(const BlvmSrnnWeights* w, const float* d, co
     BLVM_REQUIRE(!bld.overflow, "srnn_fwd: persistent program overflow");
     rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
     if (rc) return rc;
-    BLVM_HIP(hipMemsetAsync(rs.Z16, 0xFF, (size_t)(reinterpret_cast<char*>(rs.x16_end) - reinterpret_cast<char*>(rs.Z16)), s));
+    BLVM_HIP(pchain_fill_sentinel(rs.Z16, (size_t)(reinterpret_cast<char*>(rs.x16_end) - reinterpret_cast<char*>(rs.Z16)), s));
     rc = pchain_rows_to_t16(zs, Z, B, Z, rs.Z16, s);
     if (rc) return rc;
     return pchain_launch(bld.p, s);
@@ -287,7 +287,7 @@ extern "C" int blvm_srnn_latent_bwd(const BlvmSrnnWeights* w, const float* d, co
     BLVM_REQUIRE(!bld.overflow, "srnn_bwd: persistent program overflow");
     rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
     if (rc) return rc;
-    BLVM_HIP(hipMemsetAsync(ws.DZ0, 0xFF, (size_t)(reinterpret_cast<char*>(ws.x16_end) - reinterpret_cast<char*>(ws.DZ0)), s));
+    BLVM_HIP(pchain_fill_sentinel(ws.DZ0, (size_t)(reinterpret_cast<char*>(ws.x16_end) - reinterpret_cast<char*>(ws.DZ0)), s));
     TRY(pchain_launch(bld.p, s));
   }
   for (int t = Tp - 1; t >= 0 && !persistent; --t) {

@@ -163,7 +163,7 @@ extern "C" int blvm_srnn_generate(const BlvmSrnnDecodeWeights* w, const float* x
   rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
   if (rc) return rc;
   // sentinel-fill everything the launch polls, then the initial frame stack and states
-  BLVM_HIP(hipMemsetAsync(sc + b.X16, 0xFF, sizeof(float) * (b.ZS - b.X16), s));
+  BLVM_HIP(pchain_fill_sentinel(sc + b.X16, sizeof(float) * (b.ZS - b.X16), s));
   rc = pchain_rows_to_t16(x0, S, B, S, sc + b.X16, s); if (rc) return rc;
   rc = pchain_rows_to_t16(d0, R, B, R, sc + b.CP16, s, nCP); if (rc) return rc;
   rc = pchain_rows_to_t16(z0, Z, B, Z, sc + b.CP16 + xCP + (size_t)ctR * 256, s, nCP); if (rc) return rc;

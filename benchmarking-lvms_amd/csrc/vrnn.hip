@@ -489,9 +489,9 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
     if (rc) return rc;
     // sentinel-fill what the launch polls: the T16 copies, the hidden projection, and decin (the GRU link polls words of h)
-    BLVM_HIP(hipMemsetAsync(rs.H16, 0xFF, (size_t)(reinterpret_cast<char*>(rs.x16_end) - reinterpret_cast<char*>(rs.H16)), s));
-    BLVM_HIP(hipMemsetAsync(rs.GHb, 0xFF, sizeof(float) * n * 3 * R, s));
-    BLVM_HIP(hipMemsetAsync(decin, 0xFF, sizeof(float) * n * ldd, s));  // rows 0..T'-1; row T' only receives h_n
+    BLVM_HIP(pchain_fill_sentinel(rs.H16, (size_t)(reinterpret_cast<char*>(rs.x16_end) - reinterpret_cast<char*>(rs.H16)), s));
+    BLVM_HIP(pchain_fill_sentinel(rs.GHb, sizeof(float) * n * 3 * R, s));
+    BLVM_HIP(pchain_fill_sentinel(decin, sizeof(float) * n * ldd, s));  // rows 0..T'-1; row T' only receives h_n
     if (h0) BLVM_HIP(hipMemcpy2DAsync(decin + H, sizeof(float) * ldd, h0, sizeof(float) * R, sizeof(float) * R, B, hipMemcpyDeviceToDevice, s));
     else BLVM_HIP(hipMemset2DAsync(decin + H, sizeof(float) * ldd, 0, sizeof(float) * R, B, s));
     rc = pchain_rows_to_t16(h0, R, B, R, rs.H16, s);
@@ -793,7 +793,7 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
     if (rc) return rc;
     // sentinel-fill what the launch polls: GA, GB (single words) and the T16 copies
-    BLVM_HIP(hipMemsetAsync(ws.GA, 0xFF, (size_t)(reinterpret_cast<char*>(ws.x16_end) - reinterpret_cast<char*>(ws.GA)), s));
+    BLVM_HIP(pchain_fill_sentinel(ws.GA, (size_t)(reinterpret_cast<char*>(ws.x16_end) - reinterpret_cast<char*>(ws.GA)), s));
     // The batched GEMMs of the steps the chain has passed can run UNDER the rest of the chain (which keeps a quarter of the chip
     // busy): the sequence is cut into `parts` launches, after each the finished rows go to a low-priority side stream.
     const int parts = std::max(1, std::min(pchain_wgrad_parts(), T / 8));

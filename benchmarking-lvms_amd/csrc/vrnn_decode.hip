@@ -654,7 +654,7 @@ extern "C" int blvm_vrnn_generate(const BlvmVrnnDecodeWeights* w, const float* x
   rc = pchain_ctl(&bld.p.ctl.dev, &bld.p.ctl.host, &bld.p.ctl.epoch);
   if (rc) return rc;
   // sentinel-fill everything the launch polls (all step slabs), then the initial frame stack and state
-  BLVM_HIP(hipMemsetAsync(sc + b.X16, 0xFF, sizeof(float) * (b.dummyZ - b.X16), s));
+  BLVM_HIP(pchain_fill_sentinel(sc + b.X16, sizeof(float) * (b.dummyZ - b.X16), s));
   rc = pchain_rows_to_t16(x0, S, B, S, sc + b.X16, s); if (rc) return rc;
   rc = pchain_rows_to_t16(h0, R, B, R, sc + b.H16, s); if (rc) return rc;
   if (h0) BLVM_HIP(hipMemcpyAsync(sc + b.HS, h0, sizeof(float) * (size_t)B * R, hipMemcpyDeviceToDevice, s));
