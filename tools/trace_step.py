@@ -1,6 +1,6 @@
 """Diagnostic: the kernel sequence of the LAST train step in a rocprofv3 kernel trace (csv): start offset, duration, gap to the
-previous kernel's end, grid, name.  usage: python tools/trace_step.py trace.csv [anchor-substring] (default anchor: the step's first
-pchain_kernel)"""
+previous kernel's end, grid, name.  usage: python tools/trace_step.py trace.csv [anchor-substring] (default anchor: pchain_kernel = the last
+two chain launches to the end; an explicit anchor must occur once per step: one period between its last two occurrences)"""
 import csv
 import sys
 
@@ -9,6 +9,10 @@ anchor = sys.argv[2] if len(sys.argv) > 2 else "pchain_kernel"
 idx = [i for i, r in enumerate(rows) if anchor in r["Kernel_Name"]]
 # the last step starts at the second-to-last anchor launch (forward chain), give or take the kernels in front of it
 start = idx[-2] if len(idx) >= 2 else 0
+stop = len(rows)
+if len(sys.argv) > 2 and len(idx) >= 2:  # an explicit anchor that occurs ONCE per step: exactly one period
+    stop = idx[-1]
+rows = rows[:stop]
 prev_end = int(rows[start]["Start_Timestamp"])
 t0 = prev_end
 busy = 0
