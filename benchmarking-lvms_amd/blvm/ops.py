@@ -547,6 +547,7 @@ class _VRNNSeqFunction(torch.autograd.Function):
         ctx.has_h0 = h0 is not None
         ctx.save_for_backward(enc, eps, x_sl_dev, decin, mu_q, sd_q, mu_p, sd_p, z, reserve, *params)
         ctx.mark_non_differentiable(mu_q, sd_q, mu_p, sd_p, z)
+        ctx.set_materialize_grads(False)  # (else autograd fills a [T',B,Z] zero gradient per statistics output: 16 MB each at [64,16000])
         return decin, kld, kld_fn, mu_q, sd_q, mu_p, sd_p, z
 
     @staticmethod
@@ -779,6 +780,7 @@ class _SRNNLatentFunction(torch.autograd.Function):
         ctx.has_z0 = z0 is not None
         ctx.save_for_backward(d, a, eps, x_sl_dev, zs, mu_q, sd_q, mu_p, sd_p, reserve, *params)
         ctx.mark_non_differentiable(mu_q, sd_q, mu_p, sd_p)
+        ctx.set_materialize_grads(False)  # (else autograd fills a [T',B,Z] zero gradient per statistics output: 16 MB each at [64,16000])
         return zs, kld, kld_fn, mu_q, sd_q, mu_p, sd_p
 
     @staticmethod
@@ -1059,6 +1061,7 @@ class _RSSMSeqFunction(torch.autograd.Function):
         ctx_.n_fixed = len(saved)
         ctx_.save_for_backward(*saved, *params)
         ctx_.mark_non_differentiable(mu_q, sd_q, mu_p, sd_p)
+        ctx_.set_materialize_grads(False)  # (else autograd fills a [T',B,Z] zero gradient per statistics output: 16 MB each at [64,16000])
         return zs, hs, kld, kld_fn, mu_q, sd_q, mu_p, sd_p
 
     @staticmethod
