@@ -85,8 +85,8 @@ def pmc_traffic(model, B, T):
 def pmc_mfma(model, B, T, dtype):
     """Matrix-pipe utilisation of the recurrent cell's kernels from the committed rocprofv3 counter pass over this same command
     (tools/probe_pmc_mfma.sh: SQ_VALU_MFMA_BUSY_CYCLES over 4 SIMDs x 256 CUs x duration x effective clock, tools/pmc_mfma_summary.py):
-    the persistent chain kernel, the batched weight-gradient GEMM, and their duration-weighted mean (what `roofline.frac` estimates
-    from time alone).  Counters cannot be read inside the timed process: valid for the workload the pass was taken on only."""
+    the persistent chain kernel, the grouped weight-gradient launches of the step (`gemm_group_kernel`: the chain's and the encoder /
+    decoder MLPs'), and their duration-weighted mean (what `roofline.frac` estimates from time alone).  Counters cannot be read inside the timed process: valid for the workload the pass was taken on only."""
     import glob
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_vrnn_pmc_mfma_v*.json")))

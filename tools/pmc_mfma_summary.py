@@ -38,7 +38,7 @@ def main():
         row = [k[:120], n / steps, sec * 1e3 / steps, clock * 1e-9, busy, c.get("SQ_WAIT_ANY", 0) / wc, c.get("SQ_WAIT_INST_ANY", 0) / wc,
                c.get("SQ_ACTIVE_INST_ANY", 0) / wc] + [c.get(x, 0.0) / steps for x in cols]  # fmt: skip
         out.writerow([f"{v:.4g}" if isinstance(v, float) else v for v in row])
-        for tag, pat in (("pchain", "pchain_kernel"), ("wgrad_gemm", "gemm_kernel<64, 64, 1, 1")):
+        for tag, pat in (("pchain", "pchain_kernel"), ("wgrad_gemm", "gemm_group_kernel")):
             if pat in k and tag not in summary:
                 summary[tag] = dict(kernel=k[:160], dispatches_per_step=n / steps, ms_per_step=sec * 1e3 / steps, clock_GHz=clock * 1e-9, mfma_busy=busy,
                                     parked=c.get("SQ_WAIT_ANY", 0) / wc, issue_stalled=c.get("SQ_WAIT_INST_ANY", 0) / wc, issuing=c.get("SQ_ACTIVE_INST_ANY", 0) / wc)  # fmt: skip

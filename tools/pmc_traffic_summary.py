@@ -31,7 +31,7 @@ d = {
               "--warmup 1 --no-cpu-baseline --no-sweep; 3 steps averaged; FETCH_SIZE doubled per MI355X_MICROARCH.md; " + (sys.argv[4] if len(sys.argv) > 4 else ""),
     "cell_stage_kernels_read_bytes_per_step": 2 * total(fetch, "pchain_kernel"),
     "cell_stage_kernels_write_bytes_per_step": total(write, "pchain_kernel"),
-    "wgrad_gemm_read_bytes_per_step": 2 * total(fetch, "gemm_kernel<64, 64, 1, 1>"),
+    "wgrad_gemm_read_bytes_per_step": 2 * total(fetch, "gemm_group_kernel"),  # the grouped weight-gradient launches (chain + encoder / decoder MLPs)
     "all_kernels_read_bytes_per_step": 2 * total(fetch),
     "all_kernels_write_bytes_per_step": total(write),
 }
