@@ -301,7 +301,7 @@ extern "C" int blvm_async_errors_take(unsigned* last_code) {
   return (int)fresh;
 }
 
-extern "C" int blvm_version(void) { return 120; /* 0.1.2 */ }
+extern "C" int blvm_version(void) { return 130; /* 0.1.3: blvm_wgrad_group_f32 */ }
 
 extern "C" const char* blvm_last_error(void) { return blvm::g_err; }
 
