@@ -20,6 +20,12 @@ namespace blvm {
 
 namespace {
 
+// LDS operand reads of the NEXT k-pair issued in front of the current pair's MFMAs (2 = pinned with sched_group_barrier: without the
+// pins the compiler sinks the reads back next to their use; 0 = the plain loop).  Measured r03: VRNN 15.23 -> 15.18, STCN 32.93 -> 32.51,
+// CW-VAE 86.3 -> 85.9 ms/step; the weight-gradient forms +3..4 %, the K = 256 forward forms -1 %.
+#ifndef BLVM_GEMM_PIPE
+#define BLVM_GEMM_PIPE 2
+#endif
 #ifndef BLVM_GEMM_BK
 #define BLVM_GEMM_BK 16
 #endif
@@ -162,6 +168,31 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
 #pragma unroll
       for (int kk = 0; kk < BK / CS; ++kk) csum += As[(kk * CS + tid / BM) * LDA_S + tid % BM];
     }
+#if BLVM_GEMM_PIPE
+    // the operands of k-pair s + 1 are requested from LDS BEFORE the MFMAs of k-pair s are issued (two register sets): the LDS
+    // round trip hides behind TM x TN matrix instructions instead of standing in front of them
+    float a[2][TM], b[2][TN];
+    auto lds_ab = [&](int kk, float (&a_)[TM], float (&b_)[TN]) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a_[i] = As[(kk + lh) * LDA_S + wm * (BM / 2) + i * 32 + li];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b_[j] = Bs[(kk + lh) * LDB_S + wn * (BN / 2) + j * 32 + li];
+    };
+    lds_ab(0, a[0], b[0]);
+#pragma unroll
+    for (int st = 0; st < BK / 2; ++st) {
+      if (st + 1 < BK / 2) lds_ab(2 * (st + 1), a[(st + 1) & 1], b[(st + 1) & 1]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][i], b[st & 1][j], acc[i][j], 0, 0, 0);
+#if BLVM_GEMM_PIPE >= 2
+      __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);   // the DS reads of the next pair first ...
+      __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);   // ... then this pair's MFMAs
+#endif
+    }
+#else
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       float a[TM], b[TN];
@@ -175,6 +206,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+#endif
   }
 
   if (do_csum && tid / BM < CS && m0 + tid % BM < g.M) atomicAdd(g.colsum + m0 + tid % BM, csum);
