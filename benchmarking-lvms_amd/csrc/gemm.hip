@@ -29,8 +29,8 @@ namespace {
 #ifndef BLVM_GEMM_BK
 #define BLVM_GEMM_BK 16
 #endif
-constexpr int BK = BLVM_GEMM_BK;
-constexpr int KV = BK / 4;  // 16-byte vectors per tile row along k
+constexpr int BK = BLVM_GEMM_BK;  // k-tile depth of the 128-wide tiles (and the unit of the host's split arithmetic)
+constexpr int tile_bk(int bm, int bn) { return (bm == 64 && bn == 64) ? 2 * BK : BK; }
 constexpr int PAD = 4;
 
 struct GemmArgs {
@@ -65,6 +65,10 @@ __device__ __forceinline__ float4 ld4(const float* p, int n_valid, bool vec) {
 // one BM x BN output tile over the k range of split `bz` of `nz` (the body of gemm_kernel and of gemm_group_kernel)
 template <int BM, int BN, int OPA, int OPB>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, const int bz, const int nz) {
+  // k-tile depth by tile size: 64 x 64 tiles (8 MFMAs per wave and 16 k, 49 VGPRs at depth 32: still 7 waves per SIMD) run 32 deep --
+  // half the barriers per MFMA: weight-gradient forms +4..5 %, WaveNet's K = 96 convs +4 %; the 128-wide tiles would drop from 3 to
+  // 2 waves per SIMD at depth 32 (dec L3 forward 195 -> 218 us) and stay at 16.
+  constexpr int BK = tile_bk(BM, BN), KV = BK / 4;
   constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD;
   constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave in m / n
   constexpr int A_V = BM * BK / 4 / 256;     // float4 per thread per stage
@@ -517,7 +521,7 @@ int gemm_f32(int op_a, int op_b, int M, int N, int K, const float* A, int lda, c
   const int bm = big ? (m192 ? 192 : 128) : 64;
   const int bn = big ? (n192 ? 192 : 128) : 64;
   const bool bf16 = operand_bf16();
-  const int bk = bf16 ? BKB : BK;
+  const int bk = bf16 ? BKB : tile_bk(bm, bn);
   if (colsum != nullptr && (bf16 || op_a != 1 || K == 0)) {  // (the bf16 kernel stages ROUNDED operands: the bias gradient stays an fp32 sum)
     const int rc = op_a == 1 ? colsum_f32(K, M, A, lda, colsum, 1, stream) : BLVM_EINVAL;
     if (rc) return rc;
@@ -578,11 +582,12 @@ int gemm_wgrad_group(const WgradJob* jobs, int njobs, int K, hipStream_t stream)
     ++gg.n;
   }
   // ~6 workgroups per CU, k ranges of at least 32 stages
-  const int ksteps = (K + BK - 1) / BK;
+  constexpr int GBK = tile_bk(64, 64);
+  const int ksteps = (K + GBK - 1) / GBK;
   static const int want = [] { const char* e = getenv("BLVM_WGRAD_GROUP_WGS"); return e ? atoi(e) : 1536; }();
   int split = (int)((want + tiles - 1) / tiles);
-  split = std::max(1, std::min(split, ksteps / 32));
-  const int k_per_split = ((ksteps + split - 1) / split) * BK;
+  split = std::max(1, std::min(split, ksteps / 16));  // k ranges of at least 16 stages (512 rows)
+  const int k_per_split = ((ksteps + split - 1) / split) * GBK;
   split = (K + k_per_split - 1) / k_per_split;
   gg.split = split;
   int first = 0;
