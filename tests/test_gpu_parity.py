@@ -103,6 +103,15 @@ def test_wgrad_with_bias_gradient_in_one_launch(N, K, rows, split):
     assert rel_l2(db2, D[:, :N].double().sum(0)) < 3e-6
 
 
+def test_stream_ptr_is_torchs_current_stream():
+    """`_hip.stream_ptr()` (raw accessor) names the stream torch would launch on, also inside a `torch.cuda.stream(...)` scope."""
+    assert _hip.stream_ptr() == torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        assert _hip.stream_ptr() == side.cuda_stream
+    assert _hip.stream_ptr() == torch.cuda.current_stream().cuda_stream
+
+
 @pytest.mark.parametrize("rows", [16000, 4099, 600])
 def test_wgrad_group_one_launch_equals_float64(rows):
     """blvm_wgrad_group_f32: the weight + bias gradients of several layers over the same rows as one grouped launch (rows < 1024: the
