@@ -36,6 +36,10 @@ constexpr int BK = BLVM_GEMM_BK;  // k-tile depth of the 128-wide tiles (and the
 constexpr int tile_bk(int bm, int bn) { return (bm == 64 && bn == 64) ? BLVM_GEMM_BK64 : BK; }
 
 constexpr int PAD = 4;
+#ifndef BLVM_GEMM_PAD_T
+#define BLVM_GEMM_PAD_T 2
+#endif
+constexpr int PAD_T = BLVM_GEMM_PAD_T;
 
 struct GemmArgs {
   const float* A;
@@ -73,7 +77,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
   // half the barriers per MFMA: weight-gradient forms +4..5 %, WaveNet's K = 96 convs +4 %; the 128-wide tiles would drop from 3 to
   // 2 waves per SIMD at depth 32 (dec L3 forward 195 -> 218 us) and stay at 16.
   constexpr int BK = tile_bk(BM, BN), KV = BK / 4;
-  constexpr int LDA_S = BM + PAD, LDB_S = BN + PAD;
+  // row pad of the k-major LDS tiles: 4 floats keep the 16-byte stores of an OP == 1 operand aligned; an OP == 0 operand is written
+  // by scalar stores whose lanes are 4 k apart (4 rows): with a pad of 2, 4 rows are 8 banks apart and the 32 lanes of a store hit
+  // 32 banks (pad 4: 16 banks twice -- SQ_LDS_BANK_CONFLICT was 70 % of the kernel's LDS cycles)
+  // (32-deep tiles: 8 lanes per row, a pad of 1 puts 4 rows 4 banks apart)
+  constexpr int PT = BLVM_GEMM_PAD_T >= 0 ? (BK == 32 ? (PAD_T + 1) / 2 : PAD_T) : PAD;
+  constexpr int LDA_S = BM + (OPA == 0 ? PT : PAD), LDB_S = BN + (OPB == 0 ? PT : PAD);
   constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave in m / n
   constexpr int A_V = BM * BK / 4 / 256;     // float4 per thread per stage
   constexpr int B_V = BN * BK / 4 / 256;
