@@ -1065,10 +1065,14 @@ struct SeqLink {
   int ldo;
   float* o16;
 };
+// K0 / add0: the FIRST link may have its own K (its operand A16 is then [rows, K0]) and a row-major addend [B, ldadd0] stepping by
+// add0_step -- the link in front of a run of same-shape links joins the run's visit (one descriptor walk less per step, ~1 us)
 inline Desc& add_linseq(Builder& b, int ct, int wg0, int nwg, int K, bool relu, bool gated, int s_begin, int s_end, const float* A16, long a_step, int n,
-                        const SeqLink* L, long aux_step, long o16_step, int n16, float slope, int ldgate) {
+                        const SeqLink* L, long aux_step, long o16_step, int n16, float slope, int ldgate, int K0 = 0, const float* add0 = nullptr,
+                        long add0_step = 0, int ldadd0 = 0) {
   Desc& d = b.add(K_LINSEQ, ct, wg0, nwg, K, (relu ? DF_RELU : 0) | (gated ? DF_SEQ_GATE : 0), s_begin, s_end);
-  b.ptr(d, 0, A16, a_step);
+  b.ptr(d, 0, A16, a_step); b.ptr(d, 17, add0, add0_step);
+  d.i[3] = (K0 != 0 && K0 != K) ? K0 : 0; d.i[0] = ldadd0;
   for (int i = 0; i < n && i < 4; ++i) {
     b.ptr(d, 1 + i, L[i].W); b.ptr(d, 5 + i, L[i].aux, gated ? aux_step : 0); b.ptr(d, 9 + i, L[i].orm, L[i].rm_step); b.ptr(d, 13 + i, L[i].o16, o16_step);
     d.ld[i] = L[i].ldo;
@@ -1078,6 +1082,11 @@ inline Desc& add_linseq(Builder& b, int ct, int wg0, int nwg, int K, bool relu, 
   return d;
 }
 // env BLVM_PCHAIN_LINSEQ=0: one descriptor per link (A/B switch)
+// env BLVM_PCHAIN_MERGE=0: the link in front of a run keeps its own descriptor (A/B switch)
+inline bool merge_first_enabled() {
+  static const int v = [] { const char* e = getenv("BLVM_PCHAIN_MERGE"); return e ? atoi(e) : 1; }();
+  return v != 0;
+}
 inline bool linseq_enabled() {
   static const int v = [] { const char* e = getenv("BLVM_PCHAIN_LINSEQ"); return e ? atoi(e) : 1; }();
   return v != 0;

@@ -250,21 +250,27 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_kernel(const int* __restric
             const int n = d.w<RD_I + 1>();
             const bool gated = (flags & DF_SEQ_GATE) != 0;
             const float* A = d.p<0>(s);
+            const int K0 = d.w<RD_I + 3>();  // the FIRST link's K when it is not the run's (0: it is): the link in front of a run joins its visit
             for (int lq = 0; lq < n; ++lq) {  // (links outside, tiles inside: link li+1 of any tile needs link li of ALL tiles of its row tile)
               int li = lq;
               asm volatile("" : "+s"(li));  // opaque: the five lane indices below are li + constant where they are used, not five more loop counters in SGPRs
               pl.code = ((unsigned)s << 4) | (unsigned)i | ((unsigned)li << 28);
               const float* W = d.basedyn(1 + li);
+              const int Kl = (li == 0 && K0 != 0) ? K0 : K;
               auto late = [&]() {
                 __builtin_amdgcn_sched_barrier(0);
                 if (li == 0) nx.fetch(ltab, nx_i, nx_s);  // the next descriptor, once per visit, behind the first link's operand loads (every tile of it: the same lanes again)
                 const float* aux = d.pdyn(5 + li);  // bias (stride 0: the stepped pointer IS the base) | gate (stepped)
-                return LinLate{gated ? nullptr : aux, nullptr, gated ? aux : nullptr, 0, d.w<RD_I + 2>(), false, (flags & DF_RELU) != 0, d.f<0>(),
+                const float* add0 = li == 0 ? d.p<17>(s) : nullptr;  // the first link's row-major addend [B, i[0]] (null: none)
+                return LinLate{gated ? nullptr : aux, add0, gated ? aux : nullptr, d.w<RD_I + 0>(), d.w<RD_I + 2>(), false, (flags & DF_RELU) != 0, d.f<0>(),
                                Out{const_cast<float*>(d.pdyn(9 + li)), d.wdyn(RD_LD + li), false, const_cast<float*>(d.pdyn(13 + li)), d.w<RD_N16>()}};
               };
-              for (int tk = 0; tk < nt; ++tk) {  // (a run's links are plain: a partial-sum operand or a K-range is a K_LIN in front of the run)
+              // (a run's links are plain: a partial-sum operand or a K-range is a K_LIN in front of the run.  The summing link as a run's first
+              // link was built and measured, r03: the three-slab product inlined at this call site costs the WHOLE kernel +0.4 ms per
+              // VRNN step, used or not, and saves 0.08)
+              for (int tk = 0; tk < nt; ++tk) {
                 const int trc = d.tile(tk), tr0 = trc & 0xffff, tc0 = (trc >> 16) * 16;
-                tile_lin_late<NW, BF>(A, 0, true, W, K, late, tr0, tc0, B, red(), pl);
+                tile_lin_late<NW, BF>(A, 0, true, W, Kl, late, tr0, tc0, B, red(), pl);
               }
               A = d.pdyn(13 + li);  // the next link multiplies what this one stored
             }

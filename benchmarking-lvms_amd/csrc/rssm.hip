@@ -267,9 +267,18 @@ extern "C" int blvm_rssm_seq_fwd(const BlvmRssmWeights* w, const float* enc, con
       d.ld[0] = H; d.ld[3] = H; d.n16[0] = ctH; d.i[0] = H;
     }
     // L3..L5: posterior | prior MLPs on h_t
+    const bool merge1 = linseq_enabled() && merge_first_enabled();  // (the first layer opens the run: one visit per branch and step)
+    if (merge1) {
+      const SeqLink lq[3] = {{rs.Wq[0], nullptr, rs.Q[0], sH, H, rs.Q16[0]}, {rs.Wq[1], w->post_b[1], rs.Q[1], sH, H, rs.Q16[1]}, {rs.Wq[2], w->post_b[2], rs.Q[2], sH, H, rs.Q16[2]}};
+      const SeqLink lp[3] = {{rs.Wp[0], w->prior_b[0], rs.P[0], sH, H, rs.P16[0]}, {rs.Wp[1], w->prior_b[1], rs.P[1], sH, H, rs.P16[1]}, {rs.Wp[2], w->prior_b[2], rs.P[2], sH, H, rs.P16[2]}};
+      add_linseq(bld, ctH, 0, r_h, H, true, false, 0, T, rs.H16 + xH, xH, 3, lq, 0, xH, ctH, 0.f, 0, 0, rs.XQ, sH, H);
+      add_linseq(bld, ctH, r_h, r_h, H, true, false, 0, T, rs.H16 + xH, xH, 3, lp, 0, xH, ctH, 0.f, 0);
+    } else {
     lin(rs.H16 + xH, xH, rs.Wq[0], H, nullptr, rs.XQ, sH, rs.Q[0], sH, H, false, rs.Q16[0], xH, ctH, 0, r_h, DF_RELU);
     lin(rs.H16 + xH, xH, rs.Wp[0], H, w->prior_b[0], nullptr, 0, rs.P[0], sH, H, false, rs.P16[0], xH, ctH, r_h, r_h, DF_RELU);
-    if (linseq_enabled()) {  // layers 2, 3 of the posterior | prior MLP: one visit each (K_LINSEQ)
+    }
+    if (merge1) {
+    } else if (linseq_enabled()) {  // layers 2, 3 of the posterior | prior MLP: one visit each (K_LINSEQ)
       const SeqLink lq[2] = {{rs.Wq[1], w->post_b[1], rs.Q[1], sH, H, rs.Q16[1]}, {rs.Wq[2], w->post_b[2], rs.Q[2], sH, H, rs.Q16[2]}};
       const SeqLink lp[2] = {{rs.Wp[1], w->prior_b[1], rs.P[1], sH, H, rs.P16[1]}, {rs.Wp[2], w->prior_b[2], rs.P[2], sH, H, rs.P16[2]}};
       add_linseq(bld, ctH, 0, r_h, H, true, false, 0, T, rs.Q16[0], xH, 2, lq, 0, xH, ctH, 0.f, 0);
@@ -420,12 +429,25 @@ extern "C" int blvm_rssm_seq_bwd(const BlvmRssmWeights* w, const float* enc, con
       d.f[0] = fn_floor; d.f[1] = beta; d.f[2] = sd_eps; d.f[3] = 1.f;
     }
     // B2: heads -> third layers (posterior | prior) | GB[t] = GA[t+1] + DGH[t+1] W_hh
+    const bool merge1 = linseq_enabled() && merge_first_enabled();
+    auto atm = [&](float* base, long step, int t0) { return base ? base + (long)t0 * step : nullptr; };
+    if (merge1) {  // B2 .. B4 of a branch: one visit
+      const SeqLink lq[3] = {{ws.qhT, at(rs.Q[2], sH, T - 1), atm(ws.DQ[2], sH, T - 1), -sH, H, atm(ws.DQ16[2], xH, T - 1)},
+                             {ws.qT[2], at(rs.Q[1], sH, T - 1), atm(ws.DQ[1], sH, T - 1), -sH, H, atm(ws.DQ16[1], xH, T - 1)},
+                             {ws.qT[1], at(rs.Q[0], sH, T - 1), atm(ws.DQ[0], sH, T - 1), -sH, H, atm(ws.DQ16[0], xH, T - 1)}};
+      const SeqLink lp[3] = {{ws.phT, at(rs.P[2], sH, T - 1), atm(ws.DP[2], sH, T - 1), -sH, H, atm(ws.DP16[2], xH, T - 1)},
+                             {ws.pT[2], at(rs.P[1], sH, T - 1), atm(ws.DP[1], sH, T - 1), -sH, H, atm(ws.DP16[1], xH, T - 1)},
+                             {ws.pT[1], at(rs.P[0], sH, T - 1), atm(ws.DP[0], sH, T - 1), -sH, H, atm(ws.DP16[0], xH, T - 1)}};
+      add_linseq(bld, ctH, 0, r_h, H, false, true, 0, T, at(ws.DQH16, x2Z, T - 1), -x2Z, 3, lq, -sH, -xH, ctH, 0.f, H, 2 * Z);
+      add_linseq(bld, ctH, r_h, r_h, H, false, true, 0, T, at(ws.DPH16, x2Z, T - 1), -x2Z, 3, lp, -sH, -xH, ctH, 0.f, H, 2 * Z);
+    } else {
     lin(ws.DQH16, x2Z, T - 1, ws.qhT, 2 * Z, nullptr, 0, 0, 0, false, rs.Q[2], sH, ws.DQ[2], sH, H, false, ws.DQ16[2], xH, ctH, ctH, 0, r_h, 0, 0, T);
     lin(ws.DPH16, x2Z, T - 1, ws.phT, 2 * Z, nullptr, 0, 0, 0, false, rs.P[2], sH, ws.DP[2], sH, H, false, ws.DP16[2], xH, ctH, ctH, r_h, r_h, 0, 0, T);
+    }
     lin(ws.DGH16, x3H, T, ws.whhT, 3 * H, ws.GA, sH, T, H, true, nullptr, 0, ws.GB, sH, H, true, nullptr, 0, 0, ctH, 2 * r_h, r_gb, DF_GENTLE, 1, T);
     // B3, B4
-    if (linseq_enabled()) {  // one visit per branch (K_LINSEQ)
-      auto atm = [&](float* base, long step, int t0) { return base ? base + (long)t0 * step : nullptr; };
+    if (merge1) {
+    } else if (linseq_enabled()) {  // one visit per branch (K_LINSEQ)
       const SeqLink lq[2] = {{ws.qT[2], at(rs.Q[1], sH, T - 1), atm(ws.DQ[1], sH, T - 1), -sH, H, atm(ws.DQ16[1], xH, T - 1)},
                              {ws.qT[1], at(rs.Q[0], sH, T - 1), atm(ws.DQ[0], sH, T - 1), -sH, H, atm(ws.DQ16[0], xH, T - 1)}};
       const SeqLink lp[2] = {{ws.pT[2], at(rs.P[1], sH, T - 1), atm(ws.DP[1], sH, T - 1), -sH, H, atm(ws.DP16[1], xH, T - 1)},

@@ -140,9 +140,18 @@ extern "C" int blvm_srnn_latent_fwd(const BlvmSrnnWeights* w, const float* d, co
       bld.ptr(d, 0, A16, a_step); bld.ptr(d, 1, W); bld.ptr(d, 2, bias); bld.ptr(d, 3, add, sH); bld.ptr(d, 5, orm, sH); bld.ptr(d, 6, o16, xH);
       d.ld[1] = H; d.ld[3] = H; d.n16[0] = ctH; d.f[0] = slope;
     };
+    const bool merge1 = linseq_enabled() && merge_first_enabled();  // (the first layer opens the run: one visit per chain and step)
+    if (merge1) {
+      const SeqLink lp[3] = {{rs.Wp[0], nullptr, rs.P[0], sH, H, rs.P16[0]}, {rs.Wp[1], w->prior_b[1], rs.P[1], sH, H, rs.P16[1]}, {rs.Wp[2], w->prior_b[2], rs.P[2], sH, H, rs.P16[2]}};
+      const SeqLink lq[3] = {{rs.Wq[0], nullptr, rs.Q[0], sH, H, rs.Q16[0]}, {rs.Wq[1], w->post_b[1], rs.Q[1], sH, H, rs.Q16[1]}, {rs.Wq[2], w->post_b[2], rs.Q[2], sH, H, rs.Q16[2]}};
+      add_linseq(bld, ctH, 0, half, H, true, false, 0, Tp, rs.Z16, xZ, 3, lp, 0, xH, ctH, slope, 0, Z, rs.XP, sH, H);
+      add_linseq(bld, ctH, half, half, H, true, false, 0, Tp, rs.Z16, xZ, 3, lq, 0, xH, ctH, slope, 0, Z, rs.XQ, sH, H);
+    } else {
     lin(rs.Z16, xZ, rs.Wp[0], Z, nullptr, rs.XP, rs.P[0], rs.P16[0], 0);
     lin(rs.Z16, xZ, rs.Wq[0], Z, nullptr, rs.XQ, rs.Q[0], rs.Q16[0], half);
-    if (linseq_enabled()) {  // layers 2, 3 of the prior | posterior MLP: one visit each
+    }
+    if (merge1) {
+    } else if (linseq_enabled()) {  // layers 2, 3 of the prior | posterior MLP: one visit each
       const SeqLink lp[2] = {{rs.Wp[1], w->prior_b[1], rs.P[1], sH, H, rs.P16[1]}, {rs.Wp[2], w->prior_b[2], rs.P[2], sH, H, rs.P16[2]}};
       const SeqLink lq[2] = {{rs.Wq[1], w->post_b[1], rs.Q[1], sH, H, rs.Q16[1]}, {rs.Wq[2], w->post_b[2], rs.Q[2], sH, H, rs.Q16[2]}};
       add_linseq(bld, ctH, 0, half, H, true, false, 0, Tp, rs.P16[0], xH, 2, lp, 0, xH, ctH, slope, 0);
@@ -259,10 +268,23 @@ extern "C" int blvm_srnn_latent_bwd(const BlvmSrnnWeights* w, const float* d, co
       d.ld[2] = H; d.ld[3] = H; d.n16[0] = ctH; d.f[0] = slope;
     };
     // B2: heads -> third layers;  B3, B4: down to the first layers (LeakyReLU derivatives fused)
+    const bool merge1 = linseq_enabled() && merge_first_enabled();
+    auto atm = [&](float* base, long step, int t0) { return base ? base + (long)t0 * step : nullptr; };
+    if (merge1) {  // B2 .. B4 of a chain: one visit
+      const SeqLink lp[3] = {{ws.phT, at(rs.P[2], sH, T - 1), atm(ws.DP[2], sH, T - 1), -sH, H, atm(ws.DP16[2], xH, T - 1)},
+                             {ws.pT[2], at(rs.P[1], sH, T - 1), atm(ws.DP[1], sH, T - 1), -sH, H, atm(ws.DP16[1], xH, T - 1)},
+                             {ws.pT[1], at(rs.P[0], sH, T - 1), atm(ws.DP[0], sH, T - 1), -sH, H, atm(ws.DP16[0], xH, T - 1)}};
+      const SeqLink lq[3] = {{ws.qhT, at(rs.Q[2], sH, T - 1), atm(ws.DQ[2], sH, T - 1), -sH, H, atm(ws.DQ16[2], xH, T - 1)},
+                             {ws.qT[2], at(rs.Q[1], sH, T - 1), atm(ws.DQ[1], sH, T - 1), -sH, H, atm(ws.DQ16[1], xH, T - 1)},
+                             {ws.qT[1], at(rs.Q[0], sH, T - 1), atm(ws.DQ[0], sH, T - 1), -sH, H, atm(ws.DQ16[0], xH, T - 1)}};
+      add_linseq(bld, ctH, 0, half, H, false, true, 0, T, at(ws.DPH16, x2Z, T - 1), -x2Z, 3, lp, -sH, -xH, ctH, slope, H, 2 * Z);
+      add_linseq(bld, ctH, half, half, H, false, true, 0, T, at(ws.DQH16, x2Z, T - 1), -x2Z, 3, lq, -sH, -xH, ctH, slope, H, 2 * Z);
+    } else {
     lin(ws.DPH16, x2Z, ws.phT, 2 * Z, rs.P[2], ws.DP[2], ws.DP16[2], 0);
     lin(ws.DQH16, x2Z, ws.qhT, 2 * Z, rs.Q[2], ws.DQ[2], ws.DQ16[2], half);
-    if (linseq_enabled()) {  // B3, B4 of the prior | posterior: one visit each
-      auto atm = [&](float* base, long step, int t0) { return base ? base + (long)t0 * step : nullptr; };
+    }
+    if (merge1) {
+    } else if (linseq_enabled()) {  // B3, B4 of the prior | posterior: one visit each
       const SeqLink lp[2] = {{ws.pT[2], at(rs.P[1], sH, T - 1), atm(ws.DP[1], sH, T - 1), -sH, H, atm(ws.DP16[1], xH, T - 1)},
                              {ws.pT[1], at(rs.P[0], sH, T - 1), atm(ws.DP[0], sH, T - 1), -sH, H, atm(ws.DP16[0], xH, T - 1)}};
       const SeqLink lq[2] = {{ws.qT[2], at(rs.Q[1], sH, T - 1), atm(ws.DQ[1], sH, T - 1), -sH, H, atm(ws.DQ16[1], xH, T - 1)},

@@ -320,6 +320,15 @@ inline bool pchain_linseq() {
   return v != 0;
 }
 
+// the link in front of a run of same-shape links joins the run's descriptor visit (K_LINSEQ with its own K for the first link): the
+// first prior / posterior layer (K = R, the posterior's with its x-part addend) in the forward program, the heads' gradient link
+// (K = 2Z) in the backward program -- one visit less per chain and step (~1 us each, tools/probe_engine_chain.py).  16-row engine only.
+// env BLVM_PCHAIN_MERGE = 0 | 1.
+inline bool vrnn_merge_first(bool groups) {
+  static const int v = [] { const char* e = getenv("BLVM_PCHAIN_MERGE"); return e ? atoi(e) : 1; }();
+  return v != 0 && !groups && pchain_linseq();
+}
+
 // the K = 3R link of the persistent backward as three K = R links (env BLVM_PCHAIN_SPLIT3=0: one link)
 inline bool pchain_split3() {
   static int v = [] {
@@ -426,8 +435,11 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
       d.ld[1] = ldadd; d.ld[3] = ldo; d.n16[0] = n16; d.f[0] = 0.f;
     };
     // F1: first prior layer | h-half of the first posterior layer | hidden projection
-    lin(rs.H16, xR, rs.Wp[0], R, w->prior_b[0], nullptr, 0, 0, rs.P[0], sH, H, rs.P16[0], xH, ctH, ctH, 0, half, DF_RELU);
-    lin(rs.H16, xR, rs.Wq[0], R, nullptr, rs.XQ, sH, H, rs.Q[0], sH, H, rs.Q16[0], xH, ctH, ctH, half, half, DF_RELU);
+    const bool merge1 = vrnn_merge_first(groups);  // (then the first prior / posterior layer opens the run below)
+    if (!merge1) {
+      lin(rs.H16, xR, rs.Wp[0], R, w->prior_b[0], nullptr, 0, 0, rs.P[0], sH, H, rs.P16[0], xH, ctH, ctH, 0, half, DF_RELU);
+      lin(rs.H16, xR, rs.Wq[0], R, nullptr, rs.XQ, sH, H, rs.Q[0], sH, H, rs.Q16[0], xH, ctH, ctH, half, half, DF_RELU);
+    }
     auto hproj = [&](int wg0, int nwg) {
       lin(rs.H16, xR, rs.Whh, R, w->gru_bhh, nullptr, 0, 0, rs.GHb, s3R, 3 * R, nullptr, 0, 0, 3 * ctR, wg0, nwg,
           DF_RM_SC1 | DF_GENTLE | ((pchain_tune() & 16) ? DF_CANARY : 0));
@@ -435,9 +447,11 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     if (!shared) hproj(g, def_n);
     // a run of consecutive links of one shape as one descriptor: out_i = relu(A_i W_i^T + b_i), A_{i+1} = out_i
     struct SeqLink { const float* W; const float* bias; float* orm; long rm_step; int ldo; float* o16; };
-    auto linseq = [&](const float* A16, long a_step, int K, int n, const SeqLink* L, int wg0, int nwg) {
+    auto linseq = [&](const float* A16, long a_step, int K, int n, const SeqLink* L, int wg0, int nwg, int K0 = 0, const float* add0 = nullptr,
+                      long add0_step = 0, int ldadd0 = 0) {
       Desc& d = bld.add(K_LINSEQ, ctH, wg0, nwg, K, DF_RELU, 0, Tp);
-      bld.ptr(d, 0, A16, a_step);
+      bld.ptr(d, 0, A16, a_step); bld.ptr(d, 17, add0, add0_step);
+      d.i[3] = K0 != K ? K0 : 0; d.i[0] = ldadd0;
       for (int i = 0; i < n; ++i) {
         bld.ptr(d, 1 + i, L[i].W); bld.ptr(d, 5 + i, L[i].bias); bld.ptr(d, 9 + i, L[i].orm, L[i].rm_step); bld.ptr(d, 13 + i, L[i].o16, xH);
         d.ld[i] = L[i].ldo;
@@ -446,7 +460,12 @@ static int vrnn_seq_fwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     };
     const bool seq = pchain_linseq();
     // F2, F3
-    if (seq) {
+    if (seq && merge1) {  // F1 .. F3 of a chain: one visit
+      const SeqLink lp[3] = {{rs.Wp[0], w->prior_b[0], rs.P[0], sH, H, rs.P16[0]}, {rs.Wp[1], w->prior_b[1], rs.P[1], sH, H, rs.P16[1]}, {rs.Wp[2], w->prior_b[2], rs.P[2], sH, H, rs.P16[2]}};
+      const SeqLink lq[3] = {{rs.Wq[0], nullptr, rs.Q[0], sH, H, rs.Q16[0]}, {rs.Wq[1], w->post_b[1], rs.Q[1], sH, H, rs.Q16[1]}, {rs.Wq[2], w->post_b[2], rs.Q[2], sH, H, rs.Q16[2]}};
+      linseq(rs.H16, xR, H, 3, lp, 0, half, R);
+      linseq(rs.H16, xR, H, 3, lq, half, half, R, rs.XQ, sH, H);
+    } else if (seq) {
       const SeqLink lp[2] = {{rs.Wp[1], w->prior_b[1], rs.P[1], sH, H, rs.P16[1]}, {rs.Wp[2], w->prior_b[2], rs.P[2], sH, H, rs.P16[2]}};
       const SeqLink lq[2] = {{rs.Wq[1], w->post_b[1], rs.Q[1], sH, H, rs.Q16[1]}, {rs.Wq[2], w->post_b[2], rs.Q[2], sH, H, rs.Q16[2]}};
       linseq(rs.P16[0], xH, H, 2, lp, 0, half);
@@ -733,9 +752,11 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
     // B3..B5: back through phi_z layers 3, 2, 1
     // a run of consecutive backward links of one shape as one descriptor (K_LINSEQ): D_{i+1} = (D_i W_i) masked by the saved activation
     struct SeqLinkB { const float* WT; const float* gate; float* orm; float* o16; };
-    auto linseq_b = [&](const float* A16, int n, const SeqLinkB* L, int wg0, int nwg, int flags) -> Desc& {
+    auto linseq_b = [&](const float* A16, int n, const SeqLinkB* L, int wg0, int nwg, int flags, int K0 = 0, long a_x = 0) -> Desc& {
       Desc& d = bld.add(K_LINSEQ, ctH, wg0, nwg, H, flags | DF_SEQ_GATE, 0, T);
-      bld.ptr(d, 0, last(A16, xH), -xH);
+      if (a_x == 0) a_x = xH;
+      bld.ptr(d, 0, last(A16, a_x), -a_x);
+      d.i[3] = (K0 != 0 && K0 != H) ? K0 : 0;  // (the first link's own K: the link in front of the run, in the run's visit)
       for (int i = 0; i < n; ++i) {
         bld.ptr(d, 1 + i, L[i].WT); bld.ptr(d, 5 + i, last(L[i].gate, sH), -sH); bld.ptr(d, 9 + i, last(L[i].orm, sH), -sH);
         bld.ptr(d, 13 + i, last(L[i].o16, xH), -xH);
@@ -777,13 +798,20 @@ static int vrnn_seq_bwd_impl(const BlvmVrnnWeights* w, const float* enc, const f
       d.f[0] = fn_floor; d.f[1] = beta; d.f[2] = sd_eps;
     }
     // B7: heads -> last hidden layers;  B8, B9: hidden layers 2, 1  (prior | posterior)
-    for (int l = 3; l >= (seq ? 3 : 1); --l) {
+    const bool merge1 = vrnn_merge_first(groups);
+    if (seq && merge1) {  // B7 .. B9 of a chain: one visit
+      const SeqLinkB lp[3] = {{ws.phT, rs.P[2], ws.DP[2], ws.DP16[2]}, {ws.pT[2], rs.P[1], ws.DP[1], ws.DP16[1]}, {ws.pT[1], rs.P[0], ws.DP[0], ws.DP16[0]}};
+      const SeqLinkB lq[3] = {{ws.qhT, rs.Q[2], ws.DQ[2], ws.DQ16[2]}, {ws.qT[2], rs.Q[1], ws.DQ[1], ws.DQ16[1]}, {ws.qT[1], rs.Q[0], ws.DQ[0], ws.DQ16[0]}};
+      linseq_b(ws.DPH16, 3, lp, 0, half, 0, 2 * Z, x2Z);
+      linseq_b(ws.DQH16, 3, lq, half, half, 0, 2 * Z, x2Z);
+    }
+    for (int l = 3; l >= (seq ? 3 : 1) && !(seq && merge1); --l) {
       lin(l == 3 ? ws.DPH16 : ws.DP16[l], l == 3 ? x2Z : xH, l == 3 ? ws.phT : ws.pT[l], l == 3 ? 2 * Z : H, nullptr, 0, 0, rs.P[l - 1], sH, H, ws.DP[l - 1], sH, H,
           ws.DP16[l - 1], xH, ctH, ctH, 0, half, 0);
       lin(l == 3 ? ws.DQH16 : ws.DQ16[l], l == 3 ? x2Z : xH, l == 3 ? ws.qhT : ws.qT[l], l == 3 ? 2 * Z : H, nullptr, 0, 0, rs.Q[l - 1], sH, H, ws.DQ[l - 1], sH, H,
           ws.DQ16[l - 1], xH, ctH, ctH, half, half, 0);
     }
-    if (seq) {  // B8, B9 of the prior | of the posterior: one visit each
+    if (seq && !merge1) {  // B8, B9 of the prior | of the posterior: one visit each
       const SeqLinkB lp[2] = {{ws.pT[2], rs.P[1], ws.DP[1], ws.DP16[1]}, {ws.pT[1], rs.P[0], ws.DP[0], ws.DP16[0]}};
       const SeqLinkB lq[2] = {{ws.qT[2], rs.Q[1], ws.DQ[1], ws.DQ16[1]}, {ws.qT[1], rs.Q[0], ws.DQ[0], ws.DQ16[0]}};
       linseq_b(ws.DP16[2], 2, lp, 0, half, 0);
