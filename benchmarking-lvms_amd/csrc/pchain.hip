@@ -492,17 +492,20 @@ __global__ __launch_bounds__(NW * 64, 1) void pchain_rt_kernel(const int* __rest
             const int n = d.w<RD_I + 1>();
             const bool gated = (flags & DF_SEQ_GATE) != 0;
             const float* A = d.p<0>(s);
+            const int K0 = d.w<RD_I + 3>();  // the first link's own K (0: the run's), as in pchain_kernel
             for (int li = 0; li < n; ++li) {
               pl.code = ((unsigned)s << 4) | (unsigned)i | ((unsigned)li << 28);
               const float* W = d.basedyn(1 + li);
+              const int Kl = (li == 0 && K0 != 0) ? K0 : K;
               auto late = [&]() {
                 const float* aux = d.pdyn(5 + li);
-                return LinLate{gated ? nullptr : aux, nullptr, gated ? aux : nullptr, 0, d.w<RD_I + 2>(), false, (flags & DF_RELU) != 0, d.f<0>(),
+                const float* add0 = li == 0 ? d.p<17>(s) : nullptr;
+                return LinLate{gated ? nullptr : aux, add0, gated ? aux : nullptr, d.w<RD_I + 0>(), d.w<RD_I + 2>(), false, (flags & DF_RELU) != 0, d.f<0>(),
                                Out{const_cast<float*>(d.pdyn(9 + li)), d.wdyn(RD_LD + li), false, const_cast<float*>(d.pdyn(13 + li)), n16}};
               };
               for (int tk = 0; tk < nt; ++tk) {
                 const int trc = d.tile(tk), tr0 = trc & 0xffff, tc0 = (trc >> 16) * 16;
-                tile_lin_rt<NW, BF, RT, 1>(A, 0, true, W, K, late, tr0, tc0, B, red, pl);
+                tile_lin_rt<NW, BF, RT, 1>(A, 0, true, W, Kl, late, tr0, tc0, B, red, pl);
               }
               A = d.pdyn(13 + li);
             }

@@ -322,11 +322,12 @@ inline bool pchain_linseq() {
 
 // the link in front of a run of same-shape links joins the run's descriptor visit (K_LINSEQ with its own K for the first link): the
 // first prior / posterior layer (K = R, the posterior's with its x-part addend) in the forward program, the heads' gradient link
-// (K = 2Z) in the backward program -- one visit less per chain and step (~1 us each, tools/probe_engine_chain.py).  16-row engine only.
+// (K = 2Z) in the backward program -- one visit less per chain and step (~1 us each, tools/probe_engine_chain.py).
 // env BLVM_PCHAIN_MERGE = 0 | 1.
 inline bool vrnn_merge_first(bool groups) {
   static const int v = [] { const char* e = getenv("BLVM_PCHAIN_MERGE"); return e ? atoi(e) : 1; }();
-  return v != 0 && !groups && pchain_linseq();
+  (void)groups;  // (the row-group kernel takes the same descriptors)
+  return v != 0 && pchain_linseq();
 }
 
 // the K = 3R link of the persistent backward as three K = R links (env BLVM_PCHAIN_SPLIT3=0: one link)
