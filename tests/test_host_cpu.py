@@ -36,6 +36,20 @@ def test_cpu_tensor_is_refused_loudly():
         m(x, x_sl)
 
 
+def test_grouped_weight_gradient_refuses_cpu_and_misshapen_operands():
+    """`ops.wgrad_group` (one launch for the weight gradients of a chain) checks its operands on the host before any pointer reaches
+    the library: CPU tensors, non-unit column strides and row counts that differ from `rows` raise; an empty job list is a no-op."""
+    from blvm import ops
+
+    ops.wgrad_group([], 16)
+    ops.wgrad_group([(torch.zeros(16, 4), torch.zeros(16, 4), None, None)], 16)  # nothing wanted: nothing launched
+    D, X, dW = torch.zeros(16, 4), torch.zeros(16, 8), torch.zeros(4, 8)
+    with pytest.raises(_hip.BlvmHipError, match="HIP tensors"):
+        ops.wgrad_group([(D, X, dW, None)], 16)
+    with pytest.raises(_hip.BlvmHipError, match=r"rows=32"):
+        ops.wgrad_group([(D, X, dW, None)], 32)
+
+
 def test_vrnn_audio_init_and_state_dict_match_reference():
     """Same seed + same construction order => identical parameters as the reference (pinned by checksums)."""
     g = np.load(os.path.join(GOLDEN, "vrnn_full.npz"))
